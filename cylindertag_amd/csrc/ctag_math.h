@@ -1,0 +1,254 @@
+// ctag_math.h -- deterministic elementary functions shared by the HIP kernels and the CPU oracle.
+//
+// Why this exists: the reference (corner_detector.cpp) calls atan2f/cosf/sinf/atan2/sqrt and, through
+// OpenCV's fitLine, atan2/cos/sin/exp/acos.  Those libm results are not bit-portable between glibc, MSVC
+// and ROCm's OCML, and the detection path is full of knife-edge branches.  Every
+// function below is built only from IEEE-754 +,-,*,/ and sqrt in a fixed evaluation order, so the same
+// source gives the same bits under gcc (x86-64, -ffp-contract=off) and hipcc (gfx950, -ffp-contract=off).
+//
+// Accuracy: the double kernels follow the classic fdlibm argument-reduction + minimax-polynomial schemes
+// (error < 1 ulp in double).  The float entry points evaluate in double and round once, which is the
+// correctly rounded float result except in ~2^-29 of cases.  tests/test_math.py pins all of this against
+// glibc on the CPU and against the gfx950 build on the GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CTM_HD __host__ __device__ __forceinline__
+#else
+#define CTM_HD static inline
+#endif
+
+namespace ctm {
+
+CTM_HD double bits_to_f64(uint64_t u) { double d; __builtin_memcpy(&d, &u, 8); return d; }
+CTM_HD uint64_t f64_to_bits(double d) { uint64_t u; __builtin_memcpy(&u, &d, 8); return u; }
+CTM_HD float bits_to_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+CTM_HD uint32_t f32_to_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+
+CTM_HD double fabs64(double x) { return bits_to_f64(f64_to_bits(x) & 0x7fffffffffffffffULL); }
+CTM_HD float fabs32(float x) { return bits_to_f32(f32_to_bits(x) & 0x7fffffffu); }
+CTM_HD bool isnan64(double x) { return x != x; }
+
+// ---------------------------------------------------------------- atan / atan2 (double)
+CTM_HD double atan64(double x) {
+    const double hi0 = 4.63647609000806093515e-01, hi1 = 7.85398163397448278999e-01,
+                 hi2 = 9.82793723247329054082e-01, hi3 = 1.57079632679489655800e+00;
+    const double lo0 = 2.26987774529616870924e-17, lo1 = 3.06161699786838301793e-17,
+                 lo2 = 1.39033110312309984516e-17, lo3 = 6.12323399573676603587e-17;
+    const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
+                 a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
+                 a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
+                 a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
+                 a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
+                 a10 = 1.62858201153657823623e-02;
+    if (isnan64(x)) return x;
+    const bool neg = (f64_to_bits(x) >> 63) != 0;
+    double ax = fabs64(x);
+    if (ax >= 7.3786976294838206464e19) {  // 2^66: atan = +-pi/2
+        double z = hi3 + lo3;
+        return neg ? -z : z;
+    }
+    int id;
+    double t;
+    if (ax < 0.4375) {
+        if (ax < 3.725290298461914e-09) return x;  // 2^-28
+        id = -1;
+        t = ax;
+    } else if (ax < 0.6875) {
+        id = 0;
+        t = (2.0 * ax - 1.0) / (2.0 + ax);
+    } else if (ax < 1.1875) {
+        id = 1;
+        t = (ax - 1.0) / (ax + 1.0);
+    } else if (ax < 2.4375) {
+        id = 2;
+        t = (ax - 1.5) / (1.0 + 1.5 * ax);
+    } else {
+        id = 3;
+        t = -1.0 / ax;
+    }
+    const double z = t * t;
+    const double w = z * z;
+    const double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+    const double s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    double r;
+    if (id < 0) {
+        r = t - t * (s1 + s2);
+    } else {
+        const double h = id == 0 ? hi0 : id == 1 ? hi1 : id == 2 ? hi2 : hi3;
+        const double l = id == 0 ? lo0 : id == 1 ? lo1 : id == 2 ? lo2 : lo3;
+        r = h - ((t * (s1 + s2) - l) - t);
+    }
+    return neg ? -r : r;
+}
+
+CTM_HD double atan2_64(double y, double x) {
+    const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
+    const double pi_o_2 = 1.5707963267948965580E+00, pi_o_4 = 7.8539816339744827900E-01;
+    if (isnan64(x) || isnan64(y)) return x + y;
+    const bool sx = (f64_to_bits(x) >> 63) != 0, sy = (f64_to_bits(y) >> 63) != 0;
+    const double ax = fabs64(x), ay = fabs64(y);
+    const double inf = bits_to_f64(0x7ff0000000000000ULL);
+    if (ay == 0.0) {
+        if (!sx) return y;  // +-0
+        return sy ? -pi : pi;
+    }
+    if (ax == 0.0) return sy ? -pi_o_2 : pi_o_2;
+    if (ax == inf) {
+        if (ay == inf) {
+            const double v = sx ? 3.0 * pi_o_4 : pi_o_4;
+            return sy ? -v : v;
+        }
+        const double v = sx ? pi : 0.0;
+        return sy ? -v : v;
+    }
+    if (ay == inf) return sy ? -pi_o_2 : pi_o_2;
+    // exponent difference shortcut as in fdlibm: |y/x| > 2^60 or < 2^-60
+    const int ey = (int)((f64_to_bits(ay) >> 52) & 0x7ff), ex = (int)((f64_to_bits(ax) >> 52) & 0x7ff);
+    const int k = ey - ex;
+    double z;
+    if (k > 60) {
+        z = pi_o_2 + 0.5 * pi_lo;
+    } else if (sx && k < -60) {
+        z = 0.0;
+    } else {
+        z = atan64(fabs64(y / x));
+    }
+    if (!sx) return sy ? -z : z;
+    return sy ? (z - pi_lo) - pi : pi - (z - pi_lo);
+}
+
+// ---------------------------------------------------------------- sin / cos (double), |x| modest
+CTM_HD double ksin64(double x) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x;
+    const double v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x + v * (S1 + z * r);
+}
+CTM_HD double kcos64(double x) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ax = fabs64(x);
+    if (ax < 0.3) return 1.0 - (0.5 * z - z * r);
+    const double qx = ax > 0.78125 ? 0.28125 : 0.25 * ax;
+    const double hz = 0.5 * z - qx;
+    const double a = 1.0 - qx;
+    return a - (hz - z * r);
+}
+// reduce x to r in [-pi/4, pi/4], return quadrant (valid for |x| < ~1e5, far beyond what the path needs)
+CTM_HD int rem_pio2_64(double x, double* r) {
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double p1 = 1.57079632673412561417e+00, p1t = 6.07710050650619224932e-11;
+    const double p2 = 6.07710050630396597660e-11, p2t = 2.02226624879595063154e-21;
+    const double fn = __builtin_floor(x * invpio2 + 0.5);
+    const double a = x - fn * p1;
+    const double w = fn * p2;
+    const double b = a - w;
+    const double w2 = fn * p2t - ((a - b) - w);
+    *r = b - w2;
+    (void)p1t;
+    return (int)((long long)fn & 3);
+}
+CTM_HD double sin64(double x) {
+    if (fabs64(x) <= 7.85398163397448278999e-01) return ksin64(x);
+    double r;
+    const int q = rem_pio2_64(x, &r);
+    switch (q) {
+        case 0: return ksin64(r);
+        case 1: return kcos64(r);
+        case 2: return -ksin64(r);
+        default: return -kcos64(r);
+    }
+}
+CTM_HD double cos64(double x) {
+    if (fabs64(x) <= 7.85398163397448278999e-01) return kcos64(x);
+    double r;
+    const int q = rem_pio2_64(x, &r);
+    switch (q) {
+        case 0: return kcos64(r);
+        case 1: return -ksin64(r);
+        case 2: return -kcos64(r);
+        default: return ksin64(r);
+    }
+}
+
+// ---------------------------------------------------------------- exp (double), acos (double)
+CTM_HD double exp64(double x) {
+    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    if (isnan64(x)) return x;
+    if (x > 709.0) return bits_to_f64(0x7ff0000000000000ULL);
+    if (x < -708.0) return 0.0;  // callers only need float range; no double denormals here
+    const double fk = __builtin_floor(x * invln2 + 0.5);
+    const int k = (int)fk;
+    const double hi = x - fk * ln2hi;
+    const double lo = fk * ln2lo;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    // scale by 2^k (k in [-1022, 1023] given the clamps above)
+    const double scale = bits_to_f64((uint64_t)(k + 1023) << 52);
+    return y * scale;
+}
+
+// acos via atan2; exact subtraction 1-t for the float-valued t the path feeds it
+CTM_HD double acos64(double t) {
+    if (t >= 1.0) return 0.0;
+    if (t <= -1.0) return 3.1415926535897931160E+00;
+    return 2.0 * atan2_64(__builtin_sqrt(1.0 - t), __builtin_sqrt(1.0 + t));
+}
+
+// ---------------------------------------------------------------- float entry points
+CTM_HD float atan2_32(float y, float x) { return (float)atan2_64((double)y, (double)x); }
+CTM_HD float sin32(float x) { return (float)sin64((double)x); }
+CTM_HD float cos32(float x) { return (float)cos64((double)x); }
+// expf as the Welsch weight uses it: flush below the float normal range so no denormals are produced
+CTM_HD float exp32(float x) {
+    if (x < -87.0f) return 0.0f;
+    return (float)exp64((double)x);
+}
+CTM_HD float sqrt32(float x) { return __builtin_sqrtf(x); }
+CTM_HD double sqrt64(double x) { return __builtin_sqrt(x); }
+// roundf (half away from zero), as std::round(float)
+CTM_HD float round32(float x) {
+    const float ax = fabs32(x);
+    if (!(ax < 8388608.0f)) return x;
+    float r = __builtin_floorf(ax);
+    if (ax - r >= 0.5f) r += 1.0f;
+    return (f32_to_bits(x) >> 31) ? -r : r;
+}
+
+// cv::fastAtan2 (degrees, [0,360)) -- SURVEY.md App. A.8 [OCV-recall of mathfuncs_core atan_f32]
+CTM_HD float fast_atan2_deg(float y, float x) {
+    const float s = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s,
+                p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabs32(x), ay = fabs32(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.0f - a;
+    if (y < 0) a = 360.0f - a;
+    return a;
+}
+
+}  // namespace ctm

@@ -1,0 +1,63 @@
+/* ctag_types.h -- flat POD result records shared by the C ABI (include/ctag.h) and the test oracle.
+ *
+ * They flatten the reference's `struct MarkerInfo` (/root/reference/header/corner_detector.h:16-22):
+ *   markerID, featurePos[], feature_ID[], feature_ID_left[], feature_ID_right[], cornerLists[n][8],
+ *   feature_center[n], edge_length[n], cr_left[n], cr_right[n]
+ * into fixed-size per-frame storage so that a frame's result is one memcpy / one RCCL gather element.
+ * Limits come from the reference's own fixed arrays: father[100] (corner_detector.h:143) bounds the
+ * features of a frame, code[20] (corner_detector.h:152) bounds the code positions of a marker.
+ */
+#ifndef CTAG_TYPES_H
+#define CTAG_TYPES_H
+#include <stdint.h>
+
+#define CTAG_MAX_FEATURES 100 /* per frame; reference father[100] */
+#define CTAG_MAX_MARKERS 100  /* per frame; every marker owns >= 1 feature */
+#define CTAG_MAX_QUADS 1000   /* per frame; reference isVisited[1000], corner_detector.h:124 */
+#define CTAG_MAX_CODE_POS 20  /* reference code[20] */
+
+/* status of one frame */
+#define CTAG_OK 0          /* markers assigned (possibly zero markers) */
+#define CTAG_NO_CORNER 1   /* reference prints "No corner detected!" and leaves the output untouched */
+#define CTAG_NO_FEATURE 2  /* reference prints "No feature detected!" and leaves the output untouched */
+#define CTAG_ERR_ARG (-1)
+#define CTAG_ERR_HIP (-2)
+#define CTAG_ERR_LIMIT (-3) /* frame exceeded a fixed-array limit the reference would overflow (UB there) */
+#define CTAG_ERR_UNSUPPORTED (-4)
+
+/* flags (bit set) */
+#define CTAG_FLAG_QUAD_OVERFLOW 1u     /* > CTAG_MAX_QUADS quads */
+#define CTAG_FLAG_FEATURE_OVERFLOW 2u  /* > CTAG_MAX_FEATURES features */
+#define CTAG_FLAG_CODE_OVERFLOW 4u     /* a marker's code position reached CTAG_MAX_CODE_POS (marker dropped) */
+#define CTAG_FLAG_POOL_OVERFLOW 8u     /* GPU component pool exhausted (frame far outside the domain) */
+#define CTAG_FLAG_ERASE_CLAMPED 16u    /* reference UB: vector::erase past end, defined as no-op */
+
+typedef struct ctag_feature_rec {
+    int32_t pos;          /* k-th entry of MarkerInfo::featurePos for the first n_pos records, else -1 */
+    int32_t id;           /* feature_ID */
+    int32_t id_left;      /* feature_ID_left */
+    int32_t id_right;     /* feature_ID_right */
+    float corners[16];    /* cornerLists[j][0..7] as x,y pairs, full-resolution pixel coordinates */
+    float center[2];      /* feature_center[j] */
+    float edge_length;    /* edge_length[j] */
+    float cr_left;        /* cr_left[j] */
+    float cr_right;       /* cr_right[j] */
+} ctag_feature_rec;       /* 100 bytes */
+
+typedef struct ctag_marker_rec {
+    int32_t marker_id;     /* MarkerInfo::markerID (dictionary row), -1 before decoding */
+    int32_t first_feature; /* index into ctag_frame_result::features */
+    int32_t n_features;    /* cornerLists.size() */
+    int32_t n_pos;         /* featurePos.size() (<= n_features) */
+} ctag_marker_rec;
+
+typedef struct ctag_frame_result {
+    int32_t status;
+    int32_t n_markers;
+    int32_t n_features;
+    uint32_t flags;
+    ctag_marker_rec markers[CTAG_MAX_MARKERS];
+    ctag_feature_rec features[CTAG_MAX_FEATURES];
+} ctag_frame_result; /* 16 + 1600 + 10000 = 11616 bytes */
+
+#endif
