@@ -1,0 +1,252 @@
+"""ctypes binding of include/ctag.h (libctag_hip.so).  Plumbing only: no arithmetic happens here."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libctag_hip.so")
+
+MAX_FEATURES, MAX_MARKERS = 100, 100
+FEATURE_DT = np.dtype([("pos", "<i4"), ("id", "<i4"), ("id_left", "<i4"), ("id_right", "<i4"),
+                       ("corners", "<f4", (16,)), ("center", "<f4", (2,)), ("edge_length", "<f4"),
+                       ("cr_left", "<f4"), ("cr_right", "<f4")])
+MARKER_DT = np.dtype([("marker_id", "<i4"), ("first_feature", "<i4"), ("n_features", "<i4"), ("n_pos", "<i4")])
+RESULT_DT = np.dtype([("status", "<i4"), ("n_markers", "<i4"), ("n_features", "<i4"), ("flags", "<u4"),
+                      ("markers", MARKER_DT, (MAX_MARKERS,)), ("features", FEATURE_DT, (MAX_FEATURES,))])
+TRUTH_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("strip_len", "<f4", (8,)),
+                     ("corners", "<f4", (8, 8))])
+STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates", "quad", "features", "edge_refine",
+               "markers"]
+
+OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS = 1, 2, 3
+DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS = range(1, 9)
+
+# every symbol include/ctag.h declares (tests check the library exports all of them)
+EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
+           "ctag_detect_batch_device", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
+           "ctag_stage_name", "ctag_strerror", "ctag_version", "ctag_debug_fetch", "ctag_math_probe",
+           "ctag_synth_frames_device", "ctag_synth_frame_host"]
+
+
+class CtagError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        super().__init__("%s (status %d)%s" % (_strerror(status), status, (": " + what) if what else ""))
+
+
+def lib_path():
+    return _LIB
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree (hipcc cross-compiles for gfx950 without a GPU)."""
+    subprocess.check_call(["make", "-C", _HERE, "-j4"] + ([] if verbose else ["-s"]))
+
+
+_lib = None
+
+
+def load_library():
+    """Load libctag_hip.so; raises if it has not been built.  There is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the detection path has no CPU fallback)" % _LIB)
+    L = C.CDLL(_LIB)
+    vp, i32p, u8p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
+    L.ctag_create.restype = C.c_int
+    L.ctag_create.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ctag_destroy.argtypes = [vp]
+    L.ctag_destroy.restype = None
+    L.ctag_load_marker_file.restype = C.c_int
+    L.ctag_load_marker_file.argtypes = [C.c_char_p, C.POINTER(i32p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
+    L.ctag_free.argtypes = [vp]
+    L.ctag_free.restype = None
+    L.ctag_detect_u8.restype = C.c_int
+    L.ctag_detect_u8.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.c_int, vp]
+    L.ctag_detect_batch_u8.restype = C.c_int
+    L.ctag_detect_batch_u8.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int,
+                                       C.c_int, vp]
+    L.ctag_detect_batch_device.restype = C.c_int
+    L.ctag_detect_batch_device.argtypes = L.ctag_detect_batch_u8.argtypes
+    L.ctag_sync.restype = C.c_int
+    L.ctag_sync.argtypes = [vp]
+    L.ctag_stream.restype = vp
+    L.ctag_stream.argtypes = [vp]
+    L.ctag_set_option.restype = C.c_int
+    L.ctag_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.ctag_get_timings.restype = C.c_int
+    L.ctag_get_timings.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.ctag_stage_name.restype = C.c_char_p
+    L.ctag_stage_name.argtypes = [C.c_int]
+    L.ctag_strerror.restype = C.c_char_p
+    L.ctag_strerror.argtypes = [C.c_int]
+    L.ctag_version.restype = C.c_int
+    L.ctag_debug_fetch.restype = C.c_long
+    L.ctag_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+    L.ctag_math_probe.restype = C.c_int
+    L.ctag_math_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.ctag_synth_frames_device.restype = C.c_int
+    L.ctag_synth_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t,
+                                           C.c_uint64, C.c_int]
+    L.ctag_synth_frame_host.restype = C.c_int
+    L.ctag_synth_frame_host.argtypes = [i32p, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_uint64,
+                                        C.c_int, vp]
+    _lib = L
+    return L
+
+
+def _strerror(status):
+    try:
+        return load_library().ctag_strerror(status).decode()
+    except Exception:  # pragma: no cover
+        return "ctag error"
+
+
+def load_marker_file(path):
+    """CylinderTag::load_from_file through the C ABI -> (state[int32 rows x cols], feature_size)."""
+    L = load_library()
+    p = C.POINTER(C.c_int32)()
+    r, c, fs = C.c_int(), C.c_int(), C.c_int()
+    st = L.ctag_load_marker_file(os.fsencode(path), C.byref(p), C.byref(r), C.byref(c), C.byref(fs))
+    if st != 0:
+        raise CtagError(st, path)
+    try:
+        state = np.ctypeslib.as_array(p, shape=(r.value, c.value)).copy()
+    finally:
+        L.ctag_free(p)
+    return state, fs.value
+
+
+SYNTH_SEED = 0x4354616753594E00  # "CTagSYN\0", SURVEY.md 8(d)
+
+
+def synth_frame_host(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, markers=4):
+    """Host rendering of synthetic frame `frame_index` (same code path as the device generator)."""
+    L = load_library()
+    state = np.ascontiguousarray(state, dtype=np.int32)
+    img = np.zeros((rows, cols), np.uint8)
+    truth = np.zeros(1, TRUTH_DT)
+    st = L.ctag_synth_frame_host(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1],
+                                 img.ctypes.data, frame_index, rows, cols, img.strides[0], seed, markers,
+                                 truth.ctypes.data)
+    if st != 0:
+        raise CtagError(st)
+    return img, truth[0]
+
+
+class Detector:
+    """One ctag_handle (one GPU).  Mirrors the reference's usage: construct with the dictionary, call detect()."""
+
+    def __init__(self, state, feature_size, device=0):
+        self.L = load_library()
+        self.state = np.ascontiguousarray(state, dtype=np.int32)
+        self.feature_size = int(feature_size)
+        h = C.c_void_p()
+        st = self.L.ctag_create(self.state.ctypes.data_as(C.POINTER(C.c_int32)), self.state.shape[0],
+                                self.state.shape[1], self.feature_size, device, C.byref(h))
+        if st != 0:
+            raise CtagError(st, "ctag_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ctag_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt, value):
+        st = self.L.ctag_set_option(self.h, opt, int(value))
+        if st != 0:
+            raise CtagError(st, "ctag_set_option")
+
+    # ---- host-memory entry points
+    def detect(self, gray, adaptive_thresh=5, subpix=True, subpix_dist=5):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        res = np.zeros(1, RESULT_DT)
+        st = self.L.ctag_detect_u8(self.h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
+                                   adaptive_thresh, int(subpix), subpix_dist, res.ctypes.data)
+        if st < 0:
+            raise CtagError(st, "ctag_detect_u8")
+        return res[0]
+
+    def detect_batch(self, frames, adaptive_thresh=5, subpix=True, subpix_dist=5):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, rows, cols = frames.shape
+        res = np.zeros(n, RESULT_DT)
+        st = self.L.ctag_detect_batch_u8(self.h, frames.ctypes.data, n, rows, cols, frames.strides[1], frames.strides[0],
+                                         adaptive_thresh, int(subpix), subpix_dist, res.ctypes.data)
+        if st != 0:
+            raise CtagError(st, "ctag_detect_batch_u8")
+        return res
+
+    # ---- device-memory entry point (pointers are plain integers, e.g. torch.Tensor.data_ptr())
+    def detect_batch_device(self, frames_ptr, n, rows, cols, row_stride, frame_stride, out_ptr, adaptive_thresh=5,
+                            subpix=True, subpix_dist=5):
+        st = self.L.ctag_detect_batch_device(self.h, frames_ptr, n, rows, cols, row_stride, frame_stride,
+                                             adaptive_thresh, int(subpix), subpix_dist, out_ptr)
+        if st != 0:
+            raise CtagError(st, "ctag_detect_batch_device")
+
+    def sync(self):
+        st = self.L.ctag_sync(self.h)
+        if st != 0:
+            raise CtagError(st, "ctag_sync")
+
+    def stream(self):
+        return self.L.ctag_stream(self.h)
+
+    def timings(self):
+        buf = (C.c_float * len(STAGE_NAMES))()
+        n = self.L.ctag_get_timings(self.h, buf, len(STAGE_NAMES))
+        return {STAGE_NAMES[i]: float(buf[i]) for i in range(n)}
+
+    def synth_frames_device(self, frames_ptr, first, n, rows, cols, row_stride, frame_stride, seed=SYNTH_SEED, markers=4):
+        st = self.L.ctag_synth_frames_device(self.h, frames_ptr, first, n, rows, cols, row_stride, frame_stride, seed,
+                                             markers)
+        if st != 0:
+            raise CtagError(st, "ctag_synth_frames_device")
+
+    # ---- parity probes
+    def debug(self, frame, what):
+        n = self.L.ctag_debug_fetch(self.h, frame, what, None, 0)
+        if n < 0:
+            raise CtagError(-1, "ctag_debug_fetch(%d)" % what)
+        if what == DBG_HALF:
+            a = np.zeros(n, np.uint8)
+        elif what in (DBG_LABELS, DBG_CANDIDATES):
+            a = np.zeros(n, np.int32)
+        elif what == DBG_PREMARKERS:
+            a = np.zeros(1, RESULT_DT)
+        else:
+            a = np.zeros(n, np.float32)
+        if n:
+            got = self.L.ctag_debug_fetch(self.h, frame, what, a.ctypes.data, max(n, 1))
+            if got < 0:
+                raise CtagError(-2, "ctag_debug_fetch(%d)" % what)
+        if what in (DBG_CANDIDATES, DBG_CAND_QUADS):
+            return a.reshape(-1, 8)
+        if what in (DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2):
+            return a.reshape(-1, 19)
+        if what == DBG_PREMARKERS:
+            return a[0]
+        return a
+
+    def math(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float64)
+        out = np.zeros_like(a)
+        st = self.L.ctag_math_probe(self.h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+        if st != 0:
+            raise CtagError(st, "ctag_math_probe")
+        return out

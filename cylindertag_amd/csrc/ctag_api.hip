@@ -1,0 +1,619 @@
+// ctag_api.hip -- implementation of the C ABI in include/ctag.h: handle, workspace, batching, probes.
+// Host orchestration only; the arithmetic lives in k_sweep.hip / k_quad.hip / k_feature.hip.
+// There is deliberately no CPU fallback: if HIP is unavailable every entry point returns CTAG_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ctag.h"
+#include "ctag_internal.h"
+#include "ctag_math.h"
+#include "ctag_synth.h"
+
+using namespace ctag;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            std::snprintf(h->last_error, sizeof(h->last_error), "%s: %s", #expr, hipGetErrorString(e__)); \
+            return CTAG_ERR_HIP;                                                                        \
+        }                                                                                               \
+    } while (0)
+
+struct ctag_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<int32_t> dict;
+    int32_t* d_dict = nullptr;
+    int dict_rows = 0, dict_cols = 0, feature_size = 0;
+    Workspace ws;
+    int ws_rows = 0, ws_cols = 0, ws_tw = 0, ws_cap = 0;
+    int max_chunk = 1024;
+    bool timing = false;
+    bool keep_pre = false;
+    hipEvent_t ev[CTAG_NUM_STAGES + 1] = {};
+    float stage_ms[CTAG_NUM_STAGES] = {};
+    // staging for host-memory entry points
+    uint8_t* d_frames = nullptr;
+    size_t d_frames_bytes = 0;
+    ctag_frame_result* d_results = nullptr;
+    size_t d_results_count = 0;
+    ctag_synth::Frame* d_synth = nullptr;
+    size_t d_synth_count = 0;
+    int last_chunk_frames = 0;
+    char last_error[256] = {0};
+};
+
+static const char* kStageNames[CTAG_NUM_STAGES] = {"decimate", "threshold_ccl", "seam_merge", "resolve", "candidates",
+                                                    "quad",     "features",      "edge_refine", "markers"};
+
+// ---------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------
+static FrameGeom make_geom(int rows, int cols, int tw) {
+    FrameGeom g{};
+    g.rows = rows;
+    g.cols = cols;
+    g.hrows = rows / 2;
+    g.hcols = cols / 2;
+    g.hp = (g.hcols + 63) & ~63;
+    g.lp = (g.hcols + 63) & ~63;
+    g.tw = tw;
+    g.trows = g.hrows / tw + (g.hrows % tw != 0 ? 1 : 0);
+    g.tcols = g.hcols / tw + (g.hcols % tw != 0 ? 1 : 0);
+    g.tiles_x = (g.hcols + kTileW - 1) / kTileW;
+    g.tiles_y = (g.hrows + kTileH - 1) / kTileH;
+    g.max_area = (int)std::round(0.01 * g.hcols * g.hrows);  // corner_detector.cpp:88
+    return g;
+}
+
+static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int frames) {
+    if (h->ws.base && h->ws_rows == rows && h->ws_cols == cols && h->ws_cap >= frames) {
+        h->ws.g = make_geom(rows, cols, tw);
+        h->ws_tw = tw;
+        return CTAG_OK;
+    }
+    if (h->ws.base) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipFree(h->ws.base));
+        h->ws = Workspace{};
+    }
+    Workspace& W = h->ws;
+    W.g = make_geom(rows, cols, tw);
+    const FrameGeom& g = W.g;
+    const size_t F = (size_t)frames;
+    const size_t tiles = (size_t)g.tiles_x * g.tiles_y;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t o_half = take(F * g.hrows * g.hp + 256);
+    const size_t o_labels = take(F * g.hrows * g.lp * 2 + 256);
+    const size_t o_tbase = take(F * tiles * 4);
+    const size_t o_ncomp = take(F * 4);
+    const size_t o_flags = take(F * 4);
+    const size_t pool = F * kPoolCap * 4;
+    const size_t o_parent = take(pool), o_root = take(pool), o_area = take(pool), o_xmin = take(pool), o_ymin = take(pool),
+                 o_xmax = take(pool), o_ymax = take(pool), o_key = take(pool);
+    const size_t o_ncand = take(F * 4);
+    const size_t o_cand = take(F * kCandCap * sizeof(Candidate));
+    const size_t o_quads = take(F * kCandCap * sizeof(QuadOut));
+    const size_t scratch_words = (size_t)4 * kQuadScratchPoints + 2048;
+    const size_t o_scratch = take((size_t)kQuadScratchSlots * scratch_words * 4);
+    const size_t o_scr_used = take(4);
+    const size_t o_der = take(F * kCandCap * 32);
+    const size_t o_qidx = take(F * kCandCap * 4);
+    const size_t o_nq = take(F * 4), o_nf = take(F * 4), o_st = take(F * 4);
+    const size_t o_f0 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
+    const size_t o_f1 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
+    const size_t o_f2 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
+    const size_t o_pre = take(F * sizeof(ctag_frame_result));
+    void* base = nullptr;
+    HIP_TRY(hipMalloc(&base, off));
+    char* b = static_cast<char*>(base);
+    W.base = base;
+    W.bytes = off;
+    W.chunk_frames = frames;
+    W.half = reinterpret_cast<uint8_t*>(b + o_half);
+    W.labels = reinterpret_cast<uint16_t*>(b + o_labels);
+    W.tile_base = reinterpret_cast<int32_t*>(b + o_tbase);
+    W.frame_ncomp = reinterpret_cast<int32_t*>(b + o_ncomp);
+    W.frame_flags = reinterpret_cast<uint32_t*>(b + o_flags);
+    W.parent = reinterpret_cast<uint32_t*>(b + o_parent);
+    W.root_of = reinterpret_cast<int32_t*>(b + o_root);
+    W.area = reinterpret_cast<int32_t*>(b + o_area);
+    W.xmin = reinterpret_cast<int32_t*>(b + o_xmin);
+    W.ymin = reinterpret_cast<int32_t*>(b + o_ymin);
+    W.xmax = reinterpret_cast<int32_t*>(b + o_xmax);
+    W.ymax = reinterpret_cast<int32_t*>(b + o_ymax);
+    W.key = reinterpret_cast<int32_t*>(b + o_key);
+    W.ncand = reinterpret_cast<int32_t*>(b + o_ncand);
+    W.cand = reinterpret_cast<Candidate*>(b + o_cand);
+    W.quads = reinterpret_cast<QuadOut*>(b + o_quads);
+    W.quad_scratch = reinterpret_cast<uint32_t*>(b + o_scratch);
+    W.quad_scratch_used = reinterpret_cast<int32_t*>(b + o_scr_used);
+    W.quad_derived = b + o_der;
+    W.quad_index = reinterpret_cast<int32_t*>(b + o_qidx);
+    W.nquads = reinterpret_cast<int32_t*>(b + o_nq);
+    W.nfeat = reinterpret_cast<int32_t*>(b + o_nf);
+    W.status = reinterpret_cast<int32_t*>(b + o_st);
+    W.feat0 = reinterpret_cast<FeatureDev*>(b + o_f0);
+    W.feat1 = reinterpret_cast<FeatureDev*>(b + o_f1);
+    W.feat2 = reinterpret_cast<FeatureDev*>(b + o_f2);
+    W.premarkers = reinterpret_cast<ctag_frame_result*>(b + o_pre);
+    h->ws_rows = rows;
+    h->ws_cols = cols;
+    h->ws_tw = tw;
+    h->ws_cap = frames;
+    return CTAG_OK;
+}
+
+static int check_args(ctag_handle* h, const void* frames, int n, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int subpix_dist) {
+    if (!h || !frames || n < 0 || rows < 4 || cols < 4 || row_stride < cols || adaptive_thresh < 1 || subpix_dist < 0) return CTAG_ERR_ARG;
+    // The GPU decimation implements the exact-2x cubic taps; odd sizes need per-column coefficient tables
+    // (reference behaviour for odd sizes is restated in the oracle only).
+    if ((rows & 1) || (cols & 1)) return CTAG_ERR_UNSUPPORTED;
+    if (adaptive_thresh > kMaxThreshWin) return CTAG_ERR_UNSUPPORTED;
+    if (rows / 2 > 16000 || cols / 2 > 16000) return CTAG_ERR_UNSUPPORTED;
+    return CTAG_OK;
+}
+
+// enqueue the whole pipeline for `n` device-resident frames (n <= workspace capacity)
+static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
+                     ctag_frame_result* out_dev) {
+    const Workspace& ws = h->ws;
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemsetAsync(ws.frame_ncomp, 0, (size_t)n * 4, s));
+    HIP_TRY(hipMemsetAsync(ws.frame_flags, 0, (size_t)n * 4, s));
+    int st = 0;
+    auto mark = [&](int i) -> hipError_t { return h->timing ? hipEventRecord(h->ev[i], s) : hipSuccess; };
+    HIP_TRY(mark(0));
+    HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s));
+    HIP_TRY(mark(++st));
+    HIP_TRY(launch_threshold_ccl(n, ws, s));
+    HIP_TRY(mark(++st));
+    HIP_TRY(launch_seam_merge(n, ws, s));
+    HIP_TRY(mark(++st));
+    HIP_TRY(launch_resolve(n, ws, s));
+    HIP_TRY(mark(++st));
+    HIP_TRY(launch_candidates(n, ws, s));
+    HIP_TRY(mark(++st));
+    HIP_TRY(launch_quads(n, ws, s));
+    HIP_TRY(mark(++st));
+    HIP_TRY(launch_features(n, ws, p, s));
+    HIP_TRY(mark(++st));
+    HIP_TRY(launch_edge_refine(frames_dev, frame_stride, row_stride, n, ws, p, s));
+    HIP_TRY(mark(++st));
+    Workspace wtmp = ws;
+    if (!h->keep_pre) wtmp.premarkers = nullptr;
+    HIP_TRY(launch_markers(n, wtmp, p, out_dev, s));
+    HIP_TRY(mark(++st));
+    h->last_chunk_frames = n;
+    return CTAG_OK;
+}
+
+static int collect_timings(ctag_handle* h) {
+    if (!h->timing) return CTAG_OK;
+    HIP_TRY(hipEventSynchronize(h->ev[CTAG_NUM_STAGES]));
+    for (int i = 0; i < CTAG_NUM_STAGES; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        h->stage_ms[i] += ms;
+    }
+    return CTAG_OK;
+}
+
+static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                              int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev) {
+    const int rc = check_args(h, frames_dev, n, rows, cols, row_stride, adaptive_thresh, subpix_dist);
+    if (rc != CTAG_OK) return rc;
+    if (n == 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int chunk = std::min(n, h->max_chunk);
+    const int wr = ensure_workspace(h, rows, cols, adaptive_thresh, std::max(chunk, h->ws_rows == rows && h->ws_cols == cols ? h->ws_cap : 0));
+    if (wr != CTAG_OK) return wr;
+    DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict};
+    for (int i = 0; i < CTAG_NUM_STAGES; i++) h->stage_ms[i] = 0.f;
+    for (int f0 = 0; f0 < n; f0 += chunk) {
+        const int m = std::min(chunk, n - f0);
+        const int r = run_chunk(h, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0);
+        if (r != CTAG_OK) return r;
+        if (h->timing) {
+            const int t = collect_timings(h);
+            if (t != CTAG_OK) return t;
+        }
+    }
+    return CTAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small kernels that belong to the API layer
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_math_probe(int op, int n, const double* a, const double* b, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b[i];
+    double r = 0;
+    switch (op) {
+        case 0: r = ctm::atan2_64(x, y); break;
+        case 1: r = ctm::sin64(x); break;
+        case 2: r = ctm::cos64(x); break;
+        case 3: r = ctm::exp64(x); break;
+        case 4: r = ctm::acos64(x); break;
+        case 5: r = ctm::atan2_32((float)x, (float)y); break;
+        case 6: r = ctm::sin32((float)x); break;
+        case 7: r = ctm::cos32((float)x); break;
+        case 8: r = ctm::exp32((float)x); break;
+        case 9: r = ctm::fast_atan2_deg((float)x, (float)y); break;
+        case 10: r = x / y; break;
+        case 11: r = ctm::sqrt64(x); break;
+        case 12: r = (float)x / (float)y; break;
+        case 13: r = ctm::sqrt32((float)x); break;
+        case 14: r = ctm::round32((float)x); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+__global__ void k_label_roots(const uint16_t* labels, const int32_t* tile_base, const int32_t* root_of, int32_t* out, FrameGeom g) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.hcols || y >= g.hrows) return;
+    const unsigned l = labels[(size_t)y * g.lp + x];
+    int v = 0;
+    if (l) v = 1 + root_of[tile_base[(y / kTileH) * g.tiles_x + (x / kTileW)] + (int)l - 1];
+    out[(size_t)y * g.hcols + x] = v;
+}
+
+__global__ __launch_bounds__(256) void k_synth(const ctag_synth::Frame* frames, uint8_t* out, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride) {
+    __shared__ ctag_synth::Frame F;
+    const int f = blockIdx.z;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(frames + f);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&F);
+        for (int i = threadIdx.x; i < (int)(sizeof(ctag_synth::Frame) / 4); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    out[(ptrdiff_t)f * frame_stride + (ptrdiff_t)y * row_stride + x] = ctag_synth::pixel(F, x, y, rows, cols);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ctag_version(void) { return 100; }
+
+const char* ctag_strerror(int status) {
+    switch (status) {
+        case CTAG_OK: return "ok";
+        case CTAG_NO_CORNER: return "No corner detected!";
+        case CTAG_NO_FEATURE: return "No feature detected!";
+        case CTAG_ERR_ARG: return "invalid argument";
+        case CTAG_ERR_HIP: return "HIP runtime error (no usable gfx950 device?)";
+        case CTAG_ERR_LIMIT: return "frame exceeds a fixed-array limit of the reference";
+        case CTAG_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+const char* ctag_stage_name(int stage) { return (stage >= 0 && stage < CTAG_NUM_STAGES) ? kStageNames[stage] : ""; }
+
+int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_size, int device_id, ctag_handle** out) {
+    if (!out) return CTAG_ERR_ARG;
+    *out = nullptr;
+    if (!state || dict_rows < 1 || dict_cols < 1 || (long)dict_rows * dict_cols > kMaxDictCells) return CTAG_ERR_ARG;
+    for (long i = 0; i < (long)dict_rows * dict_cols; i++)
+        if (!(state[i] >= 0 && state[i] <= 63)) return CTAG_ERR_ARG;  // check_dictionary, CylinderTag.cpp:56-65
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return CTAG_ERR_HIP;
+    ctag_handle* h = new (std::nothrow) ctag_handle();
+    if (!h) return CTAG_ERR_HIP;
+    h->device = device_id;
+    h->dict.assign(state, state + (size_t)dict_rows * dict_cols);
+    h->dict_rows = dict_rows;
+    h->dict_cols = dict_cols;
+    h->feature_size = feature_size;
+    bool ok = hipSetDevice(device_id) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_dict), h->dict.size() * 4) == hipSuccess;
+    ok = ok && hipMemcpy(h->d_dict, h->dict.data(), h->dict.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    for (int i = 0; ok && i <= CTAG_NUM_STAGES; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+    if (!ok) {
+        ctag_destroy(h);
+        return CTAG_ERR_HIP;
+    }
+    *out = h;
+    return CTAG_OK;
+}
+
+void ctag_destroy(ctag_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->ws.base) (void)hipFree(h->ws.base);
+    if (h->d_dict) (void)hipFree(h->d_dict);
+    if (h->d_frames) (void)hipFree(h->d_frames);
+    if (h->d_results) (void)hipFree(h->d_results);
+    if (h->d_synth) (void)hipFree(h->d_synth);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ctag_load_marker_file(const char* path, int32_t** state, int* dict_rows, int* dict_cols, int* feature_size) {
+    if (!path || !state || !dict_rows || !dict_cols || !feature_size) return CTAG_ERR_ARG;
+    std::ifstream in(path);
+    if (!in.is_open()) return CTAG_ERR_ARG;
+    int n = 0, c = 0, fs = 0;
+    in >> n >> c >> fs;
+    if (!in || n < 1 || c < 1 || (long)n * c > (1L << 24)) return CTAG_ERR_ARG;
+    int32_t* s = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)n * c));
+    if (!s) return CTAG_ERR_ARG;
+    for (long i = 0; i < (long)n * c; i++) {
+        int v = 0;
+        in >> v;  // like the reference, a short file leaves the remaining entries at their last parsed value (0)
+        s[i] = v;
+        if (!(v >= 0 && v <= 63)) {
+            std::free(s);
+            return CTAG_ERR_ARG;
+        }
+    }
+    *state = s;
+    *dict_rows = n;
+    *dict_cols = c;
+    *feature_size = fs;
+    return CTAG_OK;
+}
+void ctag_free(void* p) { std::free(p); }
+
+int ctag_set_option(ctag_handle* h, int option, int64_t value) {
+    if (!h) return CTAG_ERR_ARG;
+    switch (option) {
+        case CTAG_OPT_MAX_CHUNK:
+            if (value < 1 || value > (1 << 20)) return CTAG_ERR_ARG;
+            h->max_chunk = (int)value;
+            return CTAG_OK;
+        case CTAG_OPT_TIMING: h->timing = value != 0; return CTAG_OK;
+        case CTAG_OPT_KEEP_PREMARKERS: h->keep_pre = value != 0; return CTAG_OK;
+        default: return CTAG_ERR_ARG;
+    }
+}
+
+int ctag_get_timings(ctag_handle* h, float* ms, int capacity) {
+    if (!h || !ms) return 0;
+    const int n = std::min(capacity, (int)CTAG_NUM_STAGES);
+    for (int i = 0; i < n; i++) ms[i] = h->stage_ms[i];
+    return n;
+}
+
+void* ctag_stream(ctag_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int ctag_sync(ctag_handle* h) {
+    if (!h) return CTAG_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CTAG_OK;
+}
+
+int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                             int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev) {
+    if (!h || !out_dev) return CTAG_ERR_ARG;
+    return detect_device_impl(h, frames_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev);
+}
+
+int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                         int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out) {
+    if (!h || !out) return CTAG_ERR_ARG;
+    const int rc = check_args(h, frames, n, rows, cols, row_stride, adaptive_thresh, subpix_dist);
+    if (rc != CTAG_OK) return rc;
+    if (n == 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int chunk = std::min(n, h->max_chunk);
+    const ptrdiff_t dstride = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;  // packed, 16-byte aligned rows on the device
+    const size_t dframe = (size_t)dstride * rows;
+    if (h->d_frames_bytes < dframe * chunk) {
+        if (h->d_frames) HIP_TRY(hipFree(h->d_frames));
+        h->d_frames = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_frames), dframe * chunk));
+        h->d_frames_bytes = dframe * chunk;
+    }
+    if (h->d_results_count < (size_t)chunk) {
+        if (h->d_results) HIP_TRY(hipFree(h->d_results));
+        h->d_results = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_results), sizeof(ctag_frame_result) * chunk));
+        h->d_results_count = chunk;
+    }
+    for (int f0 = 0; f0 < n; f0 += chunk) {
+        const int m = std::min(chunk, n - f0);
+        for (int i = 0; i < m; i++) {
+            HIP_TRY(hipMemcpy2DAsync(h->d_frames + dframe * i, dstride, frames + (ptrdiff_t)(f0 + i) * frame_stride, row_stride, cols, rows,
+                                     hipMemcpyHostToDevice, h->stream));
+        }
+        const int r = detect_device_impl(h, h->d_frames, m, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist,
+                                         h->d_results);
+        if (r != CTAG_OK) return r;
+        HIP_TRY(hipMemcpyAsync(out + f0, h->d_results, sizeof(ctag_frame_result) * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return CTAG_OK;
+}
+
+int ctag_detect_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int corner_subpix,
+                   int subpix_dist, ctag_frame_result* out) {
+    if (!h || !out) return CTAG_ERR_ARG;
+    const int r = ctag_detect_batch_u8(h, gray, 1, rows, cols, row_stride, (ptrdiff_t)row_stride * rows, adaptive_thresh, corner_subpix, subpix_dist, out);
+    if (r != CTAG_OK) return r;
+    return out->status;
+}
+
+long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t cap) {
+    if (!h || !h->ws.base || frame < 0 || frame >= h->last_chunk_frames) return -1;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -2;
+    const Workspace& W = h->ws;
+    const FrameGeom& g = W.g;
+    auto d2h = [&](void* d, const void* s, size_t bytes) { return hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    switch (what) {
+        case CTAG_DBG_HALF: {
+            const size_t n = (size_t)g.hrows * g.hcols;
+            if (dst && cap >= n) {
+                if (hipMemcpy2D(dst, g.hcols, W.half + (size_t)frame * g.hrows * g.hp, g.hp, g.hcols, g.hrows, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+            }
+            return (long)n;
+        }
+        case CTAG_DBG_LABELS: {
+            const size_t n = (size_t)g.hrows * g.hcols;
+            if (dst && cap >= n) {
+                int32_t* tmp = nullptr;
+                if (hipMalloc(reinterpret_cast<void**>(&tmp), n * 4) != hipSuccess) return -2;
+                hipLaunchKernelGGL(k_label_roots, dim3((g.hcols + 255) / 256, g.hrows), dim3(256), 0, h->stream,
+                                   W.labels + (size_t)frame * g.hrows * g.lp, W.tile_base + (size_t)frame * g.tiles_x * g.tiles_y,
+                                   W.root_of + (size_t)frame * kPoolCap, tmp, g);
+                const bool ok = hipStreamSynchronize(h->stream) == hipSuccess && d2h(dst, tmp, n * 4);
+                (void)hipFree(tmp);
+                if (!ok) return -2;
+            }
+            return (long)n;
+        }
+        case CTAG_DBG_CANDIDATES:
+        case CTAG_DBG_CAND_QUADS: {
+            int nc = 0;
+            if (!d2h(&nc, W.ncand + frame, 4)) return -2;
+            if (dst && cap >= (size_t)nc * 8 && nc > 0) {
+                std::vector<Candidate> c(nc);
+                std::vector<QuadOut> q(nc);
+                if (!d2h(c.data(), W.cand + (size_t)frame * kCandCap, sizeof(Candidate) * nc)) return -2;
+                if (!d2h(q.data(), W.quads + (size_t)frame * kCandCap, sizeof(QuadOut) * nc)) return -2;
+                if (what == CTAG_DBG_CANDIDATES) {
+                    int32_t* o = static_cast<int32_t*>(dst);
+                    for (int i = 0; i < nc; i++) {
+                        o[8 * i + 0] = c[i].area;
+                        o[8 * i + 1] = c[i].x_min;
+                        o[8 * i + 2] = c[i].y_min;
+                        o[8 * i + 3] = c[i].x_max;
+                        o[8 * i + 4] = c[i].y_max;
+                        o[8 * i + 5] = q[i].valid;
+                        o[8 * i + 6] = q[i].n_boundary;
+                        o[8 * i + 7] = c[i].root;
+                    }
+                } else {
+                    float* o = static_cast<float*>(dst);
+                    for (int i = 0; i < nc; i++)
+                        for (int k = 0; k < 8; k++) o[8 * i + k] = q[i].valid ? q[i].c[k] : 0.f;
+                }
+            }
+            return (long)nc * 8;
+        }
+        case CTAG_DBG_FEATURES0:
+        case CTAG_DBG_FEATURES1:
+        case CTAG_DBG_FEATURES2: {
+            int nf = 0;
+            if (!d2h(&nf, W.nfeat + frame, 4)) return -2;
+            if (dst && cap >= (size_t)nf * 19 && nf > 0) {
+                std::vector<FeatureDev> f(nf);
+                const FeatureDev* src = what == CTAG_DBG_FEATURES0 ? W.feat0 : what == CTAG_DBG_FEATURES1 ? W.feat1 : W.feat2;
+                if (!d2h(f.data(), src + (size_t)frame * CTAG_MAX_FEATURES, sizeof(FeatureDev) * nf)) return -2;
+                float* o = static_cast<float*>(dst);
+                for (int i = 0; i < nf; i++) {
+                    for (int k = 0; k < 16; k++) o[19 * i + k] = f[i].c[k];
+                    o[19 * i + 16] = f[i].center[0];
+                    o[19 * i + 17] = f[i].center[1];
+                    o[19 * i + 18] = f[i].angle;
+                }
+            }
+            return (long)nf * 19;
+        }
+        case CTAG_DBG_PREMARKERS: {
+            if (!h->keep_pre) return -1;
+            if (dst && cap >= 1) {
+                if (!d2h(dst, W.premarkers + frame, sizeof(ctag_frame_result))) return -2;
+            }
+            return 1;
+        }
+        default: return -1;
+    }
+}
+
+int ctag_math_probe(ctag_handle* h, int op, int n, const double* a, const double* b, double* out) {
+    if (!h || n < 0 || !a || !out) return CTAG_ERR_ARG;
+    if (n == 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&da), (size_t)n * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&db), (size_t)n * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dout), (size_t)n * 8));
+    HIP_TRY(hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (b) {
+        HIP_TRY(hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMemset(db, 0, (size_t)n * 8));
+    }
+    hipLaunchKernelGGL(k_math_probe, dim3((n + 255) / 256), dim3(256), 0, h->stream, op, n, da, db, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    return CTAG_OK;
+}
+
+int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride,
+                             ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame) {
+    if (!h || !frames_dev || n < 0 || rows < 1 || cols < 1 || row_stride < cols) return CTAG_ERR_ARG;
+    if (n == 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int step = 512;
+    if (h->d_synth_count < (size_t)step) {
+        if (h->d_synth) HIP_TRY(hipFree(h->d_synth));
+        h->d_synth = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_synth), sizeof(ctag_synth::Frame) * step));
+        h->d_synth_count = step;
+    }
+    std::vector<ctag_synth::Frame> lay(step);
+    for (int f0 = 0; f0 < n; f0 += step) {
+        const int m = std::min(step, n - f0);
+        for (int i = 0; i < m; i++)
+            ctag_synth::layout(h->dict.data(), h->dict_rows, h->dict_cols, seed, first_frame + f0 + i, rows, cols, markers_per_frame, &lay[i], nullptr);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(h->d_synth, lay.data(), sizeof(ctag_synth::Frame) * m, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_synth, dim3((cols + 255) / 256, rows, m), dim3(256), 0, h->stream, h->d_synth, frames_dev + (ptrdiff_t)f0 * frame_stride, rows,
+                           cols, row_stride, frame_stride);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CTAG_OK;
+}
+
+int ctag_synth_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows, int cols, ptrdiff_t row_stride,
+                          uint64_t seed, int markers_per_frame, ctag_synth_truth* truth) {
+    if (!state || !frame || rows < 1 || cols < 1 || row_stride < cols || dict_rows < 1 || dict_cols < 1) return CTAG_ERR_ARG;
+    ctag_synth::Frame F;
+    ctag_synth::Truth T;
+    ctag_synth::layout(state, dict_rows, dict_cols, seed, frame_index, rows, cols, markers_per_frame, &F, &T);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) frame[(ptrdiff_t)y * row_stride + x] = ctag_synth::pixel(F, x, y, rows, cols);
+    if (truth) {
+        std::memset(truth, 0, sizeof(*truth));
+        truth->n_markers = T.n;
+        for (int k = 0; k < T.n && k < 8; k++) {
+            truth->dict_row[k] = T.dict_row[k];
+            truth->strip_len[k] = T.strip_len[k];
+            for (int q = 0; q < 8; q++) truth->corners[k][q] = T.corners[k][q];
+        }
+    }
+    return CTAG_OK;
+}
+
+}  // extern "C"

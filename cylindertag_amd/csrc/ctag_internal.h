@@ -1,0 +1,128 @@
+// ctag_internal.h -- device workspace layout and kernel launch prototypes (not part of the public ABI).
+//
+// Pipeline per chunk of frames (all on one HIP stream; see DESIGN.md for the data-flow picture):
+//   K1 k_decimate          full-res u8 -> half-res u8 (bicubic 2x)              CylinderTag.cpp:79-80
+//   K2 k_threshold_ccl     half-res u8 -> per-tile u16 labels + component pool  corner_detector.cpp:28-97
+//   K3 k_seam_merge        union components across tile seams (global UF)        (part of :82)
+//   K4 k_resolve           flatten roots, fold tile-local stats into roots       (part of :82, :87-91)
+//   K5 k_candidates        area filter + OpenCV label order -> candidate list    corner_detector.cpp:87-106
+//   K6 k_quad              per candidate: boundary -> 4 lines -> quad            corner_detector.cpp:171-463
+//   K7 k_features          per frame: quad pairing, cornerObtain                 corner_detector.cpp:465-598
+//   K8 k_edge_refine       per (feature, quad): sub-pixel edge refinement        corner_detector.cpp:600-951
+//   K9 k_markers           per frame: grouping, cross ratios, dictionary decode  corner_detector.cpp:976-1324
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ctag_types.h"
+
+namespace ctag {
+
+// ---- CCL tile geometry (half-resolution pixels) ---------------------------------------------------------
+constexpr int kTileW = 320;             // 5 x 64-bit mask words per tile row
+constexpr int kTileH = 30;
+constexpr int kTileWords = kTileW / 64;
+constexpr int kRunCap = 2048;           // max row-runs per tile handled in LDS
+constexpr int kSlotCap = 640;           // max tile-local components per tile
+constexpr int kPoolCap = 8192;          // max tile-local components per frame (global pool)
+constexpr int kCandCap = 2048;          // max area-filtered candidates per frame
+constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range [1, 32]
+
+// ---- K6 limits ----------------------------------------------------------------------------------------------
+constexpr int kQuadLdsPoints = 1024;    // boundary points held in LDS; larger components use global scratch
+constexpr int kQuadScratchSlots = 64;   // global scratch slots per chunk for oversize components
+constexpr int kQuadScratchPoints = 8192;  // >= 2*(1920+1080)+4: worst-case silhouette of a 4K frame at half-res
+constexpr int kMaxDictCells = 2048;       // dictionary rows*cols supported by K9 (reference dictionary: 41*12)
+
+struct Candidate {  // one area-filtered connected component, in OpenCV label order
+    int32_t root;   // pool index of the root component (frame-local)
+    int32_t area;
+    int16_t x_min, y_min, x_max, y_max;
+};
+
+struct QuadOut {    // K6 output per candidate
+    int32_t valid;
+    int32_t n_boundary;
+    float c[8];     // 4 corners x,y (half-res coordinates), sorted as the reference leaves them
+};
+
+struct FeatureDev { // K7/K8 output per feature (reference struct featureInfo)
+    float c[16];
+    float center[2];
+    float angle;
+    int32_t pad;
+};
+
+struct FrameGeom {
+    int rows, cols;            // full-res
+    int hrows, hcols;          // half-res
+    int hp;                    // half-res pitch (bytes)
+    int lp;                    // label pitch (elements)
+    int tw;                    // adaptiveThresh window
+    int trows, tcols;          // threshold tile grid
+    int tiles_x, tiles_y;      // CCL tile grid
+    int max_area;              // round(0.01*hcols*hrows)
+};
+
+// Per-chunk device workspace (structure of arrays; one allocation, carved by Workspace::layout()).
+struct Workspace {
+    int chunk_frames = 0;
+    FrameGeom g{};
+    uint8_t* half = nullptr;        // [F][hrows][hp]
+    uint16_t* labels = nullptr;     // [F][hrows][lp]   tile-local label (0 = background)
+    int32_t* tile_base = nullptr;   // [F][tiles]       pool offset of each tile's local components
+    int32_t* frame_ncomp = nullptr; // [F]              pool fill
+    uint32_t* frame_flags = nullptr;// [F]
+    // component pool, [F][kPoolCap] each
+    uint32_t* parent = nullptr;
+    int32_t* root_of = nullptr;
+    int32_t* area = nullptr;
+    int32_t* xmin = nullptr;
+    int32_t* ymin = nullptr;
+    int32_t* xmax = nullptr;
+    int32_t* ymax = nullptr;
+    int32_t* key = nullptr;
+    // candidates
+    int32_t* ncand = nullptr;       // [F]
+    Candidate* cand = nullptr;      // [F][kCandCap]
+    QuadOut* quads = nullptr;       // [F][kCandCap]
+    uint32_t* quad_scratch = nullptr;   // [kQuadScratchSlots][...]
+    int32_t* quad_scratch_used = nullptr;
+    // features
+    void* quad_derived = nullptr;   // [F][kCandCap] x 32 B (K7 scratch)
+    int32_t* quad_index = nullptr;  // [F][kCandCap]
+    int32_t* nquads = nullptr;      // [F]
+    int32_t* nfeat = nullptr;       // [F]
+    int32_t* status = nullptr;      // [F]
+    FeatureDev* feat0 = nullptr;    // [F][CTAG_MAX_FEATURES] after featureRecovery (half-res)
+    FeatureDev* feat1 = nullptr;    // after cornerObtain
+    FeatureDev* feat2 = nullptr;    // after edgeRefine
+    ctag_frame_result* premarkers = nullptr;  // [F] (debug: before decode)
+    void* base = nullptr;
+    size_t bytes = 0;
+};
+
+struct DetectParams {
+    int adaptive_thresh;
+    int corner_subpix;
+    int subpix_dist;
+    int feature_size;
+    int dict_rows, dict_cols;
+    const int32_t* dict;  // device pointer
+};
+
+// kernel launchers (each enqueues on `s`, returns hipGetLastError())
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s);
+hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s);
+hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s);
+hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s);
+hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s);
+hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s);
+hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
+hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
+hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s);
+hipError_t launch_math_probe(int op, int n, const double* a, const double* b, double* out, hipStream_t s);
+size_t threshold_ccl_lds_bytes(int tw);
+
+}  // namespace ctag

@@ -1,0 +1,789 @@
+// k_feature.hip -- K7 quad pairing (featureRecovery / featureOrganization / cornerObtain),
+// K8 sub-pixel edge refinement (edgeRefine), K9 marker grouping, cross-ratio IDs and dictionary decode
+// (markerOrganization / featureExtraction / markerDecoder / match_dictionary).
+//   /root/reference/corner_detector.cpp:465-598, :600-951, :976-1324; call order CylinderTag.cpp:92-128.
+// Same arithmetic, types and evaluation order as the reference so the discrete decisions
+// match the oracle bit for bit; the parallel structure is this implementation's own:
+//   K7  one workgroup per frame; for each unvisited quad i the match test runs on all j > i at once and
+//       the smallest matching j wins (== the reference's first match in its sequential j loop).
+//   K8  one workgroup per (feature, quad); one lane per edge sample, the 41-step normal search is the
+//       lane's inner loop; the weighted moment sums are then accumulated in sample order by 12 lanes
+//       (6 sums x {next,last} weighting) so the doubles equal the reference's sequential sums.
+//   K9  one wave per frame; dictionary matching evaluates all (row, column, direction) hypotheses on lanes
+//       and replays the reference's order-dependent max / second-max bookkeeping afterwards.
+#include "ctag_internal.h"
+#include "ctag_math.h"
+
+namespace ctag {
+
+constexpr double kPi = 3.1415926535897932384626433832795;
+
+struct P2 {
+    float x, y;
+};
+__device__ __forceinline__ float dist2p(P2 a, P2 b) { return ctm::sqrt32((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
+// atan2(float,float)*180/CV_PI as the reference writes it: float atan2, float*int, then a double division
+__device__ __forceinline__ double angdeg(float dy, float dx) { return ctm::atan2_32(dy, dx) * 180 / kPi; }
+__device__ __forceinline__ bool solve2x2f(float a00, float a01, float a10, float a11, float b0, float b1, float& x0, float& x1) {
+    double d = (double)a00 * a11 - (double)a01 * a10;
+    if (d == 0.) return false;
+    d = 1. / d;
+    const float t = (float)(((double)b0 * a11 - (double)b1 * a01) * d);
+    x1 = (float)(((double)b1 * a00 - (double)b0 * a10) * d);
+    x0 = t;
+    return true;
+}
+
+// =====================================================================================================
+// K7
+// =====================================================================================================
+struct QuadDerived {  // per accepted quad: centre, side lengths, the two mean side directions (:473-481)
+    float cx, cy, d[4], a1, a2;
+};
+struct FeatPtrs {
+    const int32_t* ncand;
+    const QuadOut* quads;
+    QuadDerived* derived;  // [F][kCandCap]
+    int32_t* quad_index;   // [F][kCandCap] accepted-quad -> candidate index
+    int32_t* nquads;
+    int32_t* nfeat;
+    int32_t* status;
+    uint32_t* frame_flags;
+    FeatureDev* feat0;
+    FeatureDev* feat1;
+    FeatureDev* feat2;
+};
+
+__device__ __forceinline__ bool near_ang(float a, float b, float thr) {
+    return ctm::fabs32(a - b) < thr || ctm::fabs32(ctm::fabs32(a - b) - 180) < thr || ctm::fabs32(ctm::fabs32(a - b) - 360) < thr;
+}
+
+// featureOrganization (:571-598)
+__device__ void feature_organization(const float* q1, const float* q2, float c1x, float c1y, float c2x, float c2y, float feature_angle, FeatureDev* F) {
+    float angle_max = 0, angle_min = 360;
+    int pos1 = -1, pos2 = -1;
+    float a1[4], a2[4];
+    for (int i = 0; i < 4; i++) {
+        a1[i] = (float)angdeg(c1y - q1[2 * i + 1], c1x - q1[2 * i]);
+        a2[i] = (float)angdeg(c2y - q2[2 * i + 1], c2x - q2[2 * i]);
+    }
+    auto fold = [&](float a) { return fminf(360 - ctm::fabs32(a - feature_angle), ctm::fabs32(a - feature_angle)); };
+    for (int i = 0; i < 4; i++) {
+        const float v1 = fold(a1[(i + 2) % 4]) + fold(a1[(i + 3) % 4]);
+        if (v1 < angle_min) {
+            angle_min = v1;
+            pos1 = i;
+        }
+        const float v2 = fold(a2[(i + 2) % 4]) + fold(a2[(i + 3) % 4]);
+        if (v2 > angle_max) {
+            angle_max = v2;
+            pos2 = i;
+        }
+    }
+    if (pos1 < 0) pos1 = 0;
+    if (pos2 < 0) pos2 = 0;
+    for (int i = 0; i < 4; i++) {
+        F->c[2 * i] = q1[2 * ((i + pos1) % 4)];
+        F->c[2 * i + 1] = q1[2 * ((i + pos1) % 4) + 1];
+        F->c[8 + 2 * i] = q2[2 * ((i + pos2) % 4)];
+        F->c[8 + 2 * i + 1] = q2[2 * ((i + pos2) % 4) + 1];
+    }
+    F->center[0] = (F->c[0] + F->c[2] + F->c[8] + F->c[10]) / 4;
+    F->center[1] = (F->c[1] + F->c[3] + F->c[9] + F->c[11]) / 4;
+    F->angle = feature_angle;
+    F->pad = 0;
+}
+
+__global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int feature_size) {
+    __shared__ unsigned char s_vis[CTAG_MAX_QUADS];
+    __shared__ int s_scan[4];
+    __shared__ int s_best;
+    __shared__ int s_nf;
+    const int frame = blockIdx.x;
+    if (frame >= nframes) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = P.ncand[frame];
+    const QuadOut* quads = P.quads + (size_t)frame * kCandCap;
+    QuadDerived* der = P.derived + (size_t)frame * kCandCap;
+    int32_t* qidx = P.quad_index + (size_t)frame * kCandCap;
+    FeatureDev* f0 = P.feat0 + (size_t)frame * CTAG_MAX_FEATURES;
+    FeatureDev* f1 = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES;
+    FeatureDev* f2 = P.feat2 + (size_t)frame * CTAG_MAX_FEATURES;
+
+    // compact accepted quads in candidate (= OpenCV label) order
+    int Q = 0;
+    for (int base = 0; base < nc; base += 128) {
+        const int i = base + tid;
+        const int v = (i < nc && quads[i].valid) ? 1 : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        const int pre = (wave == 1 ? s_scan[0] : 0) + inc - v;
+        if (v) qidx[Q + pre] = i;
+        Q += s_scan[0] + s_scan[1];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        P.nquads[frame] = Q;
+        s_nf = 0;
+    }
+    if (Q == 0) {
+        if (tid == 0) {
+            P.nfeat[frame] = 0;
+            P.status[frame] = (P.frame_flags[frame] & CTAG_FLAG_POOL_OVERFLOW) ? CTAG_ERR_LIMIT : CTAG_NO_CORNER;
+        }
+        return;
+    }
+    if (Q > CTAG_MAX_QUADS) {
+        if (tid == 0) {
+            atomicOr(&P.frame_flags[frame], CTAG_FLAG_QUAD_OVERFLOW);
+            P.nfeat[frame] = 0;
+            P.status[frame] = CTAG_ERR_LIMIT;
+        }
+        return;
+    }
+    __syncthreads();  // qidx visible to the block (global memory, same workgroup)
+    for (int q = tid; q < Q; q += 128) {
+        const float* c = quads[qidx[q]].c;
+        QuadDerived D;
+        D.cx = (c[0] + c[2] + c[4] + c[6]) / 4;
+        D.cy = (c[1] + c[3] + c[5] + c[7]) / 4;
+        for (int j = 0; j < 4; j++) {
+            const int k = (j + 1) % 4;
+            D.d[j] = ctm::sqrt32((c[2 * j] - c[2 * k]) * (c[2 * j] - c[2 * k]) + (c[2 * j + 1] - c[2 * k + 1]) * (c[2 * j + 1] - c[2 * k + 1]));
+        }
+        D.a1 = (float)((angdeg(c[1] - c[3], c[0] - c[2]) + angdeg(c[7] - c[5], c[6] - c[4])) / 2);
+        D.a2 = (float)((angdeg(c[3] - c[5], c[2] - c[4]) + angdeg(c[1] - c[7], c[0] - c[6])) / 2);
+        der[q] = D;
+        s_vis[q] = 0;
+    }
+    __syncthreads();
+    const float thr = 5;  // threshold_angle
+    for (int i = 0; i + 1 < Q; i++) {
+        if (s_vis[i]) continue;  // uniform
+        if (tid == 0) s_best = 0x7fffffff;
+        __syncthreads();
+        const QuadDerived Di = der[i];
+        const float* ci = quads[qidx[i]].c;
+        int mine = 0x7fffffff;
+        for (int j = i + 1 + tid; j < Q && mine == 0x7fffffff; j += 128) {
+            if (s_vis[j]) continue;
+            const QuadDerived Dj = der[j];
+            const float* cj = quads[qidx[j]].c;
+            bool tag1 = false, tag2 = false;
+            float d1s = 0, d1l = 0, d2s = 0, d2l = 0, ea1 = 0, ea2 = 0;
+            const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
+            if (near_ang(fa, Di.a1, thr)) {
+                tag1 = true;
+                d1l = (Di.d[0] + Di.d[2]) / 2;
+                d1s = fminf(Di.d[1], Di.d[3]);
+                if (Di.d[1] < Di.d[3]) ea1 = (float)angdeg(ci[1] - ci[7], ci[0] - ci[6]);
+                else ea1 = (float)angdeg(ci[3] - ci[5], ci[2] - ci[4]);
+            }
+            if (near_ang(fa, Di.a2, thr)) {
+                tag1 = true;
+                d1s = fminf(Di.d[0], Di.d[2]);
+                d1l = (Di.d[1] + Di.d[3]) / 2;
+                if (Di.d[0] > Di.d[2]) ea1 = (float)angdeg(ci[1] - ci[3], ci[0] - ci[2]);
+                else ea1 = (float)angdeg(ci[5] - ci[7], ci[4] - ci[6]);
+            }
+            if (near_ang(fa, Dj.a1, thr)) {
+                tag2 = true;
+                d2l = (Dj.d[0] + Dj.d[2]) / 2;
+                d2s = fminf(Dj.d[1], Dj.d[3]);
+                if (Dj.d[1] < Dj.d[3]) ea2 = (float)angdeg(cj[1] - cj[7], cj[0] - cj[6]);
+                else ea2 = (float)angdeg(cj[3] - cj[5], cj[2] - cj[4]);
+            }
+            if (near_ang(fa, Dj.a2, thr)) {
+                tag2 = true;
+                d2s = fminf(Dj.d[0], Dj.d[2]);
+                d2l = (Dj.d[1] + Dj.d[3]) / 2;
+                if (Dj.d[0] > Dj.d[2]) ea2 = (float)angdeg(cj[1] - cj[3], cj[0] - cj[2]);
+                else ea2 = (float)angdeg(cj[5] - cj[7], cj[4] - cj[6]);
+            }
+            const float fl = dist2p(P2{Di.cx, Di.cy}, P2{Dj.cx, Dj.cy});
+            if ((tag1 && tag2) && (d1l > d1s || d2l > d2s) && near_ang(ea1, ea2, thr * 10) &&
+                (ctm::fabs32(d1s - d2s) < fminf(d1s, d2s) * 0.33) && ((d1l + d2l) > (d1s + d2s)) &&
+                ((d1l + d2l) < 15 * (d1s + d2s)) && (fl - (d1l + d2l) / 2 < 0.3 * (fl + (d1l + d2l) / 2))) {
+                mine = j;
+            }
+        }
+        if (mine != 0x7fffffff) atomicMin(&s_best, mine);
+        __syncthreads();
+        const int j = s_best;
+        __syncthreads();
+        if (j != 0x7fffffff) {
+            if (tid == 0) {
+                s_vis[i] = 1;
+                s_vis[j] = 1;
+                const int nf = s_nf;
+                if (nf < CTAG_MAX_FEATURES) {
+                    const QuadDerived Dj = der[j];
+                    const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
+                    feature_organization(ci, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[nf]);
+                }
+                s_nf = nf + 1;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const int nf = s_nf;
+    int status = CTAG_OK;
+    if (nf < feature_size) status = CTAG_NO_FEATURE;
+    else if (nf > CTAG_MAX_FEATURES) status = CTAG_ERR_LIMIT;
+    if (tid == 0) {
+        P.nfeat[frame] = min(nf, CTAG_MAX_FEATURES);
+        P.status[frame] = status;
+        if (nf > CTAG_MAX_FEATURES) atomicOr(&P.frame_flags[frame], CTAG_FLAG_FEATURE_OVERFLOW);
+    }
+    // cornerObtain (:561-569): half-res -> full-res coordinates
+    for (int k = tid; k < min(nf, CTAG_MAX_FEATURES); k += 128) {
+        FeatureDev F = f0[k];
+        for (int q = 0; q < 16; q++) F.c[q] = (F.c[q] - 0.5f) * 2 + 0.5f;
+        F.center[0] = (F.c[0] + F.c[2] + F.c[8] + F.c[10]) / 4;
+        F.center[1] = (F.c[1] + F.c[3] + F.c[9] + F.c[11]) / 4;
+        f1[k] = F;
+        f2[k] = F;
+    }
+}
+
+// =====================================================================================================
+// K8
+// =====================================================================================================
+struct RefinePtrs {
+    const uint8_t* frames;
+    ptrdiff_t frame_stride, row_stride;
+    const int32_t* nfeat;
+    const int32_t* status;
+    const FeatureDev* feat1;
+    FeatureDev* feat2;
+};
+constexpr int kRefineThreads = 128;
+
+__global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
+    __shared__ double s_bx[kRefineThreads], s_by[kRefineThreads], s_al[kRefineThreads];
+    __shared__ unsigned char s_ok[kRefineThreads];
+    __shared__ double s_acc[12];
+    __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    if (P.status[frame] != CTAG_OK) return;
+    const int fi = blockIdx.x >> 1, quad = blockIdx.x & 1;
+    if (fi >= P.nfeat[frame]) return;
+    const int tid = threadIdx.x;
+    const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi;
+    const uint8_t* __restrict__ img = P.frames + (ptrdiff_t)frame * P.frame_stride;
+    const float k255 = (float)(1.0 / 255);
+    const int off = quad * 4;
+    float cx[4], cy[4];
+    for (int i = 0; i < 4; i++) {
+        cx[i] = F->c[2 * (off + i)];
+        cy[i] = F->c[2 * (off + i) + 1];
+    }
+    for (int edge = 0; edge < 4; edge++) {
+        const int a = edge, b = (edge + 1) & 3;
+        double nx = cy[b] - cy[a];
+        double ny = -cx[b] + cx[a];
+        const double mag = ctm::sqrt64(nx * nx + ny * ny);
+        nx /= mag;
+        ny /= mag;
+        const double ns_d = mag / 8 > 128.0 ? mag / 8 : 128.0;
+        const int nsamples = (int)ns_d;
+        if (tid < 12) s_acc[tid] = 0.0;
+        __syncthreads();
+        for (int sbase = 0; sbase < nsamples; sbase += kRefineThreads) {
+            const int s = sbase + tid;
+            bool ok = false;
+            double bestx = 0, besty = 0, alpha = 0;
+            if (s < nsamples) {
+                alpha = (15.0 + s) / (nsamples + 30);
+                const double x0 = alpha * cx[a] + (1 - alpha) * cx[b];
+                const double y0 = alpha * cy[a] + (1 - alpha) * cy[b];
+                double Mn = 0, Mcount = 0;
+                const double range = subpix;
+                for (double n = -range; n <= range; n += 0.25) {
+                    const double grange = 1;
+                    const int x1 = (int)(x0 + (n + grange) * nx);
+                    const int y1 = (int)(y0 + (n + grange) * ny);
+                    if (x1 < 0 || x1 >= cols || y1 < 0 || y1 >= rows) continue;
+                    const int x2 = (int)(x0 + (n - grange) * nx);
+                    const int y2 = (int)(y0 + (n - grange) * ny);
+                    if (x2 < 0 || x2 >= cols || y2 < 0 || y2 >= rows) continue;
+                    const float g1 = (float)img[(ptrdiff_t)y1 * P.row_stride + x1] * k255;
+                    const float g2 = (float)img[(ptrdiff_t)y2 * P.row_stride + x2] * k255;
+                    if (g1 < g2) continue;
+                    const double weight = (g2 - g1) * (g2 - g1);
+                    Mn += weight * n;
+                    Mcount += weight;
+                }
+                if (Mcount != 0) {
+                    const double n0 = Mn / Mcount;
+                    bestx = x0 + n0 * nx;
+                    besty = y0 + n0 * ny;
+                    ok = true;
+                }
+            }
+            s_bx[tid] = bestx;
+            s_by[tid] = besty;
+            s_al[tid] = alpha;
+            s_ok[tid] = ok ? 1 : 0;
+            __syncthreads();
+            if (tid < 12) {  // sequential (sample-order) accumulation of one of the 12 running sums
+                const int pass = tid / 6, which = tid - pass * 6;
+                double acc = s_acc[tid];
+                const int cntS = min(kRefineThreads, nsamples - sbase);
+                for (int k = 0; k < cntS; k++) {
+                    if (!s_ok[k]) continue;
+                    const double wgt = pass == 0 ? (1 - s_al[k]) : s_al[k];
+                    const double bxk = s_bx[k], byk = s_by[k];
+                    double term;
+                    switch (which) {
+                        case 0: term = bxk * wgt; break;
+                        case 1: term = byk * wgt; break;
+                        case 2: term = bxk * bxk * wgt; break;
+                        case 3: term = bxk * byk * wgt; break;
+                        case 4: term = byk * byk * wgt; break;
+                        default: term = wgt; break;
+                    }
+                    acc += term;
+                }
+                s_acc[tid] = acc;
+            }
+            __syncthreads();
+        }
+        if (tid < 2) {
+            const double* A = s_acc + tid * 6;
+            const double Mx = A[0], My = A[1], Mxx = A[2], Mxy = A[3], Myy = A[4], N = A[5];
+            const double Ex = Mx / N, Ey = My / N;
+            const double Cxx = Mxx / N - Ex * Ex;
+            const double Cxy = Mxy / N - Ex * Ey;
+            const double Cyy = Myy / N - Ey * Ey;
+            const double normal_theta = .5 * ctm::atan2_32((float)(-2 * Cxy), (float)(Cyy - Cxx));
+            s_lines[tid][edge][0] = Ex;
+            s_lines[tid][edge][1] = Ey;
+            s_lines[tid][edge][2] = ctm::cos32((float)normal_theta);
+            s_lines[tid][edge][3] = ctm::sin32((float)normal_theta);
+        }
+        __syncthreads();
+    }
+    if (tid < 4) {  // :757-776 one refined corner per lane
+        const int it = tid;
+        const double* Ln = s_lines[0][it];
+        const double* Ll = s_lines[1][(it + 1) & 3];
+        const double A00 = Ln[3], A01 = -Ll[3];
+        const double A10 = -Ln[2], A11 = Ll[2];
+        const double B0 = -Ln[0] + Ll[0];
+        const double B1 = -Ln[1] + Ll[1];
+        const double det = A00 * A11 - A10 * A01;
+        const double W00 = A11 / det, W01 = -A01 / det;
+        const double L0 = W00 * B0 + W01 * B1;
+        const int idx = ((it + 1) & 3) + off;
+        FeatureDev* O = P.feat2 + (size_t)frame * CTAG_MAX_FEATURES + fi;
+        if (ctm::fabs64(det) > 0.001) {
+            O->c[2 * idx] = (float)(Ln[0] + L0 * A00);
+            O->c[2 * idx + 1] = (float)(Ln[1] + L0 * A10);
+        } else {
+            O->c[2 * idx] = F->c[2 * idx];
+            O->c[2 * idx + 1] = F->c[2 * idx + 1];
+        }
+    }
+}
+
+// =====================================================================================================
+// K9
+// =====================================================================================================
+struct MarkerPtrs {
+    const int32_t* nfeat;
+    const int32_t* status;
+    const uint32_t* frame_flags;
+    const FeatureDev* feat;
+    const int32_t* dict;
+    ctag_frame_result* pre;  // optional (debug)
+    ctag_frame_result* out;
+};
+
+// featureExtraction for one feature (:1056-1207); C = 8 corners (x,y), swapped in place when direction == 0
+__device__ void feature_ids(float* C, int direction, int& ID_left, int& ID_right, float& crl, float& crr, int& id, int& idl, int& idr) {
+    const float IDc[4] = {1.47f, 1.54f, 1.61f, 1.68f};
+    const float covL[4] = {0.1f, 0.035f, 0.035f, 0.035f};
+    const float covR[4] = {0.035f, 0.035f, 0.035f, 0.1f};
+    auto Pt = [&](int k) { return P2{C[2 * k], C[2 * k + 1]}; };
+    if (!direction) {
+        if (C[0] > C[8]) {
+            for (int k = 0; k < 8; k++) {
+                const float t = C[k];
+                C[k] = C[8 + k];
+                C[8 + k] = t;
+            }
+        }
+    }
+    float l1[4], l2[4];
+    l1[0] = dist2p(Pt(0), Pt(3));
+    l1[1] = dist2p(Pt(3), Pt(6));
+    l1[2] = dist2p(Pt(6), Pt(5));
+    l1[3] = dist2p(Pt(0), Pt(5));
+    l2[0] = dist2p(Pt(1), Pt(2));
+    l2[1] = dist2p(Pt(2), Pt(7));
+    l2[2] = dist2p(Pt(7), Pt(4));
+    l2[3] = dist2p(Pt(1), Pt(4));
+    crl = (l1[0] + l1[1]) * (l1[2] + l1[1]) / ((l1[1] * l1[3]));
+    crr = (l2[0] + l2[1]) * (l2[2] + l2[1]) / ((l2[1] * l2[3]));
+    struct P3 {
+        float x, y, z;
+    };
+    auto mkline = [](P2 p, P2 q, P2 on) {
+        P3 l;
+        l.x = p.y - q.y;
+        l.y = q.x - p.x;
+        l.z = -l.x * on.x - l.y * on.y;
+        return l;
+    };
+    const P3 line1 = mkline(Pt(5), Pt(4), Pt(5));
+    const P3 line2 = mkline(Pt(0), Pt(1), Pt(0));
+    const P3 lc1 = mkline(Pt(0), Pt(4), Pt(0));
+    const P3 lc2 = mkline(Pt(5), Pt(1), Pt(5));
+    const P3 ll = mkline(Pt(5), Pt(0), Pt(5));
+    const P3 lr = mkline(Pt(1), Pt(4), Pt(1));
+    P2 vanish{0, 0}, middle{0, 0}, mleft{0, 0}, mright{0, 0};
+    solve2x2f(line1.x, line1.y, line2.x, line2.y, -line1.z, -line2.z, vanish.x, vanish.y);
+    solve2x2f(lc1.x, lc1.y, lc2.x, lc2.y, -lc1.z, -lc2.z, middle.x, middle.y);
+    P3 ml;
+    ml.x = middle.y - vanish.y;
+    ml.y = vanish.x - middle.x;
+    ml.z = -ml.x * middle.x - ml.y * middle.y;
+    solve2x2f(ml.x, ml.y, ll.x, ll.y, -ml.z, -ll.z, mleft.x, mleft.y);
+    solve2x2f(ml.x, ml.y, lr.x, lr.y, -ml.z, -lr.z, mright.x, mright.y);
+    float d1, d2, d3, d4;
+    bool is_long = false;
+    d1 = dist2p(mleft, Pt(0));
+    d2 = dist2p(mleft, Pt(3));
+    d3 = dist2p(mleft, Pt(5));
+    d4 = dist2p(mleft, Pt(6));
+    if (d2 * d3 < d1 * d4) is_long = true;
+    for (int j = 0; j < 4; j++) {
+        if ((IDc[j] >= crl) && (IDc[j] - crl < covL[j])) ID_left = is_long ? 7 - j : j;
+        if ((IDc[j] < crl) && (crl - IDc[j] < covR[j])) ID_left = is_long ? 7 - j : j;
+    }
+    is_long = false;
+    d1 = dist2p(mleft, Pt(1));  // measured from middle_left again
+    d2 = dist2p(mleft, Pt(2));
+    d3 = dist2p(mleft, Pt(4));
+    d4 = dist2p(mleft, Pt(7));
+    if (d2 * d3 < d1 * d4) is_long = true;
+    for (int j = 0; j < 4; j++) {
+        if ((IDc[j] >= crr) && (IDc[j] - crr < covL[j])) ID_right = is_long ? 7 - j : j;
+        if ((IDc[j] < crr) && (crr - IDc[j] < covR[j])) ID_right = is_long ? 7 - j : j;
+    }
+    if (ctm::fabs32(l1[1] - l2[1]) > 0.05 * (l1[1] + l2[1])) {
+        idl = -1;
+        idr = -1;
+        id = -2;
+    } else {
+        idl = ID_left;
+        idr = ID_right;
+        id = ID_left * 8 + ID_right;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int feature_size, int drows, int dcols) {
+    __shared__ FeatureDev s_feat[CTAG_MAX_FEATURES];
+    __shared__ int s_father[CTAG_MAX_FEATURES];
+    __shared__ int s_group[CTAG_MAX_FEATURES];   // marker index of each feature
+    __shared__ int s_order[CTAG_MAX_FEATURES];   // features grouped by marker, in marker order, sorted
+    __shared__ int s_mfirst[CTAG_MAX_FEATURES + 1];
+    __shared__ ctag_feature_rec s_rec[CTAG_MAX_FEATURES];
+    __shared__ short s_cov[2 * kMaxDictCells];   // coverage per (dir, row, col)
+    __shared__ int s_code[CTAG_MAX_CODE_POS];
+    __shared__ int s_misc[8];
+    const int frame = blockIdx.x;
+    if (frame >= nframes) return;
+    const int tid = threadIdx.x;
+    ctag_frame_result* out = P.out + frame;
+    const int status = P.status[frame];
+    const uint32_t flags = P.frame_flags[frame];
+    const int nf = P.nfeat[frame];
+    if (status != CTAG_OK || nf == 0) {
+        if (tid == 0) {
+            out->status = status;
+            out->n_markers = 0;
+            out->n_features = 0;
+            out->flags = flags;
+            if (P.pre) {
+                P.pre[frame].status = status;
+                P.pre[frame].n_markers = 0;
+                P.pre[frame].n_features = 0;
+                P.pre[frame].flags = flags;
+            }
+        }
+        return;
+    }
+    for (int i = tid; i < nf; i += 64) s_feat[i] = P.feat[(size_t)frame * CTAG_MAX_FEATURES + i];
+    __syncthreads();
+    // ---- markerOrganization (:976-1052): thread 0 (F <= 100)
+    if (tid == 0) {
+        auto uf = [&](int x) {
+            int r = x;
+            while (s_father[r] != r) r = s_father[r];
+            while (s_father[x] != r) {  // path compression as the recursive union_find does
+                const int nx = s_father[x];
+                s_father[x] = r;
+                x = nx;
+            }
+            return r;
+        };
+        for (int i = 0; i < nf; i++) s_father[i] = i;
+        const float threshold_angle = 5, threshold_vertical = 0.5f;
+        for (int i = 0; i < nf - 1; i++) {
+            const FeatureDev& A = s_feat[i];
+            for (int j = i + 1; j < nf; j++) {
+                const FeatureDev& B = s_feat[j];
+                const float vcx = A.center[0] - B.center[0], vcy = A.center[1] - B.center[1];
+                const float vlx = A.c[0] - A.c[10], vly = A.c[1] - A.c[11];
+                const float center_angle = (vcx * vlx + vcy * vly) / ctm::sqrt32((vcx * vcx + vcy * vcy) * (vlx * vlx + vly * vly));
+                if ((ctm::fabs32(A.angle - B.angle) < threshold_angle * 2 || ctm::fabs32(180 - ctm::fabs32(A.angle - B.angle)) < threshold_angle) &&
+                    (dist2p(P2{A.center[0], A.center[1]}, P2{B.center[0], B.center[1]}) < 0.3 * dist2p(P2{A.c[0], A.c[1]}, P2{A.c[10], A.c[11]})) &&
+                    (ctm::fabs32(center_angle) < threshold_vertical)) {
+                    const int fi = uf(i), fj = uf(j);
+                    if (fi != fj) s_father[fj] = fi;
+                }
+            }
+        }
+        // groups in first-seen order (:993-1019).  father[0] is captured BEFORE the flattening loop, exactly as
+        // the reference pushes it (it may be a stale non-root: literal quirk).
+        int* db = s_mfirst;  // temporarily: father_database
+        int cnt = 0;
+        db[cnt] = s_father[0];
+        s_group[0] = cnt++;
+        for (int i = 1; i < nf; i++) s_father[i] = uf(s_father[i]);
+        for (int i = 1; i < nf; i++) {
+            int found = -1;
+            for (int j = 0; j < cnt; j++)
+                if (s_father[i] == db[j]) {
+                    found = j;
+                    break;
+                }
+            if (found < 0) {
+                db[cnt] = s_father[i];
+                found = cnt++;
+            }
+            s_group[i] = found;
+        }
+        s_misc[0] = cnt;
+        // features of each marker in ascending feature index (the order marker_ID[j] is filled)
+        int pos = 0;
+        for (int m = 0; m < cnt; m++) {
+            s_father[m] = pos;  // s_father is free now: first slot of marker m in s_order
+            for (int i = 0; i < nf; i++)
+                if (s_group[i] == m) s_order[pos++] = i;
+        }
+        s_father[cnt] = pos;
+    }
+    __syncthreads();
+    const int cnt = s_misc[0];
+    if (tid == 0) {
+        for (int m = 0; m <= cnt; m++) s_mfirst[m] = s_father[m];
+    }
+    __syncthreads();
+    // ---- per marker: edge lengths, orientation, sort, featureExtraction; thread 0 keeps ID_left/ID_right state
+    if (tid == 0) {
+        int ID_left = 0, ID_right = 0;  // reset per detect()
+        for (int m = 0; m < cnt; m++) {
+            const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
+            float marker_angle = 0;
+            for (int k = a; k < b; k++) {
+                const FeatureDev& F = s_feat[s_order[k]];
+                double angle_now = ctm::fast_atan2_deg(F.c[1] - F.c[11], F.c[0] - F.c[10]);
+                if (angle_now > 180) angle_now -= 180;
+                marker_angle = (float)(marker_angle + angle_now);
+            }
+            marker_angle /= (float)n;
+            const int direc = (ctm::fabs32(marker_angle) < 45 || ctm::fabs32(marker_angle) > 135) ? 0 : 1;
+            // insertion sort of the marker's features (std::sort on <= 16 elements; stable)
+            for (int x = a + 1; x < b; x++) {
+                const int v = s_order[x];
+                const float kv = direc == 0 ? s_feat[v].center[1] : s_feat[v].center[0];
+                int y = x - 1;
+                while (y >= a) {
+                    const float ky = direc == 0 ? s_feat[s_order[y]].center[1] : s_feat[s_order[y]].center[0];
+                    const bool before = direc == 0 ? (kv > ky) : (kv < ky);
+                    if (!before) break;
+                    s_order[y + 1] = s_order[y];
+                    y--;
+                }
+                s_order[y + 1] = v;
+            }
+            for (int k = a; k < b; k++) {
+                const FeatureDev& F = s_feat[s_order[k]];
+                ctag_feature_rec& R = s_rec[k];
+                for (int q = 0; q < 16; q++) R.corners[q] = F.c[q];
+                R.center[0] = F.center[0];
+                R.center[1] = F.center[1];
+                R.edge_length = (dist2p(P2{F.c[0], F.c[1]}, P2{F.c[2], F.c[3]}) + dist2p(P2{F.c[8], F.c[9]}, P2{F.c[10], F.c[11]}) / 2);
+                R.pos = -1;
+                int id, idl, idr;
+                feature_ids(R.corners, direc, ID_left, ID_right, R.cr_left, R.cr_right, id, idl, idr);
+                R.id = id;
+                R.id_left = idl;
+                R.id_right = idr;
+            }
+        }
+    }
+    __syncthreads();
+    if (P.pre) {  // debug copy of the markers before decoding
+        ctag_frame_result* pre = P.pre + frame;
+        if (tid == 0) {
+            pre->status = status;
+            pre->n_markers = cnt;
+            pre->n_features = nf;
+            pre->flags = flags;
+        }
+        for (int m = tid; m < cnt; m += 64) {
+            pre->markers[m].marker_id = -1;
+            pre->markers[m].first_feature = s_mfirst[m];
+            pre->markers[m].n_features = s_mfirst[m + 1] - s_mfirst[m];
+            pre->markers[m].n_pos = 0;
+        }
+        for (int k = tid; k < nf; k += 64) pre->features[k] = s_rec[k];
+    }
+    // ---- markerDecoder (:1211-1250) + match_dictionary (:1269-1324)
+    int out_markers = 0, out_features = 0;
+    uint32_t oflags = flags;
+    for (int m = 0; m < cnt; m++) {
+        const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
+        if (n < feature_size) continue;  // uniform
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 0; k < CTAG_MAX_CODE_POS; k++) s_code[k] = -1;
+            int pos_now = 0, overflow = 0;
+            s_code[0] = s_rec[a].id;
+            for (int j = 1; j < n; j++) {
+                const ctag_feature_rec &Rj = s_rec[a + j], &Rp = s_rec[a + j - 1];
+                const float dist_fea = dist2p(P2{Rj.center[0], Rj.center[1]}, P2{Rp.center[0], Rp.center[1]});
+                const float gap_f = ctm::round32(dist_fea / ((Rj.edge_length + Rp.edge_length) * 3 / 4));
+                if (!(gap_f >= 0.f && gap_f < (float)CTAG_MAX_CODE_POS)) {
+                    overflow = 1;
+                    break;
+                }
+                pos_now += (int)gap_f;
+                if (pos_now >= CTAG_MAX_CODE_POS || pos_now < 0) {
+                    overflow = 1;
+                    break;
+                }
+                s_code[pos_now] = Rj.id;
+            }
+            int legal = 0;
+            for (int k = 0; k < CTAG_MAX_CODE_POS; k++)
+                if (s_code[k] > -1) legal++;
+            s_misc[2] = pos_now;
+            s_misc[3] = overflow;
+            s_misc[4] = legal;
+        }
+        __syncthreads();
+        if (s_misc[3]) {
+            oflags |= CTAG_FLAG_CODE_OVERFLOW;
+            continue;
+        }
+        const int length = s_misc[2], legal = s_misc[4];
+        // coverage of every hypothesis, lanes over (dir, row, col)
+        const int hyp = drows * dcols;
+        for (int h = tid; h < 2 * hyp; h += 64) {
+            const int dir = h / hyp, rc = h - dir * hyp;
+            const int i = rc / dcols, j = rc - i * dcols;
+            int cov = 0;
+            if (dir == 0) {
+                for (int k = 0; k <= length; k++)
+                    if (P.dict[i * dcols + (j + k) % dcols] == s_code[k]) cov++;
+            } else {
+                for (int k = 0; k <= length; k++) {
+                    const int c = s_code[k];
+                    if (P.dict[i * dcols + (j - k + dcols) % dcols] == ((7 - c / 8) + (7 - c % 8) * 8)) cov++;
+                }
+            }
+            s_cov[h] = (short)cov;
+        }
+        __syncthreads();
+        if (tid == 0) {  // replay the order-dependent max / second bookkeeping
+            int max_cov = -1, second = -1, direc = 1, mx = 0, my = 0;
+            for (int h = 0; h < 2 * hyp; h++) {
+                const int cov = s_cov[h];
+                if (cov > max_cov) {
+                    max_cov = cov;
+                    const int dir = h / hyp, rc = h - dir * hyp;
+                    mx = rc / dcols;
+                    my = rc - mx * dcols;
+                    direc = dir == 0 ? 1 : -1;
+                } else if (cov > second) {
+                    second = cov;
+                }
+            }
+            const double lim = 0.8 * legal < legal - 1.0 ? 0.8 * legal : legal - 1.0;
+            const int good = (max_cov >= lim && max_cov > second) ? 1 : 0;
+            s_misc[5] = good;
+            if (good) {
+                ctag_marker_rec& M = out->markers[out_markers];
+                M.marker_id = mx;
+                M.first_feature = out_features;
+                M.n_features = n;
+                int np = 0;
+                for (int k = 0; k < n; k++) {
+                    ctag_feature_rec R = s_rec[a + k];
+                    if (direc == -1) {
+                        for (int q = 0; q < 8; q++) {
+                            const float t = R.corners[q];
+                            R.corners[q] = R.corners[8 + q];
+                            R.corners[8 + q] = t;
+                        }
+                    }
+                    R.pos = -1;
+                    out->features[out_features + k] = R;
+                }
+                for (int i = 0; i <= length; i++) {
+                    if (s_code[i] != -1) {
+                        out->features[out_features + np].pos = (my + direc * i + dcols) % dcols;
+                        np++;
+                    }
+                }
+                M.n_pos = np;
+            }
+        }
+        __syncthreads();
+        if (s_misc[5]) {
+            out_markers++;
+            out_features += n;
+        }
+    }
+    if (tid == 0) {
+        out->status = CTAG_OK;
+        out->n_markers = out_markers;
+        out->n_features = out_features;
+        out->flags = oflags;
+    }
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
+    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2};
+    hipLaunchKernelGGL(k_features, dim3(nframes), dim3(128), 0, s, P, nframes, p.feature_size);
+    return hipGetLastError();
+}
+hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
+    if (!p.corner_subpix) return hipSuccess;
+    RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2};
+    hipLaunchKernelGGL(k_edge_refine, dim3(CTAG_MAX_FEATURES * 2, nframes), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+    return hipGetLastError();
+}
+hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s) {
+    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out};
+    hipLaunchKernelGGL(k_markers, dim3(nframes), dim3(64), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
+    return hipGetLastError();
+}
+
+}  // namespace ctag

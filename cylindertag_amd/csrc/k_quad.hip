@@ -1,0 +1,710 @@
+// k_quad.hip -- K6: one workgroup per candidate component: silhouette boundary, ordered traversal,
+// extended Ramer-Douglas-Peucker split into <= 4 edges, robust (Welsch) line fits, quad selection.
+// GPU counterpart of corner_detector::edgeExtraction and helpers
+//   /root/reference/corner_detector.cpp:125-169 (expand_line), :171-405 (edgeExtraction),
+//   :407-418 (get_orientedEdgePoints), :420-452 (get_permutation), :454-463 (quadJudgment)
+// and of the OpenCV fitLine(DIST_L2 / DIST_WELSCH) calls inside them.
+//
+// Design (not a translation): the reference builds a bbox mask + visited image and recurses; here the
+// silhouette is kept as four sparse first-hit arrays (top/bottom per column, left/right per row), the
+// recursion is an explicit stack, expand_line's per-point refits use exact integer moment sums, the 20
+// Welsch restarts of each of the 4 edges run on 80 lanes at once (the cv::RNG pick sequence depends only
+// on the point count, so it is replayed up front), and every floating-point sum that the reference
+// accumulates sequentially is accumulated in the same order so results are bit-identical to the oracle.
+#include "ctag_internal.h"
+#include "ctag_math.h"
+
+namespace ctag {
+
+constexpr int kQuadThreads = 128;
+constexpr int kQuadLdsWords = 3072;  // 12 KB of per-component working storage in LDS
+
+struct QuadPtrs {
+    const uint16_t* labels;
+    const int32_t* tile_base;
+    const int32_t* root_of;
+    const int32_t* ncand;
+    const Candidate* cand;
+    QuadOut* quads;
+    uint32_t* scratch;
+    int32_t* scratch_used;
+    uint32_t* frame_flags;
+};
+
+__device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
+__device__ __forceinline__ int ux(uint32_t p) { return (int)(p & 0xffffu); }
+__device__ __forceinline__ int uy(uint32_t p) { return (int)(p >> 16); }
+
+// fitLine2D_wods tail: moments -> (vx, vy, x0, y0)   [SURVEY App. A.5]
+__device__ __forceinline__ void moments_to_line(double x, double y, double x2, double y2, double xy, double w, float* line) {
+    x /= w;
+    y /= w;
+    x2 /= w;
+    y2 /= w;
+    xy /= w;
+    const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
+    const float t = (float)ctm::atan2_64(2 * dxy, dx2 - dy2) / 2;
+    line[0] = (float)ctm::cos64(t);
+    line[1] = (float)ctm::sin64(t);
+    line[2] = (float)x;
+    line[3] = (float)y;
+}
+
+// determinant + solve for 2x2 CV_32F [SURVEY App. A.7]
+__device__ __forceinline__ bool solve2x2(float a00, float a01, float a10, float a11, float b0, float b1, float& x0, float& x1) {
+    double d = (double)a00 * a11 - (double)a01 * a10;
+    if (d == 0.) return false;
+    d = 1. / d;
+    const float t = (float)(((double)b0 * a11 - (double)b1 * a01) * d);
+    x1 = (float)(((double)b1 * a00 - (double)b0 * a10) * d);
+    x0 = t;
+    return true;
+}
+
+// cv::RNG (multiply-with-carry) as fitLine2D seeds it: RNG rng((uint64)-1)
+struct CvRng {
+    uint64_t state;
+    __device__ unsigned next() {
+        state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+};
+
+// One Welsch restart (the body of fitLine2D's `for k` loop) on one lane.  pts: cluster points in the order
+// the reference pushed them.  picks: the restart's initial sample (ascending).  Returns (_line, err) as they
+// stand when the reference leaves the inner loop.
+__device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks, int npick, double EPS, float* out_line, double* out_err) {
+    float line[4], prev[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
+        for (int i = 0; i < npick; i++) {  // zero-weight points add +0.0: skipping them is exact
+            const uint32_t p = pts[picks[i]];
+            const float px = (float)ux(p), py = (float)uy(p);
+            x += px;
+            y += py;
+            x2 += px * px;
+            y2 += py * py;
+            xy += px * py;
+            w += 1.f;
+        }
+        moments_to_line(x, y, x2, y2, xy, w, line);
+    }
+    const float c = 1 / 2.9846f;
+    double err = 0;
+    for (int it = 0; it < 30; it++) {
+        if (it > 0) {
+            double t = line[0] * prev[0] + line[1] * prev[1];
+            t = t < -1. ? -1. : t;
+            t = t > 1. ? 1. : t;
+            if (ctm::fabs64(ctm::acos64(t)) < 0.01f) {
+                const float dx = ctm::fabs32(line[2] - prev[2]);
+                const float dy = ctm::fabs32(line[3] - prev[3]);
+                const float d = dx > dy ? dx : dy;
+                if (d < 0.01f) break;
+            }
+        }
+        const float lx = line[2], ly = line[3], nx = line[1], ny = -line[0];
+        double sum_w = 0;
+        err = 0;
+        for (int j = 0; j < n; j++) {
+            const uint32_t p = pts[j];
+            const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
+            const float r = ctm::fabs32(nx * x + ny * y);
+            err += r;
+            sum_w += ctm::exp32(-r * r * c * c);
+        }
+        if (err < EPS) break;
+        double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
+        if (ctm::fabs64(sum_w) > 1.1920928955078125e-07) {
+            const double inv = 1. / sum_w;
+            for (int j = 0; j < n; j++) {
+                const uint32_t p = pts[j];
+                const float px = (float)ux(p), py = (float)uy(p);
+                const float r = ctm::fabs32(nx * (px - lx) + ny * (py - ly));
+                const float wj = (float)(ctm::exp32(-r * r * c * c) * inv);
+                x += wj * px;
+                y += wj * py;
+                x2 += wj * px * px;
+                y2 += wj * py * py;
+                xy += wj * px * py;
+                w += wj;
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                const uint32_t p = pts[j];
+                const float px = (float)ux(p), py = (float)uy(p);
+                x += px;
+                y += py;
+                x2 += px * px;
+                y2 += py * py;
+                xy += px * py;
+                w += 1.f;
+            }
+        }
+        prev[0] = line[0];
+        prev[1] = line[1];
+        prev[2] = line[2];
+        prev[3] = line[3];
+        moments_to_line(x, y, x2, y2, xy, w, line);
+    }
+    out_line[0] = line[0];
+    out_line[1] = line[1];
+    out_line[2] = line[2];
+    out_line[3] = line[3];
+    *out_err = err;
+}
+
+struct CornerPre {
+    float x, y, dis, ang;
+};
+
+__global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, int nframes) {
+    __shared__ uint32_t s_mem[kQuadLdsWords];
+    __shared__ uint16_t s_picks[4][20][10];
+    __shared__ double s_err[80];
+    __shared__ float s_line[80][4];
+    __shared__ unsigned long long s_sum[2];
+    __shared__ int s_i[16];
+    __shared__ float s_redf[2];
+    __shared__ int s_redi[2];
+    __shared__ int s_cl_off[5];
+
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = P.ncand[frame];
+    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
+    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * kPoolCap;
+    constexpr size_t kScratchWords = (size_t)4 * kQuadScratchPoints + 2048;
+
+    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+        __syncthreads();
+        const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
+        QuadOut* out = P.quads + (size_t)frame * kCandCap + ci;
+        const int x_min = cd.x_min, y_min = cd.y_min;
+        const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
+        const int C = min(2 * (w + h), w * h) + 1;
+        const int w2 = (w + 1) & ~1;
+        const size_t need = (size_t)(w2) + 2 * (size_t)h + 3 * (size_t)C + 72;
+        uint32_t* mem = s_mem;
+        if (need > (size_t)kQuadLdsWords) {  // block-uniform
+            if (tid == 0) s_i[0] = atomicAdd(P.scratch_used, 1);
+            __syncthreads();
+            const int slot = s_i[0];
+            if (slot >= kQuadScratchSlots || need > kScratchWords) {
+                if (tid == 0) {
+                    atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+                    out->valid = 0;
+                    out->n_boundary = 0;
+                }
+                continue;
+            }
+            mem = P.scratch + (size_t)slot * kScratchWords;
+        }
+        uint16_t* top = reinterpret_cast<uint16_t*>(mem);
+        uint16_t* bot = top + w2;
+        uint32_t* lef = mem + w2;
+        uint32_t* rig = lef + h;
+        uint32_t* bufA = rig + h;      // E
+        uint32_t* bufB = bufA + C;     // DFS stack, later ping-pong partner
+        uint32_t* CL = bufB + C + 1;   // clusters (C + 64 words)
+
+        // ---- P1: silhouette first-hit arrays (corner_detector.cpp:184-232)
+        for (int x = tid; x < w; x += kQuadThreads) {
+            top[x] = 0xffff;
+            bot[x] = 0xffff;
+        }
+        for (int y = tid; y < h; y += kQuadThreads) {
+            lef[y] = 0xffffffffu;
+            rig[y] = 0u;
+        }
+        __syncthreads();
+        for (int y = 0; y < h; y++) {
+            const int gy = y_min + y;
+            const uint16_t* lrow = limg + (size_t)gy * g.lp;
+            const int trow = (gy / kTileH) * g.tiles_x;
+            for (int xb = 0; xb < w; xb += kQuadThreads) {
+                const int x = xb + tid;
+                bool fg = false;
+                if (x < w) {
+                    const int gx = x_min + x;
+                    const unsigned l = lrow[gx];
+                    if (l) fg = rootof[tbase[trow + gx / kTileW] + (int)l - 1] == cd.root;
+                    if (fg) {
+                        if (top[x] == 0xffff) top[x] = (uint16_t)y;
+                        bot[x] = (uint16_t)y;
+                    }
+                }
+                const uint64_t b = __ballot(fg);
+                if (b && lane == 0) {
+                    const int first = xb + wave * 64 + (__ffsll((unsigned long long)b) - 1);
+                    const int last = xb + wave * 64 + (63 - __clzll((long long)b));
+                    atomicMin(&lef[y], (unsigned)first);
+                    atomicMax(&rig[y], (unsigned)(last + 1));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418), thread 0, explicit stack
+        if (tid == 0) {
+            auto member = [&](int x, int y) { return top[x] == y || bot[x] == y || lef[y] == (unsigned)x || rig[y] == (unsigned)(x + 1); };
+            auto clear = [&](int x, int y) {
+                if (top[x] == y) top[x] = 0xffff;
+                if (bot[x] == y) bot[x] = 0xffff;
+                if (lef[y] == (unsigned)x) lef[y] = 0xffffffffu;
+                if (rig[y] == (unsigned)(x + 1)) rig[y] = 0u;
+            };
+            const int xb[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+            const int yb[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+            int n = 0;
+            const int sx = 0, sy = top[0];
+            int sp = 0;
+            if (sy == 0xffff) {  // inconsistent labels (only after a flagged pool overflow): give up on this component
+                sp = -1;
+            } else {
+                bufA[n++] = pack_xy(sx + x_min, sy + y_min);
+                clear(sx, sy);
+            }
+            bufB[0] = (uint32_t)sx | ((uint32_t)sy << 14);  // x:14 y:14 j:4
+            while (sp >= 0) {
+                const uint32_t f = bufB[sp];
+                const int fx = (int)(f & 0x3fff), fy = (int)((f >> 14) & 0x3fff);
+                int j = (int)(f >> 28);
+                bool pushed = false;
+                for (; j < 8; j++) {
+                    const int nx = fx + xb[j], ny = fy + yb[j];
+                    if (ny >= 0 && ny < h && nx >= 0 && nx < w && member(nx, ny)) {
+                        if (n < C) bufA[n] = pack_xy(nx + x_min, ny + y_min);
+                        n++;
+                        clear(nx, ny);
+                        bufB[sp] = (uint32_t)nx | ((uint32_t)ny << 14) | ((uint32_t)(j + 1) << 28);
+                        if (sp + 1 <= C) {
+                            sp++;
+                            bufB[sp] = (uint32_t)nx | ((uint32_t)ny << 14);
+                        }
+                        pushed = true;
+                        break;
+                    }
+                }
+                if (!pushed) sp--;
+            }
+            s_i[1] = min(n, C);
+            s_sum[0] = 0ull;
+            s_sum[1] = 0ull;
+        }
+        __syncthreads();
+        int n = s_i[1];
+        const int n_boundary = n;
+        if (n == 0) {  // block-uniform
+            if (tid == 0) {
+                out->valid = 0;
+                out->n_boundary = 0;
+            }
+            continue;
+        }
+        // ---- P3: boundary centroid (:250-256), nearest point (:259-263), rotation (:264-275)
+        {
+            unsigned long long sx = 0, sy = 0;
+            for (int k = tid; k < n; k += kQuadThreads) {
+                sx += (unsigned)ux(bufA[k]);
+                sy += (unsigned)uy(bufA[k]);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                sx += __shfl_down(sx, d);
+                sy += __shfl_down(sy, d);
+            }
+            if (lane == 0) {
+                atomicAdd(&s_sum[0], sx);
+                atomicAdd(&s_sum[1], sy);
+            }
+        }
+        __syncthreads();
+        const float acx = (float)(1.0 * (long long)s_sum[0] / (double)(unsigned long long)n);
+        const float acy = (float)(1.0 * (long long)s_sum[1] / (double)(unsigned long long)n);
+        {
+            float bd = 3.0e38f;
+            int bi = 0x7fffffff;
+            for (int k = tid; k < n; k += kQuadThreads) {
+                const float dx = (float)ux(bufA[k]) - acx, dy = (float)uy(bufA[k]) - acy;
+                const float d = ctm::sqrt32(dx * dx + dy * dy);
+                if (d < bd || (d == bd && k < bi)) {
+                    bd = d;
+                    bi = k;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float od = __shfl_down(bd, d);
+                const int oi = __shfl_down(bi, d);
+                if (od < bd || (od == bd && oi < bi)) {
+                    bd = od;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                s_redf[wave] = bd;
+                s_redi[wave] = bi;
+            }
+        }
+        __syncthreads();
+        {
+            int b0 = s_redi[0];
+            if (s_redf[1] < s_redf[0] || (s_redf[1] == s_redf[0] && s_redi[1] < s_redi[0])) b0 = s_redi[1];
+            for (int k = tid; k < n; k += kQuadThreads) {
+                int src = k + b0;
+                if (src >= n) src -= n;
+                bufB[k] = bufA[src];
+            }
+        }
+        __syncthreads();
+        uint32_t* W = bufB;   // working list
+        uint32_t* Wn = bufA;  // next list
+        // ---- P4: extended RDP (:278-349).  Thread 0 drives; max-distance search and list surgery use all threads.
+        if (tid == 0) {
+            s_i[2] = 0;  // cnt_boundary
+            s_i[3] = 0;  // init
+            s_i[4] = 0;  // failed
+            s_cl_off[0] = 0;
+        }
+        __syncthreads();
+        while (true) {
+            int cnt = s_i[2], init = s_i[3];
+            if (n <= 0 || s_i[4] || cnt >= 4) break;  // uniform
+            auto tri2 = [&](int a) {
+                const uint32_t p0 = W[a], p2 = W[(a + 2) % n], p1 = W[(a + 1) % n];
+                const int vx = ux(p0) + ux(p2) - 2 * ux(p1), vy = uy(p0) + uy(p2) - 2 * uy(p1);
+                return vx * vx + vy * vy;
+            };
+            if (tid == 0) {
+                int end = 0;
+                if (n > 2) {
+                    int c2 = tri2(init);  // cost > 1.05  <=>  squared norm >= 2
+                    while (c2 >= 2 && init < n - 3) {
+                        init++;
+                        c2 = tri2(init);
+                    }
+                    end = init + n / 2;
+                    if (end > n - 1) end = n - 1;
+                } else {
+                    s_i[4] = 1;
+                }
+                s_i[3] = init;
+                s_i[5] = end;
+            }
+            __syncthreads();
+            if (s_i[4]) break;
+            init = s_i[3];
+            // inner split loop (:303-330)
+            while (true) {
+                const int end = s_i[5];
+                if (end <= init + 1) {
+                    if (tid == 0) s_i[4] = 1;
+                    break;
+                }
+                const uint32_t pi = W[init], pe = W[end];
+                float nl0;
+                if (ux(pi) == ux(pe)) {
+                    nl0 = 100;
+                } else {
+                    nl0 = (float)(1.0 * (uy(pe) - uy(pi)) / (ux(pe) - ux(pi)));
+                }
+                const float nl1 = -1;
+                const float d_line = -(nl0 * ux(pi) + nl1 * uy(pi));
+                const float den = ctm::sqrt32(nl0 * nl0 + 1);
+                float bd = -1.f;
+                int bi = -1;
+                for (int it = init + 1 + tid; it < end; it += kQuadThreads) {
+                    const uint32_t p = W[it];
+                    const float d = ctm::fabs32(nl0 * ux(p) + nl1 * uy(p) + d_line) / den;
+                    const int rel = it - init - 1;
+                    if (d > bd || (d == bd && rel > bi)) {
+                        bd = d;
+                        bi = rel;
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const float od = __shfl_down(bd, d);
+                    const int oi = __shfl_down(bi, d);
+                    if (od > bd || (od == bd && oi > bi)) {
+                        bd = od;
+                        bi = oi;
+                    }
+                }
+                __syncthreads();  // previous readers of s_redf / s_i[5] are done
+                if (lane == 0) {
+                    s_redf[wave] = bd;
+                    s_redi[wave] = bi;
+                }
+                __syncthreads();
+                float md = s_redf[0];
+                int mi = s_redi[0];
+                if (s_redf[1] > md || (s_redf[1] == md && s_redi[1] > mi)) {
+                    md = s_redf[1];
+                    mi = s_redi[1];
+                }
+                const int count = end - init - 1;
+                if (md > 1.8f && count > 1) {
+                    __syncthreads();
+                    if (tid == 0) s_i[5] = mi;  // literal index into dist2line
+                    __syncthreads();
+                    continue;
+                }
+                // ---- expand_line (:125-169) with exact integer moment sums, thread 0
+                if (tid == 0) {
+                    long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
+                    for (int k = init; k <= end; k++) {
+                        const long long x = ux(W[k]), y = uy(W[k]);
+                        Sx += x;
+                        Sy += y;
+                        Sxx += x * x;
+                        Syy += y * y;
+                        Sxy += x * y;
+                    }
+                    int m = end - init + 1;
+                    float line[4];
+                    moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
+                    bool fl = false, fr = false;
+                    int left = init - 1, right = end + 1, nl = 0, nr = 0;
+                    while ((!fl || !fr) && (left != right)) {
+                        if (!fl) {
+                            if (left == -1) left = n - 1;
+                            const uint32_t p = W[left];
+                            const float de = ctm::fabs32(ux(p) * line[1] - uy(p) * line[0] + line[0] * line[3] - line[1] * line[2]);
+                            if (de > 1.2f) {
+                                fl = true;
+                                continue;
+                            }
+                            const long long x = ux(p), y = uy(p);
+                            Sx += x;
+                            Sy += y;
+                            Sxx += x * x;
+                            Syy += y * y;
+                            Sxy += x * y;
+                            m++;
+                            nl++;
+                            left--;
+                            moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
+                            if (m == n) break;
+                        }
+                        if (!fr) {
+                            if (right == n) right = 0;
+                            const uint32_t p = W[right];
+                            const float de = ctm::fabs32(ux(p) * line[1] - uy(p) * line[0] + line[0] * line[3] - line[1] * line[2]);
+                            if (de > 1.2f) {
+                                fr = true;
+                                continue;
+                            }
+                            const long long x = ux(p), y = uy(p);
+                            Sx += x;
+                            Sy += y;
+                            Sxx += x * x;
+                            Syy += y * y;
+                            Sxy += x * y;
+                            m++;
+                            nr++;
+                            right++;
+                            moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
+                            if (m == n) break;
+                        }
+                    }
+                    // the span is a circular arc [a .. b] of m distinct indices
+                    const int a = ((init - nl) % n + n) % n;
+                    const int b = (end + nr) % n;
+                    const int span0 = (a > b) ? n - 1 : b;
+                    const int keep = tri2(span0) <= 1 ? 1 : 0;  // cost < 1.05 (:337-339)
+                    s_i[6] = a;
+                    s_i[7] = b;
+                    s_i[8] = m;
+                    s_i[9] = keep;
+                }
+                __syncthreads();
+                {
+                    const int a = s_i[6], b = s_i[7], m = s_i[8], keep = s_i[9];
+                    const bool wrap = a > b;
+                    const int off = s_cl_off[cnt];
+                    // cluster points in descending index order (:332-334)
+                    for (int k = tid; k < m; k += kQuadThreads) {
+                        int idx;
+                        if (!wrap) {
+                            idx = b - k;
+                        } else {
+                            idx = (k < n - a) ? (n - 1 - k) : (b - (k - (n - a)));
+                        }
+                        if (off + k < C + 64) CL[off + k] = W[idx];
+                    }
+                    // erase the span except (optionally) its largest index (:341-343)
+                    int new_n;
+                    if (!wrap) {
+                        new_n = n - m + keep;
+                        for (int k = tid; k < new_n; k += kQuadThreads) {
+                            int src;
+                            if (k < a) src = k;
+                            else if (keep && k == a) src = b;
+                            else src = k - keep + m;
+                            Wn[k] = W[src];
+                        }
+                    } else {
+                        new_n = n - m + keep;
+                        const int mid = a - b - 1;  // W[b+1 .. a-1]
+                        for (int k = tid; k < new_n; k += kQuadThreads) Wn[k] = (k < mid) ? W[b + 1 + k] : W[n - 1];
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        const int back = wrap ? 0 : a;
+                        s_cl_off[cnt + 1] = min(off + m, C + 64);
+                        s_i[2] = cnt + 1;
+                        s_i[3] = (back >= new_n) ? 0 : back;
+                        s_i[10] = new_n;
+                    }
+                    __syncthreads();
+                    n = s_i[10];
+                    uint32_t* t = W;
+                    W = Wn;
+                    Wn = t;
+                }
+                break;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        // ---- P5: four Welsch line fits (:351-359)
+        bool ok = true;
+        for (int j = 0; j < 4; j++) {
+            const int len = (j < s_i[2]) ? (s_cl_off[j + 1] - s_cl_off[j]) : 0;
+            if (len < 2) ok = false;
+        }
+        if (s_cl_off[min(s_i[2], 4)] >= C + 64) ok = false;
+        if (!ok) {
+            if (tid == 0) {
+                out->valid = 0;
+                out->n_boundary = n_boundary;
+            }
+            continue;
+        }
+        if (tid < 4) {  // replay the cv::RNG pick sequence of fitLine2D for this edge's point count
+            const int cnt_pts = s_cl_off[tid + 1] - s_cl_off[tid];
+            const int npick = min(cnt_pts, 10);
+            CvRng rng;
+            rng.state = 0xffffffffffffffffULL;
+            for (int k = 0; k < 20; k++) {
+                uint16_t* pk = s_picks[tid][k];
+                int got = 0;
+                while (got < npick) {
+                    const int j = (int)(rng.next() % (unsigned)cnt_pts);
+                    bool dup = false;
+                    for (int q = 0; q < got; q++) dup |= (pk[q] == j);
+                    if (!dup) pk[got++] = (uint16_t)j;
+                }
+                for (int a = 1; a < npick; a++) {  // ascending order = the order fitLine2D_wods visits them
+                    const uint16_t v = pk[a];
+                    int b = a - 1;
+                    while (b >= 0 && pk[b] > v) {
+                        pk[b + 1] = pk[b];
+                        b--;
+                    }
+                    pk[b + 1] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 80) {
+            const int j = tid / 20, k = tid - j * 20;
+            const int cnt_pts = s_cl_off[j + 1] - s_cl_off[j];
+            welsch_restart(CL + s_cl_off[j], cnt_pts, s_picks[j][k], min(cnt_pts, 10), cnt_pts * 1.1920928955078125e-07, s_line[tid], &s_err[tid]);
+        }
+        __syncthreads();
+        // ---- P6: intersections, angular sort, best 4-subset (:362-403, :420-463), thread 0
+        if (tid == 0) {
+            float lf[4][4];
+            for (int j = 0; j < 4; j++) {
+                const double EPS = (s_cl_off[j + 1] - s_cl_off[j]) * 1.1920928955078125e-07;
+                double min_err = 1.7976931348623157e308;
+                lf[j][0] = lf[j][1] = lf[j][2] = lf[j][3] = 0.f;
+                for (int k = 0; k < 20; k++) {
+                    const double e = s_err[j * 20 + k];
+                    if (e < min_err) {
+                        min_err = e;
+                        for (int q = 0; q < 4; q++) lf[j][q] = s_line[j * 20 + k][q];
+                        if (e < EPS) break;
+                    }
+                }
+            }
+            CornerPre cp[6];
+            int ncp = 0;
+            for (int j = 0; j < 3; j++)
+                for (int k = j + 1; k < 4; k++) {
+                    const float a00 = lf[j][1], a01 = -lf[j][0], a10 = lf[k][1], a11 = -lf[k][0];
+                    const float b0 = lf[j][1] * lf[j][2] - lf[j][0] * lf[j][3];
+                    const float b1 = lf[k][1] * lf[k][2] - lf[k][0] * lf[k][3];
+                    CornerPre c;
+                    if (solve2x2(a00, a01, a10, a11, b0, b1, c.x, c.y)) {
+                        c.dis = ctm::sqrt32((c.x - acx) * (c.x - acx) + (c.y - acy) * (c.y - acy));
+                        c.ang = (float)(ctm::atan2_32(c.y - acy, c.x - acx) * 180 / 3.1415926535897932384626433832795);
+                        if (c.dis < g.hcols && c.dis < g.hrows) cp[ncp++] = c;
+                    }
+                }
+            for (int a = 1; a < ncp; a++) {  // std::sort on <= 6 elements: insertion sort
+                const CornerPre v = cp[a];
+                int b = a - 1;
+                while (b >= 0 && v.ang < cp[b].ang) {
+                    cp[b + 1] = cp[b];
+                    b--;
+                }
+                cp[b + 1] = v;
+            }
+            float rac_min = 0.3f;
+            int best[4] = {-1, -1, -1, -1};
+            const int areaPx = cd.area;
+            for (int i0 = 0; i0 < ncp; i0++)
+                for (int i1 = i0 + 1; i1 < ncp; i1++)
+                    for (int i2 = i1 + 1; i2 < ncp; i2++)
+                        for (int i3 = i2 + 1; i3 < ncp; i3++) {
+                            const CornerPre &p0 = cp[i0], &p1 = cp[i1], &p2 = cp[i2], &p3 = cp[i3];
+                            const float s1 = p0.x * p1.y + p1.x * p2.y + p2.x * p0.y - p0.x * p2.y - p1.x * p0.y - p2.x * p1.y;
+                            const float s2 = p1.x * p2.y + p2.x * p3.y + p3.x * p1.y - p1.x * p3.y - p2.x * p1.y - p3.x * p2.y;
+                            const float s3 = p2.x * p3.y + p3.x * p0.y + p0.x * p2.y - p2.x * p0.y - p3.x * p2.y - p0.x * p3.y;
+                            const float s4 = p0.x * p1.y + p1.x * p3.y + p3.x * p0.y - p0.x * p3.y - p1.x * p0.y - p3.x * p1.y;
+                            if (ctm::fabs32(s1) < 1 || ctm::fabs32(s2) < 1 || ctm::fabs32(s3) < 1 || ctm::fabs32(s4) < 1) continue;
+                            float qa = 0;
+                            qa += p0.x * p1.y - p0.y * p1.x;
+                            qa += p1.x * p2.y - p1.y * p2.x;
+                            qa += p2.x * p3.y - p2.y * p3.x;
+                            qa += p3.x * p0.y - p3.y * p0.x;
+                            qa /= 2;
+                            const float rac = ctm::fabs32(ctm::fabs32(qa) - areaPx) / areaPx;
+                            if (rac < rac_min) {
+                                rac_min = rac;
+                                best[0] = i0;
+                                best[1] = i1;
+                                best[2] = i2;
+                                best[3] = i3;
+                            }
+                        }
+            int valid = best[0] >= 0 ? 1 : 0;
+            if (valid) {
+                for (int j = 0; j < 4; j++) {
+                    const CornerPre& c = cp[best[j]];
+                    if (c.x < 0 || c.y < 0 || c.x > g.hcols || c.y > g.hrows) valid = 0;
+                }
+            }
+            out->valid = valid;
+            out->n_boundary = n_boundary;
+            for (int j = 0; j < 4; j++) {
+                out->c[2 * j] = valid ? cp[best[j]].x : 0.f;
+                out->c[2 * j + 1] = valid ? cp[best[j]].y : 0.f;
+            }
+        }
+    }
+}
+
+hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
+    QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags};
+    (void)hipMemsetAsync(ws.quad_scratch_used, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_quad, dim3(128, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    return hipGetLastError();
+}
+
+}  // namespace ctag

@@ -1,0 +1,728 @@
+// k_sweep.hip -- the "threshold + label sweep": K1 decimate, K2 threshold + tile CCL, K3 seam merge,
+// K4 resolve, K5 candidate ordering.  Replaces, for the GPU path, the reference's
+//   resize(INTER_CUBIC) + convertTo            /root/reference/CylinderTag.cpp:79-80
+//   corner_detector::adaptiveThreshold          /root/reference/corner_detector.cpp:28-79
+//   corner_detector::connectedComponentLabeling /root/reference/corner_detector.cpp:81-107
+// HBM-bound integer/byte work: coalesced 16-byte row sweeps, LDS tiles, wave64 ballots for the row masks,
+// union-find over row runs in LDS, one global atomic union-find only for the tile seams.
+// Frames are mapped to XCDs (blockIdx % 8) so a frame's intermediates stay in one XCD's L2.
+#include "ctag_internal.h"
+
+namespace ctag {
+
+// blocks b and b+8 share an XCD (observed round-robin dispatch; speed only, never correctness)
+__device__ __forceinline__ bool map_block(int b, int per_frame, int nframes, int& frame, int& idx) {
+    const int xcd = b & 7;
+    const int i = b >> 3;
+    frame = (i / per_frame) * 8 + xcd;
+    idx = i % per_frame;
+    return frame < nframes;
+}
+static inline int grid_for(int nframes, int per_frame) { return ((nframes + 7) / 8) * 8 * per_frame; }
+
+// =====================================================================================================
+// K1: bicubic 2x decimation, u8 -> u8.  OpenCV resize(INTER_CUBIC) for an exact 2x scale has the fixed
+// taps [-192, 1216, 1216, -192]/2048 at source positions 2x-1..2x+2 (index-clamped at the borders); the
+// horizontal pass is integer, the vertical pass follows the float vector body (s0*b0 + (s1*b1 + (s2*b2 +
+// s3*b3)), round-half-even, saturate) -- SURVEY.md App. A.1; the oracle restates the same arithmetic.
+// Each lane owns 8 output pixels (one 16-byte source load per source row) and slides down a band of rows
+// keeping the four horizontal-pass rows in registers.
+// =====================================================================================================
+constexpr int kDecBand = 20;
+
+struct Raw18 {  // source pixels x0-1 .. x0+16 of one row
+    uint32_t w0, w1, w2, w3;
+    uint32_t left;    // pixel x0-1
+    uint32_t right2;  // pixels x0+16 (bits 0-7) and x0+17 (bits 8-15)
+};
+
+template <bool ALIGNED>
+__device__ __forceinline__ Raw18 load_row(const uint8_t* __restrict__ rowp, int x0, int cols, bool active, int lane) {
+    Raw18 r;
+    r.w0 = r.w1 = r.w2 = r.w3 = 0;
+    bool full = false;
+    if (active) {
+        if (ALIGNED && x0 + 16 <= cols) {
+            const uint4 v = *reinterpret_cast<const uint4*>(rowp + x0);
+            r.w0 = v.x;
+            r.w1 = v.y;
+            r.w2 = v.z;
+            r.w3 = v.w;
+            full = true;
+        } else {
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int xi = min(x0 + i, cols - 1);
+                w[i >> 2] |= (uint32_t)rowp[xi] << (8 * (i & 3));
+            }
+            r.w0 = w[0];
+            r.w1 = w[1];
+            r.w2 = w[2];
+            r.w3 = w[3];
+        }
+    }
+    uint32_t left = __shfl_up(r.w3 >> 24, 1);
+    uint32_t right2 = __shfl_down(r.w0 & 0xffffu, 1);
+    if (active) {
+        if (lane == 0) left = rowp[max(x0 - 1, 0)];
+        if (lane == 63 || !full || x0 + 32 > cols) {
+            right2 = (uint32_t)rowp[min(x0 + 16, cols - 1)] | ((uint32_t)rowp[min(x0 + 17, cols - 1)] << 8);
+        }
+    }
+    r.left = left;
+    r.right2 = right2;
+    return r;
+}
+
+__device__ __forceinline__ int px(const Raw18& r, int k) {  // k in [-1, 17]
+    if (k < 0) return (int)r.left;
+    if (k >= 16) return (int)((r.right2 >> (8 * (k - 16))) & 0xff);
+    const uint32_t w = k < 4 ? r.w0 : k < 8 ? r.w1 : k < 12 ? r.w2 : r.w3;
+    return (int)((w >> (8 * (k & 3))) & 0xff);
+}
+
+// horizontal pass / 64 : q = 19*(p[2i]+p[2i+1]) - 3*(p[2i-1]+p[2i+2])
+__device__ __forceinline__ void hpass(const Raw18& r, int q[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = 19 * (px(r, 2 * i) + px(r, 2 * i + 1)) - 3 * (px(r, 2 * i - 1) + px(r, 2 * i + 2));
+}
+
+__device__ __forceinline__ uint32_t vpass(int qa, int qb, int qc, int qd) {
+    const float scale = 1.f / (2048.f * 2048.f);
+    const float b0 = -192.f * scale, b1 = 1216.f * scale;
+    const float s0 = (float)(qa * 64), s1 = (float)(qb * 64), s2 = (float)(qc * 64), s3 = (float)(qd * 64);
+    float t = s3 * b0;
+    t = s2 * b1 + t;
+    t = s1 * b1 + t;
+    t = s0 * b0 + t;
+    int v = __float2int_rn(t);
+    v = min(max(v, 0), 255);
+    return (uint32_t)v;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
+                                                  uint8_t* __restrict__ half, FrameGeom g, int nframes, int xblocks, int yblocks) {
+    int frame, idx;
+    if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
+    const int bx = idx % xblocks, by = idx / xblocks;
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const int band = by * 4 + wy;
+    const int y_begin = band * kDecBand;
+    if (y_begin >= g.hrows) return;  // wave-uniform
+    const int y_end = min(y_begin + kDecBand, g.hrows);
+    const int hx0 = (bx * 64 + lane) * 8;
+    const int x0 = hx0 * 2;
+    const bool active = hx0 < g.hcols;
+    const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
+    uint8_t* __restrict__ dst = half + ((size_t)frame * g.hrows) * g.hp;
+    const int rmax = g.rows - 1;
+    auto rowp = [&](int r) { return src + (ptrdiff_t)min(max(r, 0), rmax) * row_stride; };
+
+    int qa[8], qb[8], qc[8], qd[8];
+    {
+        const Raw18 ra = load_row<ALIGNED>(rowp(2 * y_begin - 1), x0, g.cols, active, lane);
+        const Raw18 rb = load_row<ALIGNED>(rowp(2 * y_begin), x0, g.cols, active, lane);
+        const Raw18 rc = load_row<ALIGNED>(rowp(2 * y_begin + 1), x0, g.cols, active, lane);
+        const Raw18 rd = load_row<ALIGNED>(rowp(2 * y_begin + 2), x0, g.cols, active, lane);
+        hpass(ra, qa);
+        hpass(rb, qb);
+        hpass(rc, qc);
+        hpass(rd, qd);
+    }
+    for (int y = y_begin; y < y_end; y++) {
+        Raw18 rn0, rn1;
+        const bool more = (y + 1 < y_end);  // wave-uniform
+        if (more) {  // issue the next two source rows before the arithmetic of this output row
+            rn0 = load_row<ALIGNED>(rowp(2 * y + 3), x0, g.cols, active, lane);
+            rn1 = load_row<ALIGNED>(rowp(2 * y + 4), x0, g.cols, active, lane);
+        }
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lo |= vpass(qa[i], qb[i], qc[i], qd[i]) << (8 * i);
+#pragma unroll
+        for (int i = 0; i < 4; i++) hi |= vpass(qa[4 + i], qb[4 + i], qc[4 + i], qd[4 + i]) << (8 * i);
+        if (active) *reinterpret_cast<uint2*>(dst + (size_t)y * g.hp + hx0) = make_uint2(lo, hi);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                qa[i] = qc[i];
+                qb[i] = qd[i];
+            }
+            hpass(rn0, qc);
+            hpass(rn1, qd);
+        }
+    }
+}
+
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s) {
+    const FrameGeom& g = ws.g;
+    const int lanes = (g.hcols + 7) / 8;
+    const int xblocks = (lanes + 63) / 64;
+    const int bands = (g.hrows + kDecBand - 1) / kDecBand;
+    const int yblocks = (bands + 3) / 4;
+    const int grid = grid_for(nframes, xblocks * yblocks);
+    const bool aligned = (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0;
+    if (aligned)
+        hipLaunchKernelGGL(k_decimate<true>, dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, yblocks);
+    else
+        hipLaunchKernelGGL(k_decimate<false>, dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, yblocks);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// K2: adaptive threshold + connected components inside one 320x30 tile.
+// =====================================================================================================
+struct SweepPtrs {
+    const uint8_t* half;
+    uint16_t* labels;
+    int32_t* tile_base;
+    int32_t* frame_ncomp;
+    uint32_t* frame_flags;
+    uint32_t* parent;
+    int32_t* root_of;
+    int32_t* area;
+    int32_t* xmin;
+    int32_t* ymin;
+    int32_t* xmax;
+    int32_t* ymax;
+    int32_t* key;
+    int32_t* ncand;
+    Candidate* cand;
+};
+static SweepPtrs sweep_ptrs(const Workspace& ws) {
+    return SweepPtrs{ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
+                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.ncand, ws.cand};
+}
+
+struct CclLdsLayout {
+    int rp, rh;       // half-res staging region pitch / rows
+    int ec, er;       // extrema grid (with ring)
+    int tc, tr;       // threshold grid (tiles overlapping the CCL tile)
+    size_t off_region, off_ext, off_thr, off_mask, off_start, off_runbase, off_parent, off_lab, off_misc, total;
+};
+__host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
+    CclLdsLayout L;
+    // a tile starts at an arbitrary offset inside a threshold tile: span <= tile + 2*(tw-1) + 2*tw (ring)
+    L.rp = ((kTileW + 4 * tw + 32) + 15) & ~15;
+    L.rh = kTileH + 4 * tw;
+    L.tc = (kTileW + tw - 1) / tw + 1;
+    L.tr = (kTileH + tw - 1) / tw + 1;
+    L.ec = L.tc + 2;
+    L.er = L.tr + 2;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o = (o + bytes + 15) & ~(size_t)15;
+        return at;
+    };
+    const size_t region = (size_t)L.rp * L.rh;
+    const size_t stats = (size_t)kSlotCap * 6 * sizeof(int);
+    L.off_region = take(region > stats ? region : stats);
+    L.off_ext = take((size_t)L.ec * L.er * 2);
+    L.off_thr = take((size_t)L.tc * L.tr * 2);
+    L.off_mask = take((size_t)kTileH * kTileWords * 8);
+    L.off_start = take((size_t)kTileH * kTileWords * 8);
+    L.off_runbase = take(((size_t)kTileH * kTileWords + 1) * 4);
+    L.off_parent = take((size_t)kRunCap * 4);
+    L.off_lab = take((size_t)kRunCap * 2);
+    L.off_misc = take(64);
+    L.total = o;
+    return L;
+}
+size_t threshold_ccl_lds_bytes(int tw) { return ccl_layout(tw).total; }
+
+__device__ __forceinline__ uint64_t mask_le(int b) { return b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull); }
+
+__device__ __forceinline__ int block_excl_scan(int v, int* scratch, int& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(inc, d);
+        if (lane >= d) inc += n;
+    }
+    if (lane == 63) scratch[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; i++) base += scratch[i];
+    total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__device__ __forceinline__ unsigned lds_find(const unsigned* parent, unsigned x) {
+    unsigned p;
+    while ((p = __atomic_load_n(&parent[x], __ATOMIC_RELAXED)) != x) x = p;
+    return x;
+}
+__device__ __forceinline__ void lds_union(unsigned* parent, unsigned a, unsigned b) {
+    while (true) {
+        a = lds_find(parent, a);
+        b = lds_find(parent, b);
+        if (a == b) return;
+        if (a > b) {
+            const unsigned t = a;
+            a = b;
+            b = t;
+        }
+        const unsigned old = atomicMin(&parent[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+// adaptive threshold of one tile as an integer bound: pixel u is foreground iff u < T, where
+// fg <=> float(u)*(1/255) < min(0.3f, (maxF + minF)/2)     (corner_detector.cpp:71)
+__device__ __forceinline__ int threshold_bound(int mn, int mx) {
+    const float k = (float)(1.0 / 255);
+    const float thr = fminf(0.3f, ((float)mx * k + (float)mn * k) / 2);
+    int t = (int)(thr * 255.0f);
+    t = min(max(t, 0), 256);
+    while (t < 256 && (float)t * k < thr) t++;
+    while (t > 0 && !((float)(t - 1) * k < thr)) t--;
+    return t;
+}
+
+template <int TWC>
+__global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tw = TWC ? TWC : g.tw;
+    int frame, tile;
+    if (!map_block(blockIdx.x, g.tiles_x * g.tiles_y, nframes, frame, tile)) return;
+    const int tix = tile % g.tiles_x, tiy = tile / g.tiles_x;
+    const int tx0 = tix * kTileW, ty0 = tiy * kTileH;
+    const int tw_eff = min(kTileW, g.hcols - tx0), th_eff = min(kTileH, g.hrows - ty0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const CclLdsLayout L = ccl_layout(tw);
+    uint8_t* hr_s = smem + L.off_region;
+    uint16_t* ext_s = reinterpret_cast<uint16_t*>(smem + L.off_ext);
+    uint16_t* thr_s = reinterpret_cast<uint16_t*>(smem + L.off_thr);
+    uint64_t* mask_s = reinterpret_cast<uint64_t*>(smem + L.off_mask);
+    uint64_t* start_s = reinterpret_cast<uint64_t*>(smem + L.off_start);
+    int* runbase_s = reinterpret_cast<int*>(smem + L.off_runbase);
+    unsigned* parent_s = reinterpret_cast<unsigned*>(smem + L.off_parent);
+    uint16_t* lab_s = reinterpret_cast<uint16_t*>(smem + L.off_lab);
+    int* misc_s = reinterpret_cast<int*>(smem + L.off_misc);
+
+    // ---- geometry of the threshold tiles this CCL tile needs (its own plus a one-tile ring)
+    const int tcs0 = tx0 / tw, tcs1 = (tx0 + tw_eff - 1) / tw;  // threshold tile columns overlapping the tile
+    const int trs0 = ty0 / tw, trs1 = (ty0 + th_eff - 1) / tw;
+    const int tc0 = max(tcs0 - 1, 0), tc1 = min(tcs1 + 1, g.tcols - 1);
+    const int tr0 = max(trs0 - 1, 0), tr1 = min(trs1 + 1, g.trows - 1);
+    const int px0 = tc0 * tw, px1 = min((tc1 + 1) * tw, g.hcols);
+    const int py0 = tr0 * tw, py1 = min((tr1 + 1) * tw, g.hrows);
+    const int lx0 = px0 & ~15;
+    const uint8_t* __restrict__ himg = P.half + ((size_t)frame * g.hrows) * g.hp;
+
+    // ---- S1: stage the half-res region in LDS (16-byte chunks, coalesced along rows)
+    {
+        const int chunks = (px1 - lx0 + 15) >> 4;
+        const int nrows = py1 - py0;
+        for (int i = tid; i < chunks * nrows; i += 256) {
+            const int r = i / chunks, c = i - r * chunks;
+            const int x = lx0 + c * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (x + 16 <= g.hp) v = *reinterpret_cast<const uint4*>(himg + (size_t)(py0 + r) * g.hp + x);
+            *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = v;
+        }
+    }
+    __syncthreads();
+    // ---- S2: per-threshold-tile min / max (corner_detector.cpp:42-53)
+    {
+        const int nc = tc1 - tc0 + 1, nr = tr1 - tr0 + 1;
+        for (int i = tid; i < nc * nr; i += 256) {
+            const int r = i / nc, c = i - r * nc;
+            const int ya = (tr0 + r) * tw, yb = min(ya + tw, g.hrows);
+            const int xa = (tc0 + c) * tw, xb = min(xa + tw, g.hcols);
+            int mn = 255, mx = 0;
+            for (int y = ya; y < yb; y++) {
+                const uint8_t* row = hr_s + (size_t)(y - py0) * L.rp - lx0;
+                for (int x = xa; x < xb; x++) {
+                    const int u = row[x];
+                    mn = min(mn, u);
+                    mx = max(mx, u);
+                }
+            }
+            ext_s[r * L.ec + c] = (uint16_t)(mn | (mx << 8));
+        }
+    }
+    __syncthreads();
+    // ---- S3: 3x3 min-of-min / max-of-max for interior tiles, zero elsewhere (corner_detector.cpp:54-67, B1)
+    {
+        const int nc = tcs1 - tcs0 + 1, nr = trs1 - trs0 + 1;
+        for (int i = tid; i < nc * nr; i += 256) {
+            const int r = i / nc, c = i - r * nc;
+            const int tr = trs0 + r, tc = tcs0 + c;
+            int T = 0;
+            if (tr >= 1 && tr <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2) {
+                int mn = 255, mx = 0;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int e = ext_s[(tr + dy - tr0) * L.ec + (tc + dx - tc0)];
+                        mn = min(mn, e & 0xff);
+                        mx = max(mx, e >> 8);
+                    }
+                T = threshold_bound(mn, mx);
+            }
+            thr_s[r * L.tc + c] = (uint16_t)T;
+        }
+    }
+    __syncthreads();
+    // ---- S4: binary row masks by wave ballot (corner_detector.cpp:69-78)
+    for (int item = wave; item < kTileH * kTileWords; item += 4) {
+        const int r = item / kTileWords, w = item - r * kTileWords;
+        const int xl = w * 64 + lane;
+        bool fg = false;
+        if (r < th_eff && xl < tw_eff) {
+            const int x = tx0 + xl, y = ty0 + r;
+            const int u = hr_s[(size_t)(y - py0) * L.rp + (x - lx0)];
+            const int T = thr_s[(y / tw - trs0) * L.tc + (x / tw - tcs0)];
+            fg = u < T;
+        }
+        const uint64_t m = __ballot(fg);
+        if (lane == 0) mask_s[item] = m;
+    }
+    __syncthreads();
+    // ---- S5: run starts, run numbering
+    int nruns_mine = 0;
+    if (tid < kTileH * kTileWords) {
+        const int w = tid % kTileWords;
+        const uint64_t m = mask_s[tid];
+        const uint64_t carry = w > 0 ? (mask_s[tid - 1] >> 63) : 0ull;
+        const uint64_t st = m & ~((m << 1) | carry);
+        start_s[tid] = st;
+        nruns_mine = __popcll(st);
+    }
+    int nruns;
+    const int rb = block_excl_scan(nruns_mine, misc_s, nruns);
+    if (tid < kTileH * kTileWords) runbase_s[tid] = rb;
+    bool overflow = nruns > kRunCap;
+    for (int i = tid; i < min(nruns, kRunCap); i += 256) parent_s[i] = (unsigned)i;
+    __syncthreads();
+    auto runid = [&](int item, int b) -> int { return runbase_s[item] + __popcll(start_s[item] & mask_le(b)) - 1; };
+
+    // ---- S6: unions between vertically adjacent rows (8-connectivity)
+    if (!overflow && tid < kTileH * kTileWords && tid >= kTileWords) {
+        const int w = tid % kTileWords;
+        const uint64_t cur = mask_s[tid];
+        if (cur) {
+            const int up_item = tid - kTileWords;
+            const uint64_t up = mask_s[up_item];
+            const uint64_t curL = w > 0 ? (mask_s[tid - 1] >> 63) : 0ull, curR = w < kTileWords - 1 ? (mask_s[tid + 1] & 1ull) : 0ull;
+            const uint64_t upL = w > 0 ? (mask_s[up_item - 1] >> 63) : 0ull, upR = w < kTileWords - 1 ? (mask_s[up_item + 1] & 1ull) : 0ull;
+            const uint64_t both = cur & up;
+            const uint64_t A = both & ~((both << 1) | (curL & upL));
+            const uint64_t B = cur & ~up & ((up << 1) | upL) & ~((cur << 1) | curL);
+            const uint64_t C = cur & ~up & ((up >> 1) | (upR << 63)) & ~((cur >> 1) | (curR << 63));
+            uint64_t todo = A | B | C;
+            while (todo) {
+                const int b = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+                const unsigned c = (unsigned)runid(tid, b);
+                if ((A >> b) & 1) lds_union(parent_s, c, (unsigned)runid(up_item, b));
+                if ((B >> b) & 1) lds_union(parent_s, c, (unsigned)(b > 0 ? runid(up_item, b - 1) : runid(up_item - 1, 63)));
+                if ((C >> b) & 1) lds_union(parent_s, c, (unsigned)(b < 63 ? runid(up_item, b + 1) : runid(up_item + 1, 0)));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- S7/S8: flatten, compact roots into slots
+    int nslots = 0;
+    {
+        int roots_mine = 0;
+        const int i0 = tid * (kRunCap / 256);
+        if (!overflow) {
+            for (int k = 0; k < kRunCap / 256; k++) {
+                const int i = i0 + k;
+                if (i < nruns && parent_s[i] == (unsigned)i) roots_mine++;
+            }
+        }
+        int s = block_excl_scan(roots_mine, misc_s, nslots);
+        if (!overflow) {
+            for (int k = 0; k < kRunCap / 256; k++) {
+                const int i = i0 + k;
+                if (i < nruns && parent_s[i] == (unsigned)i) lab_s[i] = (uint16_t)(s++);
+            }
+        }
+    }
+    if (nslots > kSlotCap) overflow = true;
+    __syncthreads();
+    int* st_area = reinterpret_cast<int*>(smem + L.off_region);  // staging region is dead from here on
+    int* st_xmin = st_area + kSlotCap;
+    int* st_xmax = st_xmin + kSlotCap;
+    int* st_ymin = st_xmax + kSlotCap;
+    int* st_ymax = st_ymin + kSlotCap;
+    int* st_key = st_ymax + kSlotCap;
+    if (!overflow) {
+        for (int i = tid; i < nruns; i += 256) {
+            const unsigned r = lds_find(parent_s, (unsigned)i);
+            if (r != (unsigned)i) lab_s[i] = lab_s[r];
+        }
+        for (int i = tid; i < nslots; i += 256) {
+            st_area[i] = 0;
+            st_xmin[i] = 0x7fffffff;
+            st_xmax[i] = -1;
+            st_ymin[i] = 0x7fffffff;
+            st_ymax[i] = -1;
+            st_key[i] = 0x7fffffff;
+        }
+    }
+    __syncthreads();
+    // ---- S9: per-slot stats from run segments (area, bbox, first 2x2 block in block-raster order)
+    const int bcols = (g.hcols + 1) >> 1;
+    if (!overflow && tid < kTileH * kTileWords) {
+        const int r = tid / kTileWords, w = tid - r * kTileWords;
+        uint64_t cur = mask_s[tid];
+        while (cur) {
+            const int s = __ffsll((unsigned long long)cur) - 1;
+            const uint64_t inv = ~(cur >> s);
+            const int len = inv ? (__ffsll((unsigned long long)inv) - 1) : (64 - s);
+            const int e = s + len - 1;
+            cur = (e >= 63) ? 0ull : (cur & ~mask_le(e));
+            const int slot = lab_s[runid(tid, s)];
+            const int gx0 = tx0 + w * 64 + s, gx1 = tx0 + w * 64 + e, gy = ty0 + r;
+            atomicAdd(&st_area[slot], len);
+            atomicMin(&st_xmin[slot], gx0);
+            atomicMax(&st_xmax[slot], gx1);
+            atomicMin(&st_ymin[slot], gy);
+            atomicMax(&st_ymax[slot], gy);
+            atomicMin(&st_key[slot], (gy >> 1) * bcols + (gx0 >> 1));
+        }
+    }
+    // ---- S10: allocate the tile's components in the frame pool
+    if (tid == 0) {
+        int base = 0, ovf = overflow ? 1 : 0;
+        if (!ovf && nslots > 0) {
+            base = atomicAdd(&P.frame_ncomp[frame], nslots);
+            if (base + nslots > kPoolCap) ovf = 1;
+        }
+        misc_s[8] = ovf;
+        misc_s[9] = base;
+    }
+    __syncthreads();  // also orders the S9 LDS atomics before the reads below
+    overflow = misc_s[8] != 0;
+    const int base = misc_s[9];
+    if (overflow) {
+        if (tid == 0) {
+            atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+            P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
+        }
+    } else {
+        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
+        const size_t pool0 = (size_t)frame * kPoolCap;
+        for (int i = tid; i < nslots; i += 256) {
+            const size_t gidx = pool0 + base + i;
+            P.parent[gidx] = (unsigned)(base + i);
+            P.area[gidx] = st_area[i];
+            P.xmin[gidx] = st_xmin[i];
+            P.xmax[gidx] = st_xmax[i];
+            P.ymin[gidx] = st_ymin[i];
+            P.ymax[gidx] = st_ymax[i];
+            P.key[gidx] = st_key[i];
+        }
+    }
+    // ---- S11: per-pixel tile-local labels, 8 pixels (16 bytes) per lane
+    {
+        uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+        constexpr int groups = kTileW / 8;
+        for (int i = tid; i < kTileH * groups; i += 256) {
+            const int r = i / groups, gq = i - r * groups;
+            if (r >= th_eff || gq * 8 >= tw_eff) continue;
+            const int item = r * kTileWords + (gq >> 3);
+            const int b0 = (gq & 7) * 8;
+            const unsigned byte = overflow ? 0u : (unsigned)((mask_s[item] >> b0) & 0xff);
+            uint32_t o[4] = {0, 0, 0, 0};
+            if (byte) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if ((byte >> k) & 1) {
+                        const uint32_t lab = (uint32_t)lab_s[runid(item, b0 + k)] + 1u;
+                        o[k >> 1] |= lab << (16 * (k & 1));
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s) {
+    const FrameGeom& g = ws.g;
+    const int grid = grid_for(nframes, g.tiles_x * g.tiles_y);
+    const size_t lds = threshold_ccl_lds_bytes(g.tw);
+    const SweepPtrs P = sweep_ptrs(ws);
+    if (g.tw == 5) {
+        hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(256), lds, s, P, g, nframes);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(256), lds, s, P, g, nframes);
+    }
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// K3: merge tile-local components across tile seams with a global (per-frame pool) union-find.
+// =====================================================================================================
+__device__ __forceinline__ unsigned g_find(const uint32_t* parent, unsigned x) {
+    unsigned p;
+    while ((p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != x) x = p;
+    return x;
+}
+__device__ __forceinline__ void g_union(uint32_t* parent, unsigned a, unsigned b) {
+    while (true) {
+        a = g_find(parent, a);
+        b = g_find(parent, b);
+        if (a == b) return;
+        if (a > b) {
+            const unsigned t = a;
+            a = b;
+            b = t;
+        }
+        const unsigned old = atomicMin(&parent[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, int nframes, int per_frame_blocks) {
+    int frame, bidx;
+    if (!map_block(blockIdx.x, per_frame_blocks, nframes, frame, bidx)) return;
+    const int nh = (g.tiles_y - 1) * g.hcols;  // pixels on the lower side of horizontal seams
+    const int nv = (g.tiles_x - 1) * g.hrows;  // pixels on the right side of vertical seams
+    const int i = bidx * 256 + threadIdx.x;
+    if (i >= nh + nv) return;
+    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
+    uint32_t* parent = P.parent + (size_t)frame * kPoolCap;
+    int x, y, nx[3], ny[3];
+    if (i < nh) {
+        const int s = i / g.hcols;
+        x = i - s * g.hcols;
+        y = (s + 1) * kTileH;
+        for (int k = 0; k < 3; k++) {
+            nx[k] = x - 1 + k;
+            ny[k] = y - 1;
+        }
+    } else {
+        const int j = i - nh;
+        const int s = j / g.hrows;
+        y = j - s * g.hrows;
+        x = (s + 1) * kTileW;
+        for (int k = 0; k < 3; k++) {
+            nx[k] = x - 1;
+            ny[k] = y - 1 + k;
+        }
+    }
+    const unsigned l = limg[(size_t)y * g.lp + x];
+    if (!l) return;
+    const unsigned me = (unsigned)tbase[(y / kTileH) * g.tiles_x + (x / kTileW)] + l - 1;
+    for (int k = 0; k < 3; k++) {
+        if (nx[k] < 0 || nx[k] >= g.hcols || ny[k] < 0 || ny[k] >= g.hrows) continue;
+        const unsigned ln = limg[(size_t)ny[k] * g.lp + nx[k]];
+        if (!ln) continue;
+        const unsigned other = (unsigned)tbase[(ny[k] / kTileH) * g.tiles_x + (nx[k] / kTileW)] + ln - 1;
+        g_union(parent, me, other);
+    }
+}
+
+hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s) {
+    const FrameGeom& g = ws.g;
+    const int n = (g.tiles_y - 1) * g.hcols + (g.tiles_x - 1) * g.hrows;
+    if (n <= 0) return hipSuccess;
+    const int per_frame = (n + 255) / 256;
+    hipLaunchKernelGGL(k_seam_merge, dim3(grid_for(nframes, per_frame)), dim3(256), 0, s, sweep_ptrs(ws), g, nframes, per_frame);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// K4: flatten every pool entry to its root and fold its stats into the root.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_resolve(SweepPtrs P, int nframes, int per_frame_blocks) {
+    int frame, bidx;
+    if (!map_block(blockIdx.x, per_frame_blocks, nframes, frame, bidx)) return;
+    const int n = min(P.frame_ncomp[frame], kPoolCap);
+    const size_t pool0 = (size_t)frame * kPoolCap;
+    for (int i = bidx * 256 + threadIdx.x; i < n; i += per_frame_blocks * 256) {
+        const unsigned r = g_find(P.parent + pool0, (unsigned)i);
+        P.root_of[pool0 + i] = (int)r;
+        if (r != (unsigned)i) {
+            atomicAdd(&P.area[pool0 + r], P.area[pool0 + i]);
+            atomicMin(&P.xmin[pool0 + r], P.xmin[pool0 + i]);
+            atomicMax(&P.xmax[pool0 + r], P.xmax[pool0 + i]);
+            atomicMin(&P.ymin[pool0 + r], P.ymin[pool0 + i]);
+            atomicMax(&P.ymax[pool0 + r], P.ymax[pool0 + i]);
+            atomicMin(&P.key[pool0 + r], P.key[pool0 + i]);
+        }
+    }
+}
+hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s) {
+    const int per_frame = 2;
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(nframes, per_frame)), dim3(256), 0, s, sweep_ptrs(ws), nframes, per_frame);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// K5: area filter (corner_detector.cpp:87-91) and OpenCV label order: candidates sorted
+// by the block-raster index of their first 2x2 block.  One block per frame; rank sort in LDS.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, int nframes) {
+    __shared__ int s_idx[kCandCap];
+    __shared__ int s_key[kCandCap];
+    __shared__ int s_count;
+    const int frame = blockIdx.x;
+    if (frame >= nframes) return;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const int n = min(P.frame_ncomp[frame], kPoolCap);
+    const size_t pool0 = (size_t)frame * kPoolCap;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (P.root_of[pool0 + i] == i) {
+            const int a = P.area[pool0 + i];
+            if (!(a < 30 || a > g.max_area)) {
+                const int at = atomicAdd(&s_count, 1);
+                if (at < kCandCap) {
+                    s_idx[at] = i;
+                    s_key[at] = P.key[pool0 + i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int c = s_count;
+    if (c > kCandCap) {
+        if (threadIdx.x == 0) {
+            atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+            P.ncand[frame] = 0;
+        }
+        return;
+    }
+    if (P.frame_flags[frame] & CTAG_FLAG_POOL_OVERFLOW) c = 0;
+    if (threadIdx.x == 0) P.ncand[frame] = c;
+    Candidate* out = P.cand + (size_t)frame * kCandCap;
+    for (int i = threadIdx.x; i < c; i += 256) {
+        const int k = s_key[i];
+        int rank = 0;
+        for (int j = 0; j < c; j++) rank += (s_key[j] < k) ? 1 : 0;
+        const int idx = s_idx[i];
+        Candidate cd;
+        cd.root = idx;
+        cd.area = P.area[pool0 + idx];
+        cd.x_min = (int16_t)P.xmin[pool0 + idx];
+        cd.y_min = (int16_t)P.ymin[pool0 + idx];
+        cd.x_max = (int16_t)P.xmax[pool0 + idx];
+        cd.y_max = (int16_t)P.ymax[pool0 + idx];
+        out[rank] = cd;
+    }
+}
+hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s) {
+    hipLaunchKernelGGL(k_candidates, dim3(nframes), dim3(256), 0, s, sweep_ptrs(ws), ws.g, nframes);
+    return hipGetLastError();
+}
+
+}  // namespace ctag

@@ -1,0 +1,113 @@
+/* ctag.h -- C ABI of the MI355X-native CylinderTag detection front end (libctag_hip.so).
+ *
+ * Drop-in boundary: everything the reference does inside
+ *     void CylinderTag::detect(const Mat& img, vector<MarkerInfo>& cornerList,
+ *                              int adaptiveThresh = 5, const bool cornerSubPix = false, int cornerSubPixDist = 3)
+ *     (/root/reference/header/CylinderTag.h:21, definition /root/reference/CylinderTag.cpp:67-159)
+ * runs behind these entry points on one gfx950 device.  The reference has no FFI of its own (it is a single
+ * C++ program); the C++ class in cylindertag_amd/csrc/CylinderTag.h keeps the reference's class interface
+ * and calls this ABI, and INTEGRATION.md shows the few lines a maintainer of the reference changes.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Every function returns a CTAG_* status
+ * (include/ctag_types.h) and never throws.  The library has NO CPU fallback: without a usable HIP device
+ * ctag_create fails with CTAG_ERR_HIP.
+ */
+#ifndef CTAG_H
+#define CTAG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ctag_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ctag_handle ctag_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------------
+ * Replaces the reference constructors CylinderTag(const string&) / CylinderTag(const Mat1i&)
+ * (header/CylinderTag.h:15,18; CylinderTag.cpp:6-65): `state` is the dictionary, dict_rows x dict_cols
+ * codes in 0..63 (check_dictionary, CylinderTag.cpp:56-65), `feature_size` the third number of the
+ * .marker header (CylinderTag.cpp:24-26).  Returns CTAG_ERR_ARG for an illegal dictionary. */
+int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_size, int device_id, ctag_handle** out);
+void ctag_destroy(ctag_handle* h);
+
+/* Parses a .marker text file exactly as CylinderTag::load_from_file does (CylinderTag.cpp:16-41).
+ * On success *state is malloc()ed (free with ctag_free). */
+int ctag_load_marker_file(const char* path, int32_t** state, int* dict_rows, int* dict_cols, int* feature_size);
+void ctag_free(void* p);
+
+/* ---- detection -----------------------------------------------------------------------------------
+ * One frame, host memory in, host result out.  Replaces the body of CylinderTag::detect
+ * (CylinderTag.cpp:67-159).  `gray` is an 8-bit single-channel image with `row_stride` bytes per row.
+ * The return value is the frame status: CTAG_OK, CTAG_NO_CORNER / CTAG_NO_FEATURE (the reference's two
+ * early returns, CylinderTag.cpp:87-96, which leave the caller's vector untouched), or an error. */
+int ctag_detect_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh,
+                   int corner_subpix, int subpix_dist, ctag_frame_result* out);
+
+/* A batch of independent frames in HOST memory (frame i starts at frames + i*frame_stride).  `out` holds n
+ * results in host memory.  Returns CTAG_OK when the batch ran (per-frame status is in out[i].status). */
+int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride,
+                         ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
+                         ctag_frame_result* out);
+
+/* A batch of frames already resident in DEVICE memory; results are written to DEVICE memory `out_dev`
+ * (n records).  Work is enqueued on the handle's stream and this call returns without waiting; use
+ * ctag_sync() or stream ordering.  This is the entry point the throughput bench times. */
+int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride,
+                             ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
+                             ctag_frame_result* out_dev);
+int ctag_sync(ctag_handle* h);
+/* HIP stream (hipStream_t) all work of this handle is enqueued on */
+void* ctag_stream(ctag_handle* h);
+
+/* ---- options / introspection --------------------------------------------------------------------- */
+#define CTAG_OPT_MAX_CHUNK 1      /* frames processed per pass (workspace is sized for it); default 1024 */
+#define CTAG_OPT_TIMING 2         /* 1: bracket every kernel with HIP events (ctag_get_timings) */
+#define CTAG_OPT_KEEP_PREMARKERS 3 /* 1: keep the markers before decoding for ctag_debug_fetch */
+int ctag_set_option(ctag_handle* h, int option, int64_t value);
+
+/* Per-stage device time of the LAST ctag_detect_batch_* call, milliseconds measured with HIP events on
+ * the handle's stream (needs CTAG_OPT_TIMING).  Order: decimate, threshold_ccl, seam_merge, resolve,
+ * candidates, quad, features, edge_refine, markers.  Returns the number of stages written. */
+#define CTAG_NUM_STAGES 9
+int ctag_get_timings(ctag_handle* h, float* ms, int capacity);
+const char* ctag_stage_name(int stage);
+const char* ctag_strerror(int status);
+int ctag_version(void);
+
+/* ---- parity probes (tests only): intermediates of frame `frame` of the last chunk -------------------- */
+#define CTAG_DBG_HALF 1       /* uint8  [hrows*hcols]   half-resolution image (a1) */
+#define CTAG_DBG_LABELS 2     /* int32  [hrows*hcols]   0 = background, else 1 + frame-local root id (a2,a3) */
+#define CTAG_DBG_CANDIDATES 3 /* int32  [ncand*8]       area, x_min, y_min, x_max, y_max, has_quad, n_boundary, root */
+#define CTAG_DBG_CAND_QUADS 4 /* float  [ncand*8] */
+#define CTAG_DBG_FEATURES0 5  /* float  [nfeat*19]      after featureRecovery (half-res) */
+#define CTAG_DBG_FEATURES1 6  /* float  [nfeat*19]      after cornerObtain */
+#define CTAG_DBG_FEATURES2 7  /* float  [nfeat*19]      after edgeRefine */
+#define CTAG_DBG_PREMARKERS 8 /* ctag_frame_result      markers before decoding */
+/* returns the number of ELEMENTS available (copies min(available, capacity) elements), < 0 on error */
+long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t capacity_elems);
+
+/* evaluates the shared deterministic math (cylindertag_amd/csrc/ctag_math.h) on the device; op codes as
+ * oracle/ctag_oracle.h:ctago_math_probe.  Host arrays in/out. */
+int ctag_math_probe(ctag_handle* h, int op, int n, const double* a, const double* b, double* out);
+
+/* ---- synthetic frames (bench / tests) ---------------------------------------
+ * Frame f is a pure function of (seed + f): gray background with a ramp and noise plus `markers` planted
+ * CylinderTag strips of the given dictionary.  The same code renders on the device and on the host. */
+typedef struct ctag_synth_truth {
+    int32_t n_markers;
+    int32_t dict_row[8];
+    float strip_len[8];      /* L, full-res pixels */
+    float corners[8][8];     /* image positions of the strip's 4 outer corners */
+} ctag_synth_truth;
+int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols,
+                             ptrdiff_t row_stride, ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame);
+int ctag_synth_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows,
+                          int cols, ptrdiff_t row_stride, uint64_t seed, int markers_per_frame, ctag_synth_truth* truth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
