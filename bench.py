@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the MI355X-native CylinderTag detect() front end on BASELINE.json's config 3:
+a synthetic batch of 1920x1080 random-stripe frames, resident in HBM, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one pass of the whole detect() path (resize -> threshold -> label -> quads -> features -> sub-pixel
+refine -> decode) over one batch of frames per GPU; frames are independent, so each rank owns its own shard of
+the job (weak scaling) and the only collective is the final RCCL all-gather of the result records.
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline      the threshold+label sweep (2*W*H algorithmic bytes per frame) against 8 TB/s HBM,
+                timed with HIP events on the library's own stream
+  cpu_baseline  the CPU restatement (oracle/, "port") timed on the host cores on a bounded sample of the batch
+PyTorch is used only for device memory, synchronisation and torch.distributed.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS, COLS = 1080, 1920
+ALGO_BYTES_PER_FRAME = 2 * ROWS * COLS  # read W*H u8 once + write (W/2)(H/2) i32 labels once
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
+SWEEP_STAGES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates"]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (BASELINE config 3: 4096)")
+    ap.add_argument("--chunk", type=int, default=1024, help="frames per pipeline pass (workspace size)")
+    ap.add_argument("--markers", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-subpix", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_host, state, fs, subpix):
+    """Times the CPU restatement of detect() (oracle, kind 'port'), single thread, on the given frames."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ctag_testlib import Oracle  # the oracle is test infrastructure: used here only as the timed CPU baseline
+    orc = Oracle()
+    n = frames_host.shape[0]
+    orc.detect_fast(frames_host[0], state, fs, 5, subpix, 5)  # warm
+    t0 = time.perf_counter()
+    for i in range(n):
+        orc.detect_fast(frames_host[i], state, fs, 5, subpix, 5)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "first %d frames of the same synthetic batch, CPU restatement of detect() "
+                      "(oracle/ctag_oracle.cpp, -O2 -ffp-contract=off), 1 thread, %.1f s" % (n, dt)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import cylindertag_amd as ca
+    from cylindertag_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the detection path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
+    det = ca.Detector(state, fs, device=local_rank)
+    det.set_option(capi.OPT_MAX_CHUNK, args.chunk)
+    n = args.frames
+    subpix = not args.no_subpix
+
+    # ---- synthetic shard of this rank, generated on the device (frames [rank*n, (rank+1)*n) of the job)
+    frames = torch.empty((n, ROWS, COLS), dtype=torch.uint8, device=dev)
+    det.synth_frames_device(frames.data_ptr(), rank * n, n, ROWS, COLS, COLS, ROWS * COLS, markers=args.markers)
+    results = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    gathered = torch.empty((world * n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, results.data_ptr(), 5, subpix, 5)
+        if world > 1:
+            det.sync()  # results are produced on the library's stream
+            dist.all_gather_into_tensor(gathered, results)  # the path's only exchange: final marker lists
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel device time with HIP events on the library's stream (outside the timed region)
+    det.set_option(capi.OPT_TIMING, 1)
+    tsteps = max(1, min(args.steps, 3))
+    acc = {k: 0.0 for k in ca.STAGE_NAMES}
+    for _ in range(tsteps):
+        det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, results.data_ptr(), 5, subpix, 5)
+        det.sync()
+        for k, v in det.timings().items():
+            acc[k] += v
+    det.set_option(capi.OPT_TIMING, 0)
+    stage_ms = {k: v / tsteps for k, v in acc.items()}  # per step (n frames)
+    launches = (n + args.chunk - 1) // args.chunk
+
+    # ---- sanity on the outcome of the last step
+    res = np.frombuffer(results.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    ok_frames = int((res["status"] == 0).sum())
+    markers_found = int(res["n_markers"].sum())
+
+    if rank == 0:
+        sweep_ms = sum(stage_ms[k] for k in SWEEP_STAGES)
+        achieved = ALGO_BYTES_PER_FRAME * n / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("sweep_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "kernel": "threshold+label sweep = " + "+".join("k_" + k for k in SWEEP_STAGES),
+                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * min(n, args.chunk),
+                    "avg_launch_ms": round(sweep_ms / launches, 4), "launches_per_step": launches,
+                    "frames_per_launch": min(n, args.chunk)}
+        out = {"metric": "frames/sec detect() 1920x1080", "value": round(world * n * args.steps / dt, 2),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "synthetic 1920x1080 random-stripe frames, %d per GPU per step, %d planted "
+                                      "CTag_2f12c markers each, detect(img,5,%s,5), inputs resident in HBM"
+                                      % (n, args.markers, "true" if subpix else "false"),
+                          "frames_per_gpu": n, "chunk": args.chunk, "parallelism": "frames sharded, dp%d" % world},
+               "roofline": roofline,
+               "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
+               "frames_ok": ok_frames, "markers_decoded_last_step": markers_found}
+        if world == 1 and args.cpu_frames > 0:
+            m = min(args.cpu_frames, n)
+            out["cpu_baseline"] = cpu_baseline(frames[:m].cpu().numpy(), state, fs, subpix)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    det.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURE
 EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
            "ctag_detect_batch_device", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
            "ctag_stage_name", "ctag_strerror", "ctag_version", "ctag_debug_fetch", "ctag_math_probe",
-           "ctag_synth_frames_device", "ctag_synth_frame_host"]
+           "ctag_synth_frames_device", "ctag_synth_frame_host", "ctag_synth_layout_truth"]
 
 
 class CtagError(RuntimeError):
@@ -97,6 +97,8 @@ def load_library():
     L.ctag_synth_frame_host.restype = C.c_int
     L.ctag_synth_frame_host.argtypes = [i32p, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_uint64,
                                         C.c_int, vp]
+    L.ctag_synth_layout_truth.restype = C.c_int
+    L.ctag_synth_layout_truth.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp]
     _lib = L
     return L
 
@@ -138,6 +140,18 @@ def synth_frame_host(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, 
     if st != 0:
         raise CtagError(st)
     return img, truth[0]
+
+
+def synth_truth(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, markers=4):
+    """Planted markers (dictionary rows, strip corners) of synthetic frame `frame_index`, without rendering."""
+    L = load_library()
+    state = np.ascontiguousarray(state, dtype=np.int32)
+    truth = np.zeros(1, TRUTH_DT)
+    st = L.ctag_synth_layout_truth(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1], frame_index, rows,
+                            cols, seed, markers, truth.ctypes.data)
+    if st != 0:
+        raise CtagError(st)
+    return truth[0]
 
 
 class Detector:

@@ -596,6 +596,26 @@ int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_fram
     return CTAG_OK;
 }
 
+static void fill_truth(const ctag_synth::Truth& T, ctag_synth_truth* truth) {
+    std::memset(truth, 0, sizeof(*truth));
+    truth->n_markers = T.n;
+    for (int k = 0; k < T.n && k < 8; k++) {
+        truth->dict_row[k] = T.dict_row[k];
+        truth->strip_len[k] = T.strip_len[k];
+        for (int q = 0; q < 8; q++) truth->corners[k][q] = T.corners[k][q];
+    }
+}
+
+int ctag_synth_layout_truth(const int32_t* state, int dict_rows, int dict_cols, int frame_index, int rows, int cols, uint64_t seed,
+                     int markers_per_frame, ctag_synth_truth* truth) {
+    if (!state || !truth || rows < 1 || cols < 1 || dict_rows < 1 || dict_cols < 1) return CTAG_ERR_ARG;
+    ctag_synth::Frame F;
+    ctag_synth::Truth T;
+    ctag_synth::layout(state, dict_rows, dict_cols, seed, frame_index, rows, cols, markers_per_frame, &F, &T);
+    fill_truth(T, truth);
+    return CTAG_OK;
+}
+
 int ctag_synth_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows, int cols, ptrdiff_t row_stride,
                           uint64_t seed, int markers_per_frame, ctag_synth_truth* truth) {
     if (!state || !frame || rows < 1 || cols < 1 || row_stride < cols || dict_rows < 1 || dict_cols < 1) return CTAG_ERR_ARG;
@@ -604,15 +624,7 @@ int ctag_synth_frame_host(const int32_t* state, int dict_rows, int dict_cols, ui
     ctag_synth::layout(state, dict_rows, dict_cols, seed, frame_index, rows, cols, markers_per_frame, &F, &T);
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) frame[(ptrdiff_t)y * row_stride + x] = ctag_synth::pixel(F, x, y, rows, cols);
-    if (truth) {
-        std::memset(truth, 0, sizeof(*truth));
-        truth->n_markers = T.n;
-        for (int k = 0; k < T.n && k < 8; k++) {
-            truth->dict_row[k] = T.dict_row[k];
-            truth->strip_len[k] = T.strip_len[k];
-            for (int q = 0; q < 8; q++) truth->corners[k][q] = T.corners[k][q];
-        }
-    }
+    if (truth) fill_truth(T, truth);
     return CTAG_OK;
 }
 

@@ -505,6 +505,16 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     if (frame >= nframes) return;
     const int tid = threadIdx.x;
     ctag_frame_result* out = P.out + frame;
+    // every byte of a result record is defined (unused slots are zero): records are compared / gathered as raw bytes
+    {
+        uint32_t* w = reinterpret_cast<uint32_t*>(out);
+        for (int i = tid; i < (int)(sizeof(ctag_frame_result) / 4); i += 64) w[i] = 0u;
+        if (P.pre) {
+            uint32_t* wp = reinterpret_cast<uint32_t*>(P.pre + frame);
+            for (int i = tid; i < (int)(sizeof(ctag_frame_result) / 4); i += 64) wp[i] = 0u;
+        }
+    }
+    __syncthreads();
     const int status = P.status[frame];
     const uint32_t flags = P.frame_flags[frame];
     const int nf = P.nfeat[frame];

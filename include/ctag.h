@@ -107,6 +107,10 @@ int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_fram
 int ctag_synth_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows,
                           int cols, ptrdiff_t row_stride, uint64_t seed, int markers_per_frame, ctag_synth_truth* truth);
 
+/* planted markers of synthetic frame `frame_index` without rendering it */
+int ctag_synth_layout_truth(const int32_t* state, int dict_rows, int dict_cols, int frame_index, int rows, int cols, uint64_t seed,
+                     int markers_per_frame, ctag_synth_truth* truth);
+
 #ifdef __cplusplus
 }
 #endif

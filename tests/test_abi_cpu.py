@@ -1,0 +1,87 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports what include/ctag.h declares, the
+loaders behave like the reference's, the synthetic generator is deterministic, and -- without a GPU -- the
+detection entry points fail loudly instead of falling back to a CPU implementation."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cylindertag_amd as ca
+from cylindertag_amd import capi
+from ctag_testlib import GOLDEN, ROOT, read_marker_file
+
+
+def test_library_exports_every_declared_symbol():
+    ca.build()
+    hdr = open(os.path.join(ROOT, "include", "ctag.h")).read()
+    declared = set(re.findall(r"\b(ctag_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.EXPORTS)
+    L = capi.load_library()
+    for s in declared:
+        assert hasattr(L, s), s
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", ca.lib_path()]).decode()
+    for s in declared:
+        assert re.search(r"\bT %s\b" % s, nm), s
+    assert L.ctag_version() >= 100
+
+
+def test_result_record_layout_matches_header():
+    assert ca.RESULT_DT.itemsize == 11616 and ca.FEATURE_DT.itemsize == 100 and ca.MARKER_DT.itemsize == 16
+
+
+def test_marker_loader_matches_reference_format(tmp_path):
+    state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    ref, rfs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    assert fs == rfs == 2 and state.shape == (41, 12) and (state == ref).all()
+    bad = tmp_path / "bad.marker"
+    bad.write_text("1 3 2\n1 64 3\n")  # code outside 0..63: check_dictionary (CylinderTag.cpp:56-65)
+    with pytest.raises(ca.CtagError):
+        ca.load_marker_file(str(bad))
+    with pytest.raises(ca.CtagError):
+        ca.load_marker_file(str(tmp_path / "missing.marker"))
+
+
+def test_create_rejects_illegal_dictionary_before_touching_the_gpu():
+    L = capi.load_library()
+    h = C.c_void_p()
+    bad = np.array([[1, 2, 99]], np.int32)
+    assert L.ctag_create(bad.ctypes.data_as(C.POINTER(C.c_int32)), 1, 3, 2, 0, C.byref(h)) == -1  # CTAG_ERR_ARG
+    assert not h.value
+
+
+def test_no_cpu_fallback_without_gpu(dictionary):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    state, fs = dictionary
+    with pytest.raises(ca.CtagError) as e:
+        ca.Detector(state, fs)
+    assert e.value.status == -2  # CTAG_ERR_HIP
+
+
+def test_synthetic_generator_is_deterministic_and_planted(dictionary):
+    state, fs = dictionary
+    a, ta = ca.synth_frame_host(state, 7, rows=540, cols=960)
+    b, tb = ca.synth_frame_host(state, 7, rows=540, cols=960)
+    c, tc = ca.synth_frame_host(state, 8, rows=540, cols=960)
+    assert (a == b).all() and ta.tobytes() == tb.tobytes() and not (a == c).all()
+    assert ta["n_markers"] == 4 and (ta["strip_len"][:4] > 100).all()
+    assert a.min() < 60 and a.max() > 200  # black quads and white paper are present
+
+
+def test_strerror_messages_mirror_reference_text():
+    L = capi.load_library()
+    assert L.ctag_strerror(1) == b"No corner detected!" and L.ctag_strerror(2) == b"No feature detected!"
+    assert [L.ctag_stage_name(i).decode() for i in range(9)] == ca.STAGE_NAMES
+
+
+def test_cpp_host_layer_builds_and_keeps_reference_interface():
+    so = os.path.join(ROOT, "cylindertag_amd", "_build", "libcylindertag.so")
+    assert os.path.exists(so)
+    nm = subprocess.check_output(["nm", "-DC", "--defined-only", so]).decode()
+    assert "CylinderTag::detect(" in nm and "CylinderTag::CylinderTag(std::" in nm
+    hdr = " ".join(open(os.path.join(ROOT, "cylindertag_amd", "csrc", "CylinderTag.h")).read().split())
+    assert "int adaptiveThresh = 5, const bool cornerSubPix = false, int cornerSubPixDist = 3" in hdr

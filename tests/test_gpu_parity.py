@@ -1,0 +1,160 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden fixtures.  Bar: byte-identical result records (integer ids, positions, order AND float corners; the
+north-star tolerance is 1e-3 px, we hold 0)."""
+import os
+
+import numpy as np
+import pytest
+
+import cylindertag_amd as ca
+from cylindertag_amd import capi
+from ctag_testlib import GOLDEN, result_markers
+from sequences import avi_substitute
+
+pytestmark = pytest.mark.gpu
+
+CORNER_TOL_PX = 1e-3  # north_star tolerance; asserted in addition to byte equality where both are checked
+
+
+def assert_same_record(got, want, what=""):
+    assert got["status"] == want["status"], what
+    assert got["n_markers"] == want["n_markers"] and got["n_features"] == want["n_features"], what
+    n = int(want["n_features"])
+    for f in ("pos", "id", "id_left", "id_right"):
+        assert (got["features"][f][:n] == want["features"][f][:n]).all(), (what, f)
+    assert (got["markers"][:want["n_markers"]] == want["markers"][:want["n_markers"]]).all(), what
+    if n:
+        assert np.abs(got["features"]["corners"][:n] - want["features"]["corners"][:n]).max() <= CORNER_TOL_PX, what
+    assert got.tobytes() == want.tobytes(), what + " (byte equality)"
+
+
+def test_device_math_is_bit_identical_to_host(detector, oracle):
+    rng = np.random.RandomState(11)
+    a = np.concatenate([rng.uniform(-1e3, 1e3, 40000), rng.uniform(-1, 1, 20000), [0.0, -0.0, 1.0, -1.0, 1e-30, 3.5e4]])
+    b = np.concatenate([rng.uniform(-1e3, 1e3, 40000), rng.uniform(-1, 1, 20000), [1.0, -1.0, 0.0, 0.0, 1e30, -2.5]])
+    for op in range(15):
+        x, y = a, b
+        if op in (3, 8):
+            x = np.clip(a, -100, 80) if op == 3 else np.clip(a, -120, 80)
+        if op == 4:
+            x = np.clip(a, -1, 1).astype(np.float32).astype(np.float64)
+        if op in (11, 13):
+            x = np.abs(a)
+        g, c = detector.math(op, x, y), oracle.math(op, x, y)
+        assert g.tobytes() == c.tobytes(), "math op %d differs between gfx950 and x86-64" % op
+
+
+def test_test_bmp_every_stage(detector, oracle, dictionary, test_bmp):
+    state, fs = dictionary
+    detector.set_option(capi.OPT_KEEP_PREMARKERS, 1)
+    o = oracle.detect(test_bmp, state, fs)
+    r = detector.detect(test_bmp)
+    assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all()
+    lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+    assert ((lab > 0) == (o["binary"] > 0)).all()
+    pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
+    assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))  # same partition
+    cand = detector.debug(0, capi.DBG_CANDIDATES)
+    assert (cand[:, 0:5] == o["candidates"][:, 1:6]).all()  # area, bbox, in OpenCV label order
+    assert (cand[:, 5] == o["candidates"][:, 6]).all() and (cand[:, 6] == o["candidates"][:, 7]).all()
+    assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
+    for st, what in enumerate((capi.DBG_FEATURES0, capi.DBG_FEATURES1, capi.DBG_FEATURES2)):
+        assert detector.debug(0, what).tobytes() == o["features"][st].tobytes()
+    assert detector.debug(0, capi.DBG_PREMARKERS).tobytes() == o["premarkers"].tobytes()
+    assert_same_record(r, o["result"], "test.bmp")
+    assert [m["marker_id"] for m in result_markers(r)] == [23, 0, 1, 17, 5]
+
+
+def test_golden_fixtures(detector, test_bmp, dictionary):
+    g = np.load(os.path.join(GOLDEN, "golden_v1.npz"))
+    state, fs = dictionary
+    assert_same_record(detector.detect(test_bmp), g["bmp_result"][0], "golden test.bmp")
+    seq = avi_substitute(test_bmp, 64)  # stand-in for the reference's missing test.avi (BASELINE config 2)
+    res = detector.detect_batch(seq)
+    for k in range(64):
+        assert_same_record(res[k], g["seq_results"][k], "sequence frame %d" % k)
+    syn = np.stack([ca.synth_frame_host(state, f)[0] for f in range(8)])
+    res = detector.detect_batch(syn)
+    for k in range(8):
+        assert_same_record(res[k], g["synth_results"][k], "synthetic frame %d" % k)
+
+
+@pytest.mark.parametrize("subpix,dist,tw", [(False, 3, 5), (True, 3, 5), (True, 5, 4), (True, 5, 7)])
+def test_parameters(detector, oracle, dictionary, test_bmp, subpix, dist, tw):
+    state, fs = dictionary
+    img = test_bmp[60:1140]
+    assert_same_record(detector.detect(img, tw, subpix, dist), oracle.detect_fast(img, state, fs, tw, subpix, dist),
+                       "params subpix=%s dist=%d tw=%d" % (subpix, dist, tw))
+
+
+def test_edge_cases(detector, oracle, dictionary, test_bmp):
+    state, fs = dictionary
+    blank = np.full((600, 800), 180, np.uint8)
+    one = blank.copy()
+    one[260:340, 300:330] = 10
+    dark = np.zeros((400, 640), np.uint8)
+    rng = np.random.RandomState(3)
+    noise = rng.randint(0, 256, (360, 500)).astype(np.uint8)
+    ragged = test_bmp[3:1001, 5:1711]  # 998 x 1706: not multiples of the CCL tile, the window or 16 bytes
+    strided = np.ascontiguousarray(test_bmp[:, :1900])[:, :1888]
+    for name, img, want_status in (("blank", blank, 1), ("one quad", one, 2), ("all dark", dark, None),
+                                   ("noise", noise, None), ("ragged", ragged, None)):
+        got, want = detector.detect(img), oracle.detect_fast(img, state, fs)
+        if want_status is not None:
+            assert want["status"] == want_status
+        assert_same_record(got, want, name)
+    # non-contiguous rows (row_stride > cols) through the raw ABI
+    import ctypes as C
+    res = np.zeros(1, ca.RESULT_DT)
+    base = np.ascontiguousarray(test_bmp)
+    st = detector.L.ctag_detect_u8(detector.h, base.ctypes.data, 1200, 1888, base.strides[0], 5, 1, 5, res.ctypes.data)
+    assert st == 0
+    assert_same_record(res[0], oracle.detect_fast(base[:, :1888], state, fs), "strided")
+    with pytest.raises(ca.CtagError):
+        detector.detect(test_bmp[:, :1919])  # odd width: unsupported on the GPU path, reported loudly
+
+
+def test_batch_equals_single_and_is_repeatable(detector, dictionary):
+    state, fs = dictionary
+    frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
+    a = detector.detect_batch(frames)
+    b = detector.detect_batch(frames[::-1].copy())[::-1]
+    assert a.tobytes() == b.tobytes()  # results do not depend on batch order / neighbours
+    detector.set_option(capi.OPT_MAX_CHUNK, 4)  # 6 frames in chunks of 4 + 2
+    c = detector.detect_batch(frames)
+    detector.set_option(capi.OPT_MAX_CHUNK, 1024)
+    assert a.tobytes() == c.tobytes()
+    for k in range(6):
+        assert a[k].tobytes() == detector.detect(frames[k]).tobytes()
+
+
+def test_full_size_batch_properties(detector, oracle, dictionary):
+    """BASELINE config 3 at full size through the device-resident entry point: frames generated on the GPU equal
+    the host generator, every frame decodes exactly its planted dictionary rows, a second pass is byte-identical,
+    and a sample of frames equals the oracle."""
+    import torch
+    state, fs = dictionary
+    n, rows, cols = 512, 1080, 1920
+    frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+    detector.synth_frames_device(frames.data_ptr(), 0, n, rows, cols, cols, rows * cols)
+    host0, truth0 = ca.synth_frame_host(state, 0)
+    assert (frames[0].cpu().numpy() == host0).all()
+    out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr())
+    detector.sync()
+    a = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr())
+    detector.sync()
+    b = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    assert a.tobytes() == b.tobytes()
+    assert (a["status"] == 0).all() and (a["flags"] == 0).all()
+    exact = 0
+    for f in range(n):
+        truth = ca.synth_truth(state, f)
+        planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
+        found = sorted(int(x) for x in a[f]["markers"]["marker_id"][:a[f]["n_markers"]])
+        exact += planted == found
+        assert set(found) <= set(planted), f  # never a wrong id
+    assert exact >= int(0.97 * n)
+    for f in (0, 17, 255, 511):
+        assert_same_record(a[f], oracle.detect_fast(frames[f].cpu().numpy(), state, fs), "synthetic frame %d" % f)
