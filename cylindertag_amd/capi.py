@@ -53,6 +53,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:  # torch wheels bundle their own libamdhip64: let it load first so the process holds ONE HIP runtime
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_LIB):
         raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(the detection path has no CPU fallback)" % _LIB)

@@ -13,10 +13,13 @@
 // accumulates sequentially is accumulated in the same order so results are bit-identical to the oracle.
 #include "ctag_internal.h"
 #include "ctag_math.h"
+#include <cstdlib>
 
 namespace ctag {
 
-constexpr int kQuadThreads = 128;
+constexpr int kQuadThreads = 64;   // one wave per component: the serial phases are latency-bound, so more resident
+                                    // components per CU beat more lanes per component
+constexpr int kQuadWaves = kQuadThreads / 64;
 constexpr int kQuadLdsWords = 3072;  // 12 KB of per-component working storage in LDS
 
 struct QuadPtrs {
@@ -29,6 +32,7 @@ struct QuadPtrs {
     uint32_t* scratch;
     int32_t* scratch_used;
     uint32_t* frame_flags;
+    int dbg_stop;  // developer aid: leave the component after phase N (0 = run everything)
 };
 
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
@@ -158,6 +162,9 @@ struct CornerPre {
     float x, y, dis, ang;
 };
 
+// BIG = false: components whose working set fits the LDS budget (LDS-typed pointers, the common case);
+// BIG = true: the rare oversize components, same code on a global scratch slot.
+template <bool BIG>
 __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, int nframes) {
     __shared__ uint32_t s_mem[kQuadLdsWords];
     __shared__ uint16_t s_picks[4][20][10];
@@ -165,8 +172,8 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
     __shared__ float s_line[80][4];
     __shared__ unsigned long long s_sum[2];
     __shared__ int s_i[16];
-    __shared__ float s_redf[2];
-    __shared__ int s_redi[2];
+    __shared__ float s_redf[kQuadWaves];
+    __shared__ int s_redi[kQuadWaves];
     __shared__ int s_cl_off[5];
 
     const int frame = blockIdx.y;
@@ -187,8 +194,9 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
         const int C = min(2 * (w + h), w * h) + 1;
         const int w2 = (w + 1) & ~1;
         const size_t need = (size_t)(w2) + 2 * (size_t)h + 3 * (size_t)C + 72;
+        if (BIG != (need > (size_t)kQuadLdsWords)) continue;  // block-uniform: the other instantiation owns it
         uint32_t* mem = s_mem;
-        if (need > (size_t)kQuadLdsWords) {  // block-uniform
+        if (BIG) {
             if (tid == 0) s_i[0] = atomicAdd(P.scratch_used, 1);
             __syncthreads();
             const int slot = s_i[0];
@@ -246,8 +254,14 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
             }
         }
         __syncthreads();
-        // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418), thread 0, explicit stack
-        if (tid == 0) {
+        if (P.dbg_stop == 1) {
+            if (tid == 0) out->valid = 0;
+            continue;
+        }
+        // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): explicit stack, wave 0; lanes 0..7 test
+        // the 8 neighbours (N,NE,E,SE,S,SW,W,NW) of the current frame at once, the first hit at or after the frame's
+        // resume index wins -- the same visiting order as the reference's recursion with its moving `starter` (B7).
+        if (wave == 0) {
             auto member = [&](int x, int y) { return top[x] == y || bot[x] == y || lef[y] == (unsigned)x || rig[y] == (unsigned)(x + 1); };
             auto clear = [&](int x, int y) {
                 if (top[x] == y) top[x] = 0xffff;
@@ -255,43 +269,48 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
                 if (lef[y] == (unsigned)x) lef[y] = 0xffffffffu;
                 if (rig[y] == (unsigned)(x + 1)) rig[y] = 0u;
             };
-            const int xb[8] = {0, 1, 1, 1, 0, -1, -1, -1};
-            const int yb[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
-            int n = 0;
-            const int sx = 0, sy = top[0];
-            int sp = 0;
-            if (sy == 0xffff) {  // inconsistent labels (only after a flagged pool overflow): give up on this component
+            // x_bias = {0,1,1,1,0,-1,-1,-1}, y_bias = {-1,-1,0,1,1,1,0,-1} packed as (bias+1) in 2 bits per direction
+            const int jd = lane & 7;
+            const int dxl = (int)((0x01A9u >> (2 * jd)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * jd)) & 3u) - 1;
+            int n = 0, sp = 0;
+            const int sy0 = top[0];
+            if (sy0 == 0xffff) {  // inconsistent labels (only after a flagged pool overflow): give up on this component
                 sp = -1;
             } else {
-                bufA[n++] = pack_xy(sx + x_min, sy + y_min);
-                clear(sx, sy);
+                if (lane == 0) {
+                    bufA[0] = pack_xy(x_min, sy0 + y_min);
+                    clear(0, sy0);
+                    bufB[0] = (uint32_t)0 | ((uint32_t)sy0 << 14);  // x:14 y:14 j:4
+                }
+                n = 1;
             }
-            bufB[0] = (uint32_t)sx | ((uint32_t)sy << 14);  // x:14 y:14 j:4
             while (sp >= 0) {
                 const uint32_t f = bufB[sp];
-                const int fx = (int)(f & 0x3fff), fy = (int)((f >> 14) & 0x3fff);
-                int j = (int)(f >> 28);
-                bool pushed = false;
-                for (; j < 8; j++) {
-                    const int nx = fx + xb[j], ny = fy + yb[j];
-                    if (ny >= 0 && ny < h && nx >= 0 && nx < w && member(nx, ny)) {
-                        if (n < C) bufA[n] = pack_xy(nx + x_min, ny + y_min);
-                        n++;
-                        clear(nx, ny);
-                        bufB[sp] = (uint32_t)nx | ((uint32_t)ny << 14) | ((uint32_t)(j + 1) << 28);
-                        if (sp + 1 <= C) {
-                            sp++;
-                            bufB[sp] = (uint32_t)nx | ((uint32_t)ny << 14);
-                        }
-                        pushed = true;
-                        break;
-                    }
+                const int fx = (int)(f & 0x3fff), fy = (int)((f >> 14) & 0x3fff), j0 = (int)(f >> 28);
+                const int nx = fx + dxl, ny = fy + dyl;
+                bool hit = false;
+                if (lane < 8 && jd >= j0 && ny >= 0 && ny < h && nx >= 0 && nx < w) hit = member(nx, ny);
+                const unsigned m = (unsigned)(__ballot(hit) & 0xffull);
+                if (!m) {
+                    sp--;
+                    continue;
                 }
-                if (!pushed) sp--;
+                const int j = __ffs(m) - 1;
+                const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
+                if (lane == 0) {
+                    if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
+                    clear(hx, hy);
+                    bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
+                    if (sp + 1 <= C) bufB[sp + 1] = (uint32_t)hx | ((uint32_t)hy << 14);
+                }
+                n++;
+                if (sp + 1 <= C) sp++;
             }
-            s_i[1] = min(n, C);
-            s_sum[0] = 0ull;
-            s_sum[1] = 0ull;
+            if (lane == 0) {
+                s_i[1] = min(n, C);
+                s_sum[0] = 0ull;
+                s_sum[1] = 0ull;
+            }
         }
         __syncthreads();
         int n = s_i[1];
@@ -301,6 +320,10 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
                 out->valid = 0;
                 out->n_boundary = 0;
             }
+            continue;
+        }
+        if (P.dbg_stop == 2) {
+            if (tid == 0) out->valid = 0;
             continue;
         }
         // ---- P3: boundary centroid (:250-256), nearest point (:259-263), rotation (:264-275)
@@ -351,7 +374,12 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
         __syncthreads();
         {
             int b0 = s_redi[0];
-            if (s_redf[1] < s_redf[0] || (s_redf[1] == s_redf[0] && s_redi[1] < s_redi[0])) b0 = s_redi[1];
+            float b0d = s_redf[0];
+            for (int q = 1; q < kQuadWaves; q++)
+                if (s_redf[q] < b0d || (s_redf[q] == b0d && s_redi[q] < b0)) {
+                    b0d = s_redf[q];
+                    b0 = s_redi[q];
+                }
             for (int k = tid; k < n; k += kQuadThreads) {
                 int src = k + b0;
                 if (src >= n) src -= n;
@@ -361,6 +389,10 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
         __syncthreads();
         uint32_t* W = bufB;   // working list
         uint32_t* Wn = bufA;  // next list
+        if (P.dbg_stop == 3) {
+            if (tid == 0) out->valid = 0;
+            continue;
+        }
         // ---- P4: extended RDP (:278-349).  Thread 0 drives; max-distance search and list surgery use all threads.
         if (tid == 0) {
             s_i[2] = 0;  // cnt_boundary
@@ -441,10 +473,11 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
                 __syncthreads();
                 float md = s_redf[0];
                 int mi = s_redi[0];
-                if (s_redf[1] > md || (s_redf[1] == md && s_redi[1] > mi)) {
-                    md = s_redf[1];
-                    mi = s_redi[1];
-                }
+                for (int q = 1; q < kQuadWaves; q++)
+                    if (s_redf[q] > md || (s_redf[q] == md && s_redi[q] > mi)) {
+                        md = s_redf[q];
+                        mi = s_redi[q];
+                    }
                 const int count = end - init - 1;
                 if (md > 1.8f && count > 1) {
                     __syncthreads();
@@ -570,6 +603,10 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
             __syncthreads();
         }
         __syncthreads();
+        if (P.dbg_stop == 4) {
+            if (tid == 0) out->valid = 0;
+            continue;
+        }
         // ---- P5: four Welsch line fits (:351-359)
         bool ok = true;
         for (int j = 0; j < 4; j++) {
@@ -610,12 +647,16 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
             }
         }
         __syncthreads();
-        if (tid < 80) {
-            const int j = tid / 20, k = tid - j * 20;
+        for (int task = tid; task < 80; task += kQuadThreads) {
+            const int j = task / 20, k = task - j * 20;
             const int cnt_pts = s_cl_off[j + 1] - s_cl_off[j];
-            welsch_restart(CL + s_cl_off[j], cnt_pts, s_picks[j][k], min(cnt_pts, 10), cnt_pts * 1.1920928955078125e-07, s_line[tid], &s_err[tid]);
+            welsch_restart(CL + s_cl_off[j], cnt_pts, s_picks[j][k], min(cnt_pts, 10), cnt_pts * 1.1920928955078125e-07, s_line[task], &s_err[task]);
         }
         __syncthreads();
+        if (P.dbg_stop == 5) {
+            if (tid == 0) out->valid = 0;
+            continue;
+        }
         // ---- P6: intersections, angular sort, best 4-subset (:362-403, :420-463), thread 0
         if (tid == 0) {
             float lf[4][4];
@@ -701,9 +742,11 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
 }
 
 hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
-    QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags};
+    QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
+               getenv("CTAG_DBG_QUAD_STOP") ? atoi(getenv("CTAG_DBG_QUAD_STOP")) : 0};
     (void)hipMemsetAsync(ws.quad_scratch_used, 0, sizeof(int32_t), s);
-    hipLaunchKernelGGL(k_quad, dim3(128, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    hipLaunchKernelGGL(k_quad<false>, dim3(128, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    hipLaunchKernelGGL(k_quad<true>, dim3(4, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
     return hipGetLastError();
 }
 
