@@ -95,13 +95,13 @@ def main():
     frames = torch.empty((n, ROWS, COLS), dtype=torch.uint8, device=dev)
     det.synth_frames_device(frames.data_ptr(), rank * n, n, ROWS, COLS, COLS, ROWS * COLS, markers=args.markers)
     results = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev) if world > 1 else None
+    from cylindertag_amd.dist import gather_results
 
     def step():
         det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, results.data_ptr(), 5, subpix, 5)
         if world > 1:
             det.sync()  # results are produced on the library's stream
-            dist.all_gather_into_tensor(gathered, results)  # the path's only exchange: final marker lists
+            gather_results(results, world * n, dist)  # the path's only exchange: final marker lists (RCCL all-gather)
 
     def fence():
         if world > 1:
