@@ -34,6 +34,7 @@ struct ctag_handle {
     hipStream_t stream = nullptr;
     std::vector<int32_t> dict;
     int32_t* d_dict = nullptr;
+    uint8_t* d_pick_table = nullptr;
     int dict_rows = 0, dict_cols = 0, feature_size = 0;
     Workspace ws;
     int ws_rows = 0, ws_cols = 0, ws_tw = 0, ws_cap = 0;
@@ -79,6 +80,7 @@ static FrameGeom make_geom(int rows, int cols, int tw) {
 static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int frames) {
     if (h->ws.base && h->ws_rows == rows && h->ws_cols == cols && h->ws_cap >= frames) {
         h->ws.g = make_geom(rows, cols, tw);
+        h->ws.pick_table = h->d_pick_table;
         h->ws_tw = tw;
         return CTAG_OK;
     }
@@ -112,6 +114,12 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t scratch_words = (size_t)4 * kQuadScratchPoints + 2048;
     const size_t o_scratch = take((size_t)kQuadScratchSlots * scratch_words * 4);
     const size_t o_scr_used = take(4);
+    const size_t o_lcount = take(F * 4), o_clused = take(F * 4);
+    const size_t o_clpool = take(F * kClPool * 4);
+    const size_t o_ldesc = take(F * kLineCap * sizeof(LineDesc));
+    const size_t o_lsort = take(F * kLineCap * 4);
+    const size_t o_lfit = take(F * kLineCap * 16);
+    const size_t o_aux = take(F * kCandCap * sizeof(CandAux));
     const size_t o_der = take(F * kCandCap * 32);
     const size_t o_qidx = take(F * kCandCap * 4);
     const size_t o_nq = take(F * 4), o_nf = take(F * 4), o_st = take(F * 4);
@@ -143,6 +151,14 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.quads = reinterpret_cast<QuadOut*>(b + o_quads);
     W.quad_scratch = reinterpret_cast<uint32_t*>(b + o_scratch);
     W.quad_scratch_used = reinterpret_cast<int32_t*>(b + o_scr_used);
+    W.line_count = reinterpret_cast<int32_t*>(b + o_lcount);
+    W.clp_used = reinterpret_cast<int32_t*>(b + o_clused);
+    W.cl_pool = reinterpret_cast<uint32_t*>(b + o_clpool);
+    W.line_desc = reinterpret_cast<LineDesc*>(b + o_ldesc);
+    W.line_sorted = reinterpret_cast<int32_t*>(b + o_lsort);
+    W.line_fit = reinterpret_cast<float*>(b + o_lfit);
+    W.cand_aux = reinterpret_cast<CandAux*>(b + o_aux);
+    W.pick_table = h->d_pick_table;
     W.quad_derived = b + o_der;
     W.quad_index = reinterpret_cast<int32_t*>(b + o_qidx);
     W.nquads = reinterpret_cast<int32_t*>(b + o_nq);
@@ -329,6 +345,12 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
     ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_dict), h->dict.size() * 4) == hipSuccess;
     ok = ok && hipMemcpy(h->d_dict, h->dict.data(), h->dict.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        std::vector<uint8_t> tab((size_t)kPickN * 200);
+        build_pick_table(tab.data());
+        ok = hipMalloc(reinterpret_cast<void**>(&h->d_pick_table), tab.size()) == hipSuccess &&
+             hipMemcpy(h->d_pick_table, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
     for (int i = 0; ok && i <= CTAG_NUM_STAGES; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     if (!ok) {
         ctag_destroy(h);
@@ -344,6 +366,7 @@ void ctag_destroy(ctag_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->d_dict) (void)hipFree(h->d_dict);
+    if (h->d_pick_table) (void)hipFree(h->d_pick_table);
     if (h->d_frames) (void)hipFree(h->d_frames);
     if (h->d_results) (void)hipFree(h->d_results);
     if (h->d_synth) (void)hipFree(h->d_synth);

@@ -33,12 +33,25 @@ constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range
 constexpr int kQuadLdsPoints = 1024;    // boundary points held in LDS; larger components use global scratch
 constexpr int kQuadScratchSlots = 64;   // global scratch slots per chunk for oversize components
 constexpr int kQuadScratchPoints = 8192;  // >= 2*(1920+1080)+4: worst-case silhouette of a 4K frame at half-res
+constexpr int kLineCap = 1024;            // fitted edges per frame (4 per candidate that survives the RDP split)
+constexpr int kClPool = 32768;            // edge-cluster points per frame
+constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table
 constexpr int kMaxDictCells = 2048;       // dictionary rows*cols supported by K9 (reference dictionary: 41*12)
 
 struct Candidate {  // one area-filtered connected component, in OpenCV label order
     int32_t root;   // pool index of the root component (frame-local)
     int32_t area;
     int16_t x_min, y_min, x_max, y_max;
+};
+
+struct LineDesc {   // one edge cluster in the frame's cluster pool
+    uint32_t off;
+    int32_t n;
+};
+struct CandAux {    // k_quad_edges -> k_quad_final
+    int32_t line0;  // first of 4 consecutive line ids, -1 when the component produced no 4 edges
+    float acx, acy; // boundary centroid (area_center)
+    int32_t n_boundary;
 };
 
 struct QuadOut {    // K6 output per candidate
@@ -89,6 +102,14 @@ struct Workspace {
     QuadOut* quads = nullptr;       // [F][kCandCap]
     uint32_t* quad_scratch = nullptr;   // [kQuadScratchSlots][...]
     int32_t* quad_scratch_used = nullptr;
+    int32_t* line_count = nullptr;  // [F]
+    int32_t* clp_used = nullptr;    // [F]
+    uint32_t* cl_pool = nullptr;    // [F][kClPool]
+    LineDesc* line_desc = nullptr;  // [F][kLineCap]
+    int32_t* line_sorted = nullptr; // [F][kLineCap]
+    float* line_fit = nullptr;      // [F][kLineCap][4]
+    CandAux* cand_aux = nullptr;    // [F][kCandCap]
+    const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
     // features
     void* quad_derived = nullptr;   // [F][kCandCap] x 32 B (K7 scratch)
     int32_t* quad_index = nullptr;  // [F][kCandCap]
@@ -124,5 +145,6 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s);
 hipError_t launch_math_probe(int op, int n, const double* a, const double* b, double* out, hipStream_t s);
 size_t threshold_ccl_lds_bytes(int tw);
+void build_pick_table(uint8_t* table);  // kPickN*20*10 bytes
 
 }  // namespace ctag

@@ -32,7 +32,15 @@ struct QuadPtrs {
     uint32_t* scratch;
     int32_t* scratch_used;
     uint32_t* frame_flags;
-    int dbg_stop;  // developer aid: leave the component after phase N (0 = run everything)
+    // edge clusters handed from k_quad_edges to k_welsch / k_quad_final
+    int32_t* line_count;   // [F]
+    int32_t* clp_used;     // [F]
+    uint32_t* cl_pool;     // [F][kClPool] packed (x | y << 16) points, in the order the reference pushes them
+    LineDesc* line_desc;   // [F][kLineCap]
+    int32_t* line_sorted;  // [F][kLineCap] line ids by descending point count
+    float* line_fit;       // [F][kLineCap][4]
+    CandAux* cand_aux;     // [F][kCandCap]
+    const uint8_t* pick_table;  // [kPickN][20][10] cv::RNG initial samples of fitLine2D for every point count < kPickN
 };
 
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
@@ -165,11 +173,8 @@ struct CornerPre {
 // BIG = false: components whose working set fits the LDS budget (LDS-typed pointers, the common case);
 // BIG = true: the rare oversize components, same code on a global scratch slot.
 template <bool BIG>
-__global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, int nframes) {
+__global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGeom g, int nframes) {
     __shared__ uint32_t s_mem[kQuadLdsWords];
-    __shared__ uint16_t s_picks[4][20][10];
-    __shared__ double s_err[80];
-    __shared__ float s_line[80][4];
     __shared__ unsigned long long s_sum[2];
     __shared__ int s_i[16];
     __shared__ float s_redf[kQuadWaves];
@@ -188,7 +193,6 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
     for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
         __syncthreads();
         const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
-        QuadOut* out = P.quads + (size_t)frame * kCandCap + ci;
         const int x_min = cd.x_min, y_min = cd.y_min;
         const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
         const int C = min(2 * (w + h), w * h) + 1;
@@ -203,8 +207,9 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
             if (slot >= kQuadScratchSlots || need > kScratchWords) {
                 if (tid == 0) {
                     atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
-                    out->valid = 0;
-                    out->n_boundary = 0;
+                    CandAux* ax = P.cand_aux + (size_t)frame * kCandCap + ci;
+                    ax->line0 = -1;
+                    ax->n_boundary = 0;
                 }
                 continue;
             }
@@ -254,10 +259,6 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
             }
         }
         __syncthreads();
-        if (P.dbg_stop == 1) {
-            if (tid == 0) out->valid = 0;
-            continue;
-        }
         // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): explicit stack, wave 0; lanes 0..7 test
         // the 8 neighbours (N,NE,E,SE,S,SW,W,NW) of the current frame at once, the first hit at or after the frame's
         // resume index wins -- the same visiting order as the reference's recursion with its moving `starter` (B7).
@@ -317,13 +318,10 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
         const int n_boundary = n;
         if (n == 0) {  // block-uniform
             if (tid == 0) {
-                out->valid = 0;
-                out->n_boundary = 0;
+                CandAux* ax = P.cand_aux + (size_t)frame * kCandCap + ci;
+                ax->line0 = -1;
+                ax->n_boundary = 0;
             }
-            continue;
-        }
-        if (P.dbg_stop == 2) {
-            if (tid == 0) out->valid = 0;
             continue;
         }
         // ---- P3: boundary centroid (:250-256), nearest point (:259-263), rotation (:264-275)
@@ -389,10 +387,6 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
         __syncthreads();
         uint32_t* W = bufB;   // working list
         uint32_t* Wn = bufA;  // next list
-        if (P.dbg_stop == 3) {
-            if (tid == 0) out->valid = 0;
-            continue;
-        }
         // ---- P4: extended RDP (:278-349).  Thread 0 drives; max-distance search and list surgery use all threads.
         if (tid == 0) {
             s_i[2] = 0;  // cnt_boundary
@@ -603,151 +597,280 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad(QuadPtrs P, FrameGeom g, 
             __syncthreads();
         }
         __syncthreads();
-        if (P.dbg_stop == 4) {
-            if (tid == 0) out->valid = 0;
-            continue;
-        }
-        // ---- P5: four Welsch line fits (:351-359)
+        // ---- export: the four edge clusters go to the frame's cluster pool; k_welsch fits them, k_quad_final picks the quad
         bool ok = true;
         for (int j = 0; j < 4; j++) {
             const int len = (j < s_i[2]) ? (s_cl_off[j + 1] - s_cl_off[j]) : 0;
-            if (len < 2) ok = false;
+            if (len < 2) ok = false;  // flag_line_number (:353-357)
         }
         if (s_cl_off[min(s_i[2], 4)] >= C + 64) ok = false;
-        if (!ok) {
+        CandAux* aux = P.cand_aux + (size_t)frame * kCandCap + ci;
+        if (ok) {
+            const int total = s_cl_off[4];
             if (tid == 0) {
-                out->valid = 0;
-                out->n_boundary = n_boundary;
+                const int l0 = atomicAdd(&P.line_count[frame], 4);
+                const int p0 = atomicAdd(&P.clp_used[frame], total);
+                s_i[11] = (l0 + 4 <= kLineCap && p0 + total <= kClPool) ? l0 : -1;
+                s_i[12] = p0;
             }
-            continue;
+            __syncthreads();
+            const int l0 = s_i[11], p0 = s_i[12];
+            if (l0 < 0) {
+                ok = false;
+                if (tid == 0) atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+            } else {
+                uint32_t* dst = P.cl_pool + (size_t)frame * kClPool + p0;
+                for (int k = tid; k < total; k += kQuadThreads) dst[k] = CL[k];
+                if (tid < 4) {
+                    LineDesc d;
+                    d.off = (uint32_t)(p0 + s_cl_off[tid]);
+                    d.n = s_cl_off[tid + 1] - s_cl_off[tid];
+                    P.line_desc[(size_t)frame * kLineCap + l0 + tid] = d;
+                }
+                if (tid == 0) {
+                    aux->line0 = l0;
+                    aux->acx = acx;
+                    aux->acy = acy;
+                    aux->n_boundary = n_boundary;
+                }
+            }
         }
-        if (tid < 4) {  // replay the cv::RNG pick sequence of fitLine2D for this edge's point count
-            const int cnt_pts = s_cl_off[tid + 1] - s_cl_off[tid];
-            const int npick = min(cnt_pts, 10);
+        if (!ok && tid == 0) {
+            aux->line0 = -1;
+            aux->acx = 0.f;
+            aux->acy = 0.f;
+            aux->n_boundary = n_boundary;
+        }
+    }
+}
+
+
+// =====================================================================================================
+// K6s: per frame, order the edge clusters by descending point count so that the three edges a Welsch wave
+// fits together cost about the same (scheduling only: results do not depend on this order).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_line_sort(QuadPtrs P, int nframes) {
+    __shared__ int s_n[kLineCap];
+    const int frame = blockIdx.x;
+    if (frame >= nframes) return;
+    const int L = min(P.line_count[frame], kLineCap);
+    const LineDesc* d = P.line_desc + (size_t)frame * kLineCap;
+    for (int i = threadIdx.x; i < L; i += 256) s_n[i] = d[i].n;
+    __syncthreads();
+    int32_t* out = P.line_sorted + (size_t)frame * kLineCap;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const int ni = s_n[i];
+        int rank = 0;
+        for (int j = 0; j < L; j++) {
+            const int nj = s_n[j];
+            rank += (nj > ni || (nj == ni && j < i)) ? 1 : 0;
+        }
+        out[rank] = i;
+    }
+}
+
+// =====================================================================================================
+// K6b: fitLine(DIST_WELSCH) of three edges per wave: lanes 0-19 / 20-39 / 40-59 are the 20 restarts of one
+// edge each.  Restarts are independent once the cv::RNG pick sequence is known, and that
+// sequence depends only on the point count, so it comes from a table (or is replayed for very long edges).
+// The best-restart selection replays the reference's sequential `err < min_err` / `err < EPS` logic.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
+    __shared__ double s_err[60];
+    __shared__ float s_line[60][4];
+    __shared__ uint16_t s_pk[60][10];
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    const int L = min(P.line_count[frame], kLineCap);
+    const int first = blockIdx.x * 3;
+    if (first >= L) return;
+    const int lane = threadIdx.x;
+    const int grp = lane / 20, k = lane - grp * 20;
+    const bool active = lane < 60 && first + grp < L;
+    int lid = 0, n = 0;
+    const uint32_t* pts = nullptr;
+    if (active) {
+        lid = P.line_sorted[(size_t)frame * kLineCap + first + grp];
+        const LineDesc d = P.line_desc[(size_t)frame * kLineCap + lid];
+        n = d.n;
+        pts = P.cl_pool + (size_t)frame * kClPool + d.off;
+        const int npick = min(n, 10);
+        uint16_t* pk = s_pk[lane];
+        if (n < kPickN) {
+            const uint8_t* t = P.pick_table + ((size_t)n * 20 + k) * 10;
+            for (int q = 0; q < npick; q++) pk[q] = t[q];
+        } else {  // replay cv::RNG up to this restart
             CvRng rng;
             rng.state = 0xffffffffffffffffULL;
-            for (int k = 0; k < 20; k++) {
-                uint16_t* pk = s_picks[tid][k];
+            for (int kk = 0; kk <= k; kk++) {
                 int got = 0;
                 while (got < npick) {
-                    const int j = (int)(rng.next() % (unsigned)cnt_pts);
+                    const int j = (int)(rng.next() % (unsigned)n);
                     bool dup = false;
                     for (int q = 0; q < got; q++) dup |= (pk[q] == j);
                     if (!dup) pk[got++] = (uint16_t)j;
                 }
-                for (int a = 1; a < npick; a++) {  // ascending order = the order fitLine2D_wods visits them
-                    const uint16_t v = pk[a];
-                    int b = a - 1;
-                    while (b >= 0 && pk[b] > v) {
-                        pk[b + 1] = pk[b];
-                        b--;
-                    }
-                    pk[b + 1] = v;
-                }
             }
-        }
-        __syncthreads();
-        for (int task = tid; task < 80; task += kQuadThreads) {
-            const int j = task / 20, k = task - j * 20;
-            const int cnt_pts = s_cl_off[j + 1] - s_cl_off[j];
-            welsch_restart(CL + s_cl_off[j], cnt_pts, s_picks[j][k], min(cnt_pts, 10), cnt_pts * 1.1920928955078125e-07, s_line[task], &s_err[task]);
-        }
-        __syncthreads();
-        if (P.dbg_stop == 5) {
-            if (tid == 0) out->valid = 0;
-            continue;
-        }
-        // ---- P6: intersections, angular sort, best 4-subset (:362-403, :420-463), thread 0
-        if (tid == 0) {
-            float lf[4][4];
-            for (int j = 0; j < 4; j++) {
-                const double EPS = (s_cl_off[j + 1] - s_cl_off[j]) * 1.1920928955078125e-07;
-                double min_err = 1.7976931348623157e308;
-                lf[j][0] = lf[j][1] = lf[j][2] = lf[j][3] = 0.f;
-                for (int k = 0; k < 20; k++) {
-                    const double e = s_err[j * 20 + k];
-                    if (e < min_err) {
-                        min_err = e;
-                        for (int q = 0; q < 4; q++) lf[j][q] = s_line[j * 20 + k][q];
-                        if (e < EPS) break;
-                    }
-                }
-            }
-            CornerPre cp[6];
-            int ncp = 0;
-            for (int j = 0; j < 3; j++)
-                for (int k = j + 1; k < 4; k++) {
-                    const float a00 = lf[j][1], a01 = -lf[j][0], a10 = lf[k][1], a11 = -lf[k][0];
-                    const float b0 = lf[j][1] * lf[j][2] - lf[j][0] * lf[j][3];
-                    const float b1 = lf[k][1] * lf[k][2] - lf[k][0] * lf[k][3];
-                    CornerPre c;
-                    if (solve2x2(a00, a01, a10, a11, b0, b1, c.x, c.y)) {
-                        c.dis = ctm::sqrt32((c.x - acx) * (c.x - acx) + (c.y - acy) * (c.y - acy));
-                        c.ang = (float)(ctm::atan2_32(c.y - acy, c.x - acx) * 180 / 3.1415926535897932384626433832795);
-                        if (c.dis < g.hcols && c.dis < g.hrows) cp[ncp++] = c;
-                    }
-                }
-            for (int a = 1; a < ncp; a++) {  // std::sort on <= 6 elements: insertion sort
-                const CornerPre v = cp[a];
+            for (int a = 1; a < npick; a++) {
+                const uint16_t v = pk[a];
                 int b = a - 1;
-                while (b >= 0 && v.ang < cp[b].ang) {
-                    cp[b + 1] = cp[b];
+                while (b >= 0 && pk[b] > v) {
+                    pk[b + 1] = pk[b];
                     b--;
                 }
-                cp[b + 1] = v;
-            }
-            float rac_min = 0.3f;
-            int best[4] = {-1, -1, -1, -1};
-            const int areaPx = cd.area;
-            for (int i0 = 0; i0 < ncp; i0++)
-                for (int i1 = i0 + 1; i1 < ncp; i1++)
-                    for (int i2 = i1 + 1; i2 < ncp; i2++)
-                        for (int i3 = i2 + 1; i3 < ncp; i3++) {
-                            const CornerPre &p0 = cp[i0], &p1 = cp[i1], &p2 = cp[i2], &p3 = cp[i3];
-                            const float s1 = p0.x * p1.y + p1.x * p2.y + p2.x * p0.y - p0.x * p2.y - p1.x * p0.y - p2.x * p1.y;
-                            const float s2 = p1.x * p2.y + p2.x * p3.y + p3.x * p1.y - p1.x * p3.y - p2.x * p1.y - p3.x * p2.y;
-                            const float s3 = p2.x * p3.y + p3.x * p0.y + p0.x * p2.y - p2.x * p0.y - p3.x * p2.y - p0.x * p3.y;
-                            const float s4 = p0.x * p1.y + p1.x * p3.y + p3.x * p0.y - p0.x * p3.y - p1.x * p0.y - p3.x * p1.y;
-                            if (ctm::fabs32(s1) < 1 || ctm::fabs32(s2) < 1 || ctm::fabs32(s3) < 1 || ctm::fabs32(s4) < 1) continue;
-                            float qa = 0;
-                            qa += p0.x * p1.y - p0.y * p1.x;
-                            qa += p1.x * p2.y - p1.y * p2.x;
-                            qa += p2.x * p3.y - p2.y * p3.x;
-                            qa += p3.x * p0.y - p3.y * p0.x;
-                            qa /= 2;
-                            const float rac = ctm::fabs32(ctm::fabs32(qa) - areaPx) / areaPx;
-                            if (rac < rac_min) {
-                                rac_min = rac;
-                                best[0] = i0;
-                                best[1] = i1;
-                                best[2] = i2;
-                                best[3] = i3;
-                            }
-                        }
-            int valid = best[0] >= 0 ? 1 : 0;
-            if (valid) {
-                for (int j = 0; j < 4; j++) {
-                    const CornerPre& c = cp[best[j]];
-                    if (c.x < 0 || c.y < 0 || c.x > g.hcols || c.y > g.hrows) valid = 0;
-                }
-            }
-            out->valid = valid;
-            out->n_boundary = n_boundary;
-            for (int j = 0; j < 4; j++) {
-                out->c[2 * j] = valid ? cp[best[j]].x : 0.f;
-                out->c[2 * j + 1] = valid ? cp[best[j]].y : 0.f;
+                pk[b + 1] = v;
             }
         }
+        welsch_restart(pts, n, pk, npick, n * 1.1920928955078125e-07, s_line[lane], &s_err[lane]);
+    }
+    __syncthreads();
+    if (active && k == 0) {
+        const double EPS = n * 1.1920928955078125e-07;
+        double min_err = 1.7976931348623157e308;
+        float best[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < 20; kk++) {
+            const double e = s_err[grp * 20 + kk];
+            if (e < min_err) {
+                min_err = e;
+                for (int q = 0; q < 4; q++) best[q] = s_line[grp * 20 + kk][q];
+                if (e < EPS) break;
+            }
+        }
+        float* o = P.line_fit + ((size_t)frame * kLineCap + lid) * 4;
+        for (int q = 0; q < 4; q++) o[q] = best[q];
+    }
+}
+
+// =====================================================================================================
+// K6c: per candidate, the six pairwise intersections of its four fitted edges, angular sort and the best
+// 4-subset by RAC (corner_detector.cpp:362-403, :420-463).  One thread per candidate.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int nframes) {
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    const int ci = blockIdx.x * 64 + threadIdx.x;
+    if (ci >= P.ncand[frame]) return;
+    const CandAux aux = P.cand_aux[(size_t)frame * kCandCap + ci];
+    QuadOut* out = P.quads + (size_t)frame * kCandCap + ci;
+    out->n_boundary = aux.n_boundary;
+    if (aux.line0 < 0) {
+        out->valid = 0;
+        return;
+    }
+    const int areaPx = P.cand[(size_t)frame * kCandCap + ci].area;
+    const float acx = aux.acx, acy = aux.acy;
+    float lf[4][4];
+    {
+        const float* src = P.line_fit + ((size_t)frame * kLineCap + aux.line0) * 4;
+        for (int j = 0; j < 4; j++)
+            for (int q = 0; q < 4; q++) lf[j][q] = src[j * 4 + q];
+    }
+    CornerPre cp[6];
+    int ncp = 0;
+    for (int j = 0; j < 3; j++)
+        for (int k = j + 1; k < 4; k++) {
+            const float a00 = lf[j][1], a01 = -lf[j][0], a10 = lf[k][1], a11 = -lf[k][0];
+            const float b0 = lf[j][1] * lf[j][2] - lf[j][0] * lf[j][3];
+            const float b1 = lf[k][1] * lf[k][2] - lf[k][0] * lf[k][3];
+            CornerPre c;
+            if (solve2x2(a00, a01, a10, a11, b0, b1, c.x, c.y)) {
+                c.dis = ctm::sqrt32((c.x - acx) * (c.x - acx) + (c.y - acy) * (c.y - acy));
+                c.ang = (float)(ctm::atan2_32(c.y - acy, c.x - acx) * 180 / 3.1415926535897932384626433832795);
+                if (c.dis < g.hcols && c.dis < g.hrows) cp[ncp++] = c;
+            }
+        }
+    for (int a = 1; a < ncp; a++) {  // std::sort on <= 6 elements: insertion sort
+        const CornerPre v = cp[a];
+        int b = a - 1;
+        while (b >= 0 && v.ang < cp[b].ang) {
+            cp[b + 1] = cp[b];
+            b--;
+        }
+        cp[b + 1] = v;
+    }
+    float rac_min = 0.3f;
+    int best[4] = {-1, -1, -1, -1};
+        for (int i0 = 0; i0 < ncp; i0++)
+        for (int i1 = i0 + 1; i1 < ncp; i1++)
+            for (int i2 = i1 + 1; i2 < ncp; i2++)
+                for (int i3 = i2 + 1; i3 < ncp; i3++) {
+                    const CornerPre &p0 = cp[i0], &p1 = cp[i1], &p2 = cp[i2], &p3 = cp[i3];
+                    const float s1 = p0.x * p1.y + p1.x * p2.y + p2.x * p0.y - p0.x * p2.y - p1.x * p0.y - p2.x * p1.y;
+                    const float s2 = p1.x * p2.y + p2.x * p3.y + p3.x * p1.y - p1.x * p3.y - p2.x * p1.y - p3.x * p2.y;
+                    const float s3 = p2.x * p3.y + p3.x * p0.y + p0.x * p2.y - p2.x * p0.y - p3.x * p2.y - p0.x * p3.y;
+                    const float s4 = p0.x * p1.y + p1.x * p3.y + p3.x * p0.y - p0.x * p3.y - p1.x * p0.y - p3.x * p1.y;
+                    if (ctm::fabs32(s1) < 1 || ctm::fabs32(s2) < 1 || ctm::fabs32(s3) < 1 || ctm::fabs32(s4) < 1) continue;
+                    float qa = 0;
+                    qa += p0.x * p1.y - p0.y * p1.x;
+                    qa += p1.x * p2.y - p1.y * p2.x;
+                    qa += p2.x * p3.y - p2.y * p3.x;
+                    qa += p3.x * p0.y - p3.y * p0.x;
+                    qa /= 2;
+                    const float rac = ctm::fabs32(ctm::fabs32(qa) - areaPx) / areaPx;
+                    if (rac < rac_min) {
+                        rac_min = rac;
+                        best[0] = i0;
+                        best[1] = i1;
+                        best[2] = i2;
+                        best[3] = i3;
+                    }
+                }
+    int valid = best[0] >= 0 ? 1 : 0;
+    if (valid) {
+        for (int j = 0; j < 4; j++) {
+            const CornerPre& c = cp[best[j]];
+            if (c.x < 0 || c.y < 0 || c.x > g.hcols || c.y > g.hrows) valid = 0;
+        }
+    }
+    out->valid = valid;
+    for (int j = 0; j < 4; j++) {
+        out->c[2 * j] = valid ? cp[best[j]].x : 0.f;
+        out->c[2 * j + 1] = valid ? cp[best[j]].y : 0.f;
     }
 }
 
 hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
-               getenv("CTAG_DBG_QUAD_STOP") ? atoi(getenv("CTAG_DBG_QUAD_STOP")) : 0};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table};
     (void)hipMemsetAsync(ws.quad_scratch_used, 0, sizeof(int32_t), s);
-    hipLaunchKernelGGL(k_quad<false>, dim3(128, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
-    hipLaunchKernelGGL(k_quad<true>, dim3(4, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    (void)hipMemsetAsync(ws.line_count, 0, sizeof(int32_t) * (size_t)nframes, s);
+    (void)hipMemsetAsync(ws.clp_used, 0, sizeof(int32_t) * (size_t)nframes, s);
+    hipLaunchKernelGGL(k_quad_edges<false>, dim3(128, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    hipLaunchKernelGGL(k_quad_edges<true>, dim3(4, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
+    hipLaunchKernelGGL(k_welsch, dim3((kLineCap + 2) / 3, nframes), dim3(64), 0, s, P, nframes);
+    hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     return hipGetLastError();
+}
+
+// cv::RNG replay on the host: initial samples of fitLine2D for every point count below kPickN (ascending per restart)
+void build_pick_table(uint8_t* table) {
+    for (int n = 0; n < kPickN; n++) {
+        uint64_t state = 0xffffffffffffffffULL;
+        for (int k = 0; k < 20; k++) {
+            uint8_t* pk = table + ((size_t)n * 20 + k) * 10;
+            for (int q = 0; q < 10; q++) pk[q] = 0;
+            if (n < 2) continue;
+            const int npick = n < 10 ? n : 10;
+            int got = 0;
+            while (got < npick) {
+                state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+                const int j = (int)((unsigned)state % (unsigned)n);
+                bool dup = false;
+                for (int q = 0; q < got; q++) dup |= (pk[q] == j);
+                if (!dup) pk[got++] = (uint8_t)j;
+            }
+            for (int a = 1; a < npick; a++) {
+                const uint8_t v = pk[a];
+                int b = a - 1;
+                while (b >= 0 && pk[b] > v) {
+                    pk[b + 1] = pk[b];
+                    b--;
+                }
+                pk[b + 1] = v;
+            }
+        }
+    }
 }
 
 }  // namespace ctag
