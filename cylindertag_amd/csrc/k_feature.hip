@@ -267,9 +267,11 @@ struct RefinePtrs {
 constexpr int kRefineThreads = 128;
 
 __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
-    __shared__ double s_bx[kRefineThreads], s_by[kRefineThreads], s_al[kRefineThreads];
-    __shared__ unsigned char s_ok[kRefineThreads];
-    __shared__ double s_acc[12];
+    // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
+    // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
+    __shared__ double s_bx[4][kRefineThreads], s_by[4][kRefineThreads], s_al[4][kRefineThreads];
+    __shared__ unsigned char s_ok[4][kRefineThreads];
+    __shared__ double s_acc[48];
     __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
@@ -286,19 +288,28 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
         cx[i] = F->c[2 * (off + i)];
         cy[i] = F->c[2 * (off + i) + 1];
     }
-    for (int edge = 0; edge < 4; edge++) {
+    double enx[4], eny[4];
+    int ens[4], max_ns = 0;
+    for (int edge = 0; edge < 4; edge++) {  // :609-615
         const int a = edge, b = (edge + 1) & 3;
         double nx = cy[b] - cy[a];
         double ny = -cx[b] + cx[a];
         const double mag = ctm::sqrt64(nx * nx + ny * ny);
-        nx /= mag;
-        ny /= mag;
+        enx[edge] = nx / mag;
+        eny[edge] = ny / mag;
         const double ns_d = mag / 8 > 128.0 ? mag / 8 : 128.0;
-        const int nsamples = (int)ns_d;
-        if (tid < 12) s_acc[tid] = 0.0;
-        __syncthreads();
-        for (int sbase = 0; sbase < nsamples; sbase += kRefineThreads) {
-            const int s = sbase + tid;
+        ens[edge] = (int)ns_d;
+        max_ns = max(max_ns, ens[edge]);
+    }
+    if (tid < 48) s_acc[tid] = 0.0;
+    __syncthreads();
+    for (int sbase = 0; sbase < max_ns; sbase += kRefineThreads) {
+        const int s = sbase + tid;
+#pragma unroll
+        for (int edge = 0; edge < 4; edge++) {
+            const int a = edge, b = (edge + 1) & 3;
+            const int nsamples = ens[edge];
+            const double nx = enx[edge], ny = eny[edge];
             bool ok = false;
             double bestx = 0, besty = 0, alpha = 0;
             if (s < nsamples) {
@@ -329,49 +340,51 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                     ok = true;
                 }
             }
-            s_bx[tid] = bestx;
-            s_by[tid] = besty;
-            s_al[tid] = alpha;
-            s_ok[tid] = ok ? 1 : 0;
-            __syncthreads();
-            if (tid < 12) {  // sequential (sample-order) accumulation of one of the 12 running sums
-                const int pass = tid / 6, which = tid - pass * 6;
-                double acc = s_acc[tid];
-                const int cntS = min(kRefineThreads, nsamples - sbase);
-                for (int k = 0; k < cntS; k++) {
-                    if (!s_ok[k]) continue;
-                    const double wgt = pass == 0 ? (1 - s_al[k]) : s_al[k];
-                    const double bxk = s_bx[k], byk = s_by[k];
-                    double term;
-                    switch (which) {
-                        case 0: term = bxk * wgt; break;
-                        case 1: term = byk * wgt; break;
-                        case 2: term = bxk * bxk * wgt; break;
-                        case 3: term = bxk * byk * wgt; break;
-                        case 4: term = byk * byk * wgt; break;
-                        default: term = wgt; break;
-                    }
-                    acc += term;
-                }
-                s_acc[tid] = acc;
-            }
-            __syncthreads();
+            s_bx[edge][tid] = bestx;
+            s_by[edge][tid] = besty;
+            s_al[edge][tid] = alpha;
+            s_ok[edge][tid] = ok ? 1 : 0;
         }
-        if (tid < 2) {
-            const double* A = s_acc + tid * 6;
-            const double Mx = A[0], My = A[1], Mxx = A[2], Mxy = A[3], Myy = A[4], N = A[5];
-            const double Ex = Mx / N, Ey = My / N;
-            const double Cxx = Mxx / N - Ex * Ex;
-            const double Cxy = Mxy / N - Ex * Ey;
-            const double Cyy = Myy / N - Ey * Ey;
-            const double normal_theta = .5 * ctm::atan2_32((float)(-2 * Cxy), (float)(Cyy - Cxx));
-            s_lines[tid][edge][0] = Ex;
-            s_lines[tid][edge][1] = Ey;
-            s_lines[tid][edge][2] = ctm::cos32((float)normal_theta);
-            s_lines[tid][edge][3] = ctm::sin32((float)normal_theta);
+        __syncthreads();
+        if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
+            const int edge = tid / 12, r = tid - edge * 12;
+            const int pass = r / 6, which = r - pass * 6;
+            double acc = s_acc[tid];
+            const int cntS = min(kRefineThreads, ens[edge] - sbase);
+            for (int k = 0; k < cntS; k++) {
+                if (!s_ok[edge][k]) continue;
+                const double wgt = pass == 0 ? (1 - s_al[edge][k]) : s_al[edge][k];
+                const double bxk = s_bx[edge][k], byk = s_by[edge][k];
+                double term;
+                switch (which) {
+                    case 0: term = bxk * wgt; break;
+                    case 1: term = byk * wgt; break;
+                    case 2: term = bxk * bxk * wgt; break;
+                    case 3: term = bxk * byk * wgt; break;
+                    case 4: term = byk * byk * wgt; break;
+                    default: term = wgt; break;
+                }
+                acc += term;
+            }
+            s_acc[tid] = acc;
         }
         __syncthreads();
     }
+    if (tid < 8) {  // line of (edge, pass): :667-678 / :743-754
+        const int edge = tid >> 1, pass = tid & 1;
+        const double* A = s_acc + edge * 12 + pass * 6;
+        const double Mx = A[0], My = A[1], Mxx = A[2], Mxy = A[3], Myy = A[4], N = A[5];
+        const double Ex = Mx / N, Ey = My / N;
+        const double Cxx = Mxx / N - Ex * Ex;
+        const double Cxy = Mxy / N - Ex * Ey;
+        const double Cyy = Myy / N - Ey * Ey;
+        const double normal_theta = .5 * ctm::atan2_32((float)(-2 * Cxy), (float)(Cyy - Cxx));
+        s_lines[pass][edge][0] = Ex;
+        s_lines[pass][edge][1] = Ey;
+        s_lines[pass][edge][2] = ctm::cos32((float)normal_theta);
+        s_lines[pass][edge][3] = ctm::sin32((float)normal_theta);
+    }
+    __syncthreads();
     if (tid < 4) {  // :757-776 one refined corner per lane
         const int it = tid;
         const double* Ln = s_lines[0][it];

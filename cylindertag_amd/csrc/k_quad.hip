@@ -263,49 +263,65 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
         // the 8 neighbours (N,NE,E,SE,S,SW,W,NW) of the current frame at once, the first hit at or after the frame's
         // resume index wins -- the same visiting order as the reference's recursion with its moving `starter` (B7).
         if (wave == 0) {
-            auto member = [&](int x, int y) { return top[x] == y || bot[x] == y || lef[y] == (unsigned)x || rig[y] == (unsigned)(x + 1); };
-            auto clear = [&](int x, int y) {
-                if (top[x] == y) top[x] = 0xffff;
-                if (bot[x] == y) bot[x] = 0xffff;
-                if (lef[y] == (unsigned)x) lef[y] = 0xffffffffu;
-                if (rig[y] == (unsigned)(x + 1)) rig[y] = 0u;
-            };
             // x_bias = {0,1,1,1,0,-1,-1,-1}, y_bias = {-1,-1,0,1,1,1,0,-1} packed as (bias+1) in 2 bits per direction
             const int jd = lane & 7;
             const int dxl = (int)((0x01A9u >> (2 * jd)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * jd)) & 3u) - 1;
             int n = 0, sp = 0;
-            const int sy0 = top[0];
-            if (sy0 == 0xffff) {  // inconsistent labels (only after a flagged pool overflow): give up on this component
+            int fx = 0, fy = top[0], j0 = 0;  // top-of-stack frame lives in registers; bufB holds the frames below it
+            if (fy == 0xffff) {  // inconsistent labels (only after a flagged pool overflow): give up on this component
                 sp = -1;
             } else {
                 if (lane == 0) {
-                    bufA[0] = pack_xy(x_min, sy0 + y_min);
-                    clear(0, sy0);
-                    bufB[0] = (uint32_t)0 | ((uint32_t)sy0 << 14);  // x:14 y:14 j:4
+                    bufA[0] = pack_xy(x_min, fy + y_min);
+                    // the start pixel is the top of column 0; clear every list it heads
+                    top[0] = 0xffff;
+                    if (bot[0] == fy) bot[0] = 0xffff;
+                    if (lef[fy] == 0u) lef[fy] = 0xffffffffu;
+                    if (rig[fy] == 1u) rig[fy] = 0u;
                 }
                 n = 1;
             }
             while (sp >= 0) {
-                const uint32_t f = bufB[sp];
-                const int fx = (int)(f & 0x3fff), fy = (int)((f >> 14) & 0x3fff), j0 = (int)(f >> 28);
                 const int nx = fx + dxl, ny = fy + dyl;
-                bool hit = false;
-                if (lane < 8 && jd >= j0 && ny >= 0 && ny < h && nx >= 0 && nx < w) hit = member(nx, ny);
-                const unsigned m = (unsigned)(__ballot(hit) & 0xffull);
-                if (!m) {
+                unsigned why = 0;  // which silhouette lists hold (nx, ny): bit0 top, bit1 bottom, bit2 left, bit3 right
+                if (lane < 8 && jd >= j0 && ny >= 0 && ny < h && nx >= 0 && nx < w) {
+                    why = (top[nx] == ny ? 1u : 0u) | (bot[nx] == ny ? 2u : 0u) | (lef[ny] == (unsigned)nx ? 4u : 0u) |
+                          (rig[ny] == (unsigned)(nx + 1) ? 8u : 0u);
+                }
+                const unsigned m = (unsigned)(__ballot(why != 0) & 0xffull);
+                if (!m) {  // frame exhausted: pop
                     sp--;
+                    if (sp >= 0) {
+                        const uint32_t f = bufB[sp];
+                        fx = (int)(f & 0x3fff);
+                        fy = (int)((f >> 14) & 0x3fff);
+                        j0 = (int)(f >> 28);
+                    }
                     continue;
                 }
                 const int j = __ffs(m) - 1;
+                const unsigned hw = (unsigned)__shfl((int)why, j);
                 const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
                 if (lane == 0) {
                     if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
-                    clear(hx, hy);
-                    bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
-                    if (sp + 1 <= C) bufB[sp + 1] = (uint32_t)hx | ((uint32_t)hy << 14);
+                    if (hw & 1u) top[hx] = 0xffff;  // visited.at(hy, hx) = 0
+                    if (hw & 2u) bot[hx] = 0xffff;
+                    if (hw & 4u) lef[hy] = 0xffffffffu;
+                    if (hw & 8u) rig[hy] = 0u;
+                    // the current frame moves to the hit pixel and resumes at j+1 (B7); it becomes the frame below the top
+                    if (sp <= C) bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
                 }
                 n++;
-                if (sp + 1 <= C) sp++;
+                if (sp + 1 <= C) {
+                    sp++;
+                    fx = hx;
+                    fy = hy;
+                    j0 = 0;
+                } else {  // cannot happen (stack depth <= boundary points <= C); keep the frame we just stored
+                    fx = hx;
+                    fy = hy;
+                    j0 = j + 1;
+                }
             }
             if (lane == 0) {
                 s_i[1] = min(n, C);
