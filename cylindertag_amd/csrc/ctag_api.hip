@@ -120,6 +120,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_lsort = take(F * kLineCap * 4);
     const size_t o_lfit = take(F * kLineCap * 16);
     const size_t o_aux = take(F * kCandCap * sizeof(CandAux));
+    const size_t o_npk = take(F * 4), o_pk = take(F * kCandCap * 4);
     const size_t o_der = take(F * kCandCap * 32);
     const size_t o_qidx = take(F * kCandCap * 4);
     const size_t o_nq = take(F * 4), o_nf = take(F * 4), o_st = take(F * 4);
@@ -158,6 +159,8 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.line_sorted = reinterpret_cast<int32_t*>(b + o_lsort);
     W.line_fit = reinterpret_cast<float*>(b + o_lfit);
     W.cand_aux = reinterpret_cast<CandAux*>(b + o_aux);
+    W.npacks = reinterpret_cast<int32_t*>(b + o_npk);
+    W.packs = reinterpret_cast<uint32_t*>(b + o_pk);
     W.pick_table = h->d_pick_table;
     W.quad_derived = b + o_der;
     W.quad_index = reinterpret_cast<int32_t*>(b + o_qidx);

@@ -34,7 +34,7 @@ constexpr int kQuadLdsPoints = 1024;    // boundary points held in LDS; larger c
 constexpr int kQuadScratchSlots = 64;   // global scratch slots per chunk for oversize components
 constexpr int kQuadScratchPoints = 8192;  // >= 2*(1920+1080)+4: worst-case silhouette of a 4K frame at half-res
 constexpr int kLineCap = 1024;            // fitted edges per frame (4 per candidate that survives the RDP split)
-constexpr int kClPool = 32768;            // edge-cluster points per frame
+constexpr int kClPool = 65536;            // edge-cluster points per frame
 constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table
 constexpr int kMaxDictCells = 2048;       // dictionary rows*cols supported by K9 (reference dictionary: 41*12)
 
@@ -109,6 +109,8 @@ struct Workspace {
     int32_t* line_sorted = nullptr; // [F][kLineCap]
     float* line_fit = nullptr;      // [F][kLineCap][4]
     CandAux* cand_aux = nullptr;    // [F][kCandCap]
+    int32_t* npacks = nullptr;      // [F]
+    uint32_t* packs = nullptr;      // [F][kCandCap]
     const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
     // features
     void* quad_derived = nullptr;   // [F][kCandCap] x 32 B (K7 scratch)

@@ -13,6 +13,7 @@
 // accumulates sequentially is accumulated in the same order so results are bit-identical to the oracle.
 #include "ctag_internal.h"
 #include "ctag_math.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace ctag {
@@ -41,6 +42,9 @@ struct QuadPtrs {
     float* line_fit;       // [F][kLineCap][4]
     CandAux* cand_aux;     // [F][kCandCap]
     const uint8_t* pick_table;  // [kPickN][20][10] cv::RNG initial samples of fitLine2D for every point count < kPickN
+    int32_t* npacks;       // [F]
+    uint32_t* packs;       // [F][kCandCap] first candidate | count << 16
+    unsigned long long* stamps;  // developer aid (CTAG_QUAD_STAMPS=1): cycles per phase of k_quad_edges, else null
 };
 
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
@@ -166,6 +170,16 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
     *out_err = err;
 }
 
+// ---- sub-wave packing: 8 components per wave, 8 lanes each (k_quad_edges_packed) -------------------------
+constexpr int kPackWords = 5120;  // 20 KB of LDS shared by the up to 8 components of a wave
+constexpr int kSG = 8;
+__host__ __device__ __forceinline__ int pack_points(int w, int h) { return min(2 * (w + h), w * h) + 1; }
+// LDS words one component needs in the packed kernel: silhouette arrays + boundary list + stack / ping-pong list
+__host__ __device__ __forceinline__ int pack_need(int w, int h) {
+    const int C = pack_points(w, h);
+    return ((w + 1) & ~1) + 2 * h + 2 * C + 4;
+}
+
 struct CornerPre {
     float x, y, dis, ang;
 };
@@ -190,15 +204,24 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * kPoolCap;
     constexpr size_t kScratchWords = (size_t)4 * kQuadScratchPoints + 2048;
 
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int phase) {
+        if (P.stamps && tid == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (phase >= 0) atomicAdd(&P.stamps[phase], t - t_prev);
+            t_prev = t;
+        }
+    };
     for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
         __syncthreads();
+        stamp(-1);
         const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
         const int x_min = cd.x_min, y_min = cd.y_min;
         const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
         const int C = min(2 * (w + h), w * h) + 1;
         const int w2 = (w + 1) & ~1;
         const size_t need = (size_t)(w2) + 2 * (size_t)h + 3 * (size_t)C + 72;
-        if (BIG != (need > (size_t)kQuadLdsWords)) continue;  // block-uniform: the other instantiation owns it
+        if (BIG != (pack_need(w, h) > kPackWords)) continue;  // block-uniform: k_quad_edges_packed owns the rest
         uint32_t* mem = s_mem;
         if (BIG) {
             if (tid == 0) s_i[0] = atomicAdd(P.scratch_used, 1);
@@ -259,6 +282,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
             }
         }
         __syncthreads();
+        stamp(0);
         // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): explicit stack, wave 0; lanes 0..7 test
         // the 8 neighbours (N,NE,E,SE,S,SW,W,NW) of the current frame at once, the first hit at or after the frame's
         // resume index wins -- the same visiting order as the reference's recursion with its moving `starter` (B7).
@@ -340,6 +364,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
             }
             continue;
         }
+        stamp(1);
         // ---- P3: boundary centroid (:250-256), nearest point (:259-263), rotation (:264-275)
         {
             unsigned long long sx = 0, sy = 0;
@@ -403,6 +428,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
         __syncthreads();
         uint32_t* W = bufB;   // working list
         uint32_t* Wn = bufA;  // next list
+        stamp(2);
         // ---- P4: extended RDP (:278-349).  Thread 0 drives; max-distance search and list surgery use all threads.
         if (tid == 0) {
             s_i[2] = 0;  // cnt_boundary
@@ -613,6 +639,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
             __syncthreads();
         }
         __syncthreads();
+        stamp(3);
         // ---- export: the four edge clusters go to the frame's cluster pool; k_welsch fits them, k_quad_final picks the quad
         bool ok = true;
         for (int j = 0; j < 4; j++) {
@@ -657,9 +684,619 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
             aux->acy = 0.f;
             aux->n_boundary = n_boundary;
         }
+        stamp(4);
     }
 }
 
+
+// =====================================================================================================
+// K6p: greedy packing of a frame's candidates (in candidate order) into waves of <= 8 components whose LDS needs
+// sum to <= kPackWords.  Oversize components are skipped here; k_quad_edges<true> takes them.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes) {
+    const int frame = blockIdx.x * 64 + threadIdx.x;
+    if (frame >= nframes) return;
+    const int nc = P.ncand[frame];
+    const Candidate* cand = P.cand + (size_t)frame * kCandCap;
+    uint32_t* packs = P.packs + (size_t)frame * kCandCap;
+    int np = 0, first = -1, cnt = 0, words = 0;
+    for (int i = 0; i < nc; i++) {
+        const Candidate c = cand[i];
+        const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
+        const bool big = need > kPackWords;
+        if (cnt > 0 && (big || cnt == kSG || words + need > kPackWords)) {  // packs hold consecutive candidates
+            packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
+            cnt = 0;
+            words = 0;
+        }
+        if (big) continue;
+        if (cnt == 0) first = i;
+        cnt++;
+        words += need;
+    }
+    if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
+    P.npacks[frame] = np;
+}
+
+// wave-level ordering point for the 8-lane sub-groups (no s_barrier: the sub-groups of a wave run in lockstep;
+// this only stops the compiler from moving LDS accesses across it)
+#define SG_SYNC()                                              \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
+// expand_line (corner_detector.cpp:125-169) for one 8-lane sub-group, speculatively: in every round lane t assumes the
+// next t+1 candidate points are all accepted, builds the exact integer moment sums of that prefix and fits its line
+// (fitLine DIST_L2); the point of step t is then tested against the line of step t-1, exactly as the sequential loop
+// does, and the prefix up to the first event (distance test fails, `left == right`, or every point used) is committed.
+// All quantities that decide anything are computed from exact sums, so the outcome equals the sequential loop's.
+// Returns nl / nr = points added on the left / right side.  All 8 lanes return the same values.
+__device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, int& nl_out,
+                                               int& nr_out) {
+    long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
+    for (int k = init + sl; k <= end; k += kSG) {
+        const long long x = ux(W[k]), y = uy(W[k]);
+        Sx += x;
+        Sy += y;
+        Sxx += x * x;
+        Syy += y * y;
+        Sxy += x * y;
+    }
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) {
+        Sx += __shfl_xor(Sx, d);
+        Sy += __shfl_xor(Sy, d);
+        Sxx += __shfl_xor(Sxx, d);
+        Syy += __shfl_xor(Syy, d);
+        Sxy += __shfl_xor(Sxy, d);
+    }
+    int m = end - init + 1;
+    float line[4];
+    moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
+    bool fl = false, fr = false;
+    int left = init - 1, right = end + 1, nl = 0, nr = 0;
+    while ((!fl || !fr) && (left != right)) {
+        const int mode = (!fl && !fr) ? 0 : (!fl ? 1 : 2);  // 0: L,R alternate; 1: left only; 2: right only
+        // replay the index bookkeeping of steps 0..sl under the "all accepted" assumption
+        int l = left, r = right, q_idx = 0, cfalse_at = 99;
+        long long px = 0, py = 0, pxx = 0, pyy = 0, pxy = 0;
+        uint32_t qpt = 0;
+        for (int u = 0; u <= sl; u++) {
+            const bool stepL = mode == 0 ? ((u & 1) == 0) : (mode == 1);
+            const bool checkC = mode == 0 ? ((u & 1) == 0) : true;  // `left != right` is tested at the top of an iteration
+            if (checkC && l == r && cfalse_at == 99) cfalse_at = u;
+            int idx;
+            if (stepL) {
+                idx = (l == -1) ? n - 1 : l;
+                l = idx - 1;
+            } else {
+                idx = (r == n) ? 0 : r;
+                r = idx + 1;
+            }
+            qpt = W[idx];
+            const long long x = ux(qpt), y = uy(qpt);
+            px += x;
+            py += y;
+            pxx += x * x;
+            pyy += y * y;
+            pxy += x * y;
+            q_idx = idx;
+        }
+        float mine[4];
+        moments_to_line((double)(Sx + px), (double)(Sy + py), (double)(Sxx + pxx), (double)(Syy + pyy), (double)(Sxy + pxy),
+                        (double)(float)(m + sl + 1), mine);
+        float lp[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float up = __shfl(mine[k], lane0 + ((sl + 7) & 7));
+            lp[k] = sl == 0 ? line[k] : up;
+        }
+        const float de = ctm::fabs32(ux(qpt) * lp[1] - uy(qpt) * lp[0] + lp[0] * lp[3] - lp[1] * lp[2]);
+        const unsigned failm = (unsigned)((__ballot(de > 1.2f) >> sgshift) & 0xffull);
+        const int tf = failm ? (__ffs(failm) - 1) : 99;
+        const int tc = __shfl(cfalse_at, lane0 + 7);
+        const int te_raw = n - m - 1;  // the add of step te makes Slide.size() == edge_point.size()
+        const int te = (te_raw >= 0 && te_raw < kSG) ? te_raw : 99;
+        int accepted;
+        bool done = false, failed_step = false;
+        if (tc < 99 && tc <= tf && tc <= te) {
+            accepted = tc;
+            done = true;
+        } else if (tf < 99 && tf <= te) {
+            accepted = tf;
+            failed_step = true;
+        } else if (te < 99) {
+            accepted = te + 1;
+            done = true;
+        } else {
+            accepted = kSG;
+        }
+        if (accepted > 0) {
+            const int src = lane0 + accepted - 1;
+            Sx += __shfl(px, src);
+            Sy += __shfl(py, src);
+            Sxx += __shfl(pxx, src);
+            Syy += __shfl(pyy, src);
+            Sxy += __shfl(pxy, src);
+#pragma unroll
+            for (int k = 0; k < 4; k++) line[k] = __shfl(mine[k], src);
+            left = __shfl(l, src);
+            right = __shfl(r, src);
+            m += accepted;
+            if (mode == 0) {
+                nl += (accepted + 1) >> 1;
+                nr += accepted >> 1;
+            } else if (mode == 1) {
+                nl += accepted;
+            } else {
+                nr += accepted;
+            }
+        }
+        if (failed_step) {
+            const bool stepL = mode == 0 ? ((accepted & 1) == 0) : (mode == 1);
+            const int fidx = __shfl(q_idx, lane0 + accepted);
+            if (stepL) {
+                fl = true;
+                left = fidx;  // `left` keeps the tested (already wrapped) index
+            } else {
+                fr = true;
+                right = fidx;
+            }
+        }
+        if (done) break;
+    }
+    nl_out = nl;
+    nr_out = nr;
+}
+
+// =====================================================================================================
+// K6a (packed): the same boundary -> 4 edge clusters computation as k_quad_edges, 8 components per wave.
+// Every lane of a sub-group executes the serial control flow redundantly (uniform within the sub-group), so no
+// broadcasts are needed; loops over pixels / boundary points are strided over the 8 lanes.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes) {
+    __shared__ uint32_t s_mem[kPackWords];
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    const int lane = threadIdx.x, sub = lane >> 3, sl = lane & 7, lane0 = lane & ~7;
+    const int npk = P.npacks[frame];
+    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
+    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * kPoolCap;
+
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int phase) {  // developer aid: wave-level cycles per phase (the sub-groups reconverge between phases)
+        if (P.stamps) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (phase >= 0 && lane == 0) atomicAdd(&P.stamps[phase], t - t_prev);
+            t_prev = t;
+        }
+    };
+    for (int pk = blockIdx.x; pk < npk; pk += gridDim.x) {
+        __syncthreads();  // single-wave workgroup: the previous pack is done with s_mem
+        stamp(-1);
+        const uint32_t pw = P.packs[(size_t)frame * kCandCap + pk];
+        const int first = (int)(pw & 0xffffu), cnt = (int)(pw >> 16);
+        const bool act = sub < cnt;
+        const int ci = first + (act ? sub : 0);
+        const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
+        const int x_min = cd.x_min, y_min = cd.y_min;
+        const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
+        const int C = pack_points(w, h);
+        const int w2 = (w + 1) & ~1;
+        const int need = act ? pack_need(w, h) : 0;
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < kSG; k++) {
+            const int v = __shfl(need, k * 8);
+            if (k < sub) off += v;
+        }
+        if (!act) continue;
+        CandAux* aux = P.cand_aux + (size_t)frame * kCandCap + ci;
+        uint32_t* mem = s_mem + off;
+        uint16_t* top = reinterpret_cast<uint16_t*>(mem);
+        uint16_t* bot = top + w2;
+        uint32_t* lef = mem + w2;
+        uint32_t* rig = lef + h;
+        uint32_t* bufA = rig + h;
+        uint32_t* bufB = bufA + C;  // C + 1 words
+        const int sgshift = sub * 8;
+
+        // ---- P1: silhouette first-hit arrays (corner_detector.cpp:184-232).  Each lane reads 8 labels with one
+        // 16-byte load (64 columns per sub-group step, starting at a 16-byte aligned column), remembers the last
+        // (tile-local label, tile) -> "is my component" decision so the two dependent gathers are rare, and has
+        // the next row's load in flight while it digests the current one.
+        for (int x = sl; x < w; x += kSG) {
+            top[x] = 0xffff;
+            bot[x] = 0xffff;
+        }
+        SG_SYNC();
+        {
+            const int xa = x_min & ~7;
+            const int x_end = x_min + w;  // exclusive
+            // two-entry cache of (tile-local label, tile) -> "is my component": a row typically alternates between this
+            // component and one neighbour inside the bounding box
+            unsigned c0_l = 0xffffffffu, c1_l = 0xffffffffu;
+            int c0_t = -1, c1_t = -1;
+            bool c0_r = false, c1_r = false;
+            const int gxf = xa + 8 * sl;  // this lane's first column in chunk 0
+            int topr[8], botr[8];         // first / last foreground row of this lane's 8 columns of chunk 0 (registers)
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                topr[q] = 0xffff;
+                botr[q] = 0xffff;
+            }
+            const bool ld_ok = gxf < x_end;
+            auto load_row = [&](int y) {
+                uint4 r = make_uint4(0, 0, 0, 0);
+                if (ld_ok && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf);
+                return r;
+            };
+            auto process_row = [&](uint4 v, int y) {
+                const int gy = y_min + y;
+                const uint16_t* lrow = limg + (size_t)gy * g.lp;
+                const int trow = (gy / kTileH) * g.tiles_x;
+                unsigned lmin = 0xffffffffu, rmax = 0u;
+                for (int cb = xa; cb < x_end; cb += 64) {
+                    const int gx0 = cb + 8 * sl;
+                    if (cb != xa) {
+                        v = make_uint4(0, 0, 0, 0);
+                        if (gx0 < x_end) v = *reinterpret_cast<const uint4*>(lrow + gx0);
+                    }
+                    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                    unsigned fgbits = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const unsigned l = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        const int gx = gx0 + q;
+                        if (l && gx >= x_min && gx < x_end) {
+                            const int tile = trow + gx / kTileW;
+                            bool r;
+                            if (l == c0_l && tile == c0_t) {
+                                r = c0_r;
+                            } else if (l == c1_l && tile == c1_t) {
+                                r = c1_r;
+                            } else {
+                                r = rootof[tbase[tile] + (int)l - 1] == cd.root;
+                                c1_l = c0_l;
+                                c1_t = c0_t;
+                                c1_r = c0_r;
+                                c0_l = l;
+                                c0_t = tile;
+                                c0_r = r;
+                            }
+                            if (r) fgbits |= 1u << q;
+                        }
+                    }
+                    if (fgbits) {
+                        const int xl0 = gx0 - x_min;
+                        if (cb == xa) {
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                if ((fgbits >> q) & 1u) {
+                                    if (topr[q] == 0xffff) topr[q] = y;
+                                    botr[q] = y;
+                                }
+                            }
+                        } else {
+                            unsigned t = fgbits;
+                            while (t) {
+                                const int q = __ffs(t) - 1;
+                                t &= t - 1;
+                                if (top[xl0 + q] == 0xffff) top[xl0 + q] = (uint16_t)y;
+                                bot[xl0 + q] = (uint16_t)y;
+                            }
+                        }
+                        lmin = min(lmin, (unsigned)(xl0 + __ffs(fgbits) - 1));
+                        rmax = max(rmax, (unsigned)(xl0 + 32 - __clz(fgbits)));
+                    }
+                }
+#pragma unroll
+                for (int d = 4; d >= 1; d >>= 1) {
+                    lmin = min(lmin, (unsigned)__shfl_xor((int)lmin, d));
+                    rmax = max(rmax, (unsigned)__shfl_xor((int)rmax, d));
+                }
+                if (sl == 0) {
+                    lef[y] = lmin;
+                    rig[y] = rmax;
+                }
+            };
+            // 4 label rows in flight per lane: the scan is bound by memory latency, not by bytes
+            uint4 r0 = load_row(0), r1 = load_row(1), r2 = load_row(2), r3 = load_row(3);
+            for (int y = 0; y < h; y += 4) {
+                process_row(r0, y);
+                r0 = load_row(y + 4);
+                if (y + 1 < h) process_row(r1, y + 1);
+                r1 = load_row(y + 5);
+                if (y + 2 < h) process_row(r2, y + 2);
+                r2 = load_row(y + 6);
+                if (y + 3 < h) process_row(r3, y + 3);
+                r3 = load_row(y + 7);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int xl = gxf + q - x_min;
+                if (xl >= 0 && xl < w) {
+                    top[xl] = (uint16_t)topr[q];
+                    bot[xl] = (uint16_t)botr[q];
+                }
+            }
+        }
+        SG_SYNC();
+        stamp(0);
+        // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): lanes 0..7 of the sub-group test the
+        // 8 neighbours (N,NE,E,SE,S,SW,W,NW); the first hit at or after the frame's resume index wins (B7)
+        int n = 0;
+        {
+            const int dxl = (int)((0x01A9u >> (2 * sl)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * sl)) & 3u) - 1;
+            int sp = 0;
+            int fx = 0, fy = top[0], j0 = 0;  // top-of-stack frame in registers; bufB holds the frames below it
+            if (fy == 0xffff) {
+                sp = -1;
+            } else {
+                if (sl == 0) {
+                    bufA[0] = pack_xy(x_min, fy + y_min);
+                    top[0] = 0xffff;
+                    if (bot[0] == fy) bot[0] = 0xffff;
+                    if (lef[fy] == 0u) lef[fy] = 0xffffffffu;
+                    if (rig[fy] == 1u) rig[fy] = 0u;
+                }
+                n = 1;
+            }
+            SG_SYNC();
+            while (sp >= 0) {
+                const int nx = fx + dxl, ny = fy + dyl;
+                unsigned why = 0;
+                if (sl >= j0 && ny >= 0 && ny < h && nx >= 0 && nx < w) {
+                    why = (top[nx] == ny ? 1u : 0u) | (bot[nx] == ny ? 2u : 0u) | (lef[ny] == (unsigned)nx ? 4u : 0u) |
+                          (rig[ny] == (unsigned)(nx + 1) ? 8u : 0u);
+                }
+                const unsigned m = (unsigned)((__ballot(why != 0) >> sgshift) & 0xffull);
+                if (!m) {
+                    sp--;
+                    if (sp >= 0) {
+                        const uint32_t f = bufB[sp];
+                        fx = (int)(f & 0x3fff);
+                        fy = (int)((f >> 14) & 0x3fff);
+                        j0 = (int)(f >> 28);
+                    }
+                    continue;
+                }
+                const int j = __ffs(m) - 1;
+                const unsigned hw = (unsigned)__shfl((int)why, lane0 + j);
+                const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
+                if (sl == 0) {
+                    if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
+                    if (hw & 1u) top[hx] = 0xffff;
+                    if (hw & 2u) bot[hx] = 0xffff;
+                    if (hw & 4u) lef[hy] = 0xffffffffu;
+                    if (hw & 8u) rig[hy] = 0u;
+                    if (sp <= C) bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
+                }
+                SG_SYNC();
+                n++;
+                fx = hx;
+                fy = hy;
+                if (sp + 1 <= C) {
+                    sp++;
+                    j0 = 0;
+                } else {
+                    j0 = j + 1;
+                }
+            }
+            n = min(n, C);
+        }
+        const int n_boundary = n;
+        if (n == 0) {
+            if (sl == 0) {
+                aux->line0 = -1;
+                aux->acx = 0.f;
+                aux->acy = 0.f;
+                aux->n_boundary = 0;
+            }
+            continue;
+        }
+        SG_SYNC();
+        stamp(1);
+        // ---- P3: boundary centroid (:250-256), nearest point (:259-263), rotation (:264-275)
+        float acx, acy;
+        {
+            unsigned long long sx = 0, sy = 0;
+            for (int k = sl; k < n; k += kSG) {
+                sx += (unsigned)ux(bufA[k]);
+                sy += (unsigned)uy(bufA[k]);
+            }
+#pragma unroll
+            for (int d = 4; d >= 1; d >>= 1) {
+                sx += __shfl_xor(sx, d);
+                sy += __shfl_xor(sy, d);
+            }
+            acx = (float)(1.0 * (long long)sx / (double)(unsigned long long)n);
+            acy = (float)(1.0 * (long long)sy / (double)(unsigned long long)n);
+            float bd = 3.0e38f;
+            int bi = 0x7fffffff;
+            for (int k = sl; k < n; k += kSG) {
+                const float dx = (float)ux(bufA[k]) - acx, dy = (float)uy(bufA[k]) - acy;
+                const float d = ctm::sqrt32(dx * dx + dy * dy);
+                if (d < bd || (d == bd && k < bi)) {
+                    bd = d;
+                    bi = k;
+                }
+            }
+#pragma unroll
+            for (int d = 4; d >= 1; d >>= 1) {
+                const float od = __shfl_xor(bd, d);
+                const int oi = __shfl_xor(bi, d);
+                if (od < bd || (od == bd && oi < bi)) {
+                    bd = od;
+                    bi = oi;
+                }
+            }
+            for (int k = sl; k < n; k += kSG) {
+                int src = k + bi;
+                if (src >= n) src -= n;
+                bufB[k] = bufA[src];
+            }
+        }
+        SG_SYNC();
+        stamp(2);
+        // cluster space in the frame's pool (upper bound; the clusters are written straight to global memory)
+        int p0 = 0;
+        if (sl == 0) p0 = atomicAdd(&P.clp_used[frame], C + 64);
+        p0 = __shfl(p0, lane0);
+        if (p0 + C + 64 > kClPool) {
+            if (sl == 0) {
+                atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+                aux->line0 = -1;
+                aux->acx = 0.f;
+                aux->acy = 0.f;
+                aux->n_boundary = n_boundary;
+            }
+            continue;
+        }
+        uint32_t* CLg = P.cl_pool + (size_t)frame * kClPool + p0;
+        // ---- P4: extended RDP (:278-349), uniform control flow inside the sub-group
+        uint32_t* W = bufB;
+        uint32_t* Wn = bufA;
+        int cnt_b = 0, init = 0, cl_off[5] = {0, 0, 0, 0, 0};
+        bool failed = false;
+        while (n > 0 && !failed && cnt_b < 4) {
+            auto tri2 = [&](int a) {
+                const uint32_t q0 = W[a], q2 = W[(a + 2) % n], q1 = W[(a + 1) % n];
+                const int vx = ux(q0) + ux(q2) - 2 * ux(q1), vy = uy(q0) + uy(q2) - 2 * uy(q1);
+                return vx * vx + vy * vy;
+            };
+            if (n <= 2) {
+                failed = true;
+                break;
+            }
+            {
+                int c2 = tri2(init);  // cost > 1.05  <=>  squared norm >= 2
+                while (c2 >= 2 && init < n - 3) {
+                    init++;
+                    c2 = tri2(init);
+                }
+            }
+            int end = init + n / 2;
+            if (end > n - 1) end = n - 1;
+            while (true) {  // :303-330
+                if (end <= init + 1) {
+                    failed = true;
+                    break;
+                }
+                const uint32_t pi = W[init], pe = W[end];
+                float nl0;
+                if (ux(pi) == ux(pe)) {
+                    nl0 = 100;
+                } else {
+                    nl0 = (float)(1.0 * (uy(pe) - uy(pi)) / (ux(pe) - ux(pi)));
+                }
+                const float nl1 = -1;
+                const float d_line = -(nl0 * ux(pi) + nl1 * uy(pi));
+                const float den = ctm::sqrt32(nl0 * nl0 + 1);
+                float bd = -1.f;
+                int bi = -1;
+                for (int it = init + 1 + sl; it < end; it += kSG) {
+                    const uint32_t q = W[it];
+                    const float d = ctm::fabs32(nl0 * ux(q) + nl1 * uy(q) + d_line) / den;
+                    const int rel = it - init - 1;
+                    if (d > bd || (d == bd && rel > bi)) {
+                        bd = d;
+                        bi = rel;
+                    }
+                }
+#pragma unroll
+                for (int d = 4; d >= 1; d >>= 1) {
+                    const float od = __shfl_xor(bd, d);
+                    const int oi = __shfl_xor(bi, d);
+                    if (od > bd || (od == bd && oi > bi)) {
+                        bd = od;
+                        bi = oi;
+                    }
+                }
+                const int count = end - init - 1;
+                if (bd > 1.8f && count > 1) {
+                    end = bi;  // literal index into dist2line
+                    continue;
+                }
+                // ---- expand_line (:125-169), speculative over the sub-group's 8 lanes
+                int nl, nr;
+                sg_expand_line(W, n, init, end, sl, lane0, sgshift, nl, nr);
+                const int m = end - init + 1 + nl + nr;
+                // the span is a circular arc [a .. b] of m distinct indices
+                const int a = ((init - nl) % n + n) % n;
+                const int b = (end + nr) % n;
+                const bool wrap = a > b;
+                const int span0 = wrap ? n - 1 : b;
+                const int keep = tri2(span0) <= 1 ? 1 : 0;  // cost < 1.05 (:337-339)
+                const int offc = cl_off[cnt_b];
+                for (int k = sl; k < m; k += kSG) {  // cluster points in descending index order (:332-334)
+                    int idx;
+                    if (!wrap) {
+                        idx = b - k;
+                    } else {
+                        idx = (k < n - a) ? (n - 1 - k) : (b - (k - (n - a)));
+                    }
+                    if (offc + k < C + 64) CLg[offc + k] = W[idx];
+                }
+                const int new_n = n - m + keep;  // erase the span except (optionally) its largest index (:341-343)
+                if (!wrap) {
+                    for (int k = sl; k < new_n; k += kSG) {
+                        int src;
+                        if (k < a) src = k;
+                        else if (keep && k == a) src = b;
+                        else src = k - keep + m;
+                        Wn[k] = W[src];
+                    }
+                } else {
+                    const int mid = a - b - 1;
+                    for (int k = sl; k < new_n; k += kSG) Wn[k] = (k < mid) ? W[b + 1 + k] : W[n - 1];
+                }
+                SG_SYNC();
+                const int back = wrap ? 0 : a;
+                cl_off[cnt_b + 1] = min(offc + m, C + 64);
+                cnt_b++;
+                init = (back >= new_n) ? 0 : back;
+                n = new_n;
+                uint32_t* t = W;
+                W = Wn;
+                Wn = t;
+                break;
+            }
+        }
+        stamp(3);
+        // ---- export
+        bool ok = true;
+        for (int j = 0; j < 4; j++) {
+            const int len = (j < cnt_b) ? (cl_off[j + 1] - cl_off[j]) : 0;
+            if (len < 2) ok = false;  // flag_line_number (:353-357)
+        }
+        if (cl_off[min(cnt_b, 4)] >= C + 64) ok = false;
+        int l0 = -1;
+        if (ok) {
+            if (sl == 0) l0 = atomicAdd(&P.line_count[frame], 4);
+            l0 = __shfl(l0, lane0);
+            if (l0 + 4 > kLineCap) {
+                ok = false;
+                if (sl == 0) atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+            }
+        }
+        if (ok && sl < 4) {
+            LineDesc d;
+            d.off = (uint32_t)(p0 + cl_off[sl]);
+            d.n = cl_off[sl + 1] - cl_off[sl];
+            P.line_desc[(size_t)frame * kLineCap + l0 + sl] = d;
+        }
+        if (sl == 0) {
+            aux->line0 = ok ? l0 : -1;
+            aux->acx = ok ? acx : 0.f;
+            aux->acy = ok ? acy : 0.f;
+            aux->n_boundary = n_boundary;
+        }
+        stamp(4);
+    }
+}
 
 // =====================================================================================================
 // K6s: per frame, order the edge clusters by descending point count so that the three edges a Welsch wave
@@ -847,15 +1484,32 @@ __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int 
 
 hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.npacks, ws.packs, nullptr};
+    static unsigned long long* d_stamps = nullptr;
+    const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
+    if (want_stamps) {
+        if (!d_stamps) (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), 16 * 8);
+        (void)hipMemsetAsync(d_stamps, 0, 16 * 8, s);
+        P.stamps = d_stamps;
+    }
     (void)hipMemsetAsync(ws.quad_scratch_used, 0, sizeof(int32_t), s);
     (void)hipMemsetAsync(ws.line_count, 0, sizeof(int32_t) * (size_t)nframes, s);
     (void)hipMemsetAsync(ws.clp_used, 0, sizeof(int32_t) * (size_t)nframes, s);
-    hipLaunchKernelGGL(k_quad_edges<false>, dim3(128, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes);
+    hipLaunchKernelGGL(k_quad_edges_packed, dim3(32, nframes), dim3(64), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_quad_edges<true>, dim3(4, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     hipLaunchKernelGGL(k_welsch, dim3((kLineCap + 2) / 3, nframes), dim3(64), 0, s, P, nframes);
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    if (want_stamps) {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int i = 0; i < 5; i++) tot += h[i];
+        fprintf(stderr, "[k_quad_edges cycles] silhouette %.1f%% traversal %.1f%% centroid/rotate %.1f%% rdp %.1f%% export %.1f%% (total %llu)\n",
+                100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, tot);
+    }
     return hipGetLastError();
 }
 
