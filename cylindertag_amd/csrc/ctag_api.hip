@@ -107,7 +107,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_flags = take(F * 4);
     const size_t pool = F * kPoolCap * 4;
     const size_t o_parent = take(pool), o_root = take(pool), o_area = take(pool), o_xmin = take(pool), o_ymin = take(pool),
-                 o_xmax = take(pool), o_ymax = take(pool), o_key = take(pool);
+                 o_xmax = take(pool), o_ymax = take(pool), o_key = take(pool), o_ptile = take(pool), o_mhead = take(pool), o_mnext = take(pool);
     const size_t o_ncand = take(F * 4);
     const size_t o_cand = take(F * kCandCap * sizeof(Candidate));
     const size_t o_quads = take(F * kCandCap * sizeof(QuadOut));
@@ -147,6 +147,9 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.xmax = reinterpret_cast<int32_t*>(b + o_xmax);
     W.ymax = reinterpret_cast<int32_t*>(b + o_ymax);
     W.key = reinterpret_cast<int32_t*>(b + o_key);
+    W.pool_tile = reinterpret_cast<int32_t*>(b + o_ptile);
+    W.member_head = reinterpret_cast<int32_t*>(b + o_mhead);
+    W.member_next = reinterpret_cast<int32_t*>(b + o_mnext);
     W.ncand = reinterpret_cast<int32_t*>(b + o_ncand);
     W.cand = reinterpret_cast<Candidate*>(b + o_cand);
     W.quads = reinterpret_cast<QuadOut*>(b + o_quads);

@@ -96,6 +96,9 @@ struct Workspace {
     int32_t* xmax = nullptr;
     int32_t* ymax = nullptr;
     int32_t* key = nullptr;
+    int32_t* pool_tile = nullptr;
+    int32_t* member_head = nullptr;
+    int32_t* member_next = nullptr;
     // candidates
     int32_t* ncand = nullptr;       // [F]
     Candidate* cand = nullptr;      // [F][kCandCap]

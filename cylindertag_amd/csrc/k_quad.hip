@@ -42,8 +42,12 @@ struct QuadPtrs {
     float* line_fit;       // [F][kLineCap][4]
     CandAux* cand_aux;     // [F][kCandCap]
     const uint8_t* pick_table;  // [kPickN][20][10] cv::RNG initial samples of fitLine2D for every point count < kPickN
+    const int32_t* pool_tile;    // [F][kPoolCap]
+    const int32_t* member_head;  // [F][kPoolCap]
+    const int32_t* member_next;  // [F][kPoolCap]
     int32_t* npacks;       // [F]
     uint32_t* packs;       // [F][kCandCap] first candidate | count << 16
+    int dbg;               // developer aid (CTAG_DBG): timing experiments only
     unsigned long long* stamps;  // developer aid (CTAG_QUAD_STAMPS=1): cycles per phase of k_quad_edges, else null
 };
 
@@ -179,6 +183,8 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
     const int C = pack_points(w, h);
     return ((w + 1) & ~1) + 2 * h + 2 * C + 4;
 }
+// the packed kernel scans at most two 64-column chunks per row (16-byte aligned start); wider boxes are "big"
+__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h) { return pack_need(w, h) > kPackWords || (x_min & 7) + w > 128; }
 
 struct CornerPre {
     float x, y, dis, ang;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
         const int C = min(2 * (w + h), w * h) + 1;
         const int w2 = (w + 1) & ~1;
         const size_t need = (size_t)(w2) + 2 * (size_t)h + 3 * (size_t)C + 72;
-        if (BIG != (pack_need(w, h) > kPackWords)) continue;  // block-uniform: k_quad_edges_packed owns the rest
+        if (BIG != pack_big(x_min, w, h)) continue;  // block-uniform: k_quad_edges_packed owns the rest
         uint32_t* mem = s_mem;
         if (BIG) {
             if (tid == 0) s_i[0] = atomicAdd(P.scratch_used, 1);
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes) {
     for (int i = 0; i < nc; i++) {
         const Candidate c = cand[i];
         const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
-        const bool big = need > kPackWords;
+        const bool big = pack_big(c.x_min, c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
         if (cnt > 0 && (big || cnt == kSG || words + need > kPackWords)) {  // packs hold consecutive candidates
             packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
             cnt = 0;
@@ -903,6 +909,31 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
         uint32_t* bufB = bufA + C;  // C + 1 words
         const int sgshift = sub * 8;
 
+        stamp(6);
+        // the component's pixels carry one tile-local label per CCL tile it touches: collect those (tile, label) keys
+        // (root entry + its member list built by k_resolve) so the pixel scan needs no gathers
+        constexpr int kMaxKeys = 8;
+        uint32_t mykey[kMaxKeys];
+        int nkeys = 0;
+        bool many = false;
+        {
+            const int32_t* ptile = P.pool_tile + (size_t)frame * kPoolCap;
+            const int32_t* mnext = P.member_next + (size_t)frame * kPoolCap;
+            int e = cd.root;
+            bool first_e = true;
+#pragma unroll
+            for (int k = 0; k < kMaxKeys; k++) {
+                mykey[k] = 0xffffffffu;
+                if (e >= 0) {
+                    const int t = ptile[e];
+                    mykey[k] = ((uint32_t)t << 16) | (uint32_t)(e - tbase[t] + 1);
+                    nkeys = k + 1;
+                    e = first_e ? P.member_head[(size_t)frame * kPoolCap + e] : mnext[e];
+                    first_e = false;
+                }
+            }
+            many = e >= 0;  // more members than keys: fall back to the gather test
+        }
         // ---- P1: silhouette first-hit arrays (corner_detector.cpp:184-232).  Each lane reads 8 labels with one
         // 16-byte load (64 columns per sub-group step, starting at a 16-byte aligned column), remembers the last
         // (tile-local label, tile) -> "is my component" decision so the two dependent gathers are rare, and has
@@ -911,115 +942,141 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
             top[x] = 0xffff;
             bot[x] = 0xffff;
         }
+        for (int y = sl; y < h; y += kSG) {
+            lef[y] = 0xffffffffu;
+            rig[y] = 0u;
+        }
         SG_SYNC();
         {
             const int xa = x_min & ~7;
-            const int x_end = x_min + w;  // exclusive
-            // two-entry cache of (tile-local label, tile) -> "is my component": a row typically alternates between this
-            // component and one neighbour inside the bounding box
-            unsigned c0_l = 0xffffffffu, c1_l = 0xffffffffu;
-            int c0_t = -1, c1_t = -1;
-            bool c0_r = false, c1_r = false;
-            const int gxf = xa + 8 * sl;  // this lane's first column in chunk 0
-            int topr[8], botr[8];         // first / last foreground row of this lane's 8 columns of chunk 0 (registers)
+            const int x_end = x_min + w;  // exclusive; x_end - xa <= 128 (pack_big)
+            const int gxf = xa + 8 * sl;  // this lane's 8 columns of chunk 0; chunk 1 is 64 columns further
+            // Eight 16-byte aligned columns never straddle a 320-column tile boundary, so one lane's pixels of a chunk
+            // share a CCL tile; the component's label(s) in that tile are looked up once per tile row (every 30 rows).
+            const int tcol0 = gxf / kTileW, tcol1 = (gxf + 64) / kTileW;
+            unsigned valid0 = 0, valid1 = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                topr[q] = 0xffff;
-                botr[q] = 0xffff;
+                if (gxf + q >= x_min && gxf + q < x_end) valid0 |= 1u << q;
+                if (gxf + 64 + q >= x_min && gxf + 64 + q < x_end) valid1 |= 1u << q;
             }
-            const bool ld_ok = gxf < x_end;
+            const bool ld_ok = valid0 != 0, ld_ok1 = valid1 != 0;
+            unsigned labA0 = 0xffffffffu, labB0 = 0xffffffffu, labA1 = 0xffffffffu, labB1 = 0xffffffffu;
+            bool over0 = false, over1 = false;  // more than two labels of this component in one tile: generic test
+            int cur_trow = -1;
+            uint32_t top0[4], bot0[4], seen0[4], top1[4], bot1[4], seen1[4];  // packed halfwords: 8 columns per chunk
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                top0[d] = bot0[d] = top1[d] = bot1[d] = 0xffffffffu;
+                seen0[d] = seen1[d] = 0u;
+            }
+            stamp(5);
+            auto labels_of_tile = [&](int tile, unsigned& la, unsigned& lb, bool& over) {
+                la = 0xffffffffu;
+                lb = 0xffffffffu;
+                over = many;
+                int found = 0;
+#pragma unroll
+                for (int k = 0; k < kMaxKeys; k++) {
+                    if ((int)(mykey[k] >> 16) == tile && mykey[k] != 0xffffffffu) {
+                        if (found == 0) la = mykey[k] & 0xffffu;
+                        else if (found == 1) lb = mykey[k] & 0xffffu;
+                        else over = true;
+                        found++;
+                    }
+                }
+                if (found == 1) lb = la;
+            };
+            // generic (rare) membership test of one pixel
+            auto slow_fg = [&](unsigned l, int tile) {
+                if (!many) {
+                    const uint32_t key = ((uint32_t)tile << 16) | l;
+                    bool r = false;
+                    for (int k = 0; k < kMaxKeys; k++) r = r || (key == mykey[k]);
+                    return r;
+                }
+                return rootof[tbase[tile] + (int)l - 1] == cd.root;
+            };
+            auto fg_of = [&](const uint4& v, unsigned la, unsigned lb, bool over, int tile, unsigned valid) {
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                unsigned bits = 0;
+                if (!over) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned l0 = wv[d] & 0xffffu, l1 = wv[d] >> 16;
+                        bits |= ((l0 == la || l0 == lb) ? 1u : 0u) << (2 * d);
+                        bits |= ((l1 == la || l1 == lb) ? 1u : 0u) << (2 * d + 1);
+                    }
+                } else {
+                    for (int q = 0; q < 8; q++) {
+                        const unsigned l = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        if (l && slow_fg(l, tile)) bits |= 1u << q;
+                    }
+                }
+                return bits & valid;
+            };
+            auto note = [&](unsigned bits, int y, uint32_t* tp, uint32_t* bt, uint32_t* sn, int xl0) {
+                if (!bits) return;
+                const uint32_t ypk = (uint32_t)y * 0x10001u;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t m = ((bits >> (2 * d)) & 1u) * 0xffffu + ((bits >> (2 * d + 1)) & 1u) * 0xffff0000u;
+                    bt[d] = (bt[d] & ~m) | (ypk & m);
+                    const uint32_t nm = m & ~sn[d];
+                    tp[d] = (tp[d] & ~nm) | (ypk & nm);
+                    sn[d] |= m;
+                }
+                // row extents by LDS atomics (no result needed, so no latency is exposed)
+                atomicMin(&lef[y], (unsigned)(xl0 + __ffs(bits) - 1));
+                atomicMax(&rig[y], (unsigned)(xl0 + 32 - __clz(bits)));
+            };
             auto load_row = [&](int y) {
                 uint4 r = make_uint4(0, 0, 0, 0);
                 if (ld_ok && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf);
                 return r;
             };
-            auto process_row = [&](uint4 v, int y) {
-                const int gy = y_min + y;
-                const uint16_t* lrow = limg + (size_t)gy * g.lp;
-                const int trow = (gy / kTileH) * g.tiles_x;
-                unsigned lmin = 0xffffffffu, rmax = 0u;
-                for (int cb = xa; cb < x_end; cb += 64) {
-                    const int gx0 = cb + 8 * sl;
-                    if (cb != xa) {
-                        v = make_uint4(0, 0, 0, 0);
-                        if (gx0 < x_end) v = *reinterpret_cast<const uint4*>(lrow + gx0);
-                    }
-                    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-                    unsigned fgbits = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const unsigned l = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                        const int gx = gx0 + q;
-                        if (l && gx >= x_min && gx < x_end) {
-                            const int tile = trow + gx / kTileW;
-                            bool r;
-                            if (l == c0_l && tile == c0_t) {
-                                r = c0_r;
-                            } else if (l == c1_l && tile == c1_t) {
-                                r = c1_r;
-                            } else {
-                                r = rootof[tbase[tile] + (int)l - 1] == cd.root;
-                                c1_l = c0_l;
-                                c1_t = c0_t;
-                                c1_r = c0_r;
-                                c0_l = l;
-                                c0_t = tile;
-                                c0_r = r;
-                            }
-                            if (r) fgbits |= 1u << q;
-                        }
-                    }
-                    if (fgbits) {
-                        const int xl0 = gx0 - x_min;
-                        if (cb == xa) {
-#pragma unroll
-                            for (int q = 0; q < 8; q++) {
-                                if ((fgbits >> q) & 1u) {
-                                    if (topr[q] == 0xffff) topr[q] = y;
-                                    botr[q] = y;
-                                }
-                            }
-                        } else {
-                            unsigned t = fgbits;
-                            while (t) {
-                                const int q = __ffs(t) - 1;
-                                t &= t - 1;
-                                if (top[xl0 + q] == 0xffff) top[xl0 + q] = (uint16_t)y;
-                                bot[xl0 + q] = (uint16_t)y;
-                            }
-                        }
-                        lmin = min(lmin, (unsigned)(xl0 + __ffs(fgbits) - 1));
-                        rmax = max(rmax, (unsigned)(xl0 + 32 - __clz(fgbits)));
-                    }
-                }
-#pragma unroll
-                for (int d = 4; d >= 1; d >>= 1) {
-                    lmin = min(lmin, (unsigned)__shfl_xor((int)lmin, d));
-                    rmax = max(rmax, (unsigned)__shfl_xor((int)rmax, d));
-                }
-                if (sl == 0) {
-                    lef[y] = lmin;
-                    rig[y] = rmax;
-                }
+            auto load_row1 = [&](int y) {
+                uint4 r = make_uint4(0, 0, 0, 0);
+                if (ld_ok1 && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf + 64);
+                return r;
             };
-            // 4 label rows in flight per lane: the scan is bound by memory latency, not by bytes
+            auto process_row = [&](const uint4& v, const uint4& v1, int y) {
+                const int trow = ((y_min + y) / kTileH) * g.tiles_x;
+                if (trow != cur_trow) {
+                    cur_trow = trow;
+                    labels_of_tile(trow + tcol0, labA0, labB0, over0);
+                    labels_of_tile(trow + tcol1, labA1, labB1, over1);
+                }
+                note(fg_of(v, labA0, labB0, over0, trow + tcol0, valid0), y, top0, bot0, seen0, gxf - x_min);
+                if (ld_ok1) note(fg_of(v1, labA1, labB1, over1, trow + tcol1, valid1), y, top1, bot1, seen1, gxf + 64 - x_min);
+            };
+            // 4 label rows in flight per lane: the scan is bound by latency, not by bytes
             uint4 r0 = load_row(0), r1 = load_row(1), r2 = load_row(2), r3 = load_row(3);
+            uint4 s0 = load_row1(0), s1 = load_row1(1), s2 = load_row1(2), s3 = load_row1(3);
             for (int y = 0; y < h; y += 4) {
-                process_row(r0, y);
+                process_row(r0, s0, y);
                 r0 = load_row(y + 4);
-                if (y + 1 < h) process_row(r1, y + 1);
+                s0 = load_row1(y + 4);
+                if (y + 1 < h) process_row(r1, s1, y + 1);
                 r1 = load_row(y + 5);
-                if (y + 2 < h) process_row(r2, y + 2);
+                s1 = load_row1(y + 5);
+                if (y + 2 < h) process_row(r2, s2, y + 2);
                 r2 = load_row(y + 6);
-                if (y + 3 < h) process_row(r3, y + 3);
+                s2 = load_row1(y + 6);
+                if (y + 3 < h) process_row(r3, s3, y + 3);
                 r3 = load_row(y + 7);
+                s3 = load_row1(y + 7);
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int xl = gxf + q - x_min;
-                if (xl >= 0 && xl < w) {
-                    top[xl] = (uint16_t)topr[q];
-                    bot[xl] = (uint16_t)botr[q];
+                if ((valid0 >> q) & 1u) {
+                    top[xl] = (uint16_t)((top0[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                    bot[xl] = (uint16_t)((bot0[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                }
+                if ((valid1 >> q) & 1u) {
+                    top[xl + 64] = (uint16_t)((top1[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                    bot[xl + 64] = (uint16_t)((bot1[q >> 1] >> (16 * (q & 1))) & 0xffffu);
                 }
             }
         }
@@ -1064,7 +1121,9 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
                     continue;
                 }
                 const int j = __ffs(m) - 1;
-                const unsigned hw = (unsigned)__shfl((int)why, lane0 + j);
+                const int jb = sgshift + j;  // wave lane of the hit
+                const unsigned hw = (unsigned)((__ballot((why & 1u) != 0) >> jb) & 1ull) | ((unsigned)((__ballot((why & 2u) != 0) >> jb) & 1ull) << 1) |
+                                    ((unsigned)((__ballot((why & 4u) != 0) >> jb) & 1ull) << 2) | ((unsigned)((__ballot((why & 8u) != 0) >> jb) & 1ull) << 3);
                 const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
                 if (sl == 0) {
                     if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
@@ -1484,7 +1543,7 @@ __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int 
 
 hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.npacks, ws.packs, nullptr};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, getenv("CTAG_DBG") ? atoi(getenv("CTAG_DBG")) : 0, nullptr};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
@@ -1507,6 +1566,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
         unsigned long long tot = 0;
         for (int i = 0; i < 5; i++) tot += h[i];
+        fprintf(stderr, "[packed P1 detail] header %.1f%% keys+init %.1f%% of total\n", 100.0 * h[6] / (tot + h[5] + h[6]), 100.0 * h[5] / (tot + h[5] + h[6]));
         fprintf(stderr, "[k_quad_edges cycles] silhouette %.1f%% traversal %.1f%% centroid/rotate %.1f%% rdp %.1f%% export %.1f%% (total %llu)\n",
                 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, tot);
     }

@@ -188,12 +188,15 @@ struct SweepPtrs {
     int32_t* xmax;
     int32_t* ymax;
     int32_t* key;
+    int32_t* pool_tile;    // tile of every pool entry (K2)
+    int32_t* member_head;  // per root: head of the list of its non-root members (K4), -1 = none
+    int32_t* member_next;
     int32_t* ncand;
     Candidate* cand;
 };
 static SweepPtrs sweep_ptrs(const Workspace& ws) {
     return SweepPtrs{ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
-                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.ncand, ws.cand};
+                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand};
 }
 
 struct CclLdsLayout {
@@ -524,6 +527,8 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
             P.ymin[gidx] = st_ymin[i];
             P.ymax[gidx] = st_ymax[i];
             P.key[gidx] = st_key[i];
+            P.pool_tile[gidx] = tile;
+            P.member_head[gidx] = -1;
         }
     }
     // ---- S11: per-pixel tile-local labels, 8 pixels (16 bytes) per lane
@@ -652,6 +657,7 @@ __global__ __launch_bounds__(256) void k_resolve(SweepPtrs P, int nframes, int p
         const unsigned r = g_find(P.parent + pool0, (unsigned)i);
         P.root_of[pool0 + i] = (int)r;
         if (r != (unsigned)i) {
+            P.member_next[pool0 + i] = atomicExch(&P.member_head[pool0 + r], i);  // set membership only; order is irrelevant
             atomicAdd(&P.area[pool0 + r], P.area[pool0 + i]);
             atomicMin(&P.xmin[pool0 + r], P.xmin[pool0 + i]);
             atomicMax(&P.xmax[pool0 + r], P.xmax[pool0 + i]);
