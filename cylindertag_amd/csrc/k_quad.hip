@@ -901,12 +901,15 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
         if (!act) continue;
         CandAux* aux = P.cand_aux + (size_t)frame * kCandCap + ci;
         uint32_t* mem = s_mem + off;
-        uint16_t* top = reinterpret_cast<uint16_t*>(mem);
-        uint16_t* bot = top + w2;
-        uint32_t* lef = mem + w2;
-        uint32_t* rig = lef + h;
-        uint32_t* bufA = rig + h;
-        uint32_t* bufB = bufA + C;  // C + 1 words
+        // silhouette as two sentinel-padded arrays: tb[x+1] = (top+2) | (bottom+2) << 16 per column, lr[y+1] = (left+2) |
+        // (right+2) << 16 per row, 0 = none.  With the +2 bias a neighbour outside the box can never match, so the
+        // traversal needs no bounds checks.
+        uint32_t* tb = mem;               // w + 2 words
+        uint32_t* lr = tb + w + 2;        // h + 2 words
+        uint32_t* bufA = lr + h + 2;      // C words
+        uint32_t* bufB = bufA + C;        // C + 1 words
+        uint32_t* lef = bufA;             // P1 only: row extents by atomics (h <= C words each)
+        uint32_t* rig = bufB;
         const int sgshift = sub * 8;
 
         stamp(6);
@@ -938,10 +941,7 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
         // 16-byte load (64 columns per sub-group step, starting at a 16-byte aligned column), remembers the last
         // (tile-local label, tile) -> "is my component" decision so the two dependent gathers are rare, and has
         // the next row's load in flight while it digests the current one.
-        for (int x = sl; x < w; x += kSG) {
-            top[x] = 0xffff;
-            bot[x] = 0xffff;
-        }
+        for (int x = sl; x < w + 2; x += kSG) tb[x] = 0u;
         for (int y = sl; y < h; y += kSG) {
             lef[y] = 0xffffffffu;
             rig[y] = 0u;
@@ -1070,14 +1070,23 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int xl = gxf + q - x_min;
-                if ((valid0 >> q) & 1u) {
-                    top[xl] = (uint16_t)((top0[q >> 1] >> (16 * (q & 1))) & 0xffffu);
-                    bot[xl] = (uint16_t)((bot0[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                if ((valid0 >> q) & 1u) {  // every column of a component's bounding box holds a pixel
+                    const uint32_t t = (top0[q >> 1] >> (16 * (q & 1))) & 0xffffu, bb = (bot0[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                    tb[xl + 1] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
                 }
                 if ((valid1 >> q) & 1u) {
-                    top[xl + 64] = (uint16_t)((top1[q >> 1] >> (16 * (q & 1))) & 0xffffu);
-                    bot[xl + 64] = (uint16_t)((bot1[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                    const uint32_t t = (top1[q >> 1] >> (16 * (q & 1))) & 0xffffu, bb = (bot1[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                    tb[xl + 65] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
                 }
+            }
+            SG_SYNC();  // row extents (LDS atomics) complete
+            for (int y = sl; y < h + 2; y += kSG) {
+                uint32_t v = 0u;
+                if (y >= 1 && y <= h) {
+                    const uint32_t a = lef[y - 1], b = rig[y - 1];  // b = last + 1, 0 = empty row
+                    if (b) v = (a + 2) | ((b + 1) << 16);
+                }
+                lr[y] = v;  // lr aliases nothing that is still live: lef/rig sit in bufA/bufB
             }
         }
         SG_SYNC();
@@ -1088,29 +1097,37 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
         {
             const int dxl = (int)((0x01A9u >> (2 * sl)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * sl)) & 3u) - 1;
             int sp = 0;
-            int fx = 0, fy = top[0], j0 = 0;  // top-of-stack frame in registers; bufB holds the frames below it
-            if (fy == 0xffff) {
-                sp = -1;
-            } else {
-                if (sl == 0) {
-                    bufA[0] = pack_xy(x_min, fy + y_min);
-                    top[0] = 0xffff;
-                    if (bot[0] == fy) bot[0] = 0xffff;
-                    if (lef[fy] == 0u) lef[fy] = 0xffffffffu;
-                    if (rig[fy] == 1u) rig[fy] = 0u;
+            int fx = 0, fy = 0, j0 = 0;  // top-of-stack frame in registers; bufB holds the frames below it
+            {
+                const uint32_t c0 = tb[1];
+                if (c0 == 0u) {
+                    sp = -1;  // inconsistent labels (only after a flagged pool overflow): give up on this component
+                } else {
+                    fy = (int)(c0 & 0xffffu) - 2;  // start: top-most pixel of the left-most column (:235-244)
+                    n = 1;
                 }
-                n = 1;
+            }
+            SG_SYNC();
+            if (sp >= 0 && sl == 0) {
+                bufA[0] = pack_xy(x_min, fy + y_min);
+                // clear the start pixel from every list it heads
+                uint32_t c = tb[1];
+                if ((c >> 16) == (uint32_t)(fy + 2)) c &= 0xffffu;
+                c &= 0xffff0000u;
+                tb[1] = c;
+                uint32_t r = lr[fy + 1];
+                if ((r & 0xffffu) == 2u) r &= 0xffff0000u;
+                if ((r >> 16) == 2u) r &= 0xffffu;
+                lr[fy + 1] = r;
             }
             SG_SYNC();
             while (sp >= 0) {
                 const int nx = fx + dxl, ny = fy + dyl;
-                unsigned why = 0;
-                if (sl >= j0 && ny >= 0 && ny < h && nx >= 0 && nx < w) {
-                    why = (top[nx] == ny ? 1u : 0u) | (bot[nx] == ny ? 2u : 0u) | (lef[ny] == (unsigned)nx ? 4u : 0u) |
-                          (rig[ny] == (unsigned)(nx + 1) ? 8u : 0u);
-                }
-                const unsigned m = (unsigned)((__ballot(why != 0) >> sgshift) & 0xffull);
-                if (!m) {
+                const uint32_t c = tb[nx + 1], r = lr[ny + 1];
+                const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
+                const bool hit = sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
+                const unsigned m = (unsigned)((__ballot(hit) >> sgshift) & 0xffull);
+                if (!m) {  // frame exhausted: pop
                     sp--;
                     if (sp >= 0) {
                         const uint32_t f = bufB[sp];
@@ -1121,16 +1138,17 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
                     continue;
                 }
                 const int j = __ffs(m) - 1;
-                const int jb = sgshift + j;  // wave lane of the hit
-                const unsigned hw = (unsigned)((__ballot((why & 1u) != 0) >> jb) & 1ull) | ((unsigned)((__ballot((why & 2u) != 0) >> jb) & 1ull) << 1) |
-                                    ((unsigned)((__ballot((why & 4u) != 0) >> jb) & 1ull) << 2) | ((unsigned)((__ballot((why & 8u) != 0) >> jb) & 1ull) << 3);
                 const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
-                if (sl == 0) {
+                if (sl == j) {  // the hit lane holds the list words of (hx, hy): it appends the point and clears them
                     if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
-                    if (hw & 1u) top[hx] = 0xffff;
-                    if (hw & 2u) bot[hx] = 0xffff;
-                    if (hw & 4u) lef[hy] = 0xffffffffu;
-                    if (hw & 8u) rig[hy] = 0u;
+                    uint32_t c2 = c, r2 = r;
+                    if ((c2 & 0xffffu) == ky) c2 &= 0xffff0000u;
+                    if ((c2 >> 16) == ky) c2 &= 0xffffu;
+                    if ((r2 & 0xffffu) == kx) r2 &= 0xffff0000u;
+                    if ((r2 >> 16) == kx) r2 &= 0xffffu;
+                    tb[nx + 1] = c2;
+                    lr[ny + 1] = r2;
+                    // the current frame moves to the hit pixel and resumes at j+1 (B7); it becomes the frame below the top
                     if (sp <= C) bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
                 }
                 SG_SYNC();
