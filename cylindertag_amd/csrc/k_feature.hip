@@ -318,18 +318,25 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                 const double y0 = alpha * cy[a] + (1 - alpha) * cy[b];
                 double Mn = 0, Mcount = 0;
                 const double range = subpix;
-                for (double n = -range; n <= range; n += 0.25) {
+                // Branch-free form of the reference's loop (:627-649): the two pixel reads use clamped coordinates and are
+                // issued unconditionally, so the compiler can keep a batch of gathers in flight; a rejected step contributes
+                // weight +0.0, which leaves the running sums bit-identical to skipping it.
+                const int nsteps = 8 * subpix + 1;  // n = -range, -range+0.25, ..., +range (exact in binary)
+#pragma unroll 8
+                for (int st = 0; st < nsteps; st++) {
+                    const double n = -range + 0.25 * st;
                     const double grange = 1;
                     const int x1 = (int)(x0 + (n + grange) * nx);
                     const int y1 = (int)(y0 + (n + grange) * ny);
-                    if (x1 < 0 || x1 >= cols || y1 < 0 || y1 >= rows) continue;
                     const int x2 = (int)(x0 + (n - grange) * nx);
                     const int y2 = (int)(y0 + (n - grange) * ny);
-                    if (x2 < 0 || x2 >= cols || y2 < 0 || y2 >= rows) continue;
-                    const float g1 = (float)img[(ptrdiff_t)y1 * P.row_stride + x1] * k255;
-                    const float g2 = (float)img[(ptrdiff_t)y2 * P.row_stride + x2] * k255;
-                    if (g1 < g2) continue;
-                    const double weight = (g2 - g1) * (g2 - g1);
+                    const bool inb = !(x1 < 0 || x1 >= cols || y1 < 0 || y1 >= rows) && !(x2 < 0 || x2 >= cols || y2 < 0 || y2 >= rows);
+                    const int cx1 = min(max(x1, 0), cols - 1), cy1 = min(max(y1, 0), rows - 1);
+                    const int cx2 = min(max(x2, 0), cols - 1), cy2 = min(max(y2, 0), rows - 1);
+                    const float g1 = (float)img[(ptrdiff_t)cy1 * P.row_stride + cx1] * k255;
+                    const float g2 = (float)img[(ptrdiff_t)cy2 * P.row_stride + cx2] * k255;
+                    const bool use = inb && !(g1 < g2);
+                    const double weight = use ? (double)((g2 - g1) * (g2 - g1)) : 0.0;
                     Mn += weight * n;
                     Mcount += weight;
                 }
