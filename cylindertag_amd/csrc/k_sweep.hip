@@ -8,6 +8,10 @@
 // Frames are mapped to XCDs (blockIdx % 8) so a frame's intermediates stay in one XCD's L2.
 #include "ctag_internal.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
 namespace ctag {
 
 // blocks b and b+8 share an XCD (observed round-robin dispatch; speed only, never correctness)
@@ -193,10 +197,11 @@ struct SweepPtrs {
     int32_t* member_next;
     int32_t* ncand;
     Candidate* cand;
+    unsigned long long* stamps;  // developer aid (CTAG_CCL_STAMPS=1): cycles per phase of k_threshold_ccl, else null
 };
 static SweepPtrs sweep_ptrs(const Workspace& ws) {
     return SweepPtrs{ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
-                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand};
+                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand, nullptr};
 }
 
 struct CclLdsLayout {
@@ -238,6 +243,8 @@ size_t threshold_ccl_lds_bytes(int tw) { return ccl_layout(tw).total; }
 
 __device__ __forceinline__ uint64_t mask_le(int b) { return b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull); }
 
+constexpr int kCclThreads = 256;  // threads per 320x30 tile: the phases are short dependent chains, so more waves per tile
+                                  // shorten every barrier-to-barrier critical path and fill the CU at the same LDS footprint
 __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int& total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = v;
@@ -249,8 +256,12 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int& total) 
     if (lane == 63) scratch[w] = inc;
     __syncthreads();
     int base = 0;
-    for (int i = 0; i < w; i++) base += scratch[i];
-    total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < kCclThreads / 64; i++) {
+        if (i < w) base += scratch[i];
+        total += scratch[i];
+    }
     __syncthreads();
     return base + inc - v;
 }
@@ -288,16 +299,50 @@ __device__ __forceinline__ int threshold_bound(int mn, int mx) {
     return t;
 }
 
+// Persistent: a block walks the tiles of its XCD with stride `blocks_per_xcd`; the half-res region of the NEXT tile is
+// loaded into registers (kPre x 16 bytes per thread) while the current tile is processed, so the staging latency of
+// every tile but the first is hidden.
+struct TileRegion {
+    int frame, tile, tx0, ty0, tw_eff, th_eff;
+    int tcs0, tcs1, trs0, trs1, tc0, tc1, tr0, tr1, px0, px1, py0, py1, lx0, chunks, nrows;
+};
+__device__ __forceinline__ TileRegion tile_region(int frame, int tile, const FrameGeom& g, int tw) {
+    TileRegion t;
+    t.frame = frame;
+    t.tile = tile;
+    const int tix = tile % g.tiles_x, tiy = tile / g.tiles_x;
+    t.tx0 = tix * kTileW;
+    t.ty0 = tiy * kTileH;
+    t.tw_eff = min(kTileW, g.hcols - t.tx0);
+    t.th_eff = min(kTileH, g.hrows - t.ty0);
+    // threshold tiles this CCL tile needs: its own plus a one-tile ring
+    t.tcs0 = t.tx0 / tw;
+    t.tcs1 = (t.tx0 + t.tw_eff - 1) / tw;
+    t.trs0 = t.ty0 / tw;
+    t.trs1 = (t.ty0 + t.th_eff - 1) / tw;
+    t.tc0 = max(t.tcs0 - 1, 0);
+    t.tc1 = min(t.tcs1 + 1, g.tcols - 1);
+    t.tr0 = max(t.trs0 - 1, 0);
+    t.tr1 = min(t.trs1 + 1, g.trows - 1);
+    t.px0 = t.tc0 * tw;
+    t.px1 = min((t.tc1 + 1) * tw, g.hcols);
+    t.py0 = t.tr0 * tw;
+    t.py1 = min((t.tr1 + 1) * tw, g.hrows);
+    t.lx0 = t.px0 & ~15;
+    t.chunks = (t.px1 - t.lx0 + 15) >> 4;
+    t.nrows = t.py1 - t.py0;
+    return t;
+}
+
 template <int TWC>
-__global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
+__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes, int blocks_per_xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tw = TWC ? TWC : g.tw;
-    int frame, tile;
-    if (!map_block(blockIdx.x, g.tiles_x * g.tiles_y, nframes, frame, tile)) return;
-    const int tix = tile % g.tiles_x, tiy = tile / g.tiles_x;
-    const int tx0 = tix * kTileW, ty0 = tiy * kTileH;
-    const int tw_eff = min(kTileW, g.hcols - tx0), th_eff = min(kTileH, g.hrows - ty0);
+    constexpr int kPre = TWC == 5 ? (1024 / kCclThreads) : 0;  // 16-byte register slots per thread for the next tile's region (tw = 5: <= 4)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_frame = g.tiles_x * g.tiles_y;
+    const int xcd = blockIdx.x & 7, bk = blockIdx.x >> 3;
+    const int items = ((nframes + 7) / 8) * per_frame;  // (frame slot, tile) pairs of this XCD
 
     const CclLdsLayout L = ccl_layout(tw);
     uint8_t* hr_s = smem + L.off_region;
@@ -310,33 +355,82 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
     uint16_t* lab_s = reinterpret_cast<uint16_t*>(smem + L.off_lab);
     int* misc_s = reinterpret_cast<int*>(smem + L.off_misc);
 
-    // ---- geometry of the threshold tiles this CCL tile needs (its own plus a one-tile ring)
-    const int tcs0 = tx0 / tw, tcs1 = (tx0 + tw_eff - 1) / tw;  // threshold tile columns overlapping the tile
-    const int trs0 = ty0 / tw, trs1 = (ty0 + th_eff - 1) / tw;
-    const int tc0 = max(tcs0 - 1, 0), tc1 = min(tcs1 + 1, g.tcols - 1);
-    const int tr0 = max(trs0 - 1, 0), tr1 = min(trs1 + 1, g.trows - 1);
-    const int px0 = tc0 * tw, px1 = min((tc1 + 1) * tw, g.hcols);
-    const int py0 = tr0 * tw, py1 = min((tr1 + 1) * tw, g.hrows);
-    const int lx0 = px0 & ~15;
-    const uint8_t* __restrict__ himg = P.half + ((size_t)frame * g.hrows) * g.hp;
+    auto item_frame = [&](int it) { return (it / per_frame) * 8 + xcd; };
+    auto load_region = [&](const TileRegion& t, uint4* pre) {
+        const uint8_t* __restrict__ himg = P.half + ((size_t)t.frame * g.hrows) * g.hp;
+#pragma unroll
+        for (int q = 0; q < (kPre ? kPre : 1); q++) {
+            const int i = tid + q * kCclThreads;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < t.chunks * t.nrows) {
+                const int r = i / t.chunks, c = i - r * t.chunks;
+                const int x = t.lx0 + c * 16;
+                if (x + 16 <= g.hp) v = *reinterpret_cast<const uint4*>(himg + (size_t)(t.py0 + r) * g.hp + x);
+            }
+            pre[q] = v;
+        }
+    };
+    uint4 pre[kPre ? kPre : 1];
+    int it = bk;
+    while (it < items && item_frame(it) >= nframes) it += blocks_per_xcd;  // frame slots beyond the batch
+    if (it >= items) return;
+    TileRegion T = tile_region(item_frame(it), it % per_frame, g, tw);
+    if (kPre) load_region(T, pre);
 
+    // developer aid: per-phase cycles are kept in registers and flushed once per tile (a global atomic per stamp would
+    // cost as much as the phases it measures)
+    unsigned long long t_prev = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int phase) {
+        if (P.stamps && tid == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int q = 0; q < 10; q++)
+                if (q == phase) t_acc[q] += t - t_prev;
+            t_prev = t;
+        }
+    };
+  for (;;) {
+    const int frame = T.frame, tile = T.tile, tx0 = T.tx0, ty0 = T.ty0, tw_eff = T.tw_eff, th_eff = T.th_eff;
+    const int tcs0 = T.tcs0, tcs1 = T.tcs1, trs0 = T.trs0, trs1 = T.trs1, tc0 = T.tc0, tc1 = T.tc1, tr0 = T.tr0, tr1 = T.tr1;
+    const int py0 = T.py0, lx0 = T.lx0;
+    (void)tc1;
+    (void)tr1;
     // ---- S1: stage the half-res region in LDS (16-byte chunks, coalesced along rows)
-    {
-        const int chunks = (px1 - lx0 + 15) >> 4;
-        const int nrows = py1 - py0;
-        for (int i = tid; i < chunks * nrows; i += 256) {
-            const int r = i / chunks, c = i - r * chunks;
+    if (kPre) {
+#pragma unroll
+        for (int q = 0; q < (kPre ? kPre : 1); q++) {
+            const int i = tid + q * kCclThreads;
+            if (i < T.chunks * T.nrows) {
+                const int r = i / T.chunks, c = i - r * T.chunks;
+                *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = pre[q];
+            }
+        }
+    } else {
+        const uint8_t* __restrict__ himg = P.half + ((size_t)frame * g.hrows) * g.hp;
+        for (int i = tid; i < T.chunks * T.nrows; i += kCclThreads) {
+            const int r = i / T.chunks, c = i - r * T.chunks;
             const int x = lx0 + c * 16;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (x + 16 <= g.hp) v = *reinterpret_cast<const uint4*>(himg + (size_t)(py0 + r) * g.hp + x);
             *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = v;
         }
     }
+    // next tile of this block: issue its loads now, consume them at the top of the next iteration
+    int it_next = it + blocks_per_xcd;
+    while (it_next < items && item_frame(it_next) >= nframes) it_next += blocks_per_xcd;
+    const bool has_next = it_next < items;
+    TileRegion Tn = T;
+    if (has_next) {
+        Tn = tile_region(item_frame(it_next), it_next % per_frame, g, tw);
+        if (kPre) load_region(Tn, pre);
+    }
     __syncthreads();
+    stamp(0);
     // ---- S2: per-threshold-tile min / max (corner_detector.cpp:42-53)
     {
         const int nc = tc1 - tc0 + 1, nr = tr1 - tr0 + 1;
-        for (int i = tid; i < nc * nr; i += 256) {
+        for (int i = tid; i < nc * nr; i += kCclThreads) {
             const int r = i / nc, c = i - r * nc;
             const int ya = (tr0 + r) * tw, yb = min(ya + tw, g.hrows);
             const int xa = (tc0 + c) * tw, xb = min(xa + tw, g.hcols);
@@ -353,10 +447,11 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
         }
     }
     __syncthreads();
+    stamp(1);
     // ---- S3: 3x3 min-of-min / max-of-max for interior tiles, zero elsewhere (corner_detector.cpp:54-67, B1)
     {
         const int nc = tcs1 - tcs0 + 1, nr = trs1 - trs0 + 1;
-        for (int i = tid; i < nc * nr; i += 256) {
+        for (int i = tid; i < nc * nr; i += kCclThreads) {
             const int r = i / nc, c = i - r * nc;
             const int tr = trs0 + r, tc = tcs0 + c;
             int T = 0;
@@ -376,8 +471,9 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
         }
     }
     __syncthreads();
+    stamp(2);
     // ---- S4: binary row masks by wave ballot (corner_detector.cpp:69-78)
-    for (int item = wave; item < kTileH * kTileWords; item += 4) {
+    for (int item = wave; item < kTileH * kTileWords; item += kCclThreads / 64) {
         const int r = item / kTileWords, w = item - r * kTileWords;
         const int xl = w * 64 + lane;
         bool fg = false;
@@ -391,6 +487,7 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
         if (lane == 0) mask_s[item] = m;
     }
     __syncthreads();
+    stamp(3);
     // ---- S5: run starts, run numbering
     int nruns_mine = 0;
     if (tid < kTileH * kTileWords) {
@@ -405,10 +502,11 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
     const int rb = block_excl_scan(nruns_mine, misc_s, nruns);
     if (tid < kTileH * kTileWords) runbase_s[tid] = rb;
     bool overflow = nruns > kRunCap;
-    for (int i = tid; i < min(nruns, kRunCap); i += 256) parent_s[i] = (unsigned)i;
+    for (int i = tid; i < min(nruns, kRunCap); i += kCclThreads) parent_s[i] = (unsigned)i;
     __syncthreads();
     auto runid = [&](int item, int b) -> int { return runbase_s[item] + __popcll(start_s[item] & mask_le(b)) - 1; };
 
+    stamp(4);
     // ---- S6: unions between vertically adjacent rows (8-connectivity)
     if (!overflow && tid < kTileH * kTileWords && tid >= kTileWords) {
         const int w = tid % kTileWords;
@@ -434,20 +532,21 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
         }
     }
     __syncthreads();
+    stamp(5);
     // ---- S7/S8: flatten, compact roots into slots
     int nslots = 0;
     {
         int roots_mine = 0;
-        const int i0 = tid * (kRunCap / 256);
+        const int i0 = tid * (kRunCap / kCclThreads);
         if (!overflow) {
-            for (int k = 0; k < kRunCap / 256; k++) {
+            for (int k = 0; k < kRunCap / kCclThreads; k++) {
                 const int i = i0 + k;
                 if (i < nruns && parent_s[i] == (unsigned)i) roots_mine++;
             }
         }
         int s = block_excl_scan(roots_mine, misc_s, nslots);
         if (!overflow) {
-            for (int k = 0; k < kRunCap / 256; k++) {
+            for (int k = 0; k < kRunCap / kCclThreads; k++) {
                 const int i = i0 + k;
                 if (i < nruns && parent_s[i] == (unsigned)i) lab_s[i] = (uint16_t)(s++);
             }
@@ -462,11 +561,11 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
     int* st_ymax = st_ymin + kSlotCap;
     int* st_key = st_ymax + kSlotCap;
     if (!overflow) {
-        for (int i = tid; i < nruns; i += 256) {
+        for (int i = tid; i < nruns; i += kCclThreads) {
             const unsigned r = lds_find(parent_s, (unsigned)i);
             if (r != (unsigned)i) lab_s[i] = lab_s[r];
         }
-        for (int i = tid; i < nslots; i += 256) {
+        for (int i = tid; i < nslots; i += kCclThreads) {
             st_area[i] = 0;
             st_xmin[i] = 0x7fffffff;
             st_xmax[i] = -1;
@@ -476,6 +575,10 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
         }
     }
     __syncthreads();
+    // pool slots for this tile: the returning atomic is issued now and its result is first used after the label stores
+    int base_reg = 0;
+    if (tid == 0 && !overflow && nslots > 0) base_reg = atomicAdd(&P.frame_ncomp[frame], nslots);
+    stamp(6);
     // ---- S9: per-slot stats from run segments (area, bbox, first 2x2 block in block-raster order)
     const int bcols = (g.hcols + 1) >> 1;
     if (!overflow && tid < kTileH * kTileWords) {
@@ -497,45 +600,12 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
             atomicMin(&st_key[slot], (gy >> 1) * bcols + (gx0 >> 1));
         }
     }
-    // ---- S10: allocate the tile's components in the frame pool
-    if (tid == 0) {
-        int base = 0, ovf = overflow ? 1 : 0;
-        if (!ovf && nslots > 0) {
-            base = atomicAdd(&P.frame_ncomp[frame], nslots);
-            if (base + nslots > kPoolCap) ovf = 1;
-        }
-        misc_s[8] = ovf;
-        misc_s[9] = base;
-    }
-    __syncthreads();  // also orders the S9 LDS atomics before the reads below
-    overflow = misc_s[8] != 0;
-    const int base = misc_s[9];
-    if (overflow) {
-        if (tid == 0) {
-            atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
-            P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
-        }
-    } else {
-        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
-        const size_t pool0 = (size_t)frame * kPoolCap;
-        for (int i = tid; i < nslots; i += 256) {
-            const size_t gidx = pool0 + base + i;
-            P.parent[gidx] = (unsigned)(base + i);
-            P.area[gidx] = st_area[i];
-            P.xmin[gidx] = st_xmin[i];
-            P.xmax[gidx] = st_xmax[i];
-            P.ymin[gidx] = st_ymin[i];
-            P.ymax[gidx] = st_ymax[i];
-            P.key[gidx] = st_key[i];
-            P.pool_tile[gidx] = tile;
-            P.member_head[gidx] = -1;
-        }
-    }
+    stamp(7);
     // ---- S11: per-pixel tile-local labels, 8 pixels (16 bytes) per lane
     {
         uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
         constexpr int groups = kTileW / 8;
-        for (int i = tid; i < kTileH * groups; i += 256) {
+        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
             const int r = i / groups, gq = i - r * groups;
             if (r >= th_eff || gq * 8 >= tw_eff) continue;
             const int item = r * kTileWords + (gq >> 3);
@@ -554,19 +624,88 @@ __global__ __launch_bounds__(256) void k_threshold_ccl(SweepPtrs P, FrameGeom g,
             *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
+    stamp(8);
+    // ---- S10: publish the tile's components in the frame pool
+    if (tid == 0) {
+        int ovf = overflow ? 1 : 0;
+        if (!ovf && nslots > 0 && base_reg + nslots > kPoolCap) ovf = 1;
+        misc_s[8] = ovf;
+        misc_s[9] = base_reg;
+    }
+    __syncthreads();  // also orders the S9 LDS atomics before the reads below
+    overflow = misc_s[8] != 0;
+    const int base = misc_s[9];
+    if (overflow) {
+        if (tid == 0) {
+            atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+            P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
+        }
+    } else {
+        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
+        const size_t pool0 = (size_t)frame * kPoolCap;
+        for (int i = tid; i < nslots; i += kCclThreads) {
+            const size_t gidx = pool0 + base + i;
+            P.parent[gidx] = (unsigned)(base + i);
+            P.area[gidx] = st_area[i];
+            P.xmin[gidx] = st_xmin[i];
+            P.xmax[gidx] = st_xmax[i];
+            P.ymin[gidx] = st_ymin[i];
+            P.ymax[gidx] = st_ymax[i];
+            P.key[gidx] = st_key[i];
+            P.pool_tile[gidx] = tile;
+            P.member_head[gidx] = -1;
+        }
+    }
+    stamp(9);
+    if (P.stamps && tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            atomicAdd(&P.stamps[q], t_acc[q]);
+            t_acc[q] = 0;
+        }
+        t_prev = __builtin_amdgcn_s_memtime();
+    }
+    if (!has_next) break;
+    it = it_next;
+    T = Tn;
+    __syncthreads();  // everyone is done with this tile's LDS state
+  }
 }
 
 hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s) {
     const FrameGeom& g = ws.g;
-    const int grid = grid_for(nframes, g.tiles_x * g.tiles_y);
     const size_t lds = threshold_ccl_lds_bytes(g.tw);
-    const SweepPtrs P = sweep_ptrs(ws);
+    // persistent grid: enough blocks to fill every CU at the LDS-limited residency, never more than there are tiles
+    const int per_xcd_items = ((nframes + 7) / 8) * g.tiles_x * g.tiles_y;
+    const int resident = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1)) * 32;  // blocks per XCD (32 CUs)
+    const int mult = getenv("CTAG_CCL_WAVES") ? atoi(getenv("CTAG_CCL_WAVES")) : 0;  // developer aid: grid = mult x resident blocks (0 = one tile per block)
+    const int blocks_per_xcd = mult <= 0 ? per_xcd_items : std::max(1, std::min(per_xcd_items, resident * mult));
+    const int grid = blocks_per_xcd * 8;
+    SweepPtrs P = sweep_ptrs(ws);
+    static unsigned long long* d_stamps = nullptr;
+    const bool want_stamps = getenv("CTAG_CCL_STAMPS") != nullptr;
+    if (want_stamps) {
+        if (!d_stamps) (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), 16 * 8);
+        (void)hipMemsetAsync(d_stamps, 0, 16 * 8, s);
+        P.stamps = d_stamps;
+    }
     if (g.tw == 5) {
-        hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(256), lds, s, P, g, nframes);
+        hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes, blocks_per_xcd);
     } else {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(256), lds, s, P, g, nframes);
+        hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes, blocks_per_xcd);
+    }
+    if (want_stamps) {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int i = 0; i < 10; i++) tot += h[i];
+        static const char* nm[10] = {"S1 stage", "S2 minmax", "S3 dilate", "S4 masks", "S5 runs", "S6 unions", "S7-8 flatten", "S9 stats", "S11 labels", "S10 publish"};
+        fprintf(stderr, "[k_threshold_ccl cycles]");
+        for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[i] / tot);
+        fprintf(stderr, " (total %llu)\n", tot);
     }
     return hipGetLastError();
 }
