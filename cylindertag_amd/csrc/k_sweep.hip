@@ -79,30 +79,28 @@ __device__ __forceinline__ Raw18 load_row(const uint8_t* __restrict__ rowp, int 
     return r;
 }
 
-__device__ __forceinline__ int px(const Raw18& r, int k) {  // k in [-1, 17]
+// horizontal pass / 64 : q[i] = 19*(p[2i]+p[2i+1]) - 3*(p[2i-1]+p[2i+2])
+__device__ __forceinline__ int px(const Raw18& r, int k) {  // k in [-1, 16]
     if (k < 0) return (int)r.left;
-    if (k >= 16) return (int)((r.right2 >> (8 * (k - 16))) & 0xff);
+    if (k >= 16) return (int)(r.right2 & 0xff);
     const uint32_t w = k < 4 ? r.w0 : k < 8 ? r.w1 : k < 12 ? r.w2 : r.w3;
     return (int)((w >> (8 * (k & 3))) & 0xff);
 }
-
-// horizontal pass / 64 : q = 19*(p[2i]+p[2i+1]) - 3*(p[2i-1]+p[2i+2])
 __device__ __forceinline__ void hpass(const Raw18& r, int q[8]) {
 #pragma unroll
     for (int i = 0; i < 8; i++) q[i] = 19 * (px(r, 2 * i) + px(r, 2 * i + 1)) - 3 * (px(r, 2 * i - 1) + px(r, 2 * i + 2));
 }
 
+// vertical pass.  OpenCV's float vector body computes t = s0*b0 + (s1*b1 + (s2*b2 + s3*b3)) with s = 64*q and
+// b = {-192,1216,1216,-192} * 2^-22 and rounds half-to-even.  Every product and partial sum is a multiple of 2^-10 of
+// magnitude < 2^14, i.e. exactly representable in float, so t == V / 1024 exactly with V = 19*(qb+qc) - 3*(qa+qd) and
+// the result is the integer round-half-even of V/1024 (tests/test_oracle_cpu.py checks this identity against the
+// literal float evaluation the oracle uses).
 __device__ __forceinline__ uint32_t vpass(int qa, int qb, int qc, int qd) {
-    const float scale = 1.f / (2048.f * 2048.f);
-    const float b0 = -192.f * scale, b1 = 1216.f * scale;
-    const float s0 = (float)(qa * 64), s1 = (float)(qb * 64), s2 = (float)(qc * 64), s3 = (float)(qd * 64);
-    float t = s3 * b0;
-    t = s2 * b1 + t;
-    t = s1 * b1 + t;
-    t = s0 * b0 + t;
-    int v = __float2int_rn(t);
-    v = min(max(v, 0), 255);
-    return (uint32_t)v;
+    const int V = 19 * (qb + qc) - 3 * (qa + qd);
+    int r = (V + 512) >> 10;
+    if ((V & 1023) == 512) r &= ~1;
+    return (uint32_t)min(max(r, 0), 255);
 }
 
 template <bool ALIGNED>
@@ -135,28 +133,36 @@ __global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ fr
         hpass(rc, qc);
         hpass(rd, qd);
     }
-    for (int y = y_begin; y < y_end; y++) {
-        Raw18 rn0, rn1;
-        const bool more = (y + 1 < y_end);  // wave-uniform
-        if (more) {  // issue the next two source rows before the arithmetic of this output row
-            rn0 = load_row<ALIGNED>(rowp(2 * y + 3), x0, g.cols, active, lane);
-            rn1 = load_row<ALIGNED>(rowp(2 * y + 4), x0, g.cols, active, lane);
-        }
+    // two output rows per iteration: the four source rows of the NEXT iteration are requested before this iteration's
+    // arithmetic, so every lane keeps 64 bytes in flight (the kernel is bound by memory latency x occupancy)
+    auto emit = [&](int y, const int* a, const int* b, const int* c, const int* d) {
         uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) lo |= vpass(qa[i], qb[i], qc[i], qd[i]) << (8 * i);
+        for (int i = 0; i < 4; i++) lo |= vpass(a[i], b[i], c[i], d[i]) << (8 * i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) hi |= vpass(qa[4 + i], qb[4 + i], qc[4 + i], qd[4 + i]) << (8 * i);
+        for (int i = 0; i < 4; i++) hi |= vpass(a[4 + i], b[4 + i], c[4 + i], d[4 + i]) << (8 * i);
         if (active) *reinterpret_cast<uint2*>(dst + (size_t)y * g.hp + hx0) = make_uint2(lo, hi);
-        if (more) {
+    };
+    Raw18 n0 = load_row<ALIGNED>(rowp(2 * y_begin + 3), x0, g.cols, active, lane);
+    Raw18 n1 = load_row<ALIGNED>(rowp(2 * y_begin + 4), x0, g.cols, active, lane);
+    for (int y = y_begin; y < y_end; y += 2) {
+        // rows 2y+5, 2y+6 feed output rows y+2 (with 2y+3, 2y+4 already requested)
+        const Raw18 m0 = load_row<ALIGNED>(rowp(2 * y + 5), x0, g.cols, active, lane);
+        const Raw18 m1 = load_row<ALIGNED>(rowp(2 * y + 6), x0, g.cols, active, lane);
+        emit(y, qa, qb, qc, qd);
+        int qe[8], qf[8];
+        hpass(n0, qe);
+        hpass(n1, qf);
+        if (y + 1 < y_end) emit(y + 1, qc, qd, qe, qf);  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                qa[i] = qc[i];
-                qb[i] = qd[i];
-            }
-            hpass(rn0, qc);
-            hpass(rn1, qd);
+        for (int i = 0; i < 8; i++) {
+            qa[i] = qe[i];
+            qb[i] = qf[i];
         }
+        hpass(m0, qc);
+        hpass(m1, qd);
+        n0 = load_row<ALIGNED>(rowp(2 * y + 7), x0, g.cols, active, lane);
+        n1 = load_row<ALIGNED>(rowp(2 * y + 8), x0, g.cols, active, lane);
     }
 }
 
