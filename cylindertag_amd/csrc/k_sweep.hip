@@ -235,7 +235,7 @@ __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
     const size_t stats = (size_t)kSlotCap * 6 * sizeof(int);
     L.off_region = take(region > stats ? region : stats);
     L.off_ext = take((size_t)L.ec * L.er * 2);
-    L.off_thr = take((size_t)L.tc * L.tr * 2);
+    L.off_thr = take((size_t)L.tr * (kTileW + 8));  // per threshold-tile row: one threshold byte per tile column
     L.off_mask = take((size_t)kTileH * kTileWords * 8);
     L.off_start = take((size_t)kTileH * kTileWords * 8);
     L.off_runbase = take(((size_t)kTileH * kTileWords + 1) * 4);
@@ -249,6 +249,10 @@ size_t threshold_ccl_lds_bytes(int tw) { return ccl_layout(tw).total; }
 
 __device__ __forceinline__ uint64_t mask_le(int b) { return b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull); }
 
+// Barrier for k_threshold_ccl: its phases exchange data through LDS only, so the barrier waits for LDS traffic
+// (lgkmcnt) and NOT for vector memory (vmcnt) -- __syncthreads() would drain the next tile's prefetch loads and the
+// label stores at every phase boundary.
+#define CCL_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 constexpr int kCclThreads = 256;  // threads per 320x30 tile: the phases are short dependent chains, so more waves per tile
                                   // shorten every barrier-to-barrier critical path and fill the CU at the same LDS footprint
 __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int& total) {
@@ -260,7 +264,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int& total) 
         if (lane >= d) inc += n;
     }
     if (lane == 63) scratch[w] = inc;
-    __syncthreads();
+    CCL_SYNC();
     int base = 0;
     total = 0;
 #pragma unroll
@@ -268,7 +272,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int& total) 
         if (i < w) base += scratch[i];
         total += scratch[i];
     }
-    __syncthreads();
+    CCL_SYNC();
     return base + inc - v;
 }
 
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     const CclLdsLayout L = ccl_layout(tw);
     uint8_t* hr_s = smem + L.off_region;
     uint16_t* ext_s = reinterpret_cast<uint16_t*>(smem + L.off_ext);
-    uint16_t* thr_s = reinterpret_cast<uint16_t*>(smem + L.off_thr);
+    uint8_t* thr_s = smem + L.off_thr;  // [tile row][x - tx0], pitch kTileW + 8
     uint64_t* mask_s = reinterpret_cast<uint64_t*>(smem + L.off_mask);
     uint64_t* start_s = reinterpret_cast<uint64_t*>(smem + L.off_start);
     int* runbase_s = reinterpret_cast<int*>(smem + L.off_runbase);
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
         Tn = tile_region(item_frame(it_next), it_next % per_frame, g, tw);
         if (kPre) load_region(Tn, pre);
     }
-    __syncthreads();
+    CCL_SYNC();
     stamp(0);
     // ---- S2: per-threshold-tile min / max (corner_detector.cpp:42-53)
     {
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             ext_s[r * L.ec + c] = (uint16_t)(mn | (mx << 8));
         }
     }
-    __syncthreads();
+    CCL_SYNC();
     stamp(1);
     // ---- S3: 3x3 min-of-min / max-of-max for interior tiles, zero elsewhere (corner_detector.cpp:54-67, B1)
     {
@@ -471,28 +475,52 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
                         mn = min(mn, e & 0xff);
                         mx = max(mx, e >> 8);
                     }
-                T = threshold_bound(mn, mx);
+                T = threshold_bound(mn, mx);  // <= 77: the reference caps the threshold at 0.3
             }
-            thr_s[r * L.tc + c] = (uint16_t)T;
+            const int xa = max(tc * tw - tx0, 0), xb = min((tc + 1) * tw - tx0, tw_eff);
+            for (int x = xa; x < xb; x++) thr_s[r * (kTileW + 8) + x] = (uint8_t)T;
         }
     }
-    __syncthreads();
+    CCL_SYNC();
     stamp(2);
-    // ---- S4: binary row masks by wave ballot (corner_detector.cpp:69-78)
-    for (int item = wave; item < kTileH * kTileWords; item += kCclThreads / 64) {
-        const int r = item / kTileWords, w = item - r * kTileWords;
-        const int xl = w * 64 + lane;
-        bool fg = false;
-        if (r < th_eff && xl < tw_eff) {
-            const int x = tx0 + xl, y = ty0 + r;
-            const int u = hr_s[(size_t)(y - py0) * L.rp + (x - lx0)];
-            const int T = thr_s[(y / tw - trs0) * L.tc + (x / tw - tcs0)];
-            fg = u < T;
+    // ---- S4: binary row masks (corner_detector.cpp:69-78), 8 pixels per thread.  pixel < T is evaluated on packed bytes:
+    // T <= 77 < 128, so with the pixel's top bit handled separately the per-byte subtract (0x80 | low7) - T never borrows
+    // across bytes and its bit 7 says low7 >= T.  The four result bits of a dword are gathered with one multiply.
+    {
+        constexpr int groups = kTileW / 8;
+        uint8_t* mask_b = reinterpret_cast<uint8_t*>(mask_s);
+        const int xoff = tx0 - lx0;
+        const bool fast = (((uintptr_t)0 + xoff) & 7) == 0;  // 8-byte aligned pixel groups (always for tw = 5)
+        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
+            const int r = i / groups, gq = i - r * groups;
+            unsigned bits = 0;
+            if (r < th_eff && gq * 8 < tw_eff) {
+                const int y = ty0 + r;
+                const uint8_t* prow = hr_s + (size_t)(y - py0) * L.rp + xoff + gq * 8;
+                const uint8_t* trow = thr_s + (y / tw - trs0) * (kTileW + 8) + gq * 8;
+                uint32_t u0, u1;
+                if (fast) {
+                    const uint2 uu = *reinterpret_cast<const uint2*>(prow);
+                    u0 = uu.x;
+                    u1 = uu.y;
+                } else {
+                    u0 = (uint32_t)prow[0] | ((uint32_t)prow[1] << 8) | ((uint32_t)prow[2] << 16) | ((uint32_t)prow[3] << 24);
+                    u1 = (uint32_t)prow[4] | ((uint32_t)prow[5] << 8) | ((uint32_t)prow[6] << 16) | ((uint32_t)prow[7] << 24);
+                }
+                const uint2 tt = *reinterpret_cast<const uint2*>(trow);
+                auto lt4 = [](uint32_t u, uint32_t t) {
+                    const uint32_t ge = (((u & 0x7f7f7f7fu) | 0x80808080u) - t) & 0x80808080u;
+                    const uint32_t lt = ~(ge | u) & 0x80808080u;
+                    return (((lt >> 7) * 0x01020408u) >> 24) & 0xfu;
+                };
+                bits = lt4(u0, tt.x) | (lt4(u1, tt.y) << 4);
+                const int left = tw_eff - gq * 8;  // columns of this group inside the frame
+                if (left < 8) bits &= (1u << left) - 1u;
+            }
+            mask_b[i] = (uint8_t)bits;
         }
-        const uint64_t m = __ballot(fg);
-        if (lane == 0) mask_s[item] = m;
     }
-    __syncthreads();
+    CCL_SYNC();
     stamp(3);
     // ---- S5: run starts, run numbering
     int nruns_mine = 0;
@@ -509,7 +537,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     if (tid < kTileH * kTileWords) runbase_s[tid] = rb;
     bool overflow = nruns > kRunCap;
     for (int i = tid; i < min(nruns, kRunCap); i += kCclThreads) parent_s[i] = (unsigned)i;
-    __syncthreads();
+    CCL_SYNC();
     auto runid = [&](int item, int b) -> int { return runbase_s[item] + __popcll(start_s[item] & mask_le(b)) - 1; };
 
     stamp(4);
@@ -537,7 +565,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             }
         }
     }
-    __syncthreads();
+    CCL_SYNC();
     stamp(5);
     // ---- S7/S8: flatten, compact roots into slots
     int nslots = 0;
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
         }
     }
     if (nslots > kSlotCap) overflow = true;
-    __syncthreads();
+    CCL_SYNC();
     int* st_area = reinterpret_cast<int*>(smem + L.off_region);  // staging region is dead from here on
     int* st_xmin = st_area + kSlotCap;
     int* st_xmax = st_xmin + kSlotCap;
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             st_key[i] = 0x7fffffff;
         }
     }
-    __syncthreads();
+    CCL_SYNC();
     // pool slots for this tile: the returning atomic is issued now and its result is first used after the label stores
     int base_reg = 0;
     if (tid == 0 && !overflow && nslots > 0) base_reg = atomicAdd(&P.frame_ncomp[frame], nslots);
@@ -638,7 +666,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
         misc_s[8] = ovf;
         misc_s[9] = base_reg;
     }
-    __syncthreads();  // also orders the S9 LDS atomics before the reads below
+    CCL_SYNC();  // also orders the S9 LDS atomics before the reads below
     overflow = misc_s[8] != 0;
     const int base = misc_s[9];
     if (overflow) {
@@ -674,7 +702,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     if (!has_next) break;
     it = it_next;
     T = Tn;
-    __syncthreads();  // everyone is done with this tile's LDS state
+    CCL_SYNC();  // everyone is done with this tile's LDS state
   }
 }
 
