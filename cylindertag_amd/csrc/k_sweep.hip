@@ -572,14 +572,14 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     {
         int roots_mine = 0;
         const int i0 = tid * (kRunCap / kCclThreads);
-        if (!overflow) {
+        if (!overflow && i0 < nruns) {
             for (int k = 0; k < kRunCap / kCclThreads; k++) {
                 const int i = i0 + k;
                 if (i < nruns && parent_s[i] == (unsigned)i) roots_mine++;
             }
         }
         int s = block_excl_scan(roots_mine, misc_s, nslots);
-        if (!overflow) {
+        if (!overflow && i0 < nruns) {
             for (int k = 0; k < kRunCap / kCclThreads; k++) {
                 const int i = i0 + k;
                 if (i < nruns && parent_s[i] == (unsigned)i) lab_s[i] = (uint16_t)(s++);
@@ -647,13 +647,21 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             const unsigned byte = overflow ? 0u : (unsigned)((mask_s[item] >> b0) & 0xff);
             uint32_t o[4] = {0, 0, 0, 0};
             if (byte) {
+                // one run-id lookup per run segment of the group (a run's pixels share its label), then a select per pixel
+                unsigned rest = byte;
+                uint32_t lab8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                while (rest) {
+                    const int sb = __ffs(rest) - 1;
+                    const unsigned inv = ~(rest >> sb);
+                    const int len = __ffs(inv) - 1;  // rest >> sb has at most 8 significant bits, so inv != 0
+                    const uint32_t lab = (uint32_t)lab_s[runid(item, b0 + sb)] + 1u;
+                    const unsigned seg = ((1u << len) - 1u) << sb;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if ((byte >> k) & 1) {
-                        const uint32_t lab = (uint32_t)lab_s[runid(item, b0 + k)] + 1u;
-                        o[k >> 1] |= lab << (16 * (k & 1));
-                    }
+                    for (int k = 0; k < 8; k++) lab8[k] = ((seg >> k) & 1u) ? lab : lab8[k];
+                    rest &= ~seg;
                 }
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = lab8[2 * k] | (lab8[2 * k + 1] << 16);
             }
             *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
