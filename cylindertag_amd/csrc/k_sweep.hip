@@ -776,6 +776,9 @@ __device__ __forceinline__ void g_union(uint32_t* parent, unsigned a, unsigned b
     }
 }
 
+// Thread per seam pixel (the pixel on the lower side of a horizontal seam / right side of a vertical seam).  A union is
+// issued only where a contact between two runs BEGINS along the seam: a neighbouring seam pixel that already sees the
+// same pair of runs does the union, and adjacency across the other seam family makes the rest transitive.
 __global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, int nframes, int per_frame_blocks) {
     int frame, bidx;
     if (!map_block(blockIdx.x, per_frame_blocks, nframes, frame, bidx)) return;
@@ -786,34 +789,46 @@ __global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, in
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     uint32_t* parent = P.parent + (size_t)frame * kPoolCap;
-    int x, y, nx[3], ny[3];
+    auto lab = [&](int x, int y) -> unsigned {
+        if (x < 0 || x >= g.hcols || y < 0 || y >= g.hrows) return 0u;
+        return limg[(size_t)y * g.lp + x];
+    };
+    auto gid = [&](int x, int y, unsigned l) { return (unsigned)tbase[(y / kTileH) * g.tiles_x + (x / kTileW)] + l - 1; };
+    // along-seam coordinate s, this side c (cur) and the other side o: cur(s) = (x,y), oth(s) = neighbour across the seam
+    int x, y, dxs, dys, ox, oy;
     if (i < nh) {
-        const int s = i / g.hcols;
-        x = i - s * g.hcols;
-        y = (s + 1) * kTileH;
-        for (int k = 0; k < 3; k++) {
-            nx[k] = x - 1 + k;
-            ny[k] = y - 1;
-        }
+        const int sm = i / g.hcols;
+        x = i - sm * g.hcols;
+        y = (sm + 1) * kTileH;
+        dxs = 1;
+        dys = 0;
+        ox = 0;
+        oy = -1;
     } else {
         const int j = i - nh;
-        const int s = j / g.hrows;
-        y = j - s * g.hrows;
-        x = (s + 1) * kTileW;
-        for (int k = 0; k < 3; k++) {
-            nx[k] = x - 1;
-            ny[k] = y - 1 + k;
-        }
+        const int sm = j / g.hrows;
+        y = j - sm * g.hrows;
+        x = (sm + 1) * kTileW;
+        dxs = 0;
+        dys = 1;
+        ox = -1;
+        oy = 0;
     }
-    const unsigned l = limg[(size_t)y * g.lp + x];
-    if (!l) return;
-    const unsigned me = (unsigned)tbase[(y / kTileH) * g.tiles_x + (x / kTileW)] + l - 1;
-    for (int k = 0; k < 3; k++) {
-        if (nx[k] < 0 || nx[k] >= g.hcols || ny[k] < 0 || ny[k] >= g.hrows) continue;
-        const unsigned ln = limg[(size_t)ny[k] * g.lp + nx[k]];
-        if (!ln) continue;
-        const unsigned other = (unsigned)tbase[(ny[k] / kTileH) * g.tiles_x + (nx[k] / kTileW)] + ln - 1;
-        g_union(parent, me, other);
+    const unsigned c0 = lab(x, y);
+    if (!c0) return;
+    const unsigned o0 = lab(x + ox, y + oy);
+    const unsigned cm = lab(x - dxs, y - dys), om = lab(x - dxs + ox, y - dys + oy);  // previous position along the seam
+    const unsigned cp = lab(x + dxs, y + dys), op = lab(x + dxs + ox, y + dys + oy);  // next position
+    const unsigned me = gid(x, y, c0);
+    // the shortcuts rely on "adjacent pixels of one row/column segment inside a tile share a label"; across a tile
+    // boundary (the 4-tile corners) they could defer to each other in a circle, so they are not applied there
+    const int along = dxs ? x : y, tile_len = dxs ? kTileW : kTileH;
+    const bool same_prev = (along % tile_len) != 0, same_next = ((along + 1) % tile_len) != 0;
+    if (o0) {
+        if (!(same_prev && cm && om)) g_union(parent, me, gid(x + ox, y + oy, o0));  // contact starts here
+    } else {
+        if (om && !(same_prev && cm)) g_union(parent, me, gid(x - dxs + ox, y - dys + oy, om));  // diagonal back
+        if (op && !(same_next && cp)) g_union(parent, me, gid(x + dxs + ox, y + dys + oy, op));  // diagonal forward
     }
 }
 
