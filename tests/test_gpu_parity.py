@@ -114,6 +114,34 @@ def test_edge_cases(detector, oracle, dictionary, test_bmp):
         detector.detect(test_bmp[:, :1919])  # odd width: unsupported on the GPU path, reported loudly
 
 
+def test_components_across_tile_seams(detector, oracle, dictionary):
+    """Dark blobs, bars and diagonal chains laid across the 320x30 CCL tile seams and their 4-tile corners (half-res
+    x = 320, 640; y = 30, 60, ...): labels, areas, boxes and OpenCV order must equal the oracle's."""
+    state, fs = dictionary
+    rng = np.random.RandomState(21)
+    img = np.full((1080, 1920), 200, np.uint8)
+    for _ in range(160):
+        cx = int(rng.choice([640, 1280])) + int(rng.randint(-40, 41))        # full-res column of a vertical seam
+        cy = int(rng.randint(1, 17)) * 60 + int(rng.randint(-30, 31))         # full-res row of a horizontal seam
+        w, h = int(rng.randint(4, 70)), int(rng.randint(4, 70))
+        img[max(cy - h, 12):cy + h, max(cx - w, 12):cx + w] = 20
+    for k in range(40):  # diagonal 2x2-pixel chains through tile corners (8-connectivity only)
+        cx, cy = int(rng.choice([640, 1280])), int(rng.randint(1, 17)) * 60
+        for t in range(-12, 12):
+            x, y = cx + 2 * t, cy + (2 * t if k % 2 else -2 * t)
+            img[y:y + 2, x:x + 2] = 20
+    img[10:1070:7, 636:646] = 20  # thin bars crossing the vertical seam every few rows
+    o = oracle.detect(img, state, fs)
+    r = detector.detect(img)
+    lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+    assert ((lab > 0) == (o["binary"] > 0)).all()
+    pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
+    assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
+    cand = detector.debug(0, capi.DBG_CANDIDATES)
+    assert len(cand) == len(o["candidates"]) and (cand[:, 0:5] == o["candidates"][:, 1:6]).all()
+    assert_same_record(r, o["result"], "seam stress")
+
+
 def test_batch_equals_single_and_is_repeatable(detector, dictionary):
     state, fs = dictionary
     frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
