@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (BASELINE config 3: 4096)")
-    ap.add_argument("--chunk", type=int, default=1024, help="frames per pipeline pass (workspace size)")
+    ap.add_argument("--chunk", type=int, default=4096, help="frames per pipeline pass (workspace size)")
     ap.add_argument("--markers", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-subpix", action="store_true")
@@ -146,7 +146,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("sweep_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("sweep_bytes_per_frame") * min(n, args.chunk)  # measured per frame
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
