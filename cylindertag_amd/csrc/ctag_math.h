@@ -180,32 +180,37 @@ CTM_HD double cos64(double x) {
 }
 
 // ---------------------------------------------------------------- exp (double), acos (double)
+// exp(x) = 2^k * 2^(j/32) * exp(r),  x = (32k + j) * ln2/32 + r,  |r| <= ln2/64: a 32-entry table of correctly rounded
+// 2^(j/32) and the Taylor series of exp(r) to r^6 (truncation < 4e-17 on the reduced range); no division.
 CTM_HD double exp64(double x) {
-    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
-                 invln2 = 1.44269504088896338700e+00;
+    const double T[32] = {
+        1.00000000000000000e+00, 1.02189714865411663e+00, 1.04427378242741375e+00, 1.06714040067682370e+00,
+        1.09050773266525769e+00, 1.11438674259589243e+00, 1.13878863475669156e+00, 1.16372485877757748e+00,
+        1.18920711500272103e+00, 1.21524735998046896e+00, 1.24185781207348400e+00, 1.26905095719173322e+00,
+        1.29683955465100964e+00, 1.32523664315974132e+00, 1.35425554693689265e+00, 1.38390988196383202e+00,
+        1.41421356237309515e+00, 1.44518080697704665e+00, 1.47682614593949935e+00, 1.50916442759342284e+00,
+        1.54221082540794074e+00, 1.57598084510788650e+00, 1.61049033194925428e+00, 1.64575547815396495e+00,
+        1.68179283050742900e+00, 1.71861929812247793e+00, 1.75625216037329945e+00, 1.79470907500310717e+00,
+        1.83400808640934243e+00, 1.87416763411029996e+00, 1.91520656139714740e+00, 1.95714412417540018e+00};
+    const double inv = 4.61662413084468283841e+01;     // 32 / ln2
+    const double c_hi = 2.16608493865351192653e-02;    // ln2/32, upper bits (exact product with |n| < 2^16)
+    const double c_lo = 5.96317165397058656257e-12;    // ln2/32 - c_hi
     if (isnan64(x)) return x;
     if (x > 709.0) return bits_to_f64(0x7ff0000000000000ULL);
     if (x < -708.0) return 0.0;  // callers only need float range; no double denormals here
-    const double fk = __builtin_floor(x * invln2 + 0.5);
-    const int k = (int)fk;
-    const double r = (x - fk * ln2hi) - fk * ln2lo;  // |r| <= 0.3466
-    // exp(r) by its Taylor series to r^13 (truncation < 4e-18 on the reduced range), Horner form, no division
-    double p = 1.6059043836821613e-10;           // 1/13!
-    p = p * r + 2.08767569878681e-09;            // 1/12!
-    p = p * r + 2.505210838544172e-08;           // 1/11!
-    p = p * r + 2.755731922398589e-07;           // 1/10!
-    p = p * r + 2.7557319223985893e-06;          // 1/9!
-    p = p * r + 2.48015873015873e-05;            // 1/8!
-    p = p * r + 1.984126984126984e-04;           // 1/7!
-    p = p * r + 1.388888888888889e-03;           // 1/6!
-    p = p * r + 8.333333333333333e-03;           // 1/5!
-    p = p * r + 4.1666666666666664e-02;          // 1/4!
-    p = p * r + 1.6666666666666666e-01;          // 1/3!
+    const double fn = __builtin_floor(x * inv + 0.5);
+    const int n = (int)fn;
+    const int j = n & 31, k = (n - j) / 32;  // n = 32k + j, 0 <= j < 32 (also for negative n)
+    const double r = (x - fn * c_hi) - fn * c_lo;
+    double p = 1.3888888888888889e-03;   // 1/6!
+    p = p * r + 8.3333333333333332e-03;  // 1/5!
+    p = p * r + 4.1666666666666664e-02;  // 1/4!
+    p = p * r + 1.6666666666666666e-01;  // 1/3!
     p = p * r + 0.5;
     p = p * r + 1.0;
-    const double y = p * r + 1.0;
+    const double e = p * r + 1.0;
     const double scale = bits_to_f64((uint64_t)(k + 1023) << 52);  // 2^k, k in [-1022, 1023] given the clamps
-    return y * scale;
+    return (T[j] * e) * scale;
 }
 
 // acos via atan2; exact subtraction 1-t for the float-valued t the path feeds it
