@@ -1,0 +1,38 @@
+// ctag_demo.cpp -- the detection half of the reference's demo driver (main.cpp:28-41 read_from_image) on the HIP path:
+//   CylinderTag marker("CTag_2f12c.marker");  frame = imread(bmp) -> gray;  marker.detect(img_gray, markers, 5, true, 5);
+// Prints one line per marker: id, then "pos:id_left:id_right" per feature, then the first corner of every feature.
+// (estimatePose / drawAxis are the reference's CPU back end and GUI; they consume exactly this vector<MarkerInfo>.)
+#include <cstdio>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../csrc/CylinderTag.h"
+#include "../csrc/ctag_io.h"
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <dictionary.marker> <image.bmp> [adaptiveThresh=5] [cornerSubPix=1] [cornerSubPixDist=5]\n", argv[0]);
+        return 2;
+    }
+    try {
+        CylinderTag marker(argv[1]);
+        const ctag_host::GrayImage g = ctag_host::read_bmp_gray(argv[2]);
+        const int at = argc > 3 ? std::atoi(argv[3]) : 5, sp = argc > 4 ? std::atoi(argv[4]) : 1, sd = argc > 5 ? std::atoi(argv[5]) : 5;
+        std::vector<MarkerInfo> markers;
+        marker.detect(ctag_host::Mat(g.rows, g.cols, g.px.data()), markers, at, sp != 0, sd);
+        std::printf("markers %zu\n", markers.size());
+        for (const MarkerInfo& m : markers) {
+            std::printf("id %d n %zu :", m.markerID, m.cornerLists.size());
+            for (size_t j = 0; j < m.cornerLists.size(); j++)
+                std::printf(" %d:%d:%d", j < m.featurePos.size() ? m.featurePos[j] : -1, m.feature_ID_left[j], m.feature_ID_right[j]);
+            std::printf(" |");
+            for (size_t j = 0; j < m.cornerLists.size(); j++) std::printf(" %.9g,%.9g", m.cornerLists[j][0].x, m.cornerLists[j][0].y);
+            std::printf("\n");
+        }
+    } catch (const std::string& s) {
+        std::cerr << "error: " << s;
+        return 1;
+    }
+    return 0;
+}

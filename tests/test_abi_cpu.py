@@ -85,3 +85,31 @@ def test_cpp_host_layer_builds_and_keeps_reference_interface():
     assert "CylinderTag::detect(" in nm and "CylinderTag::CylinderTag(std::" in nm
     hdr = " ".join(open(os.path.join(ROOT, "cylindertag_amd", "csrc", "CylinderTag.h")).read().split())
     assert "int adaptiveThresh = 5, const bool cornerSubPix = false, int cornerSubPixDist = 3" in hdr
+
+
+def test_cpp_bmp_reader_matches_python_reader(test_bmp, tmp_path):
+    """Frame ingest of the host layer: the C++ BMP reader returns the same gray image as the
+    test-suite's reader for the reference's 8-bit test.bmp, and applies OpenCV's fixed-point BGR2GRAY to 24-bit files."""
+    so = C.CDLL(os.path.join(ROOT, "cylindertag_amd", "_build", "libcylindertag.so"))
+    f = so.ctag_host_read_bmp_gray
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    r, c = C.c_int(), C.c_int()
+    buf = np.zeros(1200 * 1920, np.uint8)
+    assert f(os.path.join(GOLDEN, "test.bmp").encode(), C.byref(r), C.byref(c), buf.ctypes.data, buf.size) == 0
+    assert (r.value, c.value) == (1200, 1920) and (buf.reshape(1200, 1920) == test_bmp).all()
+    # a 24-bit bottom-up BMP written by hand
+    rng = np.random.RandomState(0)
+    bgr = rng.randint(0, 256, (5, 7, 3)).astype(np.uint8)
+    rowbytes = (7 * 3 + 3) // 4 * 4
+    body = b"".join(bytes(bgr[y].tobytes()) + bytes(rowbytes - 21) for y in range(4, -1, -1))
+    hdr = b"BM" + (54 + len(body)).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little")
+    hdr += (40).to_bytes(4, "little") + (7).to_bytes(4, "little") + (5).to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little")
+    hdr += (0).to_bytes(4, "little") + len(body).to_bytes(4, "little") + bytes(16)
+    p = tmp_path / "rgb.bmp"
+    p.write_bytes(hdr + body)
+    out = np.zeros(35, np.uint8)
+    assert f(str(p).encode(), C.byref(r), C.byref(c), out.ctypes.data, out.size) == 0 and (r.value, c.value) == (5, 7)
+    b, g, rr = bgr[..., 0].astype(np.int64), bgr[..., 1].astype(np.int64), bgr[..., 2].astype(np.int64)
+    assert (out.reshape(5, 7) == ((b * 1868 + g * 9617 + rr * 4899 + 8192) >> 14)).all()
+    assert f(str(tmp_path / "missing.bmp").encode(), None, None, None, 0) == -1

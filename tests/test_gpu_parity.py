@@ -189,3 +189,44 @@ def test_full_size_batch_properties(detector, oracle, dictionary):
     flagged = [int(f) for f in np.nonzero(a["flags"])[0][:4]]
     for f in [0, 17, 255, 511] + flagged:
         assert_same_record(a[f], oracle.detect_fast(frames[f].cpu().numpy(), state, fs), "synthetic frame %d" % f)
+
+
+def test_cpp_cylindertag_class_demo(oracle, dictionary, test_bmp):
+    """The C++ `CylinderTag` host layer (reference class interface) end to end: the demo binary reads test.bmp with the
+    C++ BMP reader, calls CylinderTag::detect(img, markers, 5, true, 5) and prints the MarkerInfo vector."""
+    import subprocess
+    from ctag_testlib import ROOT
+    exe = os.path.join(ROOT, "cylindertag_amd", "_build", "ctag_demo")
+    out = subprocess.check_output([exe, os.path.join(GOLDEN, "CTag_2f12c.marker"), os.path.join(GOLDEN, "test.bmp")], timeout=120).decode()
+    lines = [l for l in out.splitlines() if l.startswith("id ")]
+    state, fs = dictionary
+    want = result_markers(oracle.detect_fast(test_bmp, state, fs))
+    assert out.splitlines()[0] == "markers %d" % len(want) and len(lines) == len(want)
+    for line, m in zip(lines, want):
+        head, corners = line.split("|")
+        toks = head.split()
+        assert int(toks[1]) == m["marker_id"] and int(toks[3]) == len(m["id"])
+        feats = [tuple(int(v) for v in t.split(":")) for t in toks[5:]]
+        assert [f[0] for f in feats][:len(m["pos"])] == m["pos"]
+        assert [f[1] for f in feats] == m["id_left"] and [f[2] for f in feats] == m["id_right"]
+        xy = np.array([[float(v) for v in c.split(",")] for c in corners.split()], np.float32)
+        assert (xy == m["corners"][:, 0:2]).all()
+    # early return: a blank frame prints the reference's message and leaves the vector untouched
+    blank = os.path.join(os.path.dirname(exe), "blank_test.bmp")
+    w, h = 640, 480
+    hdr = b"BM" + (54 + 1024 + w * h).to_bytes(4, "little") + bytes(4) + (54 + 1024).to_bytes(4, "little") + (40).to_bytes(4, "little")
+    hdr += w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (8).to_bytes(2, "little") + bytes(24)
+    pal = b"".join(bytes([i, i, i, 0]) for i in range(256))
+    open(blank, "wb").write(hdr + pal + bytes([180]) * (w * h))
+    out = subprocess.check_output([exe, os.path.join(GOLDEN, "CTag_2f12c.marker"), blank], timeout=120).decode()
+    assert "No corner detected!" in out and "markers 0" in out
+    os.remove(blank)
+
+
+def test_4k_frame(detector, oracle, dictionary):
+    """BASELINE config 5 (detect only): a 3840x2160 synthetic frame (strips of 440..840 px) equals the oracle."""
+    state, fs = dictionary
+    frame, truth = ca.synth_frame_host(state, 2, rows=2160, cols=3840)
+    got, want = detector.detect(frame), oracle.detect_fast(frame, state, fs)
+    assert_same_record(got, want, "4K synthetic frame")
+    assert sorted(int(m["marker_id"]) for m in want["markers"][:want["n_markers"]]) == sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
