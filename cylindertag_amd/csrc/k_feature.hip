@@ -283,46 +283,49 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
     const uint8_t* __restrict__ img = P.frames + (ptrdiff_t)frame * P.frame_stride;
     const float k255 = (float)(1.0 / 255);
     const int off = quad * 4;
-    float cx[4], cy[4];
-    for (int i = 0; i < 4; i++) {
-        cx[i] = F->c[2 * (off + i)];
-        cy[i] = F->c[2 * (off + i) + 1];
-    }
-    double enx[4], eny[4];
-    int ens[4], max_ns = 0;
-    for (int edge = 0; edge < 4; edge++) {  // :609-615
-        const int a = edge, b = (edge + 1) & 3;
-        double nx = cy[b] - cy[a];
-        double ny = -cx[b] + cx[a];
-        const double mag = ctm::sqrt64(nx * nx + ny * ny);
-        enx[edge] = nx / mag;
-        eny[edge] = ny / mag;
-        const double ns_d = mag / 8 > 128.0 ? mag / 8 : 128.0;
-        ens[edge] = (int)ns_d;
-        max_ns = max(max_ns, ens[edge]);
+    __shared__ float s_cx[4], s_cy[4];
+    __shared__ int s_ns[4];
+    if (tid < 4) {
+        s_cx[tid] = F->c[2 * (off + tid)];
+        s_cy[tid] = F->c[2 * (off + tid) + 1];
     }
     if (tid < 48) s_acc[tid] = 0.0;
     __syncthreads();
+    if (tid < 4) {  // :609-615
+        const int a = tid, b = (tid + 1) & 3;
+        const double nx = s_cy[b] - s_cy[a];
+        const double ny = -s_cx[b] + s_cx[a];
+        const double mag = ctm::sqrt64(nx * nx + ny * ny);
+        const double ns_d = mag / 8 > 128.0 ? mag / 8 : 128.0;
+        s_ns[tid] = (int)ns_d;
+    }
+    __syncthreads();
+    const int max_ns = max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3]));
     for (int sbase = 0; sbase < max_ns; sbase += kRefineThreads) {
         const int s = sbase + tid;
-#pragma unroll
-        for (int edge = 0; edge < 4; edge++) {
+#pragma nounroll
+        for (int edge = 0; edge < 4; edge++) {  // rolled on purpose: one copy of the search loop keeps the kernel at 5+ waves per SIMD
             const int a = edge, b = (edge + 1) & 3;
-            const int nsamples = ens[edge];
-            const double nx = enx[edge], ny = eny[edge];
+            const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
+            const int nsamples = s_ns[edge];
+            double nx = by - ay;
+            double ny = -bx + ax;
+            const double mag = ctm::sqrt64(nx * nx + ny * ny);
+            nx /= mag;
+            ny /= mag;
             bool ok = false;
             double bestx = 0, besty = 0, alpha = 0;
             if (s < nsamples) {
                 alpha = (15.0 + s) / (nsamples + 30);
-                const double x0 = alpha * cx[a] + (1 - alpha) * cx[b];
-                const double y0 = alpha * cy[a] + (1 - alpha) * cy[b];
+                const double x0 = alpha * ax + (1 - alpha) * bx;
+                const double y0 = alpha * ay + (1 - alpha) * by;
                 double Mn = 0, Mcount = 0;
                 const double range = subpix;
                 // Branch-free form of the reference's loop (:627-649): the two pixel reads use clamped coordinates and are
-                // issued unconditionally, so the compiler can keep a batch of gathers in flight; a rejected step contributes
-                // weight +0.0, which leaves the running sums bit-identical to skipping it.
+                // issued unconditionally; a rejected step contributes weight +0.0, which leaves the running sums
+                // bit-identical to skipping it.
                 const int nsteps = 8 * subpix + 1;  // n = -range, -range+0.25, ..., +range (exact in binary)
-#pragma unroll 8
+#pragma unroll 4
                 for (int st = 0; st < nsteps; st++) {
                     const double n = -range + 0.25 * st;
                     const double grange = 1;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
             const int edge = tid / 12, r = tid - edge * 12;
             const int pass = r / 6, which = r - pass * 6;
             double acc = s_acc[tid];
-            const int cntS = min(kRefineThreads, ens[edge] - sbase);
+            const int cntS = min(kRefineThreads, s_ns[edge] - sbase);
             for (int k = 0; k < cntS; k++) {
                 if (!s_ok[edge][k]) continue;
                 const double wgt = pass == 0 ? (1 - s_al[edge][k]) : s_al[edge][k];
