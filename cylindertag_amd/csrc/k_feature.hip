@@ -524,6 +524,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     __shared__ short s_cov[2 * kMaxDictCells];   // coverage per (dir, row, col)
     __shared__ int s_code[CTAG_MAX_CODE_POS];
     __shared__ int s_misc[8];
+    __shared__ unsigned long long s_pair[CTAG_MAX_FEATURES][2];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int tid = threadIdx.x;
@@ -558,7 +559,30 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     }
     for (int i = tid; i < nf; i += 64) s_feat[i] = P.feat[(size_t)frame * CTAG_MAX_FEATURES + i];
     __syncthreads();
-    // ---- markerOrganization (:976-1052): thread 0 (F <= 100)
+    // ---- markerOrganization (:976-1052).  The O(F^2) pair predicate is evaluated on all lanes into a bit matrix;
+    // thread 0 then replays the unions of the true pairs in the reference's (i, j) order, which is all the
+    // union-find state depends on.
+    for (int i = 0; i < nf - 1; i++) {
+        const FeatureDev& A = s_feat[i];
+        const float threshold_angle = 5, threshold_vertical = 0.5f;
+        const float vlx = A.c[0] - A.c[10], vly = A.c[1] - A.c[11];
+        const double reach = 0.3 * dist2p(P2{A.c[0], A.c[1]}, P2{A.c[10], A.c[11]});
+        for (int j0 = 0; j0 < 128; j0 += 64) {  // both words written (CTAG_MAX_FEATURES <= 128)
+            const int j = j0 + tid;
+            bool hit = false;
+            if (j > i && j < nf) {
+                const FeatureDev& B = s_feat[j];
+                const float vcx = A.center[0] - B.center[0], vcy = A.center[1] - B.center[1];
+                const float center_angle = (vcx * vlx + vcy * vly) / ctm::sqrt32((vcx * vcx + vcy * vcy) * (vlx * vlx + vly * vly));
+                hit = (ctm::fabs32(A.angle - B.angle) < threshold_angle * 2 || ctm::fabs32(180 - ctm::fabs32(A.angle - B.angle)) < threshold_angle) &&
+                      (dist2p(P2{A.center[0], A.center[1]}, P2{B.center[0], B.center[1]}) < reach) &&
+                      (ctm::fabs32(center_angle) < threshold_vertical);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (tid == 0) s_pair[i][j0 >> 6] = m;
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
         auto uf = [&](int x) {
             int r = x;
@@ -571,17 +595,12 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             return r;
         };
         for (int i = 0; i < nf; i++) s_father[i] = i;
-        const float threshold_angle = 5, threshold_vertical = 0.5f;
         for (int i = 0; i < nf - 1; i++) {
-            const FeatureDev& A = s_feat[i];
-            for (int j = i + 1; j < nf; j++) {
-                const FeatureDev& B = s_feat[j];
-                const float vcx = A.center[0] - B.center[0], vcy = A.center[1] - B.center[1];
-                const float vlx = A.c[0] - A.c[10], vly = A.c[1] - A.c[11];
-                const float center_angle = (vcx * vlx + vcy * vly) / ctm::sqrt32((vcx * vcx + vcy * vcy) * (vlx * vlx + vly * vly));
-                if ((ctm::fabs32(A.angle - B.angle) < threshold_angle * 2 || ctm::fabs32(180 - ctm::fabs32(A.angle - B.angle)) < threshold_angle) &&
-                    (dist2p(P2{A.center[0], A.center[1]}, P2{B.center[0], B.center[1]}) < 0.3 * dist2p(P2{A.c[0], A.c[1]}, P2{A.c[10], A.c[11]})) &&
-                    (ctm::fabs32(center_angle) < threshold_vertical)) {
+            for (int w = 0; w < 2; w++) {
+                unsigned long long m = s_pair[i][w];
+                while (m) {
+                    const int j = w * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
                     const int fi = uf(i), fj = uf(j);
                     if (fi != fj) s_father[fj] = fi;
                 }
