@@ -525,6 +525,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     __shared__ int s_code[CTAG_MAX_CODE_POS];
     __shared__ int s_misc[8];
     __shared__ unsigned long long s_pair[CTAG_MAX_FEATURES][2];
+    __shared__ int s_pos[CTAG_MAX_CODE_POS];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int tid = threadIdx.x;
@@ -642,47 +643,66 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         for (int m = 0; m <= cnt; m++) s_mfirst[m] = s_father[m];
     }
     __syncthreads();
-    // ---- per marker: edge lengths, orientation, sort, featureExtraction; thread 0 keeps ID_left/ID_right state
+    // ---- per marker (lane per marker): orientation and the sort of its features
+    for (int m = tid; m < cnt; m += 64) {
+        const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
+        float marker_angle = 0;
+        for (int k = a; k < b; k++) {
+            const FeatureDev& F = s_feat[s_order[k]];
+            double angle_now = ctm::fast_atan2_deg(F.c[1] - F.c[11], F.c[0] - F.c[10]);
+            if (angle_now > 180) angle_now -= 180;
+            marker_angle = (float)(marker_angle + angle_now);
+        }
+        marker_angle /= (float)n;
+        const int direc = (ctm::fabs32(marker_angle) < 45 || ctm::fabs32(marker_angle) > 135) ? 0 : 1;
+        // insertion sort of the marker's features (std::sort on <= 16 elements; stable)
+        for (int x = a + 1; x < b; x++) {
+            const int v = s_order[x];
+            const float kv = direc == 0 ? s_feat[v].center[1] : s_feat[v].center[0];
+            int y = x - 1;
+            while (y >= a) {
+                const float ky = direc == 0 ? s_feat[s_order[y]].center[1] : s_feat[s_order[y]].center[0];
+                const bool before = direc == 0 ? (kv > ky) : (kv < ky);
+                if (!before) break;
+                s_order[y + 1] = s_order[y];
+                y--;
+            }
+            s_order[y + 1] = v;
+        }
+        for (int k = a; k < b; k++) s_group[k] = direc;  // s_group is free now: direction of the marker owning slot k
+    }
+    __syncthreads();
+    // ---- featureExtraction (lane per feature slot).  ID_left / ID_right persist from one feature to the next when no
+    // cross-ratio band matches, so each lane reports "matched value or carry" and thread 0 replays the carry.
+    constexpr int kCarry = -99;
+    for (int k = tid; k < nf; k += 64) {
+        const FeatureDev& F = s_feat[s_order[k]];
+        ctag_feature_rec& R = s_rec[k];
+        for (int q = 0; q < 16; q++) R.corners[q] = F.c[q];
+        R.center[0] = F.center[0];
+        R.center[1] = F.center[1];
+        R.edge_length = (dist2p(P2{F.c[0], F.c[1]}, P2{F.c[2], F.c[3]}) + dist2p(P2{F.c[8], F.c[9]}, P2{F.c[10], F.c[11]}) / 2);
+        R.pos = -1;
+        int id, idl, idr, nl = kCarry, nr = kCarry;
+        feature_ids(R.corners, s_group[k], nl, nr, R.cr_left, R.cr_right, id, idl, idr);
+        R.id = id == -2 ? -2 : 0;  // -2: rejected by the edge-length test; 0: ids filled in by the replay
+        R.id_left = nl;
+        R.id_right = nr;
+    }
+    __syncthreads();
     if (tid == 0) {
-        int ID_left = 0, ID_right = 0;  // SURVEY B3: reset per detect()
-        for (int m = 0; m < cnt; m++) {
-            const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
-            float marker_angle = 0;
-            for (int k = a; k < b; k++) {
-                const FeatureDev& F = s_feat[s_order[k]];
-                double angle_now = ctm::fast_atan2_deg(F.c[1] - F.c[11], F.c[0] - F.c[10]);
-                if (angle_now > 180) angle_now -= 180;
-                marker_angle = (float)(marker_angle + angle_now);
-            }
-            marker_angle /= (float)n;
-            const int direc = (ctm::fabs32(marker_angle) < 45 || ctm::fabs32(marker_angle) > 135) ? 0 : 1;
-            // insertion sort of the marker's features (std::sort on <= 16 elements; stable)
-            for (int x = a + 1; x < b; x++) {
-                const int v = s_order[x];
-                const float kv = direc == 0 ? s_feat[v].center[1] : s_feat[v].center[0];
-                int y = x - 1;
-                while (y >= a) {
-                    const float ky = direc == 0 ? s_feat[s_order[y]].center[1] : s_feat[s_order[y]].center[0];
-                    const bool before = direc == 0 ? (kv > ky) : (kv < ky);
-                    if (!before) break;
-                    s_order[y + 1] = s_order[y];
-                    y--;
-                }
-                s_order[y + 1] = v;
-            }
-            for (int k = a; k < b; k++) {
-                const FeatureDev& F = s_feat[s_order[k]];
-                ctag_feature_rec& R = s_rec[k];
-                for (int q = 0; q < 16; q++) R.corners[q] = F.c[q];
-                R.center[0] = F.center[0];
-                R.center[1] = F.center[1];
-                R.edge_length = (dist2p(P2{F.c[0], F.c[1]}, P2{F.c[2], F.c[3]}) + dist2p(P2{F.c[8], F.c[9]}, P2{F.c[10], F.c[11]}) / 2);
-                R.pos = -1;
-                int id, idl, idr;
-                feature_ids(R.corners, direc, ID_left, ID_right, R.cr_left, R.cr_right, id, idl, idr);
-                R.id = id;
-                R.id_left = idl;
-                R.id_right = idr;
+        int ID_left = 0, ID_right = 0;  // reset per detect()
+        for (int k = 0; k < nf; k++) {
+            ctag_feature_rec& R = s_rec[k];
+            if (R.id_left != kCarry) ID_left = R.id_left;
+            if (R.id_right != kCarry) ID_right = R.id_right;
+            if (R.id == -2) {
+                R.id_left = -1;
+                R.id_right = -1;
+            } else {
+                R.id_left = ID_left;
+                R.id_right = ID_right;
+                R.id = ID_left * 8 + ID_right;
             }
         }
     }
@@ -742,69 +762,98 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             continue;
         }
         const int length = s_misc[2], legal = s_misc[4];
-        // coverage of every hypothesis, lanes over (dir, row, col)
+        // coverage of every hypothesis: each lane owns a contiguous run of (dir, row, col) in the reference's scan order
         const int hyp = drows * dcols;
-        for (int h = tid; h < 2 * hyp; h += 64) {
-            const int dir = h / hyp, rc = h - dir * hyp;
+        const int per = (2 * hyp + 63) / 64;
+        const int h_lo = min(tid * per, 2 * hyp), h_hi = min(h_lo + per, 2 * hyp);
+        int lane_max = -1;
+        for (int h = h_lo; h < h_hi; h++) {
+            const int dir = h >= hyp, rc = h - dir * hyp;
             const int i = rc / dcols, j = rc - i * dcols;
+            const int32_t* row = P.dict + i * dcols;
             int cov = 0;
             if (dir == 0) {
-                for (int k = 0; k <= length; k++)
-                    if (P.dict[i * dcols + (j + k) % dcols] == s_code[k]) cov++;
+                int c = j;
+                for (int k = 0; k <= length; k++) {
+                    if (row[c] == s_code[k]) cov++;
+                    if (++c == dcols) c = 0;
+                }
             } else {
                 for (int k = 0; k <= length; k++) {
-                    const int c = s_code[k];
-                    if (P.dict[i * dcols + (j - k + dcols) % dcols] == ((7 - c / 8) + (7 - c % 8) * 8)) cov++;
+                    const int cd = s_code[k];
+                    int c = j - k + dcols;  // (j - k + dcols) % dcols with C semantics; a negative column never matches
+                    if (c >= dcols) c -= dcols;
+                    if (c >= 0 && row[c] == ((7 - cd / 8) + (7 - cd % 8) * 8)) cov++;
                 }
             }
             s_cov[h] = (short)cov;
+            lane_max = max(lane_max, cov);
         }
-        __syncthreads();
-        if (tid == 0) {  // replay the order-dependent max / second bookkeeping
-            int max_cov = -1, second = -1, direc = 1, mx = 0, my = 0;
-            for (int h = 0; h < 2 * hyp; h++) {
-                const int cov = s_cov[h];
-                if (cov > max_cov) {
-                    max_cov = cov;
-                    const int dir = h / hyp, rc = h - dir * hyp;
-                    mx = rc / dcols;
-                    my = rc - mx * dcols;
-                    direc = dir == 0 ? 1 : -1;
-                } else if (cov > second) {
-                    second = cov;
-                }
+        // order-dependent max / second bookkeeping (:1280-1311): an element updates `second` iff it does not raise the
+        // running maximum, so every lane replays its run from the exclusive prefix maximum of the lanes before it
+        int run = lane_max;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(run, d);
+            if (tid >= d) run = max(run, o);
+        }
+        const int gmax = __shfl(run, 63);
+        run = __shfl_up(run, 1);
+        if (tid == 0) run = -1;
+        int sec = -1, first_max = 0x7fffffff;
+        for (int h = h_lo; h < h_hi; h++) {
+            const int cov = s_cov[h];
+            if (cov > run) {
+                run = cov;
+                if (cov == gmax) first_max = h;
+            } else if (cov > sec) {
+                sec = cov;
             }
+        }
+        for (int d = 32; d; d >>= 1) {
+            sec = max(sec, __shfl_xor(sec, d));
+            first_max = min(first_max, __shfl_xor(first_max, d));
+        }
+        if (tid == 0) {
+            const int max_cov = gmax, second = sec;
+            const int dir = first_max >= hyp, rc = first_max - dir * hyp;
+            const int mx = rc / dcols, my = rc - mx * dcols;
+            const int direc = dir == 0 ? 1 : -1;
             const double lim = 0.8 * legal < legal - 1.0 ? 0.8 * legal : legal - 1.0;
             const int good = (max_cov >= lim && max_cov > second) ? 1 : 0;
             s_misc[5] = good;
+            s_misc[6] = direc;
             if (good) {
                 ctag_marker_rec& M = out->markers[out_markers];
                 M.marker_id = mx;
                 M.first_feature = out_features;
                 M.n_features = n;
                 int np = 0;
-                for (int k = 0; k < n; k++) {
-                    ctag_feature_rec R = s_rec[a + k];
-                    if (direc == -1) {
-                        for (int q = 0; q < 8; q++) {
-                            const float t = R.corners[q];
-                            R.corners[q] = R.corners[8 + q];
-                            R.corners[8 + q] = t;
-                        }
-                    }
-                    R.pos = -1;
-                    out->features[out_features + k] = R;
-                }
                 for (int i = 0; i <= length; i++) {
                     if (s_code[i] != -1) {
-                        out->features[out_features + np].pos = (my + direc * i + dcols) % dcols;
+                        s_pos[np] = (my + direc * i + dcols) % dcols;
                         np++;
                     }
                 }
                 M.n_pos = np;
+                s_misc[7] = np;
             }
         }
         __syncthreads();
+        if (s_misc[5]) {
+            const int direc = s_misc[6], np = s_misc[7];
+            for (int k = tid; k < n; k += 64) {
+                ctag_feature_rec R = s_rec[a + k];
+                if (direc == -1) {
+                    for (int q = 0; q < 8; q++) {
+                        const float t = R.corners[q];
+                        R.corners[q] = R.corners[8 + q];
+                        R.corners[8 + q] = t;
+                    }
+                }
+                R.pos = k < np ? s_pos[k] : -1;
+                out->features[out_features + k] = R;
+            }
+        }
         if (s_misc[5]) {
             out_markers++;
             out_features += n;
