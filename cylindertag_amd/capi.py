@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "libctag_hip.so")
+_LIB = os.environ.get("CTAG_HIP_LIB") or os.path.join(_HERE, "_build", "libctag_hip.so")  # override: A/B builds (tools/)
 
 MAX_FEATURES, MAX_MARKERS = 100, 100
 FEATURE_DT = np.dtype([("pos", "<i4"), ("id", "<i4"), ("id_left", "<i4"), ("id_right", "<i4"),

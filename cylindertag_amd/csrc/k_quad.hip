@@ -93,7 +93,18 @@ struct CvRng {
 // One Welsch restart (the body of fitLine2D's `for k` loop) on one lane.  pts: cluster points in the order
 // the reference pushed them.  picks: the restart's initial sample (ascending).  Returns (_line, err) as they
 // stand when the reference leaves the inner loop.
-__device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks, int npick, double EPS, float* out_line, double* out_err) {
+#ifndef CTAG_WCAP
+#define CTAG_WCAP 16
+#endif
+#ifndef CTAG_WUNROLL
+#define CTAG_WUNROLL 1
+#endif
+#define CTAG_PRAGMA_(x) _Pragma(#x)
+#define CTAG_PRAGMA(x) CTAG_PRAGMA_(x)
+constexpr int kWCap = CTAG_WCAP;  // Welsch weights of the first kWCap points are kept in LDS between the two passes
+// wc: this lane's column of a [kWCap][64] float array in LDS (element j at wc[j * 64]); nullptr = always recompute
+__device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks, int npick, double EPS, float* out_line, double* out_err, float* wc = nullptr) {
+    const int ncache = wc ? min(n, kWCap) : 0;
     float line[4], prev[4] = {0.f, 0.f, 0.f, 0.f};
     {
         double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
@@ -126,8 +137,23 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
         const float lx = line[2], ly = line[3], nx = line[1], ny = -line[0];
         double sum_w = 0;
         err = 0;
-        for (int j = 0; j < n; j++) {
-            const uint32_t p = pts[j];
+        uint32_t pn0 = pts[min(0, n - 1)];  // next point, loaded one trip ahead
+        CTAG_PRAGMA(unroll CTAG_WUNROLL)
+        for (int j = 0; j < ncache; j++) {
+            const uint32_t p = pn0;
+            pn0 = pts[min(j + 1, n - 1)];
+            const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
+            const float r = ctm::fabs32(nx * x + ny * y);
+            err += r;
+            const float wj = ctm::exp32(-r * r * c * c);
+            wc[j * 64] = wj;
+            sum_w += wj;
+        }
+        uint32_t pn1 = pts[min(ncache, n - 1)];  // next point, loaded one trip ahead
+        CTAG_PRAGMA(unroll CTAG_WUNROLL)
+        for (int j = ncache; j < n; j++) {
+            const uint32_t p = pn1;
+            pn1 = pts[min(j + 1, n - 1)];
             const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
@@ -137,8 +163,25 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
         double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
         if (ctm::fabs64(sum_w) > 1.1920928955078125e-07) {
             const double inv = 1. / sum_w;
-            for (int j = 0; j < n; j++) {
-                const uint32_t p = pts[j];
+        uint32_t pn2 = pts[min(0, n - 1)];  // next point, loaded one trip ahead
+            CTAG_PRAGMA(unroll CTAG_WUNROLL)
+        for (int j = 0; j < ncache; j++) {
+                const uint32_t p = pn2;
+                pn2 = pts[min(j + 1, n - 1)];
+                const float px = (float)ux(p), py = (float)uy(p);
+                const float wj = (float)(wc[j * 64] * inv);
+                x += wj * px;
+                y += wj * py;
+                x2 += wj * px * px;
+                y2 += wj * py * py;
+                xy += wj * px * py;
+                w += wj;
+            }
+        uint32_t pn3 = pts[min(ncache, n - 1)];  // next point, loaded one trip ahead
+            CTAG_PRAGMA(unroll CTAG_WUNROLL)
+        for (int j = ncache; j < n; j++) {
+                const uint32_t p = pn3;
+                pn3 = pts[min(j + 1, n - 1)];
                 const float px = (float)ux(p), py = (float)uy(p);
                 const float r = ctm::fabs32(nx * (px - lx) + ny * (py - ly));
                 const float wj = (float)(ctm::exp32(-r * r * c * c) * inv);
@@ -150,8 +193,10 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
                 w += wj;
             }
         } else {
+            uint32_t pn4 = pts[min(0, n - 1)];  // next point, loaded one trip ahead
             for (int j = 0; j < n; j++) {
-                const uint32_t p = pts[j];
+                const uint32_t p = pn4;
+                pn4 = pts[min(j + 1, n - 1)];
                 const float px = (float)ux(p), py = (float)uy(p);
                 x += px;
                 y += py;
@@ -1409,6 +1454,7 @@ __global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
     __shared__ double s_err[60];
     __shared__ float s_line[60][4];
     __shared__ uint16_t s_pk[60][10];
+    __shared__ float s_wc[kWCap > 0 ? kWCap * 64 : 1];
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
@@ -1451,7 +1497,7 @@ __global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
                 pk[b + 1] = v;
             }
         }
-        welsch_restart(pts, n, pk, npick, n * 1.1920928955078125e-07, s_line[lane], &s_err[lane]);
+        welsch_restart(pts, n, pk, npick, n * 1.1920928955078125e-07, s_line[lane], &s_err[lane], kWCap > 0 ? s_wc + lane : nullptr);
     }
     __syncthreads();
     if (active && k == 0) {
