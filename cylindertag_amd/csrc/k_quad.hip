@@ -924,7 +924,9 @@ __global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom 
             t_prev = t;
         }
     };
-    for (int pk = blockIdx.x; pk < npk; pk += gridDim.x) {
+    // a frame's packs fill block columns 0..npk-1 only and blockIdx.x % 8 picks the XCD, so the column is rotated by
+    // the frame index: otherwise the low XCDs carry twice the work of the high ones
+    for (int pk = (blockIdx.x + frame) % gridDim.x; pk < npk; pk += gridDim.x) {
         __syncthreads();  // single-wave workgroup: the previous pack is done with s_mem
         stamp(-1);
         const uint32_t pw = P.packs[(size_t)frame * kCandCap + pk];
@@ -1524,7 +1526,7 @@ __global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
 __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int nframes) {
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
-    const int ci = blockIdx.x * 64 + threadIdx.x;
+    const int ci = (int)((blockIdx.x + frame) % gridDim.x) * 64 + threadIdx.x;  // column rotated by frame: spreads the few busy blocks over the XCDs
     if (ci >= P.ncand[frame]) return;
     const CandAux aux = P.cand_aux[(size_t)frame * kCandCap + ci];
     QuadOut* out = P.quads + (size_t)frame * kCandCap + ci;
