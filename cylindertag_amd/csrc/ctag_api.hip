@@ -188,6 +188,7 @@ static int check_args(ctag_handle* h, const void* frames, int n, int rows, int c
     if ((rows & 1) || (cols & 1)) return CTAG_ERR_UNSUPPORTED;
     if (adaptive_thresh > kMaxThreshWin) return CTAG_ERR_UNSUPPORTED;
     if (rows / 2 > 16000 || cols / 2 > 16000) return CTAG_ERR_UNSUPPORTED;
+    if (row_stride >= (1 << 24) || (long long)rows * row_stride > 0xffffffffLL) return CTAG_ERR_UNSUPPORTED;  // 32-bit pixel offsets (k_edge_refine)
     return CTAG_OK;
 }
 

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
     const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi;
     const uint8_t* __restrict__ img = P.frames + (ptrdiff_t)frame * P.frame_stride;
     const float k255 = (float)(1.0 / 255);
+    const uint32_t rs = (uint32_t)P.row_stride;
     const int off = quad * 4;
     __shared__ float s_cx[4], s_cy[4];
     __shared__ int s_ns[4];
@@ -321,27 +322,31 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                 const double y0 = alpha * ay + (1 - alpha) * by;
                 double Mn = 0, Mcount = 0;
                 const double range = subpix;
-                // Branch-free form of the reference's loop (:627-649): the two pixel reads use clamped coordinates and are
-                // issued unconditionally; a rejected step contributes weight +0.0, which leaves the running sums
-                // bit-identical to skipping it.
+                // Branch-free form of the reference's loop (:627-649): a step whose two sample pixels are not both inside
+                // the image, or whose gradient has the wrong sign, contributes weight +0.0, which leaves the running sums
+                // bit-identical to skipping it.  Pixel offsets are 32-bit (rows * row_stride < 2^32 and row_stride < 2^24
+                // are checked by the API) so the address is one v_mad_u32_u24 instead of a 64-bit multiply per pixel.
                 const int nsteps = 8 * subpix + 1;  // n = -range, -range+0.25, ..., +range (exact in binary)
+                const double grange = 1;
+                double n = -range;
 #pragma unroll 4
                 for (int st = 0; st < nsteps; st++) {
-                    const double n = -range + 0.25 * st;
-                    const double grange = 1;
-                    const int x1 = (int)(x0 + (n + grange) * nx);
-                    const int y1 = (int)(y0 + (n + grange) * ny);
-                    const int x2 = (int)(x0 + (n - grange) * nx);
-                    const int y2 = (int)(y0 + (n - grange) * ny);
-                    const bool inb = !(x1 < 0 || x1 >= cols || y1 < 0 || y1 >= rows) && !(x2 < 0 || x2 >= cols || y2 < 0 || y2 >= rows);
-                    const int cx1 = min(max(x1, 0), cols - 1), cy1 = min(max(y1, 0), rows - 1);
-                    const int cx2 = min(max(x2, 0), cols - 1), cy2 = min(max(y2, 0), rows - 1);
-                    const float g1 = (float)img[(ptrdiff_t)cy1 * P.row_stride + cx1] * k255;
-                    const float g2 = (float)img[(ptrdiff_t)cy2 * P.row_stride + cx2] * k255;
-                    const bool use = inb && !(g1 < g2);
+                    const double np = n + grange, nm = n - grange;
+                    const int x1 = (int)(x0 + np * nx);
+                    const int y1 = (int)(y0 + np * ny);
+                    const int x2 = (int)(x0 + nm * nx);
+                    const int y2 = (int)(y0 + nm * ny);
+                    const bool inb = ((unsigned)x1 < (unsigned)cols) & ((unsigned)y1 < (unsigned)rows) & ((unsigned)x2 < (unsigned)cols) &
+                                     ((unsigned)y2 < (unsigned)rows);
+                    const uint32_t o1 = inb ? __umul24((unsigned)y1, rs) + (unsigned)x1 : 0u;
+                    const uint32_t o2 = inb ? __umul24((unsigned)y2, rs) + (unsigned)x2 : 0u;
+                    const float g1 = (float)img[o1] * k255;
+                    const float g2 = (float)img[o2] * k255;
+                    const bool use = inb & !(g1 < g2);
                     const double weight = use ? (double)((g2 - g1) * (g2 - g1)) : 0.0;
                     Mn += weight * n;
                     Mcount += weight;
+                    n += 0.25;
                 }
                 if (Mcount != 0) {
                     const double n0 = Mn / Mcount;

@@ -1452,16 +1452,11 @@ __global__ __launch_bounds__(256) void k_line_sort(QuadPtrs P, int nframes) {
 // sequence depends only on the point count, so it comes from a table (or is replayed for very long edges).
 // The best-restart selection replays the reference's sequential `err < min_err` / `err < EPS` logic.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
+__device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int first, int L) {
     __shared__ double s_err[60];
     __shared__ float s_line[60][4];
     __shared__ uint16_t s_pk[60][10];
     __shared__ float s_wc[kWCap > 0 ? kWCap * 64 : 1];
-    const int frame = blockIdx.y;
-    if (frame >= nframes) return;
-    const int L = min(P.line_count[frame], kLineCap);
-    const int first = blockIdx.x * 3;
-    if (first >= L) return;
     const int lane = threadIdx.x;
     const int grp = lane / 20, k = lane - grp * 20;
     const bool active = lane < 60 && first + grp < L;
@@ -1516,6 +1511,17 @@ __global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
         }
         float* o = P.line_fit + ((size_t)frame * kLineCap + lid) * 4;
         for (int q = 0; q < 4; q++) o[q] = best[q];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    const int L = min(P.line_count[frame], kLineCap);
+    // the column is rotated by the frame index so the busy blocks of consecutive frames land on different XCDs
+    for (int first = (int)((blockIdx.x + frame) % gridDim.x) * 3; first < L; first += gridDim.x * 3) {
+        welsch_three(P, frame, first, L);
+        __syncthreads();
     }
 }
 
@@ -1624,7 +1630,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     hipLaunchKernelGGL(k_quad_edges_packed, dim3(32, nframes), dim3(64), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_quad_edges<true>, dim3(4, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
-    hipLaunchKernelGGL(k_welsch, dim3((kLineCap + 2) / 3, nframes), dim3(64), 0, s, P, nframes);
+    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : (kLineCap + 2) / 3;
+    hipLaunchKernelGGL(k_welsch, dim3(welsch_gx, nframes), dim3(64), 0, s, P, nframes);
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {
         unsigned long long h[16];
