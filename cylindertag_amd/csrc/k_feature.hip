@@ -269,8 +269,10 @@ constexpr int kRefineThreads = 128;
 __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
-    __shared__ double s_bx[4][kRefineThreads], s_by[4][kRefineThreads], s_al[4][kRefineThreads];
-    __shared__ unsigned char s_ok[4][kRefineThreads];
+    __shared__ double s_bx[4][kRefineThreads], s_by[4][kRefineThreads];
+    __shared__ double s_w[2][4][kRefineThreads];  // weight of the sample towards the next / last corner; 0 for a sample without an edge point
+    __shared__ double s_nrm[4][2];                // unit normal of each edge
+    __shared__ double s_one;
     __shared__ double s_acc[48];
     __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
     const int frame = blockIdx.y;
@@ -299,6 +301,9 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
         const double mag = ctm::sqrt64(nx * nx + ny * ny);
         const double ns_d = mag / 8 > 128.0 ? mag / 8 : 128.0;
         s_ns[tid] = (int)ns_d;
+        s_nrm[tid][0] = nx / mag;
+        s_nrm[tid][1] = ny / mag;
+        if (tid == 0) s_one = 1.0;
     }
     __syncthreads();
     const int max_ns = max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3]));
@@ -309,11 +314,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
             const int a = edge, b = (edge + 1) & 3;
             const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
             const int nsamples = s_ns[edge];
-            double nx = by - ay;
-            double ny = -bx + ax;
-            const double mag = ctm::sqrt64(nx * nx + ny * ny);
-            nx /= mag;
-            ny /= mag;
+            const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
             bool ok = false;
             double bestx = 0, besty = 0, alpha = 0;
             if (s < nsamples) {
@@ -322,31 +323,44 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                 const double y0 = alpha * ay + (1 - alpha) * by;
                 double Mn = 0, Mcount = 0;
                 const double range = subpix;
-                // Branch-free form of the reference's loop (:627-649): a step whose two sample pixels are not both inside
-                // the image, or whose gradient has the wrong sign, contributes weight +0.0, which leaves the running sums
-                // bit-identical to skipping it.  Pixel offsets are 32-bit (rows * row_stride < 2^32 and row_stride < 2^24
-                // are checked by the API) so the address is one v_mad_u32_u24 instead of a 64-bit multiply per pixel.
-                const int nsteps = 8 * subpix + 1;  // n = -range, -range+0.25, ..., +range (exact in binary)
-                const double grange = 1;
-                double n = -range;
-#pragma unroll 4
-                for (int st = 0; st < nsteps; st++) {
-                    const double np = n + grange, nm = n - grange;
-                    const int x1 = (int)(x0 + np * nx);
-                    const int y1 = (int)(y0 + np * ny);
-                    const int x2 = (int)(x0 + nm * nx);
-                    const int y2 = (int)(y0 + nm * ny);
-                    const bool inb = ((unsigned)x1 < (unsigned)cols) & ((unsigned)y1 < (unsigned)rows) & ((unsigned)x2 < (unsigned)cols) &
-                                     ((unsigned)y2 < (unsigned)rows);
-                    const uint32_t o1 = inb ? __umul24((unsigned)y1, rs) + (unsigned)x1 : 0u;
-                    const uint32_t o2 = inb ? __umul24((unsigned)y2, rs) + (unsigned)x2 : 0u;
-                    const float g1 = (float)img[o1] * k255;
-                    const float g2 = (float)img[o2] * k255;
-                    const bool use = inb & !(g1 < g2);
-                    const double weight = use ? (double)((g2 - g1) * (g2 - g1)) : 0.0;
-                    Mn += weight * n;
-                    Mcount += weight;
-                    n += 0.25;
+                // The reference's loop (:627-649) reads, at every step n = -range, -range+0.25, ..., +range, the pixels at
+                // offsets n+1 and n-1 along the normal.  The point at n-1 is the point the step 8 earlier read at n+1
+                // (same double arithmetic, hence the same pixel), so every pixel is fetched once and kept in an 8-deep
+                // register ring: the kernel is bound by these scattered byte loads.  A step whose two pixels are not both
+                // inside the image, or whose gradient has the wrong sign, contributes weight +0.0, which leaves the
+                // running sums bit-identical to skipping it.  Pixel offsets are 32-bit (checked by the API).
+                const int nsteps = 8 * subpix + 1;
+                auto sample = [&](double m) -> float {  // pixel / 255 at x0 + m * normal, -1 outside the image
+                    const int x = (int)(x0 + m * nx);
+                    const int y = (int)(y0 + m * ny);
+                    const bool in = ((unsigned)x < (unsigned)cols) & ((unsigned)y < (unsigned)rows);
+                    const uint32_t o = in ? __umul24((unsigned)y, rs) + (unsigned)x : 0u;
+                    const float g = (float)img[o] * k255;
+                    return in ? g : -1.f;
+                };
+                float ring[8];
+                double m = -range - 1;  // all offsets are multiples of 0.25: exact
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    ring[u] = sample(m);
+                    m += 0.25;
+                }
+                double n = -range;  // m == n + 1 from here on
+                for (int st0 = 0; st0 < nsteps; st0 += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (st0 + u < nsteps) {
+                            const float g1 = sample(m);
+                            const float g2 = ring[u];
+                            const bool use = (g1 >= 0.f) & (g2 >= 0.f) & !(g1 < g2);
+                            const double weight = use ? (double)((g2 - g1) * (g2 - g1)) : 0.0;
+                            Mn += weight * n;
+                            Mcount += weight;
+                            ring[u] = g1;
+                            m += 0.25;
+                            n += 0.25;
+                        }
+                    }
                 }
                 if (Mcount != 0) {
                     const double n0 = Mn / Mcount;
@@ -355,32 +369,25 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                     ok = true;
                 }
             }
-            s_bx[edge][tid] = bestx;
+            s_bx[edge][tid] = bestx;  // 0 when !ok
             s_by[edge][tid] = besty;
-            s_al[edge][tid] = alpha;
-            s_ok[edge][tid] = ok ? 1 : 0;
+            s_w[0][edge][tid] = ok ? 1 - alpha : 0.0;
+            s_w[1][edge][tid] = ok ? alpha : 0.0;
         }
         __syncthreads();
         if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
+            // every sum has the form (A * B) * w with A, B in {x, y, 1} (x * 1 and 1 * 1 are exact); a sample without an
+            // edge point has x = y = w = 0 and adds +0.0, which equals the reference skipping it
             const int edge = tid / 12, r = tid - edge * 12;
             const int pass = r / 6, which = r - pass * 6;
+            const double* pa = (which == 0 || which == 2 || which == 3) ? s_bx[edge] : (which == 5 ? &s_one : s_by[edge]);
+            const double* pb = which == 2 ? s_bx[edge] : ((which == 3 || which == 4) ? s_by[edge] : &s_one);
+            const int sa = which == 5 ? 0 : 1, sb = (which >= 2 && which <= 4) ? 1 : 0;
+            const double* pw = s_w[pass][edge];
             double acc = s_acc[tid];
             const int cntS = min(kRefineThreads, s_ns[edge] - sbase);
-            for (int k = 0; k < cntS; k++) {
-                if (!s_ok[edge][k]) continue;
-                const double wgt = pass == 0 ? (1 - s_al[edge][k]) : s_al[edge][k];
-                const double bxk = s_bx[edge][k], byk = s_by[edge][k];
-                double term;
-                switch (which) {
-                    case 0: term = bxk * wgt; break;
-                    case 1: term = byk * wgt; break;
-                    case 2: term = bxk * bxk * wgt; break;
-                    case 3: term = bxk * byk * wgt; break;
-                    case 4: term = byk * byk * wgt; break;
-                    default: term = wgt; break;
-                }
-                acc += term;
-            }
+#pragma unroll 8
+            for (int k = 0; k < cntS; k++) acc += (pa[k * sa] * pb[k * sb]) * pw[k];
             s_acc[tid] = acc;
         }
         __syncthreads();
