@@ -10,6 +10,9 @@ for d in sys.argv[1:]:
         for (_, k, c), v in per.items():
             acc[k][c].append(v)
 ctrs = sorted({c for k in acc for c in acc[k]})
-print("%-50s" % "kernel" + "".join("%18s" % c[:17] for c in ctrs))
-for k in sorted(acc):
-    print("%-50s" % k + "".join("%18.4g" % (sum(acc[k][c]) / max(1, len(acc[k][c]))) for c in ctrs))
+keep = [k for k in sorted(acc) if k.startswith(("ctag::", "void ctag::"))]
+for c in ctrs:
+    print(c)
+    for k in keep:
+        v = acc[k].get(c)
+        if v: print("    %-44s %14.5g" % (k.replace("void ", "")[:44], sum(v) / len(v)))
