@@ -41,8 +41,28 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=4096, help="frames per pipeline pass (workspace size)")
     ap.add_argument("--markers", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--host-frames", type=int, default=1024,
+                    help="frames of the host-memory (PCIe-inclusive) side measurement, 0 = skip; never `value`")
     ap.add_argument("--no-subpix", action="store_true")
     return ap.parse_args()
+
+
+def host_stream_rate(det, frames_dev, m, subpix):
+    """Side measurement (never `value`): the same frames handed over as HOST buffers through ctag_detect_batch_u8 --
+    pinned memory, uploads double-buffered against detection, results downloaded.  Bounded by PCIe."""
+    import cylindertag_amd as ca
+    host = ca.pinned_empty((m, ROWS, COLS), np.uint8)
+    host[...] = frames_dev[:m].cpu().numpy()
+    res = ca.pinned_empty((m,), ca.RESULT_DT)
+    det.detect_batch(host, 5, subpix, 5, out=res)  # warm (allocates the slabs)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        det.detect_batch(host, 5, subpix, 5, out=res)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(m / dt, 1), "unit": "frames/s", "frames": m, "host_gb_per_s": round(m * ROWS * COLS / dt / 1e9, 2),
+            "note": "ctag_detect_batch_u8: pinned host frames in, host results out, upload of sub-chunk k+1 overlapped "
+                    "with detection of sub-chunk k"}
 
 
 def cpu_baseline(frames_host, state, fs, subpix):
@@ -111,27 +131,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Per-kernel device time: HIP events recorded by the library on ITS stream around every kernel of the timed steps
+    # themselves (torch.cuda.Event would only see torch's current stream).  Reading them back costs one event
+    # synchronisation per chunk, which is inside the timed region.
+    det.set_option(capi.OPT_TIMING, 1)
+    acc = {k: 0.0 for k in ca.STAGE_NAMES}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        for k, v in det.timings().items():
+            acc[k] += v
     fence()
     dt = time.perf_counter() - t0
+    det.set_option(capi.OPT_TIMING, 0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    # ---- per-kernel device time with HIP events on the library's stream (outside the timed region)
-    det.set_option(capi.OPT_TIMING, 1)
-    tsteps = max(1, min(args.steps, 3))
-    acc = {k: 0.0 for k in ca.STAGE_NAMES}
-    for _ in range(tsteps):
-        det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, results.data_ptr(), 5, subpix, 5)
-        det.sync()
-        for k, v in det.timings().items():
-            acc[k] += v
-    det.set_option(capi.OPT_TIMING, 0)
-    stage_ms = {k: v / tsteps for k, v in acc.items()}  # per step (n frames)
+    stage_ms = {k: v / max(1, args.steps) for k, v in acc.items()}  # per step (n frames)
     launches = (n + args.chunk - 1) // args.chunk
 
     # ---- sanity on the outcome of the last step
@@ -166,6 +183,8 @@ def main():
                "roofline": roofline,
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
                "frames_ok": ok_frames, "markers_decoded_last_step": markers_found}
+        if world == 1 and args.host_frames > 0:
+            out["pcie_inclusive"] = host_stream_rate(det, frames, min(args.host_frames, n), subpix)
         if world == 1 and args.cpu_frames > 0:
             m = min(args.cpu_frames, n)
             out["cpu_baseline"] = cpu_baseline(frames[:m].cpu().numpy(), state, fs, subpix)

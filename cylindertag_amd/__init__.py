@@ -7,7 +7,7 @@ interface (``csrc/CylinderTag.h``).  This Python module is only the thin ctypes 
 missing or no GPU is usable, construction raises.
 """
 from .capi import (CtagError, Detector, FEATURE_DT, MARKER_DT, RESULT_DT, STAGE_NAMES, build, lib_path, load_library,
-                   load_marker_file, synth_frame_host, synth_truth)
+                   load_marker_file, pinned_empty, synth_frame_host, synth_truth)
 
 __all__ = ["CtagError", "Detector", "FEATURE_DT", "MARKER_DT", "RESULT_DT", "STAGE_NAMES", "build", "lib_path",
-           "load_library", "load_marker_file", "synth_frame_host", "synth_truth"]
+           "load_library", "load_marker_file", "pinned_empty", "synth_frame_host", "synth_truth"]

@@ -20,12 +20,12 @@ TRUTH_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("strip_le
 STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates", "quad", "features", "edge_refine",
                "markers"]
 
-OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS = 1, 2, 3
+OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK = 1, 2, 3, 4
 DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS = range(1, 9)
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)
 EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
-           "ctag_detect_batch_device", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
+           "ctag_detect_batch_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
            "ctag_stage_name", "ctag_strerror", "ctag_version", "ctag_debug_fetch", "ctag_math_probe",
            "ctag_synth_frames_device", "ctag_synth_frame_host", "ctag_synth_layout_truth"]
 
@@ -78,6 +78,10 @@ def load_library():
                                        C.c_int, vp]
     L.ctag_detect_batch_device.restype = C.c_int
     L.ctag_detect_batch_device.argtypes = L.ctag_detect_batch_u8.argtypes
+    L.ctag_host_alloc.restype = vp
+    L.ctag_host_alloc.argtypes = [C.c_size_t]
+    L.ctag_host_free.restype = None
+    L.ctag_host_free.argtypes = [vp]
     L.ctag_sync.restype = C.c_int
     L.ctag_sync.argtypes = [vp]
     L.ctag_stream.restype = vp
@@ -158,6 +162,33 @@ def synth_truth(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, marke
     return truth[0]
 
 
+class _Pinned:
+    """Owner of one ctag_host_alloc() block (page-locked host memory)."""
+
+    def __init__(self, nbytes):
+        self.L = load_library()
+        self.ptr = self.L.ctag_host_alloc(max(1, nbytes))
+        if not self.ptr:
+            raise MemoryError("ctag_host_alloc(%d)" % nbytes)
+        self.buf = (C.c_ubyte * max(1, nbytes)).from_address(self.ptr)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.L.ctag_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (ctag_host_alloc); the memory lives as long as the array's base."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    owner = _Pinned(n)
+    arr = np.frombuffer(owner.buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    arr_owner = owner  # keep alive through the ctypes buffer's _objects chain
+    owner.buf._pinned_owner = arr_owner
+    return arr
+
+
 class Detector:
     """One ctag_handle (one GPU).  Mirrors the reference's usage: construct with the dictionary, call detect()."""
 
@@ -198,10 +229,12 @@ class Detector:
             raise CtagError(st, "ctag_detect_u8")
         return res[0]
 
-    def detect_batch(self, frames, adaptive_thresh=5, subpix=True, subpix_dist=5):
+    def detect_batch(self, frames, adaptive_thresh=5, subpix=True, subpix_dist=5, out=None):
+        """frames: (n, rows, cols) uint8 in host memory; pass arrays from pinned_empty() to overlap upload and detection."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n, rows, cols = frames.shape
-        res = np.zeros(n, RESULT_DT)
+        res = np.zeros(n, RESULT_DT) if out is None else out
+        assert res.dtype == RESULT_DT and res.shape == (n,) and res.flags.c_contiguous
         st = self.L.ctag_detect_batch_u8(self.h, frames.ctypes.data, n, rows, cols, frames.strides[1], frames.strides[0],
                                          adaptive_thresh, int(subpix), subpix_dist, res.ctypes.data)
         if st != 0:

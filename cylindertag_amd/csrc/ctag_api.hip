@@ -43,11 +43,15 @@ struct ctag_handle {
     bool keep_pre = false;
     hipEvent_t ev[CTAG_NUM_STAGES + 1] = {};
     float stage_ms[CTAG_NUM_STAGES] = {};
-    // staging for host-memory entry points
+    // staging for host-memory entry points: two slabs of `host_sub` frames, filled on copy_stream while the
+    // other slab is being processed on `stream`
     uint8_t* d_frames = nullptr;
     size_t d_frames_bytes = 0;
     ctag_frame_result* d_results = nullptr;
     size_t d_results_count = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {}, ev_done[2] = {};
+    int host_sub = 128;
     ctag_synth::Frame* d_synth = nullptr;
     size_t d_synth_count = 0;
     int last_chunk_frames = 0;
@@ -379,6 +383,11 @@ void ctag_destroy(ctag_handle* h) {
     if (h->d_synth) (void)hipFree(h->d_synth);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) {
+        if (h->ev_copied[i]) (void)hipEventDestroy(h->ev_copied[i]);
+        if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -418,6 +427,10 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
             return CTAG_OK;
         case CTAG_OPT_TIMING: h->timing = value != 0; return CTAG_OK;
         case CTAG_OPT_KEEP_PREMARKERS: h->keep_pre = value != 0; return CTAG_OK;
+        case CTAG_OPT_HOST_SUBCHUNK:
+            if (value < 1 || value > (1 << 20)) return CTAG_ERR_ARG;
+            h->host_sub = (int)value;
+            return CTAG_OK;
         default: return CTAG_ERR_ARG;
     }
 }
@@ -450,34 +463,77 @@ int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows,
     if (rc != CTAG_OK) return rc;
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
-    const int chunk = std::min(n, h->max_chunk);
+    // Frames stream through two device slabs: while slab k is processed on the compute stream, slab k+1 is filled over
+    // PCIe on the copy stream (main.cpp:29,36,52-54 feed one frame at a time; this is the batched equivalent).  The
+    // copies only overlap when `frames` is pinned (ctag_host_alloc / hipHostRegister); pageable memory still works.
+    const int sub = std::min(n, std::min(h->max_chunk, h->host_sub));
     const ptrdiff_t dstride = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;  // packed, 16-byte aligned rows on the device
     const size_t dframe = (size_t)dstride * rows;
-    if (h->d_frames_bytes < dframe * chunk) {
+    if (h->d_frames_bytes < dframe * sub * 2) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->d_frames) HIP_TRY(hipFree(h->d_frames));
         h->d_frames = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_frames), dframe * chunk));
-        h->d_frames_bytes = dframe * chunk;
+        h->d_frames_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_frames), dframe * sub * 2));
+        h->d_frames_bytes = dframe * sub * 2;
     }
-    if (h->d_results_count < (size_t)chunk) {
+    if (h->d_results_count < (size_t)sub * 2) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->d_results) HIP_TRY(hipFree(h->d_results));
         h->d_results = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_results), sizeof(ctag_frame_result) * chunk));
-        h->d_results_count = chunk;
+        h->d_results_count = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_results), sizeof(ctag_frame_result) * sub * 2));
+        h->d_results_count = (size_t)sub * 2;
     }
-    for (int f0 = 0; f0 < n; f0 += chunk) {
-        const int m = std::min(chunk, n - f0);
-        for (int i = 0; i < m; i++) {
-            HIP_TRY(hipMemcpy2DAsync(h->d_frames + dframe * i, dstride, frames + (ptrdiff_t)(f0 + i) * frame_stride, row_stride, cols, rows,
-                                     hipMemcpyHostToDevice, h->stream));
+    if (!h->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
         }
-        const int r = detect_device_impl(h, h->d_frames, m, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist,
-                                         h->d_results);
-        if (r != CTAG_OK) return r;
-        HIP_TRY(hipMemcpyAsync(out + f0, h->d_results, sizeof(ctag_frame_result) * m, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    const bool packed = row_stride == cols && dstride == cols && frame_stride == (ptrdiff_t)rows * cols;
+    const size_t slab_frames = h->d_frames_bytes / dframe / 2;
+    const int nsub = (n + sub - 1) / sub;
+    auto upload = [&](int k) -> int {  // enqueue the upload of sub-chunk k on the copy stream
+        const int f0 = k * sub, m = std::min(sub, n - f0), slot = k & 1;
+        uint8_t* slab = h->d_frames + dframe * slab_frames * slot;
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_done[slot], 0));  // the slab's previous sub-chunk is finished
+        if (packed) {
+            HIP_TRY(hipMemcpyAsync(slab, frames + (ptrdiff_t)f0 * frame_stride, dframe * m, hipMemcpyHostToDevice, h->copy_stream));
+        } else {
+            for (int i = 0; i < m; i++)
+                HIP_TRY(hipMemcpy2DAsync(slab + dframe * i, dstride, frames + (ptrdiff_t)(f0 + i) * frame_stride, row_stride, cols, rows,
+                                         hipMemcpyHostToDevice, h->copy_stream));
+        }
+        HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
+        return CTAG_OK;
+    };
+    int r = upload(0);
+    if (r != CTAG_OK) return r;
+    for (int k = 0; k < nsub; k++) {
+        const int f0 = k * sub, m = std::min(sub, n - f0), slot = k & 1;
+        uint8_t* slab = h->d_frames + dframe * slab_frames * slot;
+        ctag_frame_result* res = h->d_results + (h->d_results_count / 2) * slot;
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
+        r = detect_device_impl(h, slab, m, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist, res);
+        if (r != CTAG_OK) return r;
+        HIP_TRY(hipEventRecord(h->ev_done[slot], h->stream));
+        // the next upload is enqueued before the result download: a download into pageable memory blocks the host
+        if (k + 1 < nsub && (r = upload(k + 1)) != CTAG_OK) return r;
+        HIP_TRY(hipMemcpyAsync(out + f0, res, sizeof(ctag_frame_result) * m, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return CTAG_OK;
+}
+
+void* ctag_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void ctag_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int ctag_detect_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int corner_subpix,

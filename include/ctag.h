@@ -51,6 +51,10 @@ int ctag_detect_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrd
 int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride,
                          ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
                          ctag_frame_result* out);
+/* Page-locked host memory for frame buffers handed to ctag_detect_batch_u8: with it the PCIe upload of sub-chunk k+1
+ * overlaps the detection of sub-chunk k (frame ingest of main.cpp:29,36,52-54).  NULL on failure. */
+void* ctag_host_alloc(size_t bytes);
+void ctag_host_free(void* p);
 
 /* A batch of frames already resident in DEVICE memory; results are written to DEVICE memory `out_dev`
  * (n records).  Work is enqueued on the handle's stream and this call returns without waiting; use
@@ -66,6 +70,7 @@ void* ctag_stream(ctag_handle* h);
 #define CTAG_OPT_MAX_CHUNK 1      /* frames processed per pass (workspace is sized for it); default 1024 */
 #define CTAG_OPT_TIMING 2         /* 1: bracket every kernel with HIP events (ctag_get_timings) */
 #define CTAG_OPT_KEEP_PREMARKERS 3 /* 1: keep the markers before decoding for ctag_debug_fetch */
+#define CTAG_OPT_HOST_SUBCHUNK 4   /* frames per upload/detect pipeline step of ctag_detect_batch_u8; default 128 */
 int ctag_set_option(ctag_handle* h, int option, int64_t value);
 
 /* Per-stage device time of the LAST ctag_detect_batch_* call, milliseconds measured with HIP events on

@@ -156,6 +156,35 @@ def test_batch_equals_single_and_is_repeatable(detector, dictionary):
         assert a[k].tobytes() == detector.detect(frames[k]).tobytes()
 
 
+def test_streamed_host_batch(detector, dictionary):
+    """ctag_detect_batch_u8 streams sub-chunks through two device slabs (upload of k+1 overlapping detection of k): the
+    results equal the single-pass ones for pinned and pageable frame memory, odd sub-chunk counts and strided rows."""
+    state, fs = dictionary
+    n = 7
+    frames = np.stack([ca.synth_frame_host(state, 300 + f)[0] for f in range(n)])
+    want = detector.detect_batch(frames)
+    pinned = ca.pinned_empty(frames.shape, np.uint8)
+    pinned[...] = frames
+    res = ca.pinned_empty((n,), ca.RESULT_DT)
+    try:
+        for sub in (1, 2, 3, 128):
+            detector.set_option(capi.OPT_HOST_SUBCHUNK, sub)
+            assert detector.detect_batch(frames).tobytes() == want.tobytes(), sub
+            got = detector.detect_batch(pinned, out=res)
+            assert got.tobytes() == want.tobytes(), sub
+        # rows with padding (row_stride > cols) take the per-frame 2-D copy path
+        detector.set_option(capi.OPT_HOST_SUBCHUNK, 2)
+        padded = np.zeros((n, frames.shape[1], frames.shape[2] + 64), np.uint8)
+        padded[:, :, :frames.shape[2]] = frames
+        view = padded[:, :, :frames.shape[2]]
+        r = np.zeros(n, ca.RESULT_DT)
+        st = detector.L.ctag_detect_batch_u8(detector.h, view.ctypes.data, n, view.shape[1], view.shape[2], view.strides[1],
+                                             view.strides[0], 5, 1, 5, r.ctypes.data)
+        assert st == 0 and r.tobytes() == want.tobytes()
+    finally:
+        detector.set_option(capi.OPT_HOST_SUBCHUNK, 128)
+
+
 def test_full_size_batch_properties(detector, oracle, dictionary):
     """BASELINE config 3 at full size through the device-resident entry point: frames generated on the GPU equal
     the host generator, every frame decodes exactly its planted dictionary rows, a second pass is byte-identical,
