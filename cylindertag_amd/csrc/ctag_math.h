@@ -220,6 +220,9 @@ CTM_HD double acos64(double t) {
     return 2.0 * atan2_64(__builtin_sqrt(1.0 - t), __builtin_sqrt(1.0 + t));
 }
 
+// smallest float t with fabs(acos64((double)t)) < 0.01f  (0x3f7ffcba = 0.99995005130767822266); see k_welsch
+constexpr float kAcosBelowTenMilli = 0.99995005130767822266f;
+
 // ---------------------------------------------------------------- float entry points
 CTM_HD float atan2_32(float y, float x) { return (float)atan2_64((double)y, (double)x); }
 CTM_HD float sin32(float x) { return (float)sin64((double)x); }
