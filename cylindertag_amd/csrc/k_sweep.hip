@@ -32,7 +32,10 @@ static inline int grid_for(int nframes, int per_frame) { return ((nframes + 7) /
 // Each lane owns 8 output pixels (one 16-byte source load per source row) and slides down a band of rows
 // keeping the four horizontal-pass rows in registers.
 // =====================================================================================================
-constexpr int kDecBand = 20;
+#ifndef CTAG_DEC_BAND
+#define CTAG_DEC_BAND 45
+#endif
+constexpr int kDecBand = CTAG_DEC_BAND;
 
 struct Raw18 {  // source pixels x0-1 .. x0+16 of one row
     uint32_t w0, w1, w2, w3;
