@@ -81,6 +81,32 @@ static FrameGeom make_geom(int rows, int cols, int tw) {
     return g;
 }
 
+// cv::resize INTER_CUBIC tap tables for one axis (resize.cpp: fx = (dx + 0.5) * scale - 0.5 in float, cubic weights with
+// A = -0.75 in float, x2048 rounded to nearest-even into short) -- SURVEY App. A.1; CylinderTag.cpp:79.
+static void build_resize_tables(int src, int dst, std::vector<int32_t>& ofs, std::vector<int16_t>& coef) {
+    ofs.assign((size_t)std::max(dst, 0), 0);
+    coef.assign((size_t)std::max(dst, 0) * 4, 0);
+    if (dst <= 0) return;
+    const double scale = (double)src / dst;
+    for (int d = 0; d < dst; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s0 = (int)std::floor(f);
+        f -= s0;
+        ofs[d] = s0;
+        const float A = -0.75f;
+        float c[4];
+        c[0] = ((A * (f + 1) - 5 * A) * (f + 1) + 8 * A) * (f + 1) - 4 * A;
+        c[1] = ((A + 2) * f - (A + 3)) * f * f + 1;
+        c[2] = ((A + 2) * (1 - f) - (A + 3)) * (1 - f) * (1 - f) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+        for (int k = 0; k < 4; k++) {
+            long r = std::lrint(c[k] * 2048.f);
+            r = std::min(std::max(r, -32768L), 32767L);
+            coef[(size_t)d * 4 + k] = (int16_t)r;
+        }
+    }
+}
+
 static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int frames) {
     if (h->ws.base && h->ws_rows == rows && h->ws_cols == cols && h->ws_cap >= frames) {
         h->ws.g = make_geom(rows, cols, tw);
@@ -132,6 +158,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_f1 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
     const size_t o_f2 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
     const size_t o_pre = take(F * sizeof(ctag_frame_result));
+    const size_t o_rzx = take((size_t)g.hcols * 4), o_rza = take((size_t)g.hcols * 8), o_rzy = take((size_t)g.hrows * 4), o_rzb = take((size_t)g.hrows * 8);
     void* base = nullptr;
     HIP_TRY(hipMalloc(&base, off));
     char* b = static_cast<char*>(base);
@@ -178,6 +205,20 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.feat1 = reinterpret_cast<FeatureDev*>(b + o_f1);
     W.feat2 = reinterpret_cast<FeatureDev*>(b + o_f2);
     W.premarkers = reinterpret_cast<ctag_frame_result*>(b + o_pre);
+    W.rz_xofs = reinterpret_cast<int32_t*>(b + o_rzx);
+    W.rz_alpha = reinterpret_cast<int16_t*>(b + o_rza);
+    W.rz_yofs = reinterpret_cast<int32_t*>(b + o_rzy);
+    W.rz_beta = reinterpret_cast<int16_t*>(b + o_rzb);
+    {   // tap tables of the general decimation (used for odd sizes only; a few KB)
+        std::vector<int32_t> xo, yo;
+        std::vector<int16_t> al, be;
+        build_resize_tables(cols, g.hcols, xo, al);
+        build_resize_tables(rows, g.hrows, yo, be);
+        HIP_TRY(hipMemcpy(W.rz_xofs, xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(W.rz_alpha, al.data(), al.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(W.rz_yofs, yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(W.rz_beta, be.data(), be.size() * 2, hipMemcpyHostToDevice));
+    }
     h->ws_rows = rows;
     h->ws_cols = cols;
     h->ws_tw = tw;
@@ -187,9 +228,6 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
 
 static int check_args(ctag_handle* h, const void* frames, int n, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int subpix_dist) {
     if (!h || !frames || n < 0 || rows < 4 || cols < 4 || row_stride < cols || adaptive_thresh < 1 || subpix_dist < 0) return CTAG_ERR_ARG;
-    // The GPU decimation implements the exact-2x cubic taps; odd sizes need per-column coefficient tables
-    // (reference behaviour for odd sizes is restated in the oracle only).
-    if ((rows & 1) || (cols & 1)) return CTAG_ERR_UNSUPPORTED;
     if (adaptive_thresh > kMaxThreshWin) return CTAG_ERR_UNSUPPORTED;
     if (rows / 2 > 16000 || cols / 2 > 16000) return CTAG_ERR_UNSUPPORTED;
     if (row_stride >= (1 << 24) || (long long)rows * row_stride > 0xffffffffLL) return CTAG_ERR_UNSUPPORTED;  // 32-bit pixel offsets (k_edge_refine)

@@ -125,6 +125,11 @@ struct Workspace {
     FeatureDev* feat1 = nullptr;    // after cornerObtain
     FeatureDev* feat2 = nullptr;    // after edgeRefine
     ctag_frame_result* premarkers = nullptr;  // [F] (debug: before decode)
+    // cubic tap tables of the general (odd-size) decimation: [hcols] / [hcols][4] / [hrows] / [hrows][4]
+    int32_t* rz_xofs = nullptr;
+    int16_t* rz_alpha = nullptr;
+    int32_t* rz_yofs = nullptr;
+    int16_t* rz_beta = nullptr;
     void* base = nullptr;
     size_t bytes = 0;
 };

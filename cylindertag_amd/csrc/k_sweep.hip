@@ -99,10 +99,12 @@ __device__ __forceinline__ void hpass(const Raw18& r, int q[8]) {
 // magnitude < 2^14, i.e. exactly representable in float, so t == V / 1024 exactly with V = 19*(qb+qc) - 3*(qa+qd) and
 // the result is the integer round-half-even of V/1024 (tests/test_oracle_cpu.py checks this identity against the
 // literal float evaluation the oracle uses).
-__device__ __forceinline__ uint32_t vpass(int qa, int qb, int qc, int qd) {
+// Output columns at or beyond (hcols & ~7) are OpenCV's scalar row tail: integer FixedPtCast, (v + 2^21) >> 22, i.e.
+// round-half-UP of V/1024 -- `tail` switches the tie rule off for those (a lane's 8 columns are all body or all tail).
+__device__ __forceinline__ uint32_t vpass(int qa, int qb, int qc, int qd, bool tail) {
     const int V = 19 * (qb + qc) - 3 * (qa + qd);
     int r = (V + 512) >> 10;
-    if ((V & 1023) == 512) r &= ~1;
+    if ((V & 1023) == 512 && !tail) r &= ~1;
     return (uint32_t)min(max(r, 0), 255);
 }
 
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ fr
     const int hx0 = (bx * 64 + lane) * 8;
     const int x0 = hx0 * 2;
     const bool active = hx0 < g.hcols;
+    const bool tail = hx0 >= (g.hcols & ~7);
     const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
     uint8_t* __restrict__ dst = half + ((size_t)frame * g.hrows) * g.hp;
     const int rmax = g.rows - 1;
@@ -141,9 +144,9 @@ __global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ fr
     auto emit = [&](int y, const int* a, const int* b, const int* c, const int* d) {
         uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) lo |= vpass(a[i], b[i], c[i], d[i]) << (8 * i);
+        for (int i = 0; i < 4; i++) lo |= vpass(a[i], b[i], c[i], d[i], tail) << (8 * i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) hi |= vpass(a[4 + i], b[4 + i], c[4 + i], d[4 + i]) << (8 * i);
+        for (int i = 0; i < 4; i++) hi |= vpass(a[4 + i], b[4 + i], c[4 + i], d[4 + i], tail) << (8 * i);
         if (active) *reinterpret_cast<uint2*>(dst + (size_t)y * g.hp + hx0) = make_uint2(lo, hi);
     };
     Raw18 n0 = load_row<ALIGNED>(rowp(2 * y_begin + 3), x0, g.cols, active, lane);
@@ -169,8 +172,54 @@ __global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ fr
     }
 }
 
+// General sizes (odd rows or cols: the scale is not exactly 2, every output column / row has its own cubic taps).
+// One thread per output pixel; the tap tables come from the host (build_resize_tables in ctag_api.hip).  Same
+// arithmetic as OpenCV's resizeGeneric_ for 8UC1 INTER_CUBIC: integer horizontal pass with per-tap index clamping,
+// float vertical pass with round-half-even for the SIMD body (x < hcols & ~7), integer FixedPtCast for the row tail.
+__global__ __launch_bounds__(256) void k_decimate_general(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
+                                                          uint8_t* __restrict__ half, FrameGeom g, int nframes, const int32_t* __restrict__ xofs,
+                                                          const int16_t* __restrict__ alpha, const int32_t* __restrict__ yofs,
+                                                          const int16_t* __restrict__ beta) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, frame = blockIdx.z;
+    if (x >= g.hcols || frame >= nframes) return;
+    const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
+    const int sx = xofs[x], sy = yofs[y];
+    int a[4], b[4], R[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        a[j] = alpha[x * 4 + j];
+        b[j] = beta[y * 4 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint8_t* S = src + (ptrdiff_t)min(max(sy - 1 + k, 0), g.rows - 1) * row_stride;
+        int v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v += (int)S[min(max(sx - 1 + j, 0), g.cols - 1)] * a[j];
+        R[k] = v;
+    }
+    int out;
+    if (x < (g.hcols & ~7)) {
+        const float scale = 1.f / (2048.f * 2048.f);
+        float t = (float)R[3] * ((float)b[3] * scale);
+        t = (float)R[2] * ((float)b[2] * scale) + t;
+        t = (float)R[1] * ((float)b[1] * scale) + t;
+        t = (float)R[0] * ((float)b[0] * scale) + t;
+        out = (int)__builtin_rintf(t);  // nearest-even, |t| < 2^16
+    } else {
+        const int v = R[0] * b[0] + R[1] * b[1] + R[2] * b[2] + R[3] * b[3];
+        out = (v + (1 << 21)) >> 22;
+    }
+    half[((size_t)frame * g.hrows + y) * g.hp + x] = (uint8_t)min(max(out, 0), 255);
+}
+
 hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s) {
     const FrameGeom& g = ws.g;
+    if ((g.rows & 1) || (g.cols & 1) || getenv("CTAG_GENERAL_RESIZE")) {  // env: developer aid, runs even sizes through the general kernel
+        hipLaunchKernelGGL(k_decimate_general, dim3((g.hcols + 255) / 256, g.hrows, nframes), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g,
+                           nframes, ws.rz_xofs, ws.rz_alpha, ws.rz_yofs, ws.rz_beta);
+        return hipGetLastError();
+    }
     const int lanes = (g.hcols + 7) / 8;
     const int xblocks = (lanes + 63) / 64;
     const int bands = (g.hrows + kDecBand - 1) / kDecBand;

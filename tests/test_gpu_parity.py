@@ -110,8 +110,37 @@ def test_edge_cases(detector, oracle, dictionary, test_bmp):
     st = detector.L.ctag_detect_u8(detector.h, base.ctypes.data, 1200, 1888, base.strides[0], 5, 1, 5, res.ctypes.data)
     assert st == 0
     assert_same_record(res[0], oracle.detect_fast(base[:, :1888], state, fs), "strided")
-    with pytest.raises(ca.CtagError):
-        detector.detect(test_bmp[:, :1919])  # odd width: unsupported on the GPU path, reported loudly
+
+
+def test_odd_sizes_and_resize_row_tail(detector, oracle, dictionary, test_bmp):
+    """Odd rows / cols: cv::resize to (cols/2, rows/2) is no longer an exact 2x, every output column and row has its
+    own cubic taps (general kernel, host-built tap tables).  And the last hcols % 8 output columns are OpenCV's scalar
+    row tail (round-half-up instead of the SIMD body's half-even) in both kernels."""
+    state, fs = dictionary
+    for name, img in (("odd width", test_bmp[:, :1919]), ("odd height", test_bmp[:1199, :1920]),
+                      ("both odd", test_bmp[1:1200, 3:1914]), ("odd small", test_bmp[200:745, 300:1151])):
+        img = np.ascontiguousarray(img)
+        o = oracle.detect(img, state, fs)
+        r = detector.detect(img)
+        assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all(), name
+        assert_same_record(r, oracle.detect_fast(img, state, fs), name)
+    # columns alternating 16 / 17 put every output pixel exactly on a rounding tie (V / 1024 = 16.5)
+    tie = np.zeros((64, 2 * 853), np.uint8)
+    tie[:, 0::2], tie[:, 1::2] = 16, 17
+    want = oracle.resize_half(tie)
+    assert (want[8:-8, 16:848] == 16).all() and (want[8:-8, 848:852] == 17).all()  # body: half-even, tail: half-up
+    detector.detect(tie)
+    assert (detector.debug(0, capi.DBG_HALF).reshape(want.shape) == want).all()
+    # the general kernel on an even size equals the exact-2x kernel
+    os.environ["CTAG_GENERAL_RESIZE"] = "1"
+    try:
+        detector.detect(tie)
+        assert (detector.debug(0, capi.DBG_HALF).reshape(want.shape) == want).all()
+        o = oracle.detect(test_bmp, state, fs)
+        detector.detect(test_bmp)
+        assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all()
+    finally:
+        del os.environ["CTAG_GENERAL_RESIZE"]
 
 
 def test_components_across_tile_seams(detector, oracle, dictionary):
