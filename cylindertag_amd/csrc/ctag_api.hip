@@ -644,7 +644,12 @@ long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t cap
         case CTAG_DBG_FEATURES2: {
             int nf = 0;
             if (!d2h(&nf, W.nfeat + frame, 4)) return -2;
-            if (dst && cap >= (size_t)nf * 19 && nf > 0) {
+            int fst = 0;
+            if (!d2h(&fst, W.status + frame, 4)) return -2;
+            if (dst && cap >= (size_t)nf * 19 && nf > 0 && fst != CTAG_OK && what != CTAG_DBG_FEATURES0) {
+                // early return ("No feature detected!", fewer features than featureSize): cornerObtain / edgeRefine never ran
+                std::memset(dst, 0, (size_t)nf * 19 * sizeof(float));
+            } else if (dst && cap >= (size_t)nf * 19 && nf > 0) {
                 std::vector<FeatureDev> f(nf);
                 const FeatureDev* src = what == CTAG_DBG_FEATURES0 ? W.feat0 : what == CTAG_DBG_FEATURES1 ? W.feat1 : W.feat2;
                 if (!d2h(f.data(), src + (size_t)frame * CTAG_MAX_FEATURES, sizeof(FeatureDev) * nf)) return -2;

@@ -143,6 +143,92 @@ def test_odd_sizes_and_resize_row_tail(detector, oracle, dictionary, test_bmp):
         del os.environ["CTAG_GENERAL_RESIZE"]
 
 
+def _random_shapes_frame(state, seed, rows=720, cols=1152):
+    """A synthetic marker frame (cropped to rows x cols) overlaid with a random population of dark shapes: rotated
+    rectangles and quads of many sizes (incl. long bars wider than 128 half-res px and blobs near the 1 % area limit),
+    rings, L-shapes, stacked quad pairs (feature candidates), tiny specks, some touching the frame border or a marker."""
+    rng = np.random.RandomState(1000 + seed)
+    base = ca.synth_frame_host(state, 500 + seed)[0]
+    y0, x0 = rng.randint(0, base.shape[0] - rows + 1), rng.randint(0, base.shape[1] - cols + 1)
+    img = base[y0:y0 + rows, x0:x0 + cols].astype(np.float32)
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    k = float(np.sqrt(rows * cols / (1080.0 * 1920.0)))  # shape sizes follow the frame size (area limit = 1 % of it)
+
+    def poly(pts, level):
+        pts = np.asarray(pts, np.float32)
+        inside = np.ones((rows, cols), bool)
+        n = len(pts)
+        e0, e1 = pts[1] - pts[0], pts[2] - pts[1]
+        sign = np.sign(e0[0] * e1[1] - e0[1] * e1[0]) or 1.0
+        for i in range(n):
+            a, b = pts[i], pts[(i + 1) % n]
+            inside &= sign * ((b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0])) >= 0
+        img[inside] = level
+
+    def rect(cx, cy, w, h, ang, level):
+        c, s_ = np.cos(ang), np.sin(ang)
+        poly([(cx + c * dx - s_ * dy, cy + s_ * dx + c * dy) for dx, dy in ((-w / 2, -h / 2), (w / 2, -h / 2), (w / 2, h / 2), (-w / 2, h / 2))], level)
+
+    for _ in range(rng.randint(25, 60)):
+        kind = rng.randint(0, 7)
+        cx, cy, ang = rng.uniform(0, cols), rng.uniform(0, rows), rng.uniform(0, np.pi)
+        dark = rng.randint(10, 60)
+        if kind == 0:
+            rect(cx, cy, k * rng.uniform(16, 120), k * rng.uniform(16, 120), ang, dark)
+        elif kind == 1:  # long bar
+            rect(cx, cy, k * rng.uniform(200, 420), k * rng.uniform(14, 40), ang * (rng.rand() < 0.5), dark)
+        elif kind == 2:  # ring
+            w, h = k * rng.uniform(60, 160), k * rng.uniform(60, 160)
+            rect(cx, cy, w, h, ang, dark)
+            rect(cx, cy, w * 0.6, h * 0.6, ang, 200)
+        elif kind == 3:  # L-shape
+            w = k * rng.uniform(60, 140)
+            rect(cx, cy, w, w / 4, ang, dark)
+            c, s_ = np.cos(ang), np.sin(ang)
+            rect(cx - c * w * 3 / 8 - s_ * w * 3 / 8, cy - s_ * w * 3 / 8 + c * w * 3 / 8, w / 4, w, ang, dark)
+        elif kind == 4:  # stacked pair of narrow quads: a feature candidate
+            w, h, gap = k * rng.uniform(20, 50), k * rng.uniform(60, 160), k * rng.uniform(8, 20)
+            c, s_ = np.cos(ang), np.sin(ang)
+            for sgn in (-1, 1):
+                off = sgn * (h / 2 + gap / 2)
+                rect(cx - s_ * off, cy + c * off, w, h * rng.uniform(0.5, 1.0), ang, dark)
+        elif kind == 5:  # irregular convex quad
+            r = k * rng.uniform(20, 90)
+            angs = np.sort(rng.uniform(0, 2 * np.pi, 4))
+            poly([(cx + r * np.cos(a), cy + r * np.sin(a)) for a in angs], dark)
+        else:  # specks
+            for _k in range(6):
+                rect(cx + rng.uniform(-40, 40), cy + rng.uniform(-40, 40), rng.uniform(2, 14), rng.uniform(2, 14), ang, dark)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_random_shapes_fuzz(detector, oracle, dictionary):
+    """Differential test on frames that are NOT markers: every stage the debug interface exposes (half image, label
+    partition, candidate list in OpenCV order, per-candidate quads, features, result record) equals the oracle's."""
+    state, fs = dictionary
+    detector.set_option(capi.OPT_KEEP_PREMARKERS, 1)
+    try:
+        for seed in range(int(os.environ.get("CTAG_FUZZ_SEEDS", "16"))):  # raise for a longer hunt
+            rows, cols = ((720, 1152), (540, 960), (1080, 1920), (601, 1023))[seed % 4]
+            img = _random_shapes_frame(state, seed, rows, cols)
+            o = oracle.detect(img, state, fs)
+            r = detector.detect(img)
+            what = "fuzz seed %d" % seed
+            assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all(), what
+            lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+            assert ((lab > 0) == (o["binary"] > 0)).all(), what
+            pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
+            assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1])), what
+            cand = detector.debug(0, capi.DBG_CANDIDATES)
+            assert cand.shape[0] == o["candidates"].shape[0] and (cand[:, 0:7] == o["candidates"][:, 1:8]).all(), what
+            assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes(), what
+            for st, which in enumerate((capi.DBG_FEATURES0, capi.DBG_FEATURES1, capi.DBG_FEATURES2)):
+                assert detector.debug(0, which).tobytes() == o["features"][st].tobytes(), (what, st)
+            assert_same_record(r, oracle.detect_fast(img, state, fs), what)
+    finally:
+        detector.set_option(capi.OPT_KEEP_PREMARKERS, 0)
+
+
 def test_components_across_tile_seams(detector, oracle, dictionary):
     """Dark blobs, bars and diagonal chains laid across the 320x30 CCL tile seams and their 4-tile corners (half-res
     x = 320, 640; y = 30, 60, ...): labels, areas, boxes and OpenCV order must equal the oracle's."""
