@@ -396,11 +396,40 @@ __device__ __forceinline__ TileRegion tile_region(int frame, int tile, const Fra
     return t;
 }
 
+// packed 16-bit min / max (v_pk_min_u16 / v_pk_max_u16): bytes are split into even / odd halves for them
+typedef unsigned short ctag_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    ctag_us2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const ctag_us2 r = __builtin_elementwise_min(x, y);
+    uint32_t o;
+    __builtin_memcpy(&o, &r, 4);
+    return o;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    ctag_us2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const ctag_us2 r = __builtin_elementwise_max(x, y);
+    uint32_t o;
+    __builtin_memcpy(&o, &r, 4);
+    return o;
+}
+// four pixel < threshold tests on packed bytes -> 4 bits.  T <= 77 < 128: with the pixel's top bit handled separately the
+// per-byte subtract (0x80 | low7) - T never borrows across bytes and its bit 7 says low7 >= T; one multiply gathers the bits.
+__device__ __forceinline__ uint32_t lt4_bytes(uint32_t u, uint32_t t) {
+    const uint32_t ge = (((u & 0x7f7f7f7fu) | 0x80808080u) - t) & 0x80808080u;
+    const uint32_t lt = ~(ge | u) & 0x80808080u;
+    return (((lt >> 7) * 0x01020408u) >> 24) & 0xfu;
+}
+constexpr int kVPitch = 352;  // column extrema per threshold-tile row: 5 + 320 + 5 columns from an 8-aligned start
+
 template <int TWC>
 __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes, int blocks_per_xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tw = TWC ? TWC : g.tw;
-    constexpr int kPre = TWC == 5 ? (1024 / kCclThreads) : 0;  // 16-byte register slots per thread for the next tile's region (tw = 5: <= 4)
+    constexpr int kPre = 0;  // register prefetch of the next tile's region: measured slower, the tw = 5 path keeps its pixels in registers instead
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_frame = g.tiles_x * g.tiles_y;
     const int xcd = blockIdx.x & 7, bk = blockIdx.x >> 3;
@@ -458,26 +487,6 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     const int py0 = T.py0, lx0 = T.lx0;
     (void)tc1;
     (void)tr1;
-    // ---- S1: stage the half-res region in LDS (16-byte chunks, coalesced along rows)
-    if (kPre) {
-#pragma unroll
-        for (int q = 0; q < (kPre ? kPre : 1); q++) {
-            const int i = tid + q * kCclThreads;
-            if (i < T.chunks * T.nrows) {
-                const int r = i / T.chunks, c = i - r * T.chunks;
-                *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = pre[q];
-            }
-        }
-    } else {
-        const uint8_t* __restrict__ himg = P.half + ((size_t)frame * g.hrows) * g.hp;
-        for (int i = tid; i < T.chunks * T.nrows; i += kCclThreads) {
-            const int r = i / T.chunks, c = i - r * T.chunks;
-            const int x = lx0 + c * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (x + 16 <= g.hp) v = *reinterpret_cast<const uint4*>(himg + (size_t)(py0 + r) * g.hp + x);
-            *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = v;
-        }
-    }
     // next tile of this block: issue its loads now, consume them at the top of the next iteration
     int it_next = it + blocks_per_xcd;
     while (it_next < items && item_frame(it_next) >= nframes) it_next += blocks_per_xcd;
@@ -487,24 +496,68 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
         Tn = tile_region(item_frame(it_next), it_next % per_frame, g, tw);
         if (kPre) load_region(Tn, pre);
     }
+  if constexpr (TWC == 5) {
+    // ---- front end for the 5x5 window: no LDS staging.  An item is (threshold-tile row, 8-pixel column group); the thread
+    // loads its 5 x 8 pixels straight into registers, reduces them vertically on packed bytes and leaves one min / max per
+    // COLUMN in LDS; a thread per threshold tile then combines 5 columns.  The pixels stay in registers for the compare.
+    const uint8_t* __restrict__ himg = P.half + ((size_t)frame * g.hrows) * g.hp;
+    uint8_t* vmin_s = hr_s;                          // [<= 8][kVPitch]
+    uint8_t* vmax_s = hr_s + 8 * kVPitch;
+    const int lx8 = T.px0 & ~7;
+    const int ng = (T.px1 - lx8 + 7) >> 3;           // <= 43
+    const int ncr = tr1 - tr0 + 1;                   // <= 8
+    const int nitems = ng * ncr;
+    uint2 pix[2][5];
+    int it_cr[2] = {-1, -1}, it_g[2] = {0, 0};
+    if (tid < kTileH * kTileWords) mask_s[tid] = 0ull;  // rows / groups outside the frame stay background
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = tid + q * kCclThreads;
+        if (i < nitems) {
+            const int cr = i / ng, gq = i - cr * ng;
+            it_cr[q] = cr;
+            it_g[q] = gq;
+            const int gx = lx8 + gq * 8;
+            const int y0 = (tr0 + cr) * 5;
+            const uint8_t* __restrict__ p0 = himg + gx;
+#pragma unroll
+            for (int k = 0; k < 5; k++)  // rows past the frame repeat the last row: duplicates do not change a min / max
+                pix[q][k] = *reinterpret_cast<const uint2*>(p0 + (size_t)min(y0 + k, g.hrows - 1) * g.hp);
+            uint32_t mnE0 = 0x00ff00ffu, mnO0 = 0x00ff00ffu, mnE1 = 0x00ff00ffu, mnO1 = 0x00ff00ffu, mxE0 = 0, mxO0 = 0, mxE1 = 0, mxO1 = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t e0 = pix[q][k].x & 0x00ff00ffu, o0 = (pix[q][k].x >> 8) & 0x00ff00ffu;
+                const uint32_t e1 = pix[q][k].y & 0x00ff00ffu, o1 = (pix[q][k].y >> 8) & 0x00ff00ffu;
+                mnE0 = pk_min_u16(mnE0, e0);
+                mnO0 = pk_min_u16(mnO0, o0);
+                mnE1 = pk_min_u16(mnE1, e1);
+                mnO1 = pk_min_u16(mnO1, o1);
+                mxE0 = pk_max_u16(mxE0, e0);
+                mxO0 = pk_max_u16(mxO0, o0);
+                mxE1 = pk_max_u16(mxE1, e1);
+                mxO1 = pk_max_u16(mxO1, o1);
+            }
+            // columns at or beyond the frame width are neutral (255 for the min, 0 for the max)
+            const int nvalid = min(max(g.hcols - gx, 0), 8);
+            const uint64_t vm = nvalid >= 8 ? ~0ull : ((1ull << (8 * nvalid)) - 1ull);
+            const uint32_t vm0 = (uint32_t)vm, vm1 = (uint32_t)(vm >> 32);
+            const uint2 mn = make_uint2((mnE0 | (mnO0 << 8)) | ~vm0, (mnE1 | (mnO1 << 8)) | ~vm1);
+            const uint2 mx = make_uint2((mxE0 | (mxO0 << 8)) & vm0, (mxE1 | (mxO1 << 8)) & vm1);
+            *reinterpret_cast<uint2*>(vmin_s + cr * kVPitch + gq * 8) = mn;
+            *reinterpret_cast<uint2*>(vmax_s + cr * kVPitch + gq * 8) = mx;
+        }
+    }
     CCL_SYNC();
     stamp(0);
-    // ---- S2: per-threshold-tile min / max (corner_detector.cpp:42-53)
+    // ---- per-threshold-tile min / max (corner_detector.cpp:42-53): 5 column extrema each
     {
-        const int nc = tc1 - tc0 + 1, nr = tr1 - tr0 + 1;
-        for (int i = tid; i < nc * nr; i += kCclThreads) {
+        const int nc = tc1 - tc0 + 1;
+        for (int i = tid; i < nc * ncr; i += kCclThreads) {
             const int r = i / nc, c = i - r * nc;
-            const int ya = (tr0 + r) * tw, yb = min(ya + tw, g.hrows);
-            const int xa = (tc0 + c) * tw, xb = min(xa + tw, g.hcols);
-            int mn = 255, mx = 0;
-            for (int y = ya; y < yb; y++) {
-                const uint8_t* row = hr_s + (size_t)(y - py0) * L.rp - lx0;
-                for (int x = xa; x < xb; x++) {
-                    const int u = row[x];
-                    mn = min(mn, u);
-                    mx = max(mx, u);
-                }
-            }
+            const uint8_t* a = vmin_s + r * kVPitch + (tc0 + c) * 5 - lx8;
+            const uint8_t* b = vmax_s + r * kVPitch + (tc0 + c) * 5 - lx8;
+            const int mn = min(min(min((int)a[0], (int)a[1]), min((int)a[2], (int)a[3])), (int)a[4]);
+            const int mx = max(max(max((int)b[0], (int)b[1]), max((int)b[2], (int)b[3])), (int)b[4]);
             ext_s[r * L.ec + c] = (uint16_t)(mn | (mx << 8));
         }
     }
@@ -535,45 +588,139 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     }
     CCL_SYNC();
     stamp(2);
-    // ---- S4: binary row masks (corner_detector.cpp:69-78), 8 pixels per thread.  pixel < T is evaluated on packed bytes:
-    // T <= 77 < 128, so with the pixel's top bit handled separately the per-byte subtract (0x80 | low7) - T never borrows
-    // across bytes and its bit 7 says low7 >= T.  The four result bits of a dword are gathered with one multiply.
+    // ---- binary row masks (corner_detector.cpp:69-78) from the pixels still in registers
     {
-        constexpr int groups = kTileW / 8;
         uint8_t* mask_b = reinterpret_cast<uint8_t*>(mask_s);
-        const int xoff = tx0 - lx0;
-        const bool fast = (((uintptr_t)0 + xoff) & 7) == 0;  // 8-byte aligned pixel groups (always for tw = 5)
-        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
-            const int r = i / groups, gq = i - r * groups;
-            unsigned bits = 0;
-            if (r < th_eff && gq * 8 < tw_eff) {
-                const int y = ty0 + r;
-                const uint8_t* prow = hr_s + (size_t)(y - py0) * L.rp + xoff + gq * 8;
-                const uint8_t* trow = thr_s + (y / tw - trs0) * (kTileW + 8) + gq * 8;
-                uint32_t u0, u1;
-                if (fast) {
-                    const uint2 uu = *reinterpret_cast<const uint2*>(prow);
-                    u0 = uu.x;
-                    u1 = uu.y;
-                } else {
-                    u0 = (uint32_t)prow[0] | ((uint32_t)prow[1] << 8) | ((uint32_t)prow[2] << 16) | ((uint32_t)prow[3] << 24);
-                    u1 = (uint32_t)prow[4] | ((uint32_t)prow[5] << 8) | ((uint32_t)prow[6] << 16) | ((uint32_t)prow[7] << 24);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int tr = tr0 + it_cr[q];
+            const int cx = lx8 + it_g[q] * 8 - tx0;
+            if (it_cr[q] >= 0 && tr >= trs0 && tr <= trs1 && cx >= 0 && cx < tw_eff) {
+                const uint2 tt = *reinterpret_cast<const uint2*>(thr_s + (tr - trs0) * (kTileW + 8) + cx);
+                const int left = tw_eff - cx;
+                const unsigned keep = left < 8 ? (1u << left) - 1u : 0xffu;
+                const int r0 = tr * 5 - ty0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    if (r0 + k < th_eff) {
+                        const unsigned bits = (lt4_bytes(pix[q][k].x, tt.x) | (lt4_bytes(pix[q][k].y, tt.y) << 4)) & keep;
+                        mask_b[(r0 + k) * (kTileW / 8) + (cx >> 3)] = (uint8_t)bits;
+                    }
                 }
-                const uint2 tt = *reinterpret_cast<const uint2*>(trow);
-                auto lt4 = [](uint32_t u, uint32_t t) {
-                    const uint32_t ge = (((u & 0x7f7f7f7fu) | 0x80808080u) - t) & 0x80808080u;
-                    const uint32_t lt = ~(ge | u) & 0x80808080u;
-                    return (((lt >> 7) * 0x01020408u) >> 24) & 0xfu;
-                };
-                bits = lt4(u0, tt.x) | (lt4(u1, tt.y) << 4);
-                const int left = tw_eff - gq * 8;  // columns of this group inside the frame
-                if (left < 8) bits &= (1u << left) - 1u;
             }
-            mask_b[i] = (uint8_t)bits;
         }
     }
     CCL_SYNC();
     stamp(3);
+  } else {
+        // ---- S1: stage the half-res region in LDS (16-byte chunks, coalesced along rows)
+        if (kPre) {
+    #pragma unroll
+            for (int q = 0; q < (kPre ? kPre : 1); q++) {
+                const int i = tid + q * kCclThreads;
+                if (i < T.chunks * T.nrows) {
+                    const int r = i / T.chunks, c = i - r * T.chunks;
+                    *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = pre[q];
+                }
+            }
+        } else {
+            const uint8_t* __restrict__ himg = P.half + ((size_t)frame * g.hrows) * g.hp;
+            for (int i = tid; i < T.chunks * T.nrows; i += kCclThreads) {
+                const int r = i / T.chunks, c = i - r * T.chunks;
+                const int x = lx0 + c * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (x + 16 <= g.hp) v = *reinterpret_cast<const uint4*>(himg + (size_t)(py0 + r) * g.hp + x);
+                *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = v;
+            }
+        }
+        CCL_SYNC();
+        stamp(0);
+        // ---- S2: per-threshold-tile min / max (corner_detector.cpp:42-53)
+        {
+            const int nc = tc1 - tc0 + 1, nr = tr1 - tr0 + 1;
+            for (int i = tid; i < nc * nr; i += kCclThreads) {
+                const int r = i / nc, c = i - r * nc;
+                const int ya = (tr0 + r) * tw, yb = min(ya + tw, g.hrows);
+                const int xa = (tc0 + c) * tw, xb = min(xa + tw, g.hcols);
+                int mn = 255, mx = 0;
+                for (int y = ya; y < yb; y++) {
+                    const uint8_t* row = hr_s + (size_t)(y - py0) * L.rp - lx0;
+                    for (int x = xa; x < xb; x++) {
+                        const int u = row[x];
+                        mn = min(mn, u);
+                        mx = max(mx, u);
+                    }
+                }
+                ext_s[r * L.ec + c] = (uint16_t)(mn | (mx << 8));
+            }
+        }
+        CCL_SYNC();
+        stamp(1);
+        // ---- S3: 3x3 min-of-min / max-of-max for interior tiles, zero elsewhere (corner_detector.cpp:54-67, B1)
+        {
+            const int nc = tcs1 - tcs0 + 1, nr = trs1 - trs0 + 1;
+            for (int i = tid; i < nc * nr; i += kCclThreads) {
+                const int r = i / nc, c = i - r * nc;
+                const int tr = trs0 + r, tc = tcs0 + c;
+                int T = 0;
+                if (tr >= 1 && tr <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2) {
+                    int mn = 255, mx = 0;
+    #pragma unroll
+                    for (int dy = -1; dy <= 1; dy++)
+    #pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            const int e = ext_s[(tr + dy - tr0) * L.ec + (tc + dx - tc0)];
+                            mn = min(mn, e & 0xff);
+                            mx = max(mx, e >> 8);
+                        }
+                    T = threshold_bound(mn, mx);  // <= 77: the reference caps the threshold at 0.3
+                }
+                const int xa = max(tc * tw - tx0, 0), xb = min((tc + 1) * tw - tx0, tw_eff);
+                for (int x = xa; x < xb; x++) thr_s[r * (kTileW + 8) + x] = (uint8_t)T;
+            }
+        }
+        CCL_SYNC();
+        stamp(2);
+        // ---- S4: binary row masks (corner_detector.cpp:69-78), 8 pixels per thread.  pixel < T is evaluated on packed bytes:
+        // T <= 77 < 128, so with the pixel's top bit handled separately the per-byte subtract (0x80 | low7) - T never borrows
+        // across bytes and its bit 7 says low7 >= T.  The four result bits of a dword are gathered with one multiply.
+        {
+            constexpr int groups = kTileW / 8;
+            uint8_t* mask_b = reinterpret_cast<uint8_t*>(mask_s);
+            const int xoff = tx0 - lx0;
+            const bool fast = (((uintptr_t)0 + xoff) & 7) == 0;  // 8-byte aligned pixel groups (always for tw = 5)
+            for (int i = tid; i < kTileH * groups; i += kCclThreads) {
+                const int r = i / groups, gq = i - r * groups;
+                unsigned bits = 0;
+                if (r < th_eff && gq * 8 < tw_eff) {
+                    const int y = ty0 + r;
+                    const uint8_t* prow = hr_s + (size_t)(y - py0) * L.rp + xoff + gq * 8;
+                    const uint8_t* trow = thr_s + (y / tw - trs0) * (kTileW + 8) + gq * 8;
+                    uint32_t u0, u1;
+                    if (fast) {
+                        const uint2 uu = *reinterpret_cast<const uint2*>(prow);
+                        u0 = uu.x;
+                        u1 = uu.y;
+                    } else {
+                        u0 = (uint32_t)prow[0] | ((uint32_t)prow[1] << 8) | ((uint32_t)prow[2] << 16) | ((uint32_t)prow[3] << 24);
+                        u1 = (uint32_t)prow[4] | ((uint32_t)prow[5] << 8) | ((uint32_t)prow[6] << 16) | ((uint32_t)prow[7] << 24);
+                    }
+                    const uint2 tt = *reinterpret_cast<const uint2*>(trow);
+                    auto lt4 = [](uint32_t u, uint32_t t) {
+                        const uint32_t ge = (((u & 0x7f7f7f7fu) | 0x80808080u) - t) & 0x80808080u;
+                        const uint32_t lt = ~(ge | u) & 0x80808080u;
+                        return (((lt >> 7) * 0x01020408u) >> 24) & 0xfu;
+                    };
+                    bits = lt4(u0, tt.x) | (lt4(u1, tt.y) << 4);
+                    const int left = tw_eff - gq * 8;  // columns of this group inside the frame
+                    if (left < 8) bits &= (1u << left) - 1u;
+                }
+                mask_b[i] = (uint8_t)bits;
+            }
+        }
+        CCL_SYNC();
+        stamp(3);
+  }
     // ---- S5: run starts, run numbering
     int nruns_mine = 0;
     if (tid < kTileH * kTileWords) {
