@@ -361,9 +361,7 @@ __device__ __forceinline__ int threshold_bound(int mn, int mx) {
     return t;
 }
 
-// Persistent: a block walks the tiles of its XCD with stride `blocks_per_xcd`; the half-res region of the NEXT tile is
-// loaded into registers (kPre x 16 bytes per thread) while the current tile is processed, so the staging latency of
-// every tile but the first is hidden.
+// geometry of one CCL tile and of the threshold tiles / pixels it needs
 struct TileRegion {
     int frame, tile, tx0, ty0, tw_eff, th_eff;
     int tcs0, tcs1, trs0, trs1, tc0, tc1, tr0, tr1, px0, px1, py0, py1, lx0, chunks, nrows;
@@ -423,17 +421,17 @@ __device__ __forceinline__ uint32_t lt4_bytes(uint32_t u, uint32_t t) {
     const uint32_t lt = ~(ge | u) & 0x80808080u;
     return (((lt >> 7) * 0x01020408u) >> 24) & 0xfu;
 }
+// exact n / d for n < 1024, d <= 66 from the 16-bit reciprocal m = ceil(65536 / d):  n * (m d - 65536) < 65536
+__device__ __forceinline__ int div_small(int n, int m16) { return (int)(((unsigned)n * (unsigned)m16) >> 16); }
+__device__ __forceinline__ int recip16(int d) { return (65536 + d - 1) / d; }
 constexpr int kVPitch = 352;  // column extrema per threshold-tile row: 5 + 320 + 5 columns from an 8-aligned start
 
 template <int TWC>
-__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes, int blocks_per_xcd) {
+__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tw = TWC ? TWC : g.tw;
-    constexpr int kPre = 0;  // register prefetch of the next tile's region: measured slower, the tw = 5 path keeps its pixels in registers instead
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_frame = g.tiles_x * g.tiles_y;
-    const int xcd = blockIdx.x & 7, bk = blockIdx.x >> 3;
-    const int items = ((nframes + 7) / 8) * per_frame;  // (frame slot, tile) pairs of this XCD
 
     const CclLdsLayout L = ccl_layout(tw);
     uint8_t* hr_s = smem + L.off_region;
@@ -446,27 +444,10 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     uint16_t* lab_s = reinterpret_cast<uint16_t*>(smem + L.off_lab);
     int* misc_s = reinterpret_cast<int*>(smem + L.off_misc);
 
-    auto item_frame = [&](int it) { return (it / per_frame) * 8 + xcd; };
-    auto load_region = [&](const TileRegion& t, uint4* pre) {
-        const uint8_t* __restrict__ himg = P.half + ((size_t)t.frame * g.hrows) * g.hp;
-#pragma unroll
-        for (int q = 0; q < (kPre ? kPre : 1); q++) {
-            const int i = tid + q * kCclThreads;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i < t.chunks * t.nrows) {
-                const int r = i / t.chunks, c = i - r * t.chunks;
-                const int x = t.lx0 + c * 16;
-                if (x + 16 <= g.hp) v = *reinterpret_cast<const uint4*>(himg + (size_t)(t.py0 + r) * g.hp + x);
-            }
-            pre[q] = v;
-        }
-    };
-    uint4 pre[kPre ? kPre : 1];
-    int it = bk;
-    while (it < items && item_frame(it) >= nframes) it += blocks_per_xcd;  // frame slots beyond the batch
-    if (it >= items) return;
-    TileRegion T = tile_region(item_frame(it), it % per_frame, g, tw);
-    if (kPre) load_region(T, pre);
+    // one tile per block; blocks b and b+8 share an XCD, so a frame's tiles stay on one XCD (map_block)
+    int frame0, tile0;
+    if (!map_block(blockIdx.x, per_frame, nframes, frame0, tile0)) return;
+    const TileRegion T = tile_region(frame0, tile0, g, tw);
 
     // developer aid: per-phase cycles are kept in registers and flushed once per tile (a global atomic per stamp would
     // cost as much as the phases it measures)
@@ -481,21 +462,14 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             t_prev = t;
         }
     };
-  for (;;) {
+  {
     const int frame = T.frame, tile = T.tile, tx0 = T.tx0, ty0 = T.ty0, tw_eff = T.tw_eff, th_eff = T.th_eff;
     const int tcs0 = T.tcs0, tcs1 = T.tcs1, trs0 = T.trs0, trs1 = T.trs1, tc0 = T.tc0, tc1 = T.tc1, tr0 = T.tr0, tr1 = T.tr1;
     const int py0 = T.py0, lx0 = T.lx0;
     (void)tc1;
     (void)tr1;
-    // next tile of this block: issue its loads now, consume them at the top of the next iteration
-    int it_next = it + blocks_per_xcd;
-    while (it_next < items && item_frame(it_next) >= nframes) it_next += blocks_per_xcd;
-    const bool has_next = it_next < items;
-    TileRegion Tn = T;
-    if (has_next) {
-        Tn = tile_region(item_frame(it_next), it_next % per_frame, g, tw);
-        if (kPre) load_region(Tn, pre);
-    }
+    (void)py0;
+    (void)lx0;
   if constexpr (TWC == 5) {
     // ---- front end for the 5x5 window: no LDS staging.  An item is (threshold-tile row, 8-pixel column group); the thread
     // loads its 5 x 8 pixels straight into registers, reduces them vertically on packed bytes and leaves one min / max per
@@ -507,6 +481,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     const int ng = (T.px1 - lx8 + 7) >> 3;           // <= 43
     const int ncr = tr1 - tr0 + 1;                   // <= 8
     const int nitems = ng * ncr;
+    const int m_ng = recip16(ng);  // wave-uniform: one division instead of one per item
     uint2 pix[2][5];
     int it_cr[2] = {-1, -1}, it_g[2] = {0, 0};
     if (tid < kTileH * kTileWords) mask_s[tid] = 0ull;  // rows / groups outside the frame stay background
@@ -514,7 +489,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     for (int q = 0; q < 2; q++) {
         const int i = tid + q * kCclThreads;
         if (i < nitems) {
-            const int cr = i / ng, gq = i - cr * ng;
+            const int cr = div_small(i, m_ng), gq = i - cr * ng;
             it_cr[q] = cr;
             it_g[q] = gq;
             const int gx = lx8 + gq * 8;
@@ -552,8 +527,9 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     // ---- per-threshold-tile min / max (corner_detector.cpp:42-53): 5 column extrema each
     {
         const int nc = tc1 - tc0 + 1;
+        const int m_nc = recip16(nc);
         for (int i = tid; i < nc * ncr; i += kCclThreads) {
-            const int r = i / nc, c = i - r * nc;
+            const int r = div_small(i, m_nc), c = i - r * nc;
             const uint8_t* a = vmin_s + r * kVPitch + (tc0 + c) * 5 - lx8;
             const uint8_t* b = vmax_s + r * kVPitch + (tc0 + c) * 5 - lx8;
             const int mn = min(min(min((int)a[0], (int)a[1]), min((int)a[2], (int)a[3])), (int)a[4]);
@@ -566,8 +542,9 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     // ---- S3: 3x3 min-of-min / max-of-max for interior tiles, zero elsewhere (corner_detector.cpp:54-67, B1)
     {
         const int nc = tcs1 - tcs0 + 1, nr = trs1 - trs0 + 1;
+        const int m_nc = recip16(nc);
         for (int i = tid; i < nc * nr; i += kCclThreads) {
-            const int r = i / nc, c = i - r * nc;
+            const int r = div_small(i, m_nc), c = i - r * nc;
             const int tr = trs0 + r, tc = tcs0 + c;
             int T = 0;
             if (tr >= 1 && tr <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2) {
@@ -614,16 +591,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     stamp(3);
   } else {
         // ---- S1: stage the half-res region in LDS (16-byte chunks, coalesced along rows)
-        if (kPre) {
-    #pragma unroll
-            for (int q = 0; q < (kPre ? kPre : 1); q++) {
-                const int i = tid + q * kCclThreads;
-                if (i < T.chunks * T.nrows) {
-                    const int r = i / T.chunks, c = i - r * T.chunks;
-                    *reinterpret_cast<uint4*>(hr_s + (size_t)r * L.rp + c * 16) = pre[q];
-                }
-            }
-        } else {
+        {
             const uint8_t* __restrict__ himg = P.half + ((size_t)frame * g.hrows) * g.hp;
             for (int i = tid; i < T.chunks * T.nrows; i += kCclThreads) {
                 const int r = i / T.chunks, c = i - r * T.chunks;
@@ -906,22 +874,13 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
         }
         t_prev = __builtin_amdgcn_s_memtime();
     }
-    if (!has_next) break;
-    it = it_next;
-    T = Tn;
-    CCL_SYNC();  // everyone is done with this tile's LDS state
   }
 }
 
 hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s) {
     const FrameGeom& g = ws.g;
     const size_t lds = threshold_ccl_lds_bytes(g.tw);
-    // persistent grid: enough blocks to fill every CU at the LDS-limited residency, never more than there are tiles
-    const int per_xcd_items = ((nframes + 7) / 8) * g.tiles_x * g.tiles_y;
-    const int resident = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1)) * 32;  // blocks per XCD (32 CUs)
-    const int mult = getenv("CTAG_CCL_WAVES") ? atoi(getenv("CTAG_CCL_WAVES")) : 0;  // developer aid: grid = mult x resident blocks (0 = one tile per block)
-    const int blocks_per_xcd = mult <= 0 ? per_xcd_items : std::max(1, std::min(per_xcd_items, resident * mult));
-    const int grid = blocks_per_xcd * 8;
+    const int grid = grid_for(nframes, g.tiles_x * g.tiles_y);  // one 320x30 tile per block
     SweepPtrs P = sweep_ptrs(ws);
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_CCL_STAMPS") != nullptr;
@@ -931,11 +890,11 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s)
         P.stamps = d_stamps;
     }
     if (g.tw == 5) {
-        hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes, blocks_per_xcd);
+        hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
     } else {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes, blocks_per_xcd);
+        hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
     }
     if (want_stamps) {
         unsigned long long h[16];
