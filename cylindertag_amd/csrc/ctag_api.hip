@@ -405,6 +405,10 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
         ctag_destroy(h);
         return CTAG_ERR_HIP;
     }
+    if (upload_threshold_table() != hipSuccess) {
+        ctag_destroy(h);
+        return CTAG_ERR_HIP;
+    }
     *out = h;
     return CTAG_OK;
 }

@@ -155,6 +155,7 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s);
 hipError_t launch_math_probe(int op, int n, const double* a, const double* b, double* out, hipStream_t s);
 size_t threshold_ccl_lds_bytes(int tw);
+hipError_t upload_threshold_table();  // once per device before the first K2 launch
 void build_pick_table(uint8_t* table);  // kPickN*20*10 bytes
 
 }  // namespace ctag

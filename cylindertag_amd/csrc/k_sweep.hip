@@ -256,10 +256,12 @@ struct SweepPtrs {
     int32_t* ncand;
     Candidate* cand;
     unsigned long long* stamps;  // developer aid (CTAG_CCL_STAMPS=1): cycles per phase of k_threshold_ccl, else null
+    size_t pool_stride;    // bytes between consecutive pool arrays (parent, root_of, area, xmin, ymin, xmax, ymax, key, pool_tile, member_head, member_next)
 };
 static SweepPtrs sweep_ptrs(const Workspace& ws) {
     return SweepPtrs{ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
-                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand, nullptr};
+                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand, nullptr,
+                     (size_t)(reinterpret_cast<const char*>(ws.root_of) - reinterpret_cast<const char*>(ws.parent))};
 }
 
 struct CclLdsLayout {
@@ -351,15 +353,31 @@ __device__ __forceinline__ void lds_union(unsigned* parent, unsigned a, unsigned
 
 // adaptive threshold of one tile as an integer bound: pixel u is foreground iff u < T, where
 // fg <=> float(u)*(1/255) < min(0.3f, (maxF + minF)/2)     (corner_detector.cpp:71)
-__device__ __forceinline__ int threshold_bound(int mn, int mx) {
+__host__ __device__ __forceinline__ int threshold_bound(int mn, int mx) {
     const float k = (float)(1.0 / 255);
-    const float thr = fminf(0.3f, ((float)mx * k + (float)mn * k) / 2);
+    const float a = ((float)mx * k + (float)mn * k) / 2;
+    const float thr = a < 0.3f ? a : 0.3f;
     int t = (int)(thr * 255.0f);
-    t = min(max(t, 0), 256);
+    t = t < 0 ? 0 : (t > 256 ? 256 : t);
     while (t < 256 && (float)t * k < thr) t++;
     while (t > 0 && !((float)(t - 1) * k < thr)) t--;
     return t;
 }
+// The bound is 77 (the 0.3 cap) once mn + mx >= 154 and otherwise depends on both operands (the two products round
+// separately): a 154 x 154 byte table, built on the host with the function above when a handle is created, replaces the
+// float search in the kernel (most threshold tiles are bright and never touch it).
+constexpr int kThrDim = 154;
+__device__ uint8_t g_thr_table[kThrDim * kThrDim];
+hipError_t upload_threshold_table() {
+    static uint8_t host[kThrDim * kThrDim];
+    for (int mn = 0; mn < kThrDim; mn++)
+        for (int mx = 0; mx < kThrDim; mx++) host[mn * kThrDim + mx] = (uint8_t)threshold_bound(mn, mx);
+    for (int mn = 0; mn < 256; mn++)
+        for (int mx = mn; mx < 256; mx++)
+            if (mn + mx >= kThrDim && threshold_bound(mn, mx) != 77) return hipErrorAssert;  // the shortcut the kernel relies on
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_thr_table), host, sizeof(host));
+}
+__device__ __forceinline__ int threshold_lookup(int mn, int mx) { return mn + mx >= kThrDim ? 77 : (int)g_thr_table[mn * kThrDim + mx]; }
 
 // geometry of one CCL tile and of the threshold tiles / pixels it needs
 struct TileRegion {
@@ -557,7 +575,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
                         mn = min(mn, e & 0xff);
                         mx = max(mx, e >> 8);
                     }
-                T = threshold_bound(mn, mx);  // <= 77: the reference caps the threshold at 0.3
+                T = threshold_lookup(mn, mx);  // <= 77: the reference caps the threshold at 0.3
             }
             const int xa = max(tc * tw - tx0, 0), xb = min((tc + 1) * tw - tx0, tw_eff);
             for (int x = xa; x < xb; x++) thr_s[r * (kTileW + 8) + x] = (uint8_t)T;
@@ -854,15 +872,18 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
         const size_t pool0 = (size_t)frame * kPoolCap;
         for (int i = tid; i < nslots; i += kCclThreads) {
             const size_t gidx = pool0 + base + i;
-            P.parent[gidx] = (unsigned)(base + i);
-            P.area[gidx] = st_area[i];
-            P.xmin[gidx] = st_xmin[i];
-            P.xmax[gidx] = st_xmax[i];
-            P.ymin[gidx] = st_ymin[i];
-            P.ymax[gidx] = st_ymax[i];
-            P.key[gidx] = st_key[i];
-            P.pool_tile[gidx] = tile;
-            P.member_head[gidx] = -1;
+            // the pool arrays are carved back to back at a fixed stride: one base pointer instead of nine
+            char* q = reinterpret_cast<char*>(P.parent + gidx);
+            const size_t ps = P.pool_stride;
+            *reinterpret_cast<unsigned*>(q) = (unsigned)(base + i);        // parent
+            *reinterpret_cast<int*>(q + 2 * ps) = st_area[i];               // area
+            *reinterpret_cast<int*>(q + 3 * ps) = st_xmin[i];
+            *reinterpret_cast<int*>(q + 4 * ps) = st_ymin[i];
+            *reinterpret_cast<int*>(q + 5 * ps) = st_xmax[i];
+            *reinterpret_cast<int*>(q + 6 * ps) = st_ymax[i];
+            *reinterpret_cast<int*>(q + 7 * ps) = st_key[i];
+            *reinterpret_cast<int*>(q + 8 * ps) = tile;                     // pool_tile
+            *reinterpret_cast<int*>(q + 9 * ps) = -1;                       // member_head
         }
     }
     stamp(9);
