@@ -955,53 +955,25 @@ __device__ __forceinline__ void g_union(uint32_t* parent, unsigned a, unsigned b
     }
 }
 
-// Thread per seam pixel (the pixel on the lower side of a horizontal seam / right side of a vertical seam).  A union is
+// One seam pixel (the pixel on the lower side of a horizontal seam / right side of a vertical seam).  A union is
 // issued only where a contact between two runs BEGINS along the seam: a neighbouring seam pixel that already sees the
 // same pair of runs does the union, and adjacency across the other seam family makes the rest transitive.
-__global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, int nframes, int per_frame_blocks) {
-    int frame, bidx;
-    if (!map_block(blockIdx.x, per_frame_blocks, nframes, frame, bidx)) return;
-    const int nh = (g.tiles_y - 1) * g.hcols;  // pixels on the lower side of horizontal seams
-    const int nv = (g.tiles_x - 1) * g.hrows;  // pixels on the right side of vertical seams
-    const int i = bidx * 256 + threadIdx.x;
-    if (i >= nh + nv) return;
-    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
-    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
-    uint32_t* parent = P.parent + (size_t)frame * kPoolCap;
-    auto lab = [&](int x, int y) -> unsigned {
-        if (x < 0 || x >= g.hcols || y < 0 || y >= g.hrows) return 0u;
-        return limg[(size_t)y * g.lp + x];
+__device__ __forceinline__ void seam_pixel(const uint16_t* __restrict__ limg, const int32_t* __restrict__ tbase, uint32_t* parent, const FrameGeom& g,
+                                           int x, int y, bool horizontal, unsigned c0) {
+    auto lab = [&](int xx, int yy) -> unsigned {
+        if (xx < 0 || xx >= g.hcols || yy < 0 || yy >= g.hrows) return 0u;
+        return limg[(size_t)yy * g.lp + xx];
     };
-    auto gid = [&](int x, int y, unsigned l) { return (unsigned)tbase[(y / kTileH) * g.tiles_x + (x / kTileW)] + l - 1; };
-    // along-seam coordinate s, this side c (cur) and the other side o: cur(s) = (x,y), oth(s) = neighbour across the seam
-    int x, y, dxs, dys, ox, oy;
-    if (i < nh) {
-        const int sm = i / g.hcols;
-        x = i - sm * g.hcols;
-        y = (sm + 1) * kTileH;
-        dxs = 1;
-        dys = 0;
-        ox = 0;
-        oy = -1;
-    } else {
-        const int j = i - nh;
-        const int sm = j / g.hrows;
-        y = j - sm * g.hrows;
-        x = (sm + 1) * kTileW;
-        dxs = 0;
-        dys = 1;
-        ox = -1;
-        oy = 0;
-    }
-    const unsigned c0 = lab(x, y);
-    if (!c0) return;
+    auto gid = [&](int xx, int yy, unsigned l) { return (unsigned)tbase[(yy / kTileH) * g.tiles_x + (xx / kTileW)] + l - 1; };
+    // along-seam step (dxs, dys); (ox, oy) leads to the neighbour across the seam
+    const int dxs = horizontal ? 1 : 0, dys = horizontal ? 0 : 1, ox = horizontal ? 0 : -1, oy = horizontal ? -1 : 0;
     const unsigned o0 = lab(x + ox, y + oy);
     const unsigned cm = lab(x - dxs, y - dys), om = lab(x - dxs + ox, y - dys + oy);  // previous position along the seam
     const unsigned cp = lab(x + dxs, y + dys), op = lab(x + dxs + ox, y + dys + oy);  // next position
     const unsigned me = gid(x, y, c0);
     // the shortcuts rely on "adjacent pixels of one row/column segment inside a tile share a label"; across a tile
     // boundary (the 4-tile corners) they could defer to each other in a circle, so they are not applied there
-    const int along = dxs ? x : y, tile_len = dxs ? kTileW : kTileH;
+    const int along = horizontal ? x : y, tile_len = horizontal ? kTileW : kTileH;
     const bool same_prev = (along % tile_len) != 0, same_next = ((along + 1) % tile_len) != 0;
     if (o0) {
         if (!(same_prev && cm && om)) g_union(parent, me, gid(x + ox, y + oy, o0));  // contact starts here
@@ -1011,9 +983,42 @@ __global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, in
     }
 }
 
+// Horizontal seams: a thread takes 8 consecutive seam pixels with one 16-byte label load and leaves at once when they are
+// all background (nine out of ten are); vertical seams: a thread per pixel.
+__global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, int nframes, int per_frame_blocks) {
+    int frame, bidx;
+    if (!map_block(blockIdx.x, per_frame_blocks, nframes, frame, bidx)) return;
+    const int hc8 = (g.hcols + 7) >> 3;
+    const int nh = (g.tiles_y - 1) * hc8;      // 8-pixel groups on the lower side of horizontal seams
+    const int nv = (g.tiles_x - 1) * g.hrows;  // pixels on the right side of vertical seams
+    const int i = bidx * 256 + threadIdx.x;
+    if (i >= nh + nv) return;
+    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
+    uint32_t* parent = P.parent + (size_t)frame * kPoolCap;
+    if (i < nh) {
+        const int sm = i / hc8;
+        const int x0 = (i - sm * hc8) * 8, y = (sm + 1) * kTileH;
+        const uint4 v = *reinterpret_cast<const uint4*>(limg + (size_t)y * g.lp + x0);  // lp is a multiple of 64: in bounds, aligned
+        if ((v.x | v.y | v.z | v.w) == 0u) return;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned c0 = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            if (c0 && x0 + k < g.hcols) seam_pixel(limg, tbase, parent, g, x0 + k, y, true, c0);
+        }
+    } else {
+        const int j = i - nh;
+        const int sm = j / g.hrows;
+        const int y = j - sm * g.hrows, x = (sm + 1) * kTileW;
+        const unsigned c0 = limg[(size_t)y * g.lp + x];
+        if (c0) seam_pixel(limg, tbase, parent, g, x, y, false, c0);
+    }
+}
+
 hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s) {
     const FrameGeom& g = ws.g;
-    const int n = (g.tiles_y - 1) * g.hcols + (g.tiles_x - 1) * g.hrows;
+    const int n = (g.tiles_y - 1) * ((g.hcols + 7) >> 3) + (g.tiles_x - 1) * g.hrows;
     if (n <= 0) return hipSuccess;
     const int per_frame = (n + 255) / 256;
     hipLaunchKernelGGL(k_seam_merge, dim3(grid_for(nframes, per_frame)), dim3(256), 0, s, sweep_ptrs(ws), g, nframes, per_frame);
