@@ -89,9 +89,26 @@ __device__ __forceinline__ int px(const Raw18& r, int k) {  // k in [-1, 16]
     const uint32_t w = k < 4 ? r.w0 : k < 8 ? r.w1 : k < 12 ? r.w2 : r.w3;
     return (int)((w >> (8 * (k & 3))) & 0xff);
 }
-__device__ __forceinline__ void hpass(const Raw18& r, int q[8]) {
+// The horizontal-pass values lie in [-1530, 9690]: two per register as int16 halves the kernel's largest live set (six
+// rows of eight values), which is what limits its occupancy; the sums qb+qc and qa+qd are formed on the packed pairs.
+typedef short ctag_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_s16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ uint32_t pk_add_s16(uint32_t a, uint32_t b) {
+    ctag_s2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const ctag_s2 r = x + y;
+    uint32_t o;
+    __builtin_memcpy(&o, &r, 4);
+    return o;
+}
+__device__ __forceinline__ void hpass(const Raw18& r, uint32_t q[4]) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) q[i] = 19 * (px(r, 2 * i) + px(r, 2 * i + 1)) - 3 * (px(r, 2 * i - 1) + px(r, 2 * i + 2));
+    for (int i = 0; i < 4; i++) {
+        const int q0 = 19 * (px(r, 4 * i) + px(r, 4 * i + 1)) - 3 * (px(r, 4 * i - 1) + px(r, 4 * i + 2));
+        const int q1 = 19 * (px(r, 4 * i + 2) + px(r, 4 * i + 3)) - 3 * (px(r, 4 * i + 1) + px(r, 4 * i + 4));
+        q[i] = pack_s16(q0, q1);
+    }
 }
 
 // vertical pass.  OpenCV's float vector body computes t = s0*b0 + (s1*b1 + (s2*b2 + s3*b3)) with s = 64*q and
@@ -101,15 +118,21 @@ __device__ __forceinline__ void hpass(const Raw18& r, int q[8]) {
 // literal float evaluation the oracle uses).
 // Output columns at or beyond (hcols & ~7) are OpenCV's scalar row tail: integer FixedPtCast, (v + 2^21) >> 22, i.e.
 // round-half-UP of V/1024 -- `tail` switches the tie rule off for those (a lane's 8 columns are all body or all tail).
-__device__ __forceinline__ uint32_t vpass(int qa, int qb, int qc, int qd, bool tail) {
-    const int V = 19 * (qb + qc) - 3 * (qa + qd);
+__device__ __forceinline__ uint32_t vround(int V, bool tail) {
     int r = (V + 512) >> 10;
     if ((V & 1023) == 512 && !tail) r &= ~1;
     return (uint32_t)min(max(r, 0), 255);
 }
+// two output pixels from packed rows: S1 = qb + qc and S2 = qa + qd stay inside int16 (|.| <= 19380)
+__device__ __forceinline__ uint32_t vpass2(uint32_t qa, uint32_t qb, uint32_t qc, uint32_t qd, bool tail) {
+    const uint32_t s1 = pk_add_s16(qb, qc), s2 = pk_add_s16(qa, qd);
+    const int v0 = 19 * (int)(short)(s1 & 0xffffu) - 3 * (int)(short)(s2 & 0xffffu);
+    const int v1 = 19 * ((int)s1 >> 16) - 3 * ((int)s2 >> 16);
+    return vround(v0, tail) | (vround(v1, tail) << 8);
+}
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_decimate(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
                                                   uint8_t* __restrict__ half, FrameGeom g, int nframes, int xblocks, int yblocks) {
     int frame, idx;
     if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
@@ -128,7 +151,7 @@ __global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ fr
     const int rmax = g.rows - 1;
     auto rowp = [&](int r) { return src + (ptrdiff_t)min(max(r, 0), rmax) * row_stride; };
 
-    int qa[8], qb[8], qc[8], qd[8];
+    uint32_t qa[4], qb[4], qc[4], qd[4];
     {
         const Raw18 ra = load_row<ALIGNED>(rowp(2 * y_begin - 1), x0, g.cols, active, lane);
         const Raw18 rb = load_row<ALIGNED>(rowp(2 * y_begin), x0, g.cols, active, lane);
@@ -141,12 +164,9 @@ __global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ fr
     }
     // two output rows per iteration: the four source rows of the NEXT iteration are requested before this iteration's
     // arithmetic, so every lane keeps 64 bytes in flight (the kernel is bound by memory latency x occupancy)
-    auto emit = [&](int y, const int* a, const int* b, const int* c, const int* d) {
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) lo |= vpass(a[i], b[i], c[i], d[i], tail) << (8 * i);
-#pragma unroll
-        for (int i = 0; i < 4; i++) hi |= vpass(a[4 + i], b[4 + i], c[4 + i], d[4 + i], tail) << (8 * i);
+    auto emit = [&](int y, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
+        const uint32_t lo = vpass2(a[0], b[0], c[0], d[0], tail) | (vpass2(a[1], b[1], c[1], d[1], tail) << 16);
+        const uint32_t hi = vpass2(a[2], b[2], c[2], d[2], tail) | (vpass2(a[3], b[3], c[3], d[3], tail) << 16);
         if (active) *reinterpret_cast<uint2*>(dst + (size_t)y * g.hp + hx0) = make_uint2(lo, hi);
     };
     Raw18 n0 = load_row<ALIGNED>(rowp(2 * y_begin + 3), x0, g.cols, active, lane);
@@ -156,12 +176,12 @@ __global__ __launch_bounds__(256) void k_decimate(const uint8_t* __restrict__ fr
         const Raw18 m0 = load_row<ALIGNED>(rowp(2 * y + 5), x0, g.cols, active, lane);
         const Raw18 m1 = load_row<ALIGNED>(rowp(2 * y + 6), x0, g.cols, active, lane);
         emit(y, qa, qb, qc, qd);
-        int qe[8], qf[8];
+        uint32_t qe[4], qf[4];
         hpass(n0, qe);
         hpass(n1, qf);
         if (y + 1 < y_end) emit(y + 1, qc, qd, qe, qf);  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 4; i++) {
             qa[i] = qe[i];
             qb[i] = qf[i];
         }
