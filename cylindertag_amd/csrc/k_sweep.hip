@@ -288,7 +288,7 @@ struct CclLdsLayout {
     int rp, rh;       // half-res staging region pitch / rows
     int ec, er;       // extrema grid (with ring)
     int tc, tr;       // threshold grid (tiles overlapping the CCL tile)
-    size_t off_region, off_ext, off_thr, off_mask, off_start, off_runbase, off_parent, off_lab, off_misc, total;
+    size_t off_region, off_ext, off_thr, off_mask, off_start, off_runbase, off_parent, off_lab, off_misc, off_stats, total;
 };
 __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
     CclLdsLayout L;
@@ -305,11 +305,34 @@ __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
         o = (o + bytes + 15) & ~(size_t)15;
         return at;
     };
-    const size_t region = (size_t)L.rp * L.rh;
     const size_t stats = (size_t)kSlotCap * 6 * sizeof(int);
+    const size_t ext = (size_t)L.ec * L.er * 2;
+    const size_t thr = (size_t)L.tr * (kTileW + 8);  // per threshold-tile row: one threshold byte per tile column
+    if (tw == 5) {
+        // Compact layout of the 5x5 front end (7 blocks per CU instead of 4).  Lifetimes: column extrema + tile extrema live
+        // until the thresholds exist, the run parents from S5 to the end of S8, the per-slot statistics from then on --
+        // the statistics overlay all three; the threshold bytes are dead before the run labels are first written.
+        const size_t parent = (size_t)kRunCap * 4, vbuf = (size_t)2 * 8 * 352;
+        const size_t front = parent + vbuf + ext;
+        L.off_stats = take(front > stats ? front : stats);
+        L.off_parent = L.off_stats;
+        L.off_region = L.off_parent + parent;
+        L.off_ext = L.off_region + vbuf;
+        L.off_mask = take((size_t)kTileH * kTileWords * 8);
+        L.off_start = take((size_t)kTileH * kTileWords * 8);
+        L.off_runbase = take(((size_t)kTileH * kTileWords + 1) * 4);
+        const size_t lab = (size_t)kRunCap * 2;
+        L.off_lab = take(lab > thr ? lab : thr);
+        L.off_thr = L.off_lab;
+        L.off_misc = take(64);
+        L.total = o;
+        return L;
+    }
+    const size_t region = (size_t)L.rp * L.rh;
     L.off_region = take(region > stats ? region : stats);
-    L.off_ext = take((size_t)L.ec * L.er * 2);
-    L.off_thr = take((size_t)L.tr * (kTileW + 8));  // per threshold-tile row: one threshold byte per tile column
+    L.off_stats = L.off_region;
+    L.off_ext = take(ext);
+    L.off_thr = take(thr);
     L.off_mask = take((size_t)kTileH * kTileWords * 8);
     L.off_start = take((size_t)kTileH * kTileWords * 8);
     L.off_runbase = take(((size_t)kTileH * kTileWords + 1) * 4);
@@ -793,7 +816,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     }
     if (nslots > kSlotCap) overflow = true;
     CCL_SYNC();
-    int* st_area = reinterpret_cast<int*>(smem + L.off_region);  // staging region is dead from here on
+    int* st_area = reinterpret_cast<int*>(smem + L.off_stats);  // overlays buffers that are dead from here on (see ccl_layout)
     int* st_xmin = st_area + kSlotCap;
     int* st_xmax = st_xmin + kSlotCap;
     int* st_ymin = st_xmax + kSlotCap;
@@ -804,6 +827,9 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             const unsigned r = lds_find(parent_s, (unsigned)i);
             if (r != (unsigned)i) lab_s[i] = lab_s[r];
         }
+    }
+    CCL_SYNC();  // the statistics below overlay the run parents
+    if (!overflow) {
         for (int i = tid; i < nslots; i += kCclThreads) {
             st_area[i] = 0;
             st_xmin[i] = 0x7fffffff;
