@@ -151,7 +151,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_lfit = take(F * kLineCap * 16);
     const size_t o_aux = take(F * kCandCap * sizeof(CandAux));
     const size_t o_npk = take(F * 4), o_pk = take(F * kCandCap * 4);
-    const size_t o_der = take(F * kCandCap * 32);
+    const size_t o_der = take(F * kCandCap * 48);
     const size_t o_qidx = take(F * kCandCap * 4);
     const size_t o_nq = take(F * 4), o_nf = take(F * 4), o_st = take(F * 4);
     const size_t o_f0 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));

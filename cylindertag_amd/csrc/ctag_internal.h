@@ -33,8 +33,8 @@ constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range
 constexpr int kQuadLdsPoints = 1024;    // boundary points held in LDS; larger components use global scratch
 constexpr int kQuadScratchSlots = 64;   // global scratch slots per chunk for oversize components
 constexpr int kQuadScratchPoints = 8192;  // >= 2*(1920+1080)+4: worst-case silhouette of a 4K frame at half-res
-constexpr int kLineCap = 1024;            // fitted edges per frame (4 per candidate that survives the RDP split)
-constexpr int kClPool = 65536;            // edge-cluster points per frame
+constexpr int kLineCap = 4 * kCandCap;     // fitted edges per frame (4 per candidate that survives the RDP split)
+constexpr int kClPool = 262144;           // edge-cluster points per frame (a candidate reserves its boundary capacity + 64)
 constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table
 constexpr int kMaxDictCells = 2048;       // dictionary rows*cols supported by K9 (reference dictionary: 41*12)
 
@@ -116,7 +116,7 @@ struct Workspace {
     uint32_t* packs = nullptr;      // [F][kCandCap]
     const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
     // features
-    void* quad_derived = nullptr;   // [F][kCandCap] x 32 B (K7 scratch)
+    void* quad_derived = nullptr;   // [F][kCandCap] x 48 B (K7 scratch)
     int32_t* quad_index = nullptr;  // [F][kCandCap]
     int32_t* nquads = nullptr;      // [F]
     int32_t* nfeat = nullptr;       // [F]

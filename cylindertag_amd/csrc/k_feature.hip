@@ -39,7 +39,9 @@ __device__ __forceinline__ bool solve2x2f(float a00, float a01, float a10, float
 // =====================================================================================================
 struct QuadDerived {  // per accepted quad: centre, side lengths, the two mean side directions (:473-481)
     float cx, cy, d[4], a1, a2;
+    float e[4];  // the four edge directions the pair test may ask for (:497-539), computed once per quad instead of per pair
 };
+static_assert(sizeof(QuadDerived) == 48, "workspace carve in ctag_api.hip");
 struct FeatPtrs {
     const int32_t* ncand;
     const QuadOut* quads;
@@ -94,11 +96,50 @@ __device__ void feature_organization(const float* q1, const float* q2, float c1x
     F->pad = 0;
 }
 
+// the pair test of featureRecovery (:483-548) for quads i < j; pure in (Di, Dj)
+__device__ __forceinline__ bool feature_pair(const QuadDerived& Di, const QuadDerived& Dj) {
+    const float thr = 5;  // threshold_angle
+    bool tag1 = false, tag2 = false;
+    float d1s = 0, d1l = 0, d2s = 0, d2l = 0, ea1 = 0, ea2 = 0;
+    const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
+    if (near_ang(fa, Di.a1, thr)) {
+        tag1 = true;
+        d1l = (Di.d[0] + Di.d[2]) / 2;
+        d1s = fminf(Di.d[1], Di.d[3]);
+        ea1 = Di.d[1] < Di.d[3] ? Di.e[0] : Di.e[1];
+    }
+    if (near_ang(fa, Di.a2, thr)) {
+        tag1 = true;
+        d1s = fminf(Di.d[0], Di.d[2]);
+        d1l = (Di.d[1] + Di.d[3]) / 2;
+        ea1 = Di.d[0] > Di.d[2] ? Di.e[2] : Di.e[3];
+    }
+    if (near_ang(fa, Dj.a1, thr)) {
+        tag2 = true;
+        d2l = (Dj.d[0] + Dj.d[2]) / 2;
+        d2s = fminf(Dj.d[1], Dj.d[3]);
+        ea2 = Dj.d[1] < Dj.d[3] ? Dj.e[0] : Dj.e[1];
+    }
+    if (near_ang(fa, Dj.a2, thr)) {
+        tag2 = true;
+        d2s = fminf(Dj.d[0], Dj.d[2]);
+        d2l = (Dj.d[1] + Dj.d[3]) / 2;
+        ea2 = Dj.d[0] > Dj.d[2] ? Dj.e[2] : Dj.e[3];
+    }
+    const float fl = dist2p(P2{Di.cx, Di.cy}, P2{Dj.cx, Dj.cy});
+    return (tag1 && tag2) && (d1l > d1s || d2l > d2s) && near_ang(ea1, ea2, thr * 10) && (ctm::fabs32(d1s - d2s) < fminf(d1s, d2s) * 0.33) &&
+           ((d1l + d2l) > (d1s + d2s)) && ((d1l + d2l) < 15 * (d1s + d2s)) && (fl - (d1l + d2l) / 2 < 0.3 * (fl + (d1l + d2l) / 2));
+}
+
 __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int feature_size) {
     __shared__ unsigned char s_vis[CTAG_MAX_QUADS];
     __shared__ int s_scan[4];
     __shared__ int s_best;
     __shared__ int s_nf;
+    constexpr int kPairCap = 192;  // quads per frame handled by the all-pairs path (a frame has 50-80)
+    __shared__ QuadDerived s_der[kPairCap];
+    __shared__ uint32_t s_pred[kPairCap * (kPairCap / 32)];
+    __shared__ uint32_t s_match[CTAG_MAX_FEATURES];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,77 +200,81 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         }
         D.a1 = (float)((angdeg(c[1] - c[3], c[0] - c[2]) + angdeg(c[7] - c[5], c[6] - c[4])) / 2);
         D.a2 = (float)((angdeg(c[3] - c[5], c[2] - c[4]) + angdeg(c[1] - c[7], c[0] - c[6])) / 2);
+        D.e[0] = (float)angdeg(c[1] - c[7], c[0] - c[6]);
+        D.e[1] = (float)angdeg(c[3] - c[5], c[2] - c[4]);
+        D.e[2] = (float)angdeg(c[1] - c[3], c[0] - c[2]);
+        D.e[3] = (float)angdeg(c[5] - c[7], c[4] - c[6]);
         der[q] = D;
         s_vis[q] = 0;
     }
     __syncthreads();
-    const float thr = 5;  // threshold_angle
-    for (int i = 0; i + 1 < Q; i++) {
-        if (s_vis[i]) continue;  // uniform
-        if (tid == 0) s_best = 0x7fffffff;
+    // ---- greedy pairing (:483-553): quad i takes the first unvisited j > i that passes the pair test.  The test does not
+    // depend on the visited flags, so for Q <= kPairCap it is evaluated for all pairs at once (every lane busy, one atan2 per
+    // pair) into a bit matrix, one lane replays the greedy order on the bits, and the matches are organised in parallel.
+    if (Q <= kPairCap) {
+        for (int q = tid; q < Q; q += 128) s_der[q] = der[q];
+        for (int w = tid; w < Q * (kPairCap / 32); w += 128) s_pred[w] = 0u;
         __syncthreads();
-        const QuadDerived Di = der[i];
-        const float* ci = quads[qidx[i]].c;
-        int mine = 0x7fffffff;
-        for (int j = i + 1 + tid; j < Q && mine == 0x7fffffff; j += 128) {
-            if (s_vis[j]) continue;
-            const QuadDerived Dj = der[j];
-            const float* cj = quads[qidx[j]].c;
-            bool tag1 = false, tag2 = false;
-            float d1s = 0, d1l = 0, d2s = 0, d2l = 0, ea1 = 0, ea2 = 0;
-            const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
-            if (near_ang(fa, Di.a1, thr)) {
-                tag1 = true;
-                d1l = (Di.d[0] + Di.d[2]) / 2;
-                d1s = fminf(Di.d[1], Di.d[3]);
-                if (Di.d[1] < Di.d[3]) ea1 = (float)angdeg(ci[1] - ci[7], ci[0] - ci[6]);
-                else ea1 = (float)angdeg(ci[3] - ci[5], ci[2] - ci[4]);
-            }
-            if (near_ang(fa, Di.a2, thr)) {
-                tag1 = true;
-                d1s = fminf(Di.d[0], Di.d[2]);
-                d1l = (Di.d[1] + Di.d[3]) / 2;
-                if (Di.d[0] > Di.d[2]) ea1 = (float)angdeg(ci[1] - ci[3], ci[0] - ci[2]);
-                else ea1 = (float)angdeg(ci[5] - ci[7], ci[4] - ci[6]);
-            }
-            if (near_ang(fa, Dj.a1, thr)) {
-                tag2 = true;
-                d2l = (Dj.d[0] + Dj.d[2]) / 2;
-                d2s = fminf(Dj.d[1], Dj.d[3]);
-                if (Dj.d[1] < Dj.d[3]) ea2 = (float)angdeg(cj[1] - cj[7], cj[0] - cj[6]);
-                else ea2 = (float)angdeg(cj[3] - cj[5], cj[2] - cj[4]);
-            }
-            if (near_ang(fa, Dj.a2, thr)) {
-                tag2 = true;
-                d2s = fminf(Dj.d[0], Dj.d[2]);
-                d2l = (Dj.d[1] + Dj.d[3]) / 2;
-                if (Dj.d[0] > Dj.d[2]) ea2 = (float)angdeg(cj[1] - cj[3], cj[0] - cj[2]);
-                else ea2 = (float)angdeg(cj[5] - cj[7], cj[4] - cj[6]);
-            }
-            const float fl = dist2p(P2{Di.cx, Di.cy}, P2{Dj.cx, Dj.cy});
-            if ((tag1 && tag2) && (d1l > d1s || d2l > d2s) && near_ang(ea1, ea2, thr * 10) &&
-                (ctm::fabs32(d1s - d2s) < fminf(d1s, d2s) * 0.33) && ((d1l + d2l) > (d1s + d2s)) &&
-                ((d1l + d2l) < 15 * (d1s + d2s)) && (fl - (d1l + d2l) / 2 < 0.3 * (fl + (d1l + d2l) / 2))) {
-                mine = j;
-            }
+        for (int idx = tid; idx < Q * Q; idx += 128) {
+            const int i = idx / Q, j = idx - i * Q;
+            if (j > i && feature_pair(s_der[i], s_der[j])) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));
         }
-        if (mine != 0x7fffffff) atomicMin(&s_best, mine);
         __syncthreads();
-        const int j = s_best;
-        __syncthreads();
-        if (j != 0x7fffffff) {
-            if (tid == 0) {
-                s_vis[i] = 1;
-                s_vis[j] = 1;
-                const int nf = s_nf;
-                if (nf < CTAG_MAX_FEATURES) {
-                    const QuadDerived Dj = der[j];
-                    const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
-                    feature_organization(ci, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[nf]);
+        if (tid == 0) {
+            uint32_t vis[kPairCap / 32];
+            for (int w = 0; w < kPairCap / 32; w++) vis[w] = 0u;
+            int nm = 0;
+            for (int i = 0; i + 1 < Q; i++) {
+                if ((vis[i >> 5] >> (i & 31)) & 1u) continue;
+                int j = -1;
+                for (int w = (i + 1) >> 5; w < (Q + 31) >> 5 && j < 0; w++) {
+                    const uint32_t m = s_pred[i * (kPairCap / 32) + w] & ~vis[w];
+                    if (m) j = w * 32 + __ffs(m) - 1;
                 }
-                s_nf = nf + 1;
+                if (j < 0) continue;
+                vis[i >> 5] |= 1u << (i & 31);
+                vis[j >> 5] |= 1u << (j & 31);
+                if (nm < CTAG_MAX_FEATURES) s_match[nm] = (uint32_t)i | ((uint32_t)j << 16);
+                nm++;
             }
+            s_nf = nm;
+        }
+        __syncthreads();
+        for (int k = tid; k < min(s_nf, CTAG_MAX_FEATURES); k += 128) {
+            const int i = (int)(s_match[k] & 0xffffu), j = (int)(s_match[k] >> 16);
+            const QuadDerived &Di = s_der[i], &Dj = s_der[j];
+            const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
+            feature_organization(quads[qidx[i]].c, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[k]);
+        }
+    } else {
+        for (int i = 0; i + 1 < Q; i++) {
+            if (s_vis[i]) continue;  // uniform
+            if (tid == 0) s_best = 0x7fffffff;
             __syncthreads();
+            const QuadDerived Di = der[i];
+            int mine = 0x7fffffff;
+            for (int j = i + 1 + tid; j < Q && mine == 0x7fffffff; j += 128) {
+                if (s_vis[j]) continue;
+                if (feature_pair(Di, der[j])) mine = j;
+            }
+            if (mine != 0x7fffffff) atomicMin(&s_best, mine);
+            __syncthreads();
+            const int j = s_best;
+            __syncthreads();
+            if (j != 0x7fffffff) {
+                if (tid == 0) {
+                    s_vis[i] = 1;
+                    s_vis[j] = 1;
+                    const int nf = s_nf;
+                    if (nf < CTAG_MAX_FEATURES) {
+                        const QuadDerived Dj = der[j];
+                        const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
+                        feature_organization(quads[qidx[i]].c, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[nf]);
+                    }
+                    s_nf = nf + 1;
+                }
+                __syncthreads();
+            }
         }
     }
     __syncthreads();
@@ -237,6 +282,9 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
     int status = CTAG_OK;
     if (nf < feature_size) status = CTAG_NO_FEATURE;
     else if (nf > CTAG_MAX_FEATURES) status = CTAG_ERR_LIMIT;
+    // a GPU-only capacity was exceeded upstream (tile runs / slots, component pool, candidates, edge pools): part of the
+    // frame was dropped, so the frame is reported as such instead of as a (possibly wrong) detection
+    if (P.frame_flags[frame] & CTAG_FLAG_POOL_OVERFLOW) status = CTAG_ERR_LIMIT;
     if (tid == 0) {
         P.nfeat[frame] = min(nf, CTAG_MAX_FEATURES);
         P.status[frame] = status;

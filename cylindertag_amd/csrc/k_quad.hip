@@ -1637,7 +1637,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     hipLaunchKernelGGL(k_quad_edges_packed, dim3(32, nframes), dim3(64), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_quad_edges<true>, dim3(4, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
-    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : (kLineCap + 2) / 3;
+    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 342;  // block columns per frame; a column loops when a frame has more edge triples
     hipLaunchKernelGGL(k_welsch, dim3(welsch_gx, nframes), dim3(64), 0, s, P, nframes);
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {

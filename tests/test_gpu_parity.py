@@ -97,8 +97,17 @@ def test_edge_cases(detector, oracle, dictionary, test_bmp):
     noise = rng.randint(0, 256, (360, 500)).astype(np.uint8)
     ragged = test_bmp[3:1001, 5:1711]  # 998 x 1706: not multiples of the CCL tile, the window or 16 bytes
     strided = np.ascontiguousarray(test_bmp[:, :1900])[:, :1888]
+    # more accepted quads than k_features' all-pairs path holds (192): a marker frame plus a lattice of dark squares on
+    # its bright areas -> the row-by-row path, with real features among the quads
+    grid = ca.synth_frame_host(state, 7)[0].copy()
+    for gy in range(20):
+        for gx in range(24):
+            y0, x0 = 20 + gy * 52 + (gx % 3), 20 + gx * 78 + (gy % 5)
+            h, w = 22 + (gx + gy) % 7, 26 + (3 * gx + gy) % 9
+            if grid[y0 - 6:y0 + h + 6, x0 - 6:x0 + w + 6].min() > 120:
+                grid[y0:y0 + h, x0:x0 + w] = 20
     for name, img, want_status in (("blank", blank, 1), ("one quad", one, 2), ("all dark", dark, None),
-                                   ("noise", noise, None), ("ragged", ragged, None)):
+                                   ("noise", noise, None), ("ragged", ragged, None), ("grid of squares", grid, None)):
         got, want = detector.detect(img), oracle.detect_fast(img, state, fs)
         if want_status is not None:
             assert want["status"] == want_status
