@@ -31,7 +31,7 @@ constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range
 
 // ---- K6 limits ----------------------------------------------------------------------------------------------
 constexpr int kQuadLdsPoints = 1024;    // boundary points held in LDS; larger components use global scratch
-constexpr int kQuadScratchSlots = 64;   // global scratch slots per chunk for oversize components
+constexpr int kQuadScratchSlots = 1024; // global scratch slots = persistent blocks of the oversize-component kernel (139 KB each)
 constexpr int kQuadScratchPoints = 8192;  // >= 2*(1920+1080)+4: worst-case silhouette of a 4K frame at half-res
 constexpr int kLineCap = 4 * kCandCap;     // fitted edges per frame (4 per candidate that survives the RDP split)
 constexpr int kClPool = 262144;           // edge-cluster points per frame (a candidate reserves its boundary capacity + 64)

@@ -253,13 +253,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
     __shared__ int s_redi[kQuadWaves];
     __shared__ int s_cl_off[5];
 
-    const int frame = blockIdx.y;
-    if (frame >= nframes) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nc = P.ncand[frame];
-    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
-    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
-    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * kPoolCap;
     constexpr size_t kScratchWords = (size_t)4 * kQuadScratchPoints + 2048;
 
     unsigned long long t_prev = 0;
@@ -270,7 +264,16 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
             t_prev = t;
         }
     };
-    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+    // Persistent blocks: block b owns global scratch slot b for the whole launch and walks the (frame, column) items
+    // b, b + gridDim.x, ...; column c of a frame takes that frame's candidates c, c + 4, ...  (a slot per component would
+    // run out on a batch with many oversize components)
+    for (int item = blockIdx.x; item < 4 * nframes; item += gridDim.x) {
+    const int frame = item >> 2;
+    const int nc = P.ncand[frame];
+    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
+    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * kPoolCap;
+    for (int ci = item & 3; ci < nc; ci += 4) {
         __syncthreads();
         stamp(-1);
         const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
@@ -282,9 +285,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
         if (BIG != pack_big(x_min, w, h)) continue;  // block-uniform: k_quad_edges_packed owns the rest
         uint32_t* mem = s_mem;
         if (BIG) {
-            if (tid == 0) s_i[0] = atomicAdd(P.scratch_used, 1);
-            __syncthreads();
-            const int slot = s_i[0];
+            const int slot = blockIdx.x;
             if (slot >= kQuadScratchSlots || need > kScratchWords) {
                 if (tid == 0) {
                     atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
@@ -743,6 +744,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
             aux->n_boundary = n_boundary;
         }
         stamp(4);
+    }
     }
 }
 
@@ -1630,12 +1632,11 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
         (void)hipMemsetAsync(d_stamps, 0, 16 * 8, s);
         P.stamps = d_stamps;
     }
-    (void)hipMemsetAsync(ws.quad_scratch_used, 0, sizeof(int32_t), s);
     (void)hipMemsetAsync(ws.line_count, 0, sizeof(int32_t) * (size_t)nframes, s);
     (void)hipMemsetAsync(ws.clp_used, 0, sizeof(int32_t) * (size_t)nframes, s);
     hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes);
     hipLaunchKernelGGL(k_quad_edges_packed, dim3(32, nframes), dim3(64), 0, s, P, ws.g, nframes);
-    hipLaunchKernelGGL(k_quad_edges<true>, dim3(4, nframes), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(4 * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 342;  // block columns per frame; a column loops when a frame has more edge triples
     hipLaunchKernelGGL(k_welsch, dim3(welsch_gx, nframes), dim3(64), 0, s, P, nframes);

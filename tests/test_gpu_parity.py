@@ -309,6 +309,32 @@ def test_streamed_host_batch(detector, dictionary):
         detector.set_option(capi.OPT_HOST_SUBCHUNK, 128)
 
 
+def test_batch_with_many_oversize_components(detector, oracle, dictionary):
+    """Long bars are wider than the 8-per-wave packed contour kernel takes (> 121 half-res px): they go through the
+    oversize kernel, whose persistent blocks each own one global scratch slot.  24 frames x 24 bars = 576 oversize
+    components in one launch (the first implementation ran out of scratch at 64 per launch)."""
+    state, fs = dictionary
+    rng = np.random.RandomState(77)
+    frames = []
+    for f in range(24):
+        img = (rng.randint(0, 7, (1080, 1920)) + 190).astype(np.uint8)
+        for k in range(24):
+            y = 20 + k * 43 + rng.randint(0, 6)
+            x = rng.randint(10, 400)
+            img[y:y + rng.randint(10, 16), x:x + rng.randint(520, 720)] = 25 + (f + k) % 20
+        frames.append(img)
+    frames = np.stack(frames)
+    got = detector.detect_batch(frames)
+    assert (got["flags"] == 0).all()
+    for f in (0, 13, 23):
+        want = oracle.detect_fast(frames[f], state, fs)
+        assert_same_record(got[f], want, "bars frame %d" % f)
+        detector.detect(frames[f])
+        o = oracle.detect(frames[f], state, fs)
+        assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
+        assert o["candidates"].shape[0] >= 10
+
+
 def test_full_size_batch_properties(detector, oracle, dictionary):
     """BASELINE config 3 at full size through the device-resident entry point: frames generated on the GPU equal
     the host generator, every frame decodes exactly its planted dictionary rows, a second pass is byte-identical,
