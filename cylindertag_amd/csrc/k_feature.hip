@@ -586,6 +586,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     __shared__ int s_misc[8];
     __shared__ unsigned long long s_pair[CTAG_MAX_FEATURES][2];
     __shared__ int s_pos[CTAG_MAX_CODE_POS];
+    __shared__ uint8_t s_dict[kMaxDictCells];  // dictionary entries are 0..63 (checked at load): one byte each
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int tid = threadIdx.x;
@@ -619,6 +620,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         return;
     }
     for (int i = tid; i < nf; i += 64) s_feat[i] = P.feat[(size_t)frame * CTAG_MAX_FEATURES + i];
+    for (int i = tid; i < drows * dcols; i += 64) s_dict[i] = (uint8_t)P.dict[i];
     __syncthreads();
     // ---- markerOrganization (:976-1052).  The O(F^2) pair predicate is evaluated on all lanes into a bit matrix;
     // thread 0 then replays the unions of the true pairs in the reference's (i, j) order, which is all the
@@ -827,27 +829,37 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         const int per = (2 * hyp + 63) / 64;
         const int h_lo = min(tid * per, 2 * hyp), h_hi = min(h_lo + per, 2 * hyp);
         int lane_max = -1;
-        for (int h = h_lo; h < h_hi; h++) {
-            const int dir = h >= hyp, rc = h - dir * hyp;
-            const int i = rc / dcols, j = rc - i * dcols;
-            const int32_t* row = P.dict + i * dcols;
-            int cov = 0;
-            if (dir == 0) {
-                int c = j;
-                for (int k = 0; k <= length; k++) {
-                    if (row[c] == s_code[k]) cov++;
-                    if (++c == dcols) c = 0;
+        {
+            int dir = h_lo >= hyp ? 1 : 0;
+            const int rc0 = h_lo - dir * hyp;
+            int i = rc0 / dcols, j = rc0 - i * dcols;  // one division per lane; (dir, i, j) advance incrementally
+            for (int h = h_lo; h < h_hi; h++) {
+                const uint8_t* row = s_dict + i * dcols;
+                int cov = 0;
+                if (dir == 0) {
+                    int c = j;
+                    for (int k = 0; k <= length; k++) {
+                        if ((int)row[c] == s_code[k]) cov++;
+                        if (++c == dcols) c = 0;
+                    }
+                } else {
+                    for (int k = 0; k <= length; k++) {
+                        const int cd = s_code[k];
+                        int c = j - k + dcols;  // (j - k + dcols) % dcols with C semantics; a negative column never matches
+                        if (c >= dcols) c -= dcols;
+                        if (c >= 0 && (int)row[c] == ((7 - cd / 8) + (7 - cd % 8) * 8)) cov++;
+                    }
                 }
-            } else {
-                for (int k = 0; k <= length; k++) {
-                    const int cd = s_code[k];
-                    int c = j - k + dcols;  // (j - k + dcols) % dcols with C semantics; a negative column never matches
-                    if (c >= dcols) c -= dcols;
-                    if (c >= 0 && row[c] == ((7 - cd / 8) + (7 - cd % 8) * 8)) cov++;
+                s_cov[h] = (short)cov;
+                lane_max = max(lane_max, cov);
+                if (++j == dcols) {
+                    j = 0;
+                    if (++i == drows) {
+                        i = 0;
+                        dir = 1;
+                    }
                 }
             }
-            s_cov[h] = (short)cov;
-            lane_max = max(lane_max, cov);
         }
         // order-dependent max / second bookkeeping (:1280-1311): an element updates `second` iff it does not raise the
         // running maximum, so every lane replays its run from the exclusive prefix maximum of the lanes before it
