@@ -114,16 +114,26 @@ def main():
     # ---- synthetic shard of this rank, generated on the device (frames [rank*n, (rank+1)*n) of the job)
     frames = torch.empty((n, ROWS, COLS), dtype=torch.uint8, device=dev)
     det.synth_frames_device(frames.data_ptr(), rank * n, n, ROWS, COLS, COLS, ROWS * COLS, markers=args.markers)
-    results = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
-    from cylindertag_amd.dist import gather_results
+    # two result buffers: the gather of step k (RCCL, its own stream) overlaps the detection of step k+1
+    result_bufs = [torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    results = result_bufs[0]
+    from cylindertag_amd.dist import gather_results_async
+    pending = []
+    step_no = [0]
 
     def step():
-        det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, results.data_ptr(), 5, subpix, 5)
+        buf = result_bufs[step_no[0] % len(result_bufs)]
+        step_no[0] += 1
+        if len(pending) == len(result_bufs):
+            pending.pop(0).wait()  # the gather that read this buffer two steps ago
+        det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, buf.data_ptr(), 5, subpix, 5)
         if world > 1:
             det.sync()  # results are produced on the library's stream
-            gather_results(results, world * n, dist)  # the path's only exchange: final marker lists (RCCL all-gather)
+            pending.append(gather_results_async(buf, world * n, dist))  # the path's only exchange: final marker lists (RCCL all-gather)
 
     def fence():
+        while pending:
+            pending.pop(0).wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -152,6 +162,7 @@ def main():
     launches = (n + args.chunk - 1) // args.chunk
 
     # ---- sanity on the outcome of the last step
+    results = result_bufs[(step_no[0] - 1) % len(result_bufs)]
     res = np.frombuffer(results.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
     ok_frames = int((res["status"] == 0).sum())
     markers_found = int(res["n_markers"].sum())

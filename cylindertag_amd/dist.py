@@ -13,14 +13,32 @@ def shard_range(n_frames, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_results(local, n_total, dist=None):
-    """all-gather per-rank result records (torch uint8 tensor [n_local, record_bytes]) into frame order.
+class _Gather:
+    """Handle of one (possibly still running) gather: wait() returns the [n_total, record_bytes] tensor in frame order."""
+
+    def __init__(self, out, work, counts, width, local):
+        self.out, self.work, self.counts, self.width, self.local = out, work, counts, width, local
+
+    def wait(self):
+        import torch
+        if self.work is None:
+            return self.local
+        self.work.wait()
+        if self.out.is_cuda:  # nccl: wait() only orders the current stream behind the collective
+            torch.cuda.current_stream(self.out.device).synchronize()
+        parts = [self.out[r * self.width:r * self.width + (hi - lo)] for r, (lo, hi) in enumerate(self.counts)]
+        return torch.cat(parts, 0)
+
+
+def gather_results_async(local, n_total, dist=None):
+    """Starts the all-gather of per-rank result records (torch uint8 tensor [n_local, record_bytes]) and returns a
+    handle; the collective runs while the caller enqueues the next batch.  `local` must stay untouched until wait().
 
     Ranks may own different counts (shard_range); shards are padded to the largest one for the collective and
-    trimmed afterwards.  Returns a tensor [n_total, record_bytes] identical on every rank."""
+    trimmed afterwards."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
+        return _Gather(None, None, None, 0, local)
     world = dist.get_world_size()
     counts = [shard_range(n_total, r, world) for r in range(world)]
     width = max(hi - lo for lo, hi in counts)
@@ -29,9 +47,13 @@ def gather_results(local, n_total, dist=None):
         pad = torch.zeros((width - local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
         padded = torch.cat([local, pad], 0)
     out = torch.empty((world * width, local.shape[1]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded.contiguous())
-    parts = [out[r * width:r * width + (hi - lo)] for r, (lo, hi) in enumerate(counts)]
-    return torch.cat(parts, 0)
+    work = dist.all_gather_into_tensor(out, padded.contiguous(), async_op=True)
+    return _Gather(out, work, counts, width, local)
+
+
+def gather_results(local, n_total, dist=None):
+    """Blocking form: returns a tensor [n_total, record_bytes] identical on every rank."""
+    return gather_results_async(local, n_total, dist).wait()
 
 
 def records_from_tensor(t, dtype):
