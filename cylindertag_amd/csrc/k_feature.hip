@@ -317,8 +317,11 @@ constexpr int kRefineThreads = 128;
 __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
-    __shared__ double s_bx[4][kRefineThreads], s_by[4][kRefineThreads];
-    __shared__ double s_w[2][4][kRefineThreads];  // weight of the sample towards the next / last corner; 0 for a sample without an edge point
+    // 16 columns of per-sample values: rows 0-3 x of edge 0-3, 4-7 y, 8-11 weight towards the next corner, 12-15 towards the
+    // last one (0 for a sample without an edge point).  The odd row length puts the 16 rows on 16 different LDS bank
+    // pairs: the accumulation reads one element of up to 9 rows per instruction.
+    __shared__ double s_v[16][kRefineThreads + 1];
+    double (*s_bx)[kRefineThreads + 1] = s_v, (*s_by)[kRefineThreads + 1] = s_v + 4;
     __shared__ double s_nrm[4][2];                // unit normal of each edge
     __shared__ double s_one;
     __shared__ double s_acc[48];
@@ -419,8 +422,8 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
             }
             s_bx[edge][tid] = bestx;  // 0 when !ok
             s_by[edge][tid] = besty;
-            s_w[0][edge][tid] = ok ? 1 - alpha : 0.0;
-            s_w[1][edge][tid] = ok ? alpha : 0.0;
+            s_v[8 + edge][tid] = ok ? 1 - alpha : 0.0;
+            s_v[12 + edge][tid] = ok ? alpha : 0.0;
         }
         __syncthreads();
         if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
             const double* pa = (which == 0 || which == 2 || which == 3) ? s_bx[edge] : (which == 5 ? &s_one : s_by[edge]);
             const double* pb = which == 2 ? s_bx[edge] : ((which == 3 || which == 4) ? s_by[edge] : &s_one);
             const int sa = which == 5 ? 0 : 1, sb = (which >= 2 && which <= 4) ? 1 : 0;
-            const double* pw = s_w[pass][edge];
+            const double* pw = s_v[8 + 4 * pass + edge];
             double acc = s_acc[tid];
             const int cntS = min(kRefineThreads, s_ns[edge] - sbase);
 #pragma unroll 8
