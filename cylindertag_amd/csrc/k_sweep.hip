@@ -539,7 +539,9 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     uint8_t* vmin_s = hr_s;                          // [<= 8][kVPitch]
     uint8_t* vmax_s = hr_s + 8 * kVPitch;
     const int lx8 = T.px0 & ~7;
-    const int ng = (T.px1 - lx8 + 7) >> 3;           // <= 43
+    // groups run to the END of the last threshold tile, not to the frame edge: a partial last tile reads 5 column extrema,
+    // and the columns past the frame must hold the neutral values rather than stale LDS
+    const int ng = ((tc1 + 1) * 5 - lx8 + 7) >> 3;   // <= 43
     const int ncr = tr1 - tr0 + 1;                   // <= 8
     const int nitems = ng * ncr;
     const int m_ng = recip16(ng);  // wave-uniform: one division instead of one per item
@@ -556,9 +558,10 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             const int gx = lx8 + gq * 8;
             const int y0 = (tr0 + cr) * 5;
             const uint8_t* __restrict__ p0 = himg + gx;
+            const bool any_col = gx < g.hcols;  // a group wholly past the frame edge is not read at all
 #pragma unroll
             for (int k = 0; k < 5; k++)  // rows past the frame repeat the last row: duplicates do not change a min / max
-                pix[q][k] = *reinterpret_cast<const uint2*>(p0 + (size_t)min(y0 + k, g.hrows - 1) * g.hp);
+                pix[q][k] = any_col ? *reinterpret_cast<const uint2*>(p0 + (size_t)min(y0 + k, g.hrows - 1) * g.hp) : make_uint2(0u, 0u);
             uint32_t mnE0 = 0x00ff00ffu, mnO0 = 0x00ff00ffu, mnE1 = 0x00ff00ffu, mnO1 = 0x00ff00ffu, mxE0 = 0, mxO0 = 0, mxE1 = 0, mxO1 = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
