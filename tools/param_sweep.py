@@ -19,10 +19,10 @@ for case in range(n):
         img = ca.synth_frame_host(state, 2000 + case)[0]
     elif kind == 1:
         y0, x0 = rng.randint(0, 100), rng.randint(0, 200)
-        img = np.ascontiguousarray(bmp[y0:y0 + rng.randint(700, 1100), x0:x0 + rng.randint(1200, 1700)])
+        img = np.ascontiguousarray(bmp[y0:y0 + rng.randint(500, 1100), x0:x0 + rng.randint(700, 1700)])
     else:
         img = ca.synth_frame_host(state, 3000 + case)[0]
-        h, w = rng.randint(500, 1080), rng.randint(800, 1920)
+        h, w = rng.randint(300, 1081), rng.randint(400, 1921)  # any size, odd ones included
         img = np.ascontiguousarray(img[:h, :w])
     tw = int(rng.choice([3, 4, 5, 5, 5, 6, 7, 9, 12]))
     subpix = bool(rng.rand() < 0.8)
