@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--host-frames", type=int, default=1024,
                     help="frames of the host-memory (PCIe-inclusive) side measurement, 0 = skip; never `value`")
+    ap.add_argument("--size", default="1920x1080", help="frame size WxH; the headline metric is 1920x1080 (other sizes are side measurements)")
     ap.add_argument("--no-subpix", action="store_true")
     return ap.parse_args()
 
@@ -82,7 +83,10 @@ def cpu_baseline(frames_host, state, fs, subpix):
 
 
 def main():
+    global ROWS, COLS, ALGO_BYTES_PER_FRAME
     args = parse_args()
+    COLS, ROWS = (int(v) for v in args.size.lower().split("x"))
+    ALGO_BYTES_PER_FRAME = 2 * ROWS * COLS
     import torch
     import cylindertag_amd as ca
     from cylindertag_amd import capi
@@ -172,7 +176,7 @@ def main():
         achieved = ALGO_BYTES_PER_FRAME * n / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (ROWS, COLS) == (1080, 1920):  # the PMC passes were collected on the 1080p workload
             try:
                 traffic = json.load(open(tpath)).get("sweep_bytes_per_frame") * min(n, args.chunk)  # measured per frame
             except Exception:
@@ -183,11 +187,11 @@ def main():
                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * min(n, args.chunk),
                     "avg_launch_ms": round(sweep_ms / launches, 4), "launches_per_step": launches,
                     "frames_per_launch": min(n, args.chunk)}
-        out = {"metric": "frames/sec detect() 1920x1080", "value": round(world * n * args.steps / dt, 2),
+        out = {"metric": "frames/sec detect() %dx%d" % (COLS, ROWS), "value": round(world * n * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "synthetic 1920x1080 random-stripe frames, %d per GPU per step, %d planted "
+               "config": {"workload": "synthetic %dx%d random-stripe frames," % (COLS, ROWS) + " %d per GPU per step, %d planted "
                                       "CTag_2f12c markers each, detect(img,5,%s,5), inputs resident in HBM"
                                       % (n, args.markers, "true" if subpix else "false"),
                           "frames_per_gpu": n, "chunk": args.chunk, "parallelism": "frames sharded, dp%d" % world},
