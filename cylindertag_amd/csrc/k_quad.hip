@@ -235,8 +235,12 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
     const int C = pack_points(w, h);
     return ((w + 1) & ~1) + 2 * h + 2 * C + 4;
 }
-// the packed kernel scans at most two 64-column chunks per row (16-byte aligned start); wider boxes are "big"
-__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h) { return pack_need(w, h) > kPackWords || (x_min & 7) + w > 128; }
+// the packed kernel takes every component whose working set fits the wave's LDS budget (the silhouette scan walks a wide
+// box in passes of 128 columns); the rest are "big" and go to k_quad_edges<true>
+__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h) {
+    (void)x_min;
+    return pack_need(w, h) > kPackWords;
+}
 
 struct CornerPre {
     float x, y, dis, ang;
@@ -1003,9 +1007,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
             rig[y] = 0u;
         }
         SG_SYNC();
-        {
-            const int xa = x_min & ~7;
-            const int x_end = x_min + w;  // exclusive; x_end - xa <= 128 (pack_big)
+        for (int xa = x_min & ~7; xa < x_min + w; xa += 128) {  // one pass per 128 columns of the box
+            const int x_end = x_min + w;  // exclusive
             const int gxf = xa + 8 * sl;  // this lane's 8 columns of chunk 0; chunk 1 is 64 columns further
             // Eight 16-byte aligned columns never straddle a 320-column tile boundary, so one lane's pixels of a chunk
             // share a CCL tile; the component's label(s) in that tile are looked up once per tile row (every 30 rows).
@@ -1135,6 +1138,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
                     tb[xl + 65] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
                 }
             }
+        }
+        {
             SG_SYNC();  // row extents (LDS atomics) complete
             for (int y = sl; y < h + 2; y += kSG) {
                 uint32_t v = 0u;

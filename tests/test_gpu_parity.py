@@ -312,9 +312,9 @@ def test_streamed_host_batch(detector, dictionary):
 
 
 def test_batch_with_many_oversize_components(detector, oracle, dictionary):
-    """Long bars are wider than the 8-per-wave packed contour kernel takes (> 121 half-res px): they go through the
-    oversize kernel, whose persistent blocks each own one global scratch slot.  24 frames x 24 bars = 576 oversize
-    components in one launch (the first implementation ran out of scratch at 64 per launch)."""
+    """Wide components: long bars (260-360 half-res px wide) take the packed contour kernel's multi-pass silhouette scan
+    (128 columns per pass); very long thin ones exceed its LDS budget and go through the oversize kernel, whose
+    persistent blocks each own one global scratch slot (the first implementation ran out of scratch at 64 per launch)."""
     state, fs = dictionary
     rng = np.random.RandomState(77)
     frames = []
@@ -325,10 +325,18 @@ def test_batch_with_many_oversize_components(detector, oracle, dictionary):
             x = rng.randint(10, 400)
             img[y:y + rng.randint(10, 16), x:x + rng.randint(520, 720)] = 25 + (f + k) % 20
         frames.append(img)
+    # shallow diagonal lines: bounding boxes ~940 x 120 half-res px with ~2100 boundary points exceed the packed kernel's
+    # LDS budget -> the oversize kernel (global scratch, one persistent block per slot)
+    for f in (3, 17):
+        img = frames[f]
+        yy, xx = np.mgrid[0:1080, 0:1920]
+        for k in range(3):
+            d = yy - (150 + 300 * k + 0.125 * xx)
+            img[(np.abs(d) < 3.0) & (xx > 20) & (xx < 1900)] = 30
     frames = np.stack(frames)
     got = detector.detect_batch(frames)
     assert (got["flags"] == 0).all()
-    for f in (0, 13, 23):
+    for f in (0, 3, 13, 17, 23):
         want = oracle.detect_fast(frames[f], state, fs)
         assert_same_record(got[f], want, "bars frame %d" % f)
         detector.detect(frames[f])
