@@ -47,7 +47,6 @@ struct QuadPtrs {
     const int32_t* member_next;  // [F][kPoolCap]
     int32_t* npacks;       // [F]
     uint32_t* packs;       // [F][kCandCap] first candidate | count << 16
-    int dbg;               // developer aid (CTAG_DBG): timing experiments only
     unsigned long long* stamps;  // developer aid (CTAG_QUAD_STAMPS=1): cycles per phase of k_quad_edges, else null
 };
 
@@ -1629,7 +1628,7 @@ __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int 
 
 hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, getenv("CTAG_DBG") ? atoi(getenv("CTAG_DBG")) : 0, nullptr};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, nullptr};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
