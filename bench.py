@@ -175,7 +175,9 @@ def main():
         sweep_ms = sum(stage_ms[k] for k in SWEEP_STAGES)
         achieved = ALGO_BYTES_PER_FRAME * n / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))  # per-round PMC passes; latest round wins
+        tpath = cands[-1] if cands else ""
         if os.path.exists(tpath) and (ROWS, COLS) == (1080, 1920):  # the PMC passes were collected on the 1080p workload
             try:
                 traffic = json.load(open(tpath)).get("sweep_bytes_per_frame") * min(n, args.chunk)  # measured per frame

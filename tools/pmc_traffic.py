@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE; collected separately as MI355X_MICROARCH.md prescribes) into
-profiles/pmc_traffic.json: HBM bytes per launch of the threshold+label sweep kernels.
+profiles/rNN_pmc_traffic.json: HBM bytes per launch of the threshold+label sweep kernels.
 gfx950 corrections from the guide: both counters are in KiB; FETCH_SIZE reports half of the bytes of wide coalesced
 streaming reads, so it is doubled for the streaming kernels (k_decimate, k_threshold_ccl)."""
 import csv, glob, json, os, sys, collections
@@ -30,7 +30,8 @@ def main(fetch_dir, write_dir, frames_per_launch, tag):
            "sweep_bytes_per_frame": total / frames_per_launch, "kernels": detail,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; KiB -> bytes; "
                      "FETCH_SIZE doubled for the wide streaming-read kernels (gfx950 correction, MI355X_MICROARCH.md)"}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    rnd = (tag or "r01")[:3]
+    json.dump(out, open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "")
