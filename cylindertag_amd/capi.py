@@ -28,6 +28,24 @@ EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", 
            "ctag_detect_batch_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
            "ctag_stage_name", "ctag_strerror", "ctag_version", "ctag_debug_fetch", "ctag_math_probe",
            "ctag_synth_frames_device", "ctag_synth_frame_host", "ctag_synth_layout_truth"]
+# ... and include/ctag_pose.h
+POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag_model_get_view", "ctag_camera_load",
+                "ctag_pose_batch_device", "ctag_estimate_pose", "ctag_pose_last_ms"]
+EXPORTS = EXPORTS + POSE_EXPORTS
+
+POSE_DT = np.dtype([("status", "<i4"), ("model_index", "<i4"), ("frame", "<i4"), ("marker", "<i4"),
+                    ("n_points", "<i4"), ("iterations", "<i4"), ("rvec", "<f8", (3,)), ("tvec", "<f8", (3,)),
+                    ("rvec0", "<f8", (3,)), ("tvec0", "<f8", (3,)), ("cost0", "<f8"), ("cost", "<f8")])
+POSE_OK, POSE_NO_MODEL, POSE_TOO_FEW, POSE_BAD_POS, POSE_DEGENERATE = range(5)
+
+
+class CameraC(C.Structure):  # ctag_camera
+    _fields_ = [("K", C.c_float * 9), ("dist", C.c_float * 14), ("n_dist", C.c_int32)]
+
+
+class ModelViewC(C.Structure):  # ctag_model_view
+    _fields_ = [("n_models", C.c_int32), ("model_size", C.c_int32), ("marker_id", C.POINTER(C.c_int32)),
+                ("base", C.POINTER(C.c_float)), ("axis", C.POINTER(C.c_float)), ("corners", C.POINTER(C.c_float))]
 
 
 class CtagError(RuntimeError):
@@ -107,6 +125,22 @@ def load_library():
                                         C.c_int, vp]
     L.ctag_synth_layout_truth.restype = C.c_int
     L.ctag_synth_layout_truth.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp]
+    L.ctag_model_load.restype = C.c_int
+    L.ctag_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.ctag_model_create.restype = C.c_int
+    L.ctag_model_create.argtypes = [C.POINTER(ModelViewC), C.POINTER(vp)]
+    L.ctag_model_free.restype = None
+    L.ctag_model_free.argtypes = [vp]
+    L.ctag_model_get_view.restype = C.c_int
+    L.ctag_model_get_view.argtypes = [vp, C.POINTER(ModelViewC)]
+    L.ctag_camera_load.restype = C.c_int
+    L.ctag_camera_load.argtypes = [C.c_char_p, C.POINTER(CameraC)]
+    L.ctag_pose_batch_device.restype = C.c_int
+    L.ctag_pose_batch_device.argtypes = [vp, vp, C.c_int, vp, C.POINTER(CameraC), vp, vp, C.c_int]
+    L.ctag_estimate_pose.restype = C.c_int
+    L.ctag_estimate_pose.argtypes = [vp, vp, vp, C.POINTER(CameraC), vp]
+    L.ctag_pose_last_ms.restype = C.c_float
+    L.ctag_pose_last_ms.argtypes = [vp]
     _lib = L
     return L
 
@@ -131,6 +165,67 @@ def load_marker_file(path):
     finally:
         L.ctag_free(p)
     return state, fs.value
+
+
+class Model:
+    """ctag_model: the reference's vector<ModelInfo> (CylinderTag::loadModel, CylinderTag.cpp:161-190)."""
+
+    def __init__(self, path=None, ids=None, corners=None, model_size=None, base=None, axis=None):
+        self.L = load_library()
+        m = C.c_void_p()
+        if path is not None:
+            st = self.L.ctag_model_load(os.fsencode(path), C.byref(m))
+        else:
+            ids = np.ascontiguousarray(ids, np.int32)
+            corners = np.ascontiguousarray(corners, np.float32)
+            base = np.ascontiguousarray(base if base is not None else np.zeros((ids.size, 3)), np.float32)
+            axis = np.ascontiguousarray(axis if axis is not None else np.zeros((ids.size, 3)), np.float32)
+            fp = C.POINTER(C.c_float)
+            v = ModelViewC(ids.size, int(model_size), ids.ctypes.data_as(C.POINTER(C.c_int32)), base.ctypes.data_as(fp),
+                           axis.ctypes.data_as(fp), corners.ctypes.data_as(fp))
+            st = self.L.ctag_model_create(C.byref(v), C.byref(m))
+        if st != 0:
+            raise CtagError(st, "model %s" % (path or "from arrays"))
+        self.m = m
+
+    def view(self):
+        v = ModelViewC()
+        self.L.ctag_model_get_view(self.m, C.byref(v))
+        n, size = v.n_models, v.model_size
+        return {"ids": np.ctypeslib.as_array(v.marker_id, (n,)).copy(), "size": size,
+                "base": np.ctypeslib.as_array(v.base, (n, 3)).copy(), "axis": np.ctypeslib.as_array(v.axis, (n, 3)).copy(),
+                "corners": np.ctypeslib.as_array(v.corners, (n, size * 8, 3)).copy()}
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.L.ctag_model_free(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_camera(path):
+    """CylinderTag::loadCamera (CylinderTag.cpp:192-196) through the C ABI -> CameraC."""
+    cam = CameraC()
+    st = load_library().ctag_camera_load(os.fsencode(path), C.byref(cam))
+    if st != 0:
+        raise CtagError(st, path)
+    return cam
+
+
+def make_camera(K, dist):
+    cam = CameraC()
+    for i, v in enumerate(np.asarray(K, np.float32).ravel()):
+        cam.K[i] = float(v)
+    d = np.asarray(dist, np.float32).ravel()
+    for i in range(d.size):
+        cam.dist[i] = float(d[i])
+    cam.n_dist = int(d.size)
+    return cam
 
 
 SYNTH_SEED = 0x4354616753594E00  # "CTagSYN\0", SURVEY.md 8(d)
@@ -267,6 +362,28 @@ class Detector:
                                              markers)
         if st != 0:
             raise CtagError(st, "ctag_synth_frames_device")
+
+    # ---- pose back end (include/ctag_pose.h)
+    def estimate_pose(self, result, model, camera):
+        """One frame: host ctag_frame_result record -> POSE_DT records, one per marker (CylinderTag::estimatePose
+        before its erase of the model-less entries)."""
+        res = np.ascontiguousarray(result).reshape(1)
+        assert res.dtype == RESULT_DT
+        n = int(res[0]["n_markers"]) if res[0]["status"] == 0 else 0
+        out = np.zeros(max(n, 1), POSE_DT)
+        st = self.L.ctag_estimate_pose(self.h, res.ctypes.data, model.m, C.byref(camera), out.ctypes.data)
+        if st != 0:
+            raise CtagError(st, "ctag_estimate_pose")
+        return out[:n]
+
+    def pose_batch_device(self, results_ptr, n_frames, model, camera, offsets_ptr, poses_ptr, capacity):
+        st = self.L.ctag_pose_batch_device(self.h, results_ptr, n_frames, model.m, C.byref(camera), offsets_ptr, poses_ptr,
+                                           capacity)
+        if st != 0:
+            raise CtagError(st, "ctag_pose_batch_device")
+
+    def pose_last_ms(self):
+        return float(self.L.ctag_pose_last_ms(self.h))
 
     # ---- parity probes
     def debug(self, frame, what):

@@ -56,7 +56,19 @@ struct ctag_handle {
     size_t d_synth_count = 0;
     int last_chunk_frames = 0;
     char last_error[256] = {0};
+    // state of the pose back end (k_pose.hip), created on first use
+    void* pose_state = nullptr;
+    void (*pose_state_free)(void*) = nullptr;
 };
+
+namespace ctag {
+void** handle_pose_slot(ctag_handle* h, void (*free_fn)(void*)) {
+    h->pose_state_free = free_fn;
+    return &h->pose_state;
+}
+bool handle_timing(const ctag_handle* h) { return h->timing; }
+int handle_device(const ctag_handle* h) { return h->device; }
+}  // namespace ctag
 
 static const char* kStageNames[CTAG_NUM_STAGES] = {"decimate", "threshold_ccl", "seam_merge", "resolve", "candidates",
                                                     "quad",     "features",      "edge_refine", "markers"};
@@ -423,6 +435,7 @@ void ctag_destroy(ctag_handle* h) {
     if (h->d_frames) (void)hipFree(h->d_frames);
     if (h->d_results) (void)hipFree(h->d_results);
     if (h->d_synth) (void)hipFree(h->d_synth);
+    if (h->pose_state && h->pose_state_free) h->pose_state_free(h->pose_state);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {

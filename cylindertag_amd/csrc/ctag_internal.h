@@ -17,6 +17,8 @@
 
 #include "../../include/ctag_types.h"
 
+struct ctag_handle;
+
 namespace ctag {
 
 // ---- CCL tile geometry (half-resolution pixels) ---------------------------------------------------------
@@ -157,5 +159,11 @@ hipError_t launch_math_probe(int op, int n, const double* a, const double* b, do
 size_t threshold_ccl_lds_bytes(int tw);
 hipError_t upload_threshold_table();  // once per device before the first K2 launch
 void build_pick_table(uint8_t* table);  // kPickN*20*10 bytes
+
+
+// accessors of the opaque handle for the pose back end (k_pose.hip)
+void** handle_pose_slot(struct ::ctag_handle* h, void (*free_fn)(void*));
+bool handle_timing(const struct ::ctag_handle* h);
+int handle_device(const struct ::ctag_handle* h);
 
 }  // namespace ctag

@@ -16,7 +16,7 @@ from ctag_testlib import GOLDEN, ROOT, read_marker_file
 
 def test_library_exports_every_declared_symbol():
     ca.build()
-    hdr = open(os.path.join(ROOT, "include", "ctag.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "ctag.h")).read() + open(os.path.join(ROOT, "include", "ctag_pose.h")).read()
     declared = set(re.findall(r"\b(ctag_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(capi.EXPORTS)
     L = capi.load_library()
@@ -30,6 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_result_record_layout_matches_header():
     assert ca.RESULT_DT.itemsize == 11616 and ca.FEATURE_DT.itemsize == 100 and ca.MARKER_DT.itemsize == 16
+    assert ca.POSE_DT.itemsize == 136 and C.sizeof(capi.CameraC) == 96
 
 
 def test_marker_loader_matches_reference_format(tmp_path):

@@ -1,0 +1,220 @@
+"""CPU tests of the pose back end: the oracle (oracle/ctag_pose_oracle.cpp) against
+independent numpy/scipy statements of the same mathematics, and the OpenCV-free loaders of the product library
+against independent readers.  No GPU, no compute call into the HIP library."""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import least_squares
+
+import cylindertag_amd as ca
+from ctag_testlib import GOLDEN, Oracle, read_bmp_gray, read_marker_file
+from pose_testlib import (PoseOracle, make_camera, make_model_view, project, read_camera_yml, read_model_file, rodrigues,
+                          synth_pose_results)
+
+MODEL_PATH = os.path.join(GOLDEN, "CTag_2f12c.model")
+CAM_PATH = os.path.join(GOLDEN, "cameraParams.yml")
+
+
+@pytest.fixture(scope="module")
+def env():
+    K, dist = read_camera_yml(CAM_PATH)
+    model = read_model_file(MODEL_PATH)
+    return {"K": K, "dist": dist, "model": model, "cam": make_camera(K, dist), "mv": make_model_view(model),
+            "po": PoseOracle()}
+
+
+def test_model_loader_matches_independent_reader():
+    """ctag_model_load (CylinderTag::loadModel, CylinderTag.cpp:161-190) vs a separate Python reader."""
+    m = ca.Model(MODEL_PATH).view()
+    ref = read_model_file(MODEL_PATH)
+    assert list(m["ids"]) == [0, 1, 5, 17, 21, 23] and m["size"] == 12
+    for k in ("ids", "base", "axis", "corners"):
+        assert np.array_equal(m[k], ref[k]), k
+
+
+def test_camera_loader_matches_independent_reader():
+    """ctag_camera_load (the two FileStorage nodes of CylinderTag.cpp:192-196)."""
+    cam = ca.load_camera(CAM_PATH)
+    K, dist = read_camera_yml(CAM_PATH)
+    assert np.array_equal(np.array(cam.K, np.float32).reshape(3, 3), K)
+    assert cam.n_dist == 5 and np.array_equal(np.array(cam.dist, np.float32)[:5], dist)
+    assert abs(cam.K[0] - 4328.54769903027) < 1e-3 and abs(cam.dist[4] + 40.4793454220120) < 1e-5
+
+
+def test_loader_errors(tmp_path):
+    with pytest.raises(ca.CtagError):
+        ca.Model(str(tmp_path / "missing.model"))
+    bad = tmp_path / "bad.model"
+    bad.write_text("1 1\n0\n0 0 0\n0 1 0\n9 1 2 3\n")  # corner id outside model_size*8
+    with pytest.raises(ca.CtagError):
+        ca.Model(str(bad))
+    with pytest.raises(ca.CtagError):
+        ca.load_camera(str(tmp_path / "missing.yml"))
+    y = tmp_path / "cam.yml"
+    y.write_text("%YAML:1.0\n---\ncameraMatrix: !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: d\n   data: [ 1000., 0., 320., 0.,\n"
+                 "       1001., 240., 0., 0., 1. ]\ndistCoeffs: !!opencv-matrix\n   rows: 1\n   cols: 4\n   dt: d\n"
+                 "   data: [ 0.1, -0.2, 0.001, 0.002 ]\n")
+    cam = ca.load_camera(str(y))
+    assert cam.n_dist == 4 and cam.K[4] == 1001.0 and abs(cam.dist[3] - 0.002) < 1e-9
+
+
+def test_undistort_inverts_the_distortion_model(env):
+    """cv::undistortPoints' 5 fixed-point iterations invert cv::projectPoints' distortion to well below a pixel."""
+    rng = np.random.default_rng(3)
+    xn = rng.uniform(-0.2, 0.2, (200, 2))
+    K, d = env["K"].astype(np.float64), env["dist"].astype(np.float64)
+    r2 = (xn ** 2).sum(1)
+    rad = 1 + d[0] * r2 + d[1] * r2 ** 2 + d[4] * r2 ** 3
+    xd = xn * rad[:, None]
+    uv = np.stack([K[0, 0] * xd[:, 0] + K[0, 2], K[1, 1] * xd[:, 1] + K[1, 2]], 1).astype(np.float32)
+    back = env["po"].undistort(env["cam"], uv, False)
+    assert np.abs(back - xn).max() * K[0, 0] < 2e-3  # pixels (float32 input rounding + 5 iterations)
+    px = env["po"].undistort(env["cam"], uv, True)
+    assert np.allclose(px, np.stack([K[0, 0] * back[:, 0] + K[0, 2], K[1, 1] * back[:, 1] + K[1, 2]], 1), atol=1e-9)
+
+
+def _random_pose(rng, X):
+    c = X.mean(0)
+    rv = rng.normal(0, 0.3, 3)
+    R = rodrigues(rv)
+    return rv, c - R @ c + rng.normal(0, 1, 3) * np.array([40., 30., 60.])
+
+
+def test_epnp_recovers_exact_poses(env):
+    """Noise-free projections (no distortion): solvePnP(EPNP) returns the pose itself."""
+    rng = np.random.default_rng(5)
+    cam0 = make_camera(env["K"], np.zeros(5, np.float32))
+    for trial in range(20):
+        mi = trial % 6
+        X = env["model"]["corners"][mi][8 * (trial % 5):8 * (trial % 5) + 8 * (2 + trial % 7)].astype(np.float64)
+        rv, tv = _random_pose(rng, X)
+        img = project(env["K"], np.zeros(5), rv, tv, X, distort=False)
+        st, r, t = env["po"].epnp(cam0, X, img)
+        assert st == 0
+        # float32 image points: ~1e-4 px of input rounding
+        assert np.abs(rodrigues(r) - rodrigues(rv)).max() < 2e-4, trial
+        assert np.abs(t - tv).max() < 0.2, trial
+        it, r2, t2, c0, c1 = env["po"].ba(cam0, X, img, r, t)
+        assert c1 <= c0 and c1 < 1e-5
+        assert np.abs(t2 - tv).max() < 0.05
+
+
+def test_ba_reaches_the_least_squares_minimum(env):
+    """PoseBA (the restated Ceres LM) ends at the same minimum scipy's trust-region solver finds for the same residual."""
+    rng = np.random.default_rng(7)
+    K = env["K"].astype(np.float64)
+    for trial in range(12):
+        X = env["model"]["corners"][trial % 6][:8 * (2 + trial % 6)].astype(np.float64)
+        rv, tv = _random_pose(rng, X)
+        img = (project(env["K"], env["dist"], rv, tv, X) + rng.normal(0, 0.3, (X.shape[0], 2))).astype(np.float32)
+        st, r0, t0 = env["po"].epnp(env["cam"], X, img)
+        assert st == 0
+        it, r, t, c0, c1 = env["po"].ba(env["cam"], X, img, r0, t0)
+        assert 0 < it <= 50 and c1 <= c0
+        obs = env["po"].undistort(env["cam"], img, True).astype(np.float32).astype(np.float64)
+        Xf = X.astype(np.float32).astype(np.float64)
+
+        def resid(p):
+            P = Xf @ rodrigues(p[:3]).T + p[3:]
+            return np.concatenate([K[0, 0] * P[:, 0] / P[:, 2] + K[0, 2] - obs[:, 0],
+                                   K[1, 1] * P[:, 1] / P[:, 2] + K[1, 2] - obs[:, 1]])
+
+        sol = least_squares(resid, np.concatenate([r0, t0]), method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15,
+                            x_scale="jac")
+        assert abs(0.5 * (resid(np.concatenate([r, t])) ** 2).sum() - c1) < 1e-9 * max(1.0, c1)
+        assert c1 <= sol.cost * (1 + 1e-9) + 1e-12, (trial, c1, sol.cost)
+        assert np.abs(r - sol.x[:3]).max() < 1e-6 and np.abs(t - sol.x[3:]).max() < 1e-4 * np.abs(t).max(), trial
+
+
+def test_correspondence_builder_follows_the_reference(env):
+    """pose_estimation.cpp:72-95 restated in Python vs the oracle."""
+    recs, _ = synth_pose_results(env["model"], env["K"], env["dist"], 40, 11)
+    po, mv, model = env["po"], env["mv"], env["model"]
+    checked = 0
+    for r in recs:
+        for m in range(r["n_markers"]):
+            M = r["markers"][m]
+            idx = np.where(model["ids"] == M["marker_id"])[0]
+            if idx.size == 0:
+                continue
+            mi = int(idx[0])
+            feats = r["features"][M["first_feature"]:M["first_feature"] + M["n_features"]]
+            img, obj = [], []
+            nf = len(feats)
+            for j, F in enumerate(feats):
+                ad = abs(int(F["id_left"]) - int(F["id_right"]))
+                if nf > 3:
+                    if j == 0 and (ad > 1 or F["id_right"] == -1):
+                        continue
+                    if j == nf - 1 and (ad > 1 or F["id_right"] == -1):
+                        continue
+                ks = [0, 1, 4, 5] + ([2, 3, 6, 7] if (ad < 3 and F["id_right"] != -1) else [])
+                for k in ks:
+                    img.append(F["corners"][2 * k:2 * k + 2])
+                    obj.append(model["corners"][mi][F["pos"] * 8 + k])
+            st, o, i = po.correspondences(r, m, mv, mi)
+            assert st == 0 and np.array_equal(o, np.array(obj, np.float32).reshape(-1, 3))
+            assert np.array_equal(i, np.array(img, np.float32).reshape(-1, 2))
+            checked += 1
+    assert checked > 50
+
+
+def test_pose_frame_statuses(env):
+    recs, truth = synth_pose_results(env["model"], env["K"], env["dist"], 60, 13)
+    seen = set()
+    for f, r in enumerate(recs):
+        poses = env["po"].pose_frame(r, env["mv"], env["cam"], f)
+        assert len(poses) == r["n_markers"]
+        for p, (mi, rv, tv) in zip(poses, truth[f]):
+            seen.add(int(p["status"]))
+            assert p["frame"] == f and p["model_index"] == mi
+            if mi < 0:
+                assert p["status"] == ca.capi.POSE_NO_MODEL
+            elif p["status"] == 0 and p["n_points"] >= 12:
+                assert p["cost"] <= p["cost0"] * (1 + 1e-12)
+                M = r["markers"][p["marker"]]
+                c = r["features"][M["first_feature"]:M["first_feature"] + M["n_features"]]["corners"].reshape(-1, 2)
+                if (c[:, 0] > 0).all() and (c[:, 0] < 1920).all() and (c[:, 1] > 0).all() and (c[:, 1] < 1200).all():
+                    # inside the image the 5-iteration undistortion has converged: rms px at 0.2 px noise
+                    assert np.sqrt(2 * p["cost"] / p["n_points"]) < 1.0
+    assert {0, 1} <= seen
+    bad = recs[0].copy()
+    bad["status"] = 0
+    bad["n_markers"] = 1
+    bad["markers"][0] = (0, 0, 2, 2)
+    bad["features"][0]["pos"] = 12  # outside model_size
+    assert env["po"].pose_frame(bad, env["mv"], env["cam"])[0]["status"] == ca.capi.POSE_BAD_POS
+    few = bad.copy()
+    few["markers"][0] = (0, 0, 5, 5)
+    for j in range(5):
+        few["features"][j]["pos"] = j
+        few["features"][j]["id_left"], few["features"][j]["id_right"] = 5, -1  # first/last skipped, others 4 points
+    p = env["po"].pose_frame(few, env["mv"], env["cam"])[0]
+    assert p["n_points"] == 12
+    one = bad.copy()
+    one["markers"][0] = (0, 0, 4, 4)
+    for j in range(4):
+        one["features"][j]["pos"] = j
+        one["features"][j]["id_left"], one["features"][j]["id_right"] = 5, -1
+    one["features"][1]["id_left"], one["features"][1]["id_right"] = 5, 2  # 4 points from feature 1, 4 from feature 2
+    assert env["po"].pose_frame(one, env["mv"], env["cam"])[0]["n_points"] == 8
+
+
+def test_reference_scene_gets_subpixel_poses(env):
+    """The reference's own data end to end: test.bmp -> detect (oracle) -> pose with CTag_2f12c.model and
+    cameraParams.yml.  Every decoded marker has a model and reprojects with a sub-pixel RMS, which ties together the
+    corner order of the detector, the correspondence builder and the model file."""
+    state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    res = Oracle().detect_fast(read_bmp_gray(os.path.join(GOLDEN, "test.bmp")), state, fs, 5, True, 5)
+    poses = env["po"].pose_frame(res, env["mv"], env["cam"])
+    ids = [int(res["markers"][p["marker"]]["marker_id"]) for p in poses]
+    assert ids == [23, 0, 1, 17, 5]
+    assert [int(p["model_index"]) for p in poses] == [5, 0, 1, 3, 2]  # PoseInfo::markerID is the model INDEX
+    for p in poses:
+        assert p["status"] == 0 and 0 < p["iterations"] <= 50 and p["cost"] <= p["cost0"]
+        rms = np.sqrt(2 * p["cost"] / p["n_points"])
+        assert rms < 0.6, rms
+        assert 200 < p["tvec"][2] < 1200  # millimetres in front of the camera
+        # EPnP is already close: BA moves the pose by millimetres
+        assert np.abs(p["tvec"] - p["tvec0"]).max() < 5.0

@@ -1,0 +1,102 @@
+"""GPU parity of the pose back end (k_pose.hip through the C ABI of include/ctag_pose.h) against the CPU oracle.
+
+Floating point (FP64): the stated bar is |rvec diff| <= 1e-9 rad and |tvec diff| <= 1e-9 * max(1, |tvec|) with equal
+status / model index / point count.  The kernel accumulates every sum in the oracle's order and shares its
+deterministic math header, so the records are in fact required to be byte-identical here; the tolerance is the
+fallback bar should a toolchain change break bit-equality (the assertion message then says which one failed)."""
+import os
+
+import numpy as np
+import pytest
+
+import cylindertag_amd as ca
+from ctag_testlib import GOLDEN, read_bmp_gray
+from pose_testlib import PoseOracle, make_camera, make_model_view, read_camera_yml, read_model_file, synth_pose_results
+
+pytestmark = pytest.mark.gpu
+
+MODEL_PATH = os.path.join(GOLDEN, "CTag_2f12c.model")
+CAM_PATH = os.path.join(GOLDEN, "cameraParams.yml")
+
+
+@pytest.fixture(scope="module")
+def env():
+    K, dist = read_camera_yml(CAM_PATH)
+    model = read_model_file(MODEL_PATH)
+    state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    det = ca.Detector(state, fs, device=0)
+    e = {"K": K, "dist": dist, "model": model, "cam_o": make_camera(K, dist), "mv": make_model_view(model),
+         "po": PoseOracle(), "det": det, "M": ca.Model(MODEL_PATH), "cam": ca.load_camera(CAM_PATH)}
+    yield e
+    det.close()
+
+
+def assert_pose_parity(got, want, what):
+    assert len(got) == len(want), what
+    for k in ("status", "model_index", "frame", "marker", "n_points"):
+        assert np.array_equal(got[k], want[k]), (what, k)
+    ok = want["status"] == 0
+    for k in ("rvec", "rvec0"):
+        assert np.abs(got[k][ok] - want[k][ok]).max(initial=0) <= 1e-9, (what, k)
+    for k in ("tvec", "tvec0"):
+        scale = np.maximum(1.0, np.abs(want[k][ok]).max(axis=1, initial=0))[:, None]
+        assert (np.abs(got[k][ok] - want[k][ok]) / scale).max(initial=0) <= 1e-9, (what, k)
+    assert got.tobytes() == want.tobytes(), "%s: within tolerance but not byte-identical" % what
+
+
+def test_reference_scene_pose_parity(env):
+    """test.bmp -> HIP detect -> HIP pose == oracle pose of the same records; sub-pixel reprojection RMS."""
+    res = env["det"].detect(read_bmp_gray(os.path.join(GOLDEN, "test.bmp")), 5, True, 5)
+    got = env["det"].estimate_pose(res, env["M"], env["cam"])
+    want = env["po"].pose_frame(res, env["mv"], env["cam_o"])
+    assert_pose_parity(got, want, "test.bmp")
+    assert [int(p["model_index"]) for p in got] == [5, 0, 1, 3, 2]
+    for p in got:
+        assert np.sqrt(2 * p["cost"] / p["n_points"]) < 0.6
+
+
+def test_batch_pose_parity_device_records(env):
+    """512 frames of synthetic detection records in HBM (random poses of the reference's models, every branch of the
+    correspondence builder, markers without a model, 4-point and 160-point markers) through ctag_pose_batch_device."""
+    import torch
+    recs, truth = synth_pose_results(env["model"], env["K"], env["dist"], 512, 1)
+    d = torch.from_numpy(recs.view(np.uint8).reshape(len(recs), -1)).cuda()
+    off = torch.zeros(len(recs) + 1, dtype=torch.int32, device="cuda")
+    cap = int(recs["n_markers"].sum())
+    poses = torch.zeros(max(cap, 1) * ca.POSE_DT.itemsize, dtype=torch.uint8, device="cuda")
+    env["det"].pose_batch_device(d.data_ptr(), len(recs), env["M"], env["cam"], off.data_ptr(), poses.data_ptr(), cap)
+    env["det"].sync()
+    offs = off.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == cap and np.array_equal(np.diff(offs), recs["n_markers"])
+    P = poses.cpu().numpy().view(ca.POSE_DT)[:cap]
+    for f in range(len(recs)):
+        want = env["po"].pose_frame(recs[f], env["mv"], env["cam_o"], f)
+        assert_pose_parity(P[offs[f]:offs[f + 1]], want, "frame %d" % f)
+    assert {0, 1} <= set(int(s) for s in P["status"])
+    good = [np.abs(P[offs[f] + k]["tvec"] - tv).max() for f in range(len(recs)) for k, (mi, rv, tv) in enumerate(truth[f])
+            if P[offs[f] + k]["status"] == 0 and P[offs[f] + k]["n_points"] >= 16]
+    assert np.median(good) < 1.0  # millimetres at 0.2 px noise
+
+
+def test_pose_edge_cases(env):
+    """Frames without markers, failed frames, capacity smaller than the batch, bad feature positions."""
+    import torch
+    recs, _ = synth_pose_results(env["model"], env["K"], env["dist"], 16, 5)
+    recs[3]["status"] = 1           # CTAG_NO_CORNER frame: no pose records
+    recs[4]["n_markers"] = 0
+    recs[5]["features"][0]["pos"] = 12   # outside the model
+    d = torch.from_numpy(recs.view(np.uint8).reshape(len(recs), -1)).cuda()
+    off = torch.zeros(len(recs) + 1, dtype=torch.int32, device="cuda")
+    need = int(sum(r["n_markers"] for r in recs if r["status"] == 0))
+    for cap in (need, max(need - 3, 1)):
+        poses = torch.zeros(need * ca.POSE_DT.itemsize, dtype=torch.uint8, device="cuda")
+        env["det"].pose_batch_device(d.data_ptr(), len(recs), env["M"], env["cam"], off.data_ptr(), poses.data_ptr(), cap)
+        env["det"].sync()
+        offs = off.cpu().numpy()
+        assert offs[-1] == need and offs[4] == offs[3] and offs[5] == offs[4]
+        P = poses.cpu().numpy().view(ca.POSE_DT)
+        want = np.concatenate([env["po"].pose_frame(recs[f], env["mv"], env["cam_o"], f) for f in range(len(recs))])
+        assert P[:cap].tobytes() == want[:cap].tobytes()
+        assert not P[cap:need].view(np.uint8).any()  # surplus not computed
+    # single-frame host entry point on a frame whose status is not OK: no records, no error
+    assert len(env["det"].estimate_pose(recs[3], env["M"], env["cam"])) == 0
