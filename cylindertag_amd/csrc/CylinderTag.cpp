@@ -7,10 +7,12 @@
 #include <iostream>
 
 #include "ctag.h"
+#include "ctag_pose.h"
 
 using ctag_host::Mat;
 using ctag_host::Mat1i;
 using ctag_host::Point2f;
+using ctag_host::Point3f;
 
 CylinderTag::CylinderTag(const std::string& path, int device_id) {
     load_from_file(path);
@@ -132,5 +134,136 @@ void CylinderTag::detectBatch(const unsigned char* frames, int n, int rows, int 
     for (int i = 0; i < n; i++) {
         status[i] = res[i].status;
         if (res[i].status == CTAG_OK) unflatten(res[i], lists[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pose back end (include/ctag_pose.h)
+// ---------------------------------------------------------------------------------------------------------------
+
+// reference: CylinderTag::loadModel, CylinderTag.cpp:161-190
+void CylinderTag::loadModel(const std::string& path, std::vector<ModelInfo>& reconstruct_model) {
+    ctag_model* m = nullptr;
+    if (ctag_model_load(path.c_str(), &m) != CTAG_OK) throw __FUNCTION__ + std::string(", ") + "could not open the model file\n";
+    ctag_model_view v;
+    ctag_model_get_view(m, &v);
+    reconstruct_model.resize((size_t)v.n_models);
+    for (int i = 0; i < v.n_models; i++) {
+        ModelInfo& mi = reconstruct_model[(size_t)i];
+        mi.MarkerID = v.marker_id[i];
+        mi.base = Point3f(v.base[3 * i], v.base[3 * i + 1], v.base[3 * i + 2]);
+        mi.axis = Point3f(v.axis[3 * i], v.axis[3 * i + 1], v.axis[3 * i + 2]);
+        mi.corners.resize((size_t)v.model_size * 8);
+        const float* c = v.corners + (size_t)i * v.model_size * 24;
+        for (int j = 0; j < v.model_size * 8; j++) mi.corners[(size_t)j] = Point3f(c[3 * j], c[3 * j + 1], c[3 * j + 2]);
+    }
+    ctag_model_free(m);
+}
+
+// reference: CylinderTag::loadCamera, CylinderTag.cpp:192-196 (cv::FileStorage there)
+void CylinderTag::loadCamera(const std::string& path, CamInfo& camera) {
+    ctag_camera c;
+    if (ctag_camera_load(path.c_str(), &c) != CTAG_OK) throw __FUNCTION__ + std::string(", ") + "could not read the camera file\n";
+#ifdef CTAG_WITH_OPENCV
+    camera.Intrinsic = cv::Mat(3, 3, CV_32F, c.K).clone();
+    camera.distCoeffs = cv::Mat(c.n_dist, 1, CV_32F, c.dist).clone();
+#else
+    std::memcpy(camera.Intrinsic, c.K, sizeof(c.K));
+    camera.distCoeffs.assign(c.dist, c.dist + c.n_dist);
+#endif
+}
+
+static void flatten(const std::vector<MarkerInfo>& markers, ctag_frame_result& r) {
+    std::memset(&r, 0, sizeof(r));
+    r.status = CTAG_OK;
+    int nf = 0;
+    for (size_t m = 0; m < markers.size() && m < CTAG_MAX_MARKERS; m++) {
+        const MarkerInfo& mi = markers[m];
+        const int n = (int)mi.cornerLists.size();
+        if (nf + n > CTAG_MAX_FEATURES) break;
+        ctag_marker_rec& M = r.markers[r.n_markers++];
+        M.marker_id = mi.markerID;
+        M.first_feature = nf;
+        M.n_features = n;
+        M.n_pos = (int)mi.featurePos.size() < n ? (int)mi.featurePos.size() : n;
+        for (int j = 0; j < n; j++) {
+            ctag_feature_rec& F = r.features[nf + j];
+            F.pos = j < M.n_pos ? mi.featurePos[(size_t)j] : -1;
+            F.id = j < (int)mi.feature_ID.size() ? mi.feature_ID[(size_t)j] : -1;
+            F.id_left = j < (int)mi.feature_ID_left.size() ? mi.feature_ID_left[(size_t)j] : -1;
+            F.id_right = j < (int)mi.feature_ID_right.size() ? mi.feature_ID_right[(size_t)j] : -1;
+            for (int k = 0; k < 8 && k < (int)mi.cornerLists[(size_t)j].size(); k++) {
+                F.corners[2 * k] = mi.cornerLists[(size_t)j][(size_t)k].x;
+                F.corners[2 * k + 1] = mi.cornerLists[(size_t)j][(size_t)k].y;
+            }
+        }
+        nf += n;
+    }
+    r.n_features = nf;
+}
+
+// reference: CylinderTag::estimatePose, CylinderTag.cpp:198-209 (+ PoseEstimator::PnPSolver / PoseBA)
+void CylinderTag::estimatePose(const Mat& img, std::vector<MarkerInfo> markers, std::vector<ModelInfo> reconstruct_model, CamInfo camera,
+                               std::vector<PoseInfo>& pose, bool useDensePoseRefine) {
+    (void)img;
+    (void)useDensePoseRefine;
+    pose.clear();
+    if (markers.empty()) return;
+    // vector<ModelInfo> -> ctag_model (every model must hold the same number of corners, as loadModel produces)
+    const size_t nm = reconstruct_model.size();
+    const size_t per = nm ? reconstruct_model[0].corners.size() : 8;
+    std::vector<int32_t> ids(nm);
+    std::vector<float> base(nm * 3), axis(nm * 3), corners(nm * per * 3);
+    for (size_t i = 0; i < nm; i++) {
+        const ModelInfo& mi = reconstruct_model[i];
+        if (mi.corners.size() != per || per % 8 != 0) throw __FUNCTION__ + std::string(", ") + "illegal model\n";
+        ids[i] = mi.MarkerID;
+        base[3 * i] = mi.base.x, base[3 * i + 1] = mi.base.y, base[3 * i + 2] = mi.base.z;
+        axis[3 * i] = mi.axis.x, axis[3 * i + 1] = mi.axis.y, axis[3 * i + 2] = mi.axis.z;
+        for (size_t j = 0; j < per; j++) {
+            corners[(i * per + j) * 3] = mi.corners[j].x;
+            corners[(i * per + j) * 3 + 1] = mi.corners[j].y;
+            corners[(i * per + j) * 3 + 2] = mi.corners[j].z;
+        }
+    }
+    ctag_model_view v{(int32_t)nm, (int32_t)(per / 8 ? per / 8 : 1), ids.data(), base.data(), axis.data(), corners.data()};
+    ctag_model* model = nullptr;
+    if (ctag_model_create(&v, &model) != CTAG_OK) throw __FUNCTION__ + std::string(", ") + "illegal model\n";
+    ctag_camera cam;
+    std::memset(&cam, 0, sizeof(cam));
+#ifdef CTAG_WITH_OPENCV
+    cv::Mat Kf, Df;
+    camera.Intrinsic.convertTo(Kf, CV_32F);
+    camera.distCoeffs.convertTo(Df, CV_32F);
+    for (int i = 0; i < 9; i++) cam.K[i] = Kf.at<float>(i / 3, i % 3);
+    cam.n_dist = (int)Df.total() > 14 ? 14 : (int)Df.total();
+    for (int i = 0; i < cam.n_dist; i++) cam.dist[i] = Df.ptr<float>(0)[i];
+#else
+    std::memcpy(cam.K, camera.Intrinsic, sizeof(cam.K));
+    cam.n_dist = camera.distCoeffs.size() > 14 ? 14 : (int)camera.distCoeffs.size();
+    for (int i = 0; i < cam.n_dist; i++) cam.dist[i] = camera.distCoeffs[(size_t)i];
+#endif
+    ctag_frame_result res;
+    flatten(markers, res);
+    std::vector<ctag_pose_rec> rec((size_t)res.n_markers);
+    const int st = ctag_estimate_pose(h_, &res, model, &cam, rec.data());
+    ctag_model_free(model);
+    if (st != CTAG_OK) throw __FUNCTION__ + std::string(", ") + ctag_strerror(st) + "\n";
+    for (const ctag_pose_rec& p : rec) {
+        if (p.status == CTAG_POSE_NO_MODEL) continue;  // pose.erase(remove_if(markerID == -1)), CylinderTag.cpp:206-208
+        if (p.status != CTAG_POSE_OK)  // cv::solvePnP throws on < 4 points; an out-of-model position is UB in the reference
+            throw __FUNCTION__ + std::string(", ") + "marker without a usable point set\n";
+        PoseInfo pi;
+        pi.markerID = p.model_index;
+#ifdef CTAG_WITH_OPENCV
+        pi.rvec = (cv::Mat_<double>(3, 1) << p.rvec[0], p.rvec[1], p.rvec[2]);
+        pi.tvec = (cv::Mat_<double>(3, 1) << p.tvec[0], p.tvec[1], p.tvec[2]);
+#else
+        for (int i = 0; i < 3; i++) {
+            pi.rvec[i] = p.rvec[i];
+            pi.tvec[i] = p.tvec[i];
+        }
+#endif
+        pose.push_back(pi);
     }
 }

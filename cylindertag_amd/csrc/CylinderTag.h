@@ -3,8 +3,9 @@
 // Mirrors /root/reference/header/CylinderTag.h:12-52 and the structs of header/corner_detector.h:10-22 for the
 // detection path: same class name, constructor forms, detect() signature, MarkerInfo field names, the same
 // `throw std::string` error behaviour of the loaders (CylinderTag.cpp:21,39,51,61) and the same two stdout
-// messages with untouched output on the early returns (CylinderTag.cpp:87-96).  loadModel / loadCamera /
-// estimatePose / drawAxis are the reference's pose back end and GUI: out of scope, they stay in the reference.
+// messages with untouched output on the early returns (CylinderTag.cpp:87-96).  loadModel / loadCamera / estimatePose
+// (header/CylinderTag.h:24-30, CylinderTag.cpp:161-209) are here too, on the GPU pose back end of include/ctag_pose.h
+// (EPnP + LM per marker, k_pose.hip); drawAxis is the reference's GUI and stays there.
 //
 // Build with -DCTAG_WITH_OPENCV to use cv::Mat / cv::Point2f / cv::Mat1i (drop-in next to the reference's
 // pose_estimation.cpp); without it a minimal stand-alone Mat / Point2f is used (this image has no OpenCV).
@@ -23,6 +24,7 @@ namespace ctag_host {
 using cv::Mat;
 using cv::Mat1i;
 using cv::Point2f;
+using cv::Point3f;
 }  // namespace ctag_host
 #else
 namespace ctag_host {
@@ -30,6 +32,11 @@ struct Point2f {
     float x = 0.f, y = 0.f;
     Point2f() = default;
     Point2f(float x_, float y_) : x(x_), y(y_) {}
+};
+struct Point3f {
+    float x = 0.f, y = 0.f, z = 0.f;
+    Point3f() = default;
+    Point3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
 };
 // borrowed 8-bit single-channel image view (what detect() needs from cv::Mat)
 struct Mat {
@@ -63,6 +70,33 @@ struct MarkerInfo {
     std::vector<float> edge_length, cr_left, cr_right;
 };
 
+// reference: header/pose_estimation.h:12-25.  With OpenCV the matrices are cv::Mat exactly as in the reference
+// (Intrinsic / distCoeffs CV_32F as cameraParams.yml stores them, rvec / tvec 3x1 CV_64F as solvePnP creates them);
+// without it plain arrays of the same element types.
+#ifdef CTAG_WITH_OPENCV
+struct CamInfo {
+    cv::Mat Intrinsic, distCoeffs;
+};
+struct PoseInfo {
+    int markerID;
+    cv::Mat rvec, tvec;
+};
+#else
+struct CamInfo {
+    float Intrinsic[9] = {0};       // row-major 3x3
+    std::vector<float> distCoeffs;  // k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]]
+};
+struct PoseInfo {
+    int markerID = -1;
+    double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+};
+#endif
+struct ModelInfo {
+    int MarkerID = -1;
+    ctag_host::Point3f axis, base;
+    std::vector<ctag_host::Point3f> corners;
+};
+
 class CylinderTag {
    public:
     // Load state matrix of CylinderTag from file (reference: CylinderTag.cpp:6-9, 16-41)
@@ -83,6 +117,17 @@ class CylinderTag {
     void detectBatch(const unsigned char* frames, int n, int rows, int cols, size_t row_stride, size_t frame_stride,
                      std::vector<std::vector<MarkerInfo>>& lists, std::vector<int>& status, int adaptiveThresh = 5,
                      const bool cornerSubPix = false, int cornerSubPixDist = 3);
+
+    // Load the reconstructed marker models / the camera (reference: header/CylinderTag.h:24,27; CylinderTag.cpp:161-196;
+    // both throw std::string when the file cannot be read)
+    void loadModel(const std::string& path, std::vector<ModelInfo>& reconstruct_model);
+    void loadCamera(const std::string& path, CamInfo& camera);
+
+    // Estimate the pose of the markers (reference: header/CylinderTag.h:30, CylinderTag.cpp:198-209): one PoseInfo per
+    // marker that has a model, PoseInfo::markerID = index into reconstruct_model (pose_estimation.cpp:59,69).
+    // useDensePoseRefine is accepted and ignored: the reference's DenseSolver is empty (pose_estimation.cpp:145-148).
+    void estimatePose(const ctag_host::Mat& img, std::vector<MarkerInfo> markers, std::vector<ModelInfo> reconstruct_model, CamInfo camera,
+                      std::vector<PoseInfo>& pose, bool useDensePoseRefine = false);
 
     int featureSize() const { return featureSize_; }
     ctag_handle* handle() const { return h_; }

@@ -94,6 +94,68 @@ CTM_HD void jacobi_eig(double* a, double* v, double* w) {
     for (int i = 0; i < N; i++) w[i] = a[i * N + i];
 }
 
+// Round-robin ("circle method") pair ordering for N = 12: 11 rounds of 6 disjoint pairs cover every pair once.  Pairs of
+// one round touch disjoint rows/columns, so a round's six rotations can be applied side by side (k_pose.hip) and still
+// equal this sequential sweep bit for bit: rotation j's parameters read only (a_pp, a_qq, a_pq) of its own pair, which
+// no other rotation of the round modifies.
+CTM_HD void rr12_pair(int round, int slot, int& p, int& q) {
+    int a, b;
+    if (slot == 0) {
+        a = 11;
+        b = round;
+    } else {
+        a = (round + slot) % 11;
+        b = (round + 11 - slot) % 11;
+    }
+    p = a < b ? a : b;
+    q = a < b ? b : a;
+}
+
+// jacobi_eig<12> with the round-robin ordering (same rotation formulas, same stopping rule)
+CTM_HD void jacobi_eig_rr12(double* a, double* v, double* w) {
+    const int N = 12;
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) v[i * N + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double sm = 0.0;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) sm += ctm::fabs64(a[p * N + q]);
+        if (sm == 0.0) break;
+        for (int round = 0; round < 11; round++) {
+            for (int slot = 0; slot < 6; slot++) {
+                int p, q;
+                rr12_pair(round, slot, p, q);
+                const JacobiRot r = jacobi_rot(a[p * N + p], a[q * N + q], a[p * N + q], sweep);
+                if (r.zero) {
+                    a[p * N + q] = 0.0;
+                    a[q * N + p] = 0.0;
+                    continue;
+                }
+                if (!r.rotate) continue;
+                a[p * N + p] -= r.h;
+                a[q * N + q] += r.h;
+                a[p * N + q] = 0.0;
+                a[q * N + p] = 0.0;
+                for (int k = 0; k < N; k++) {
+                    if (k != p && k != q) {
+                        double x = a[k * N + p], y = a[k * N + q];
+                        jacobi_apply(x, y, r.s, r.tau);
+                        a[k * N + p] = x;
+                        a[p * N + k] = x;
+                        a[k * N + q] = y;
+                        a[q * N + k] = y;
+                    }
+                    double vx = v[k * N + p], vy = v[k * N + q];
+                    jacobi_apply(vx, vy, r.s, r.tau);
+                    v[k * N + p] = vx;
+                    v[k * N + q] = vy;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < N; i++) w[i] = a[i * N + i];
+}
+
 // order[] = indices of w sorted by DESCENDING value (stable: ties keep index order) -- the order cvSVD reports
 template <int N>
 CTM_HD void sort_desc(const double* w, int* order) {

@@ -12,7 +12,7 @@
 // coordinates, camera-frame points, residuals and Jacobian rows); every SUM the CPU path accumulates sequentially over
 // the points is accumulated by ONE lane in the same order (lane = matrix entry: 144 entries of M^T M, 21+6+1 entries of
 // the normal equations), so the result does not depend on the wave width and equals the sequential evaluation bit for
-// bit.  The 12x12 symmetric eigenproblem runs as cyclic Jacobi with the rotation applied by 12 lanes.
+// bit.  The 12x12 symmetric eigenproblem runs as cyclic Jacobi in round-robin order, six disjoint rotations at a time.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -41,9 +41,11 @@ struct PoseModelDev {
 };
 
 constexpr int kPoseMaxPts = CTAG_POSE_MAX_POINTS;
+constexpr int kPoseSmallPts = 96;  // dictionaries of <= 12 columns (the reference's CTag_2f12c): 16 KB of LDS, two waves per SIMD
 constexpr int kJStride = 15;  // 12 Jacobian entries + 2 residuals per point, odd stride: conflict-free lane-per-point writes
 
 // LDS image of one marker's problem (doubles)
+template <int kPoseMaxPts>
 struct PoseLds {
     double X[kPoseMaxPts * 3];    // world points
     double OBS[kPoseMaxPts * 2];  // BA observations (undistorted, through K, rounded to float)
@@ -56,7 +58,7 @@ struct PoseLds {
             double E[kPoseMaxPts];       // per-point reprojection error
         } e;
         struct {
-            double JR[64 * kJStride];
+            double JR[kPoseMaxPts * kJStride];  // per point: 2 x 6 column-scaled Jacobian entries, 2 residuals
         } b;
     } u;
     double cws[12], ccs[12], ci[9];
@@ -65,8 +67,10 @@ struct PoseLds {
     double betas[16];
     double Rs[36], ts[12], rep[4];
     double s9[9], s3a[3], s3b[3];
-    double red[32];
+    double red[34];
     double x[6];
+    double rot[18];
+    int rflag[6];
     int jac_flag;
 };
 
@@ -182,9 +186,10 @@ __global__ __launch_bounds__(256) void k_pose_offsets(const ctag_frame_result* _
     }
 }
 
-__global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict__ res, int n_frames, const int32_t* __restrict__ offsets,
+template <int PTS, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_pose(const ctag_frame_result* __restrict__ res, int n_frames, const int32_t* __restrict__ offsets,
                                              PoseModelDev model, PoseCam cam, ctag_pose_rec* __restrict__ out, int capacity) {
-    __shared__ PoseLds S;
+    __shared__ PoseLds<PTS> S;
     const int lane = threadIdx.x;
     const int total = min(offsets[n_frames], capacity);
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -226,6 +231,10 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
                     break;
                 }
                 const int cnt = (ad < 3 && idr != -1) ? 8 : 4;
+                if (n + cnt > model.model_size * 8 || n + cnt > PTS) {  // repeated positions: more points than the model has
+                    status = CTAG_POSE_BAD_POS;
+                    break;
+                }
                 if (lane < cnt) {
                     const int k = lane < 2 ? lane : lane < 4 ? lane + 2 : lane < 6 ? lane - 2 : lane;  // 0 1 4 5 2 3 6 7
                     const int i = n + lane;
@@ -338,46 +347,85 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
         }
         wave_sync();
         PROF_MARK(2);
-        // cyclic Jacobi, ctl::jacobi_eig<12> with the k-loop on 12 lanes
+        // cyclic Jacobi with the round-robin pair order of ctl::jacobi_eig_rr12: the six rotations of a round are computed
+        // by six lanes and applied side by side (15 lanes own the 2x2 blocks between two pairs, 6 the pairs' own entries,
+        // 72 lane-tasks the eigenvector columns); bit-identical to the sequential sweep, see ctl::rr12_pair
         for (int sweep = 0; sweep < 60; sweep++) {
             double sm = 0.0;
             for (int p = 0; p < 11; p++)
                 for (int q = p + 1; q < 12; q++) sm += ctm::fabs64(S.u.e.A[p * 12 + q]);
             if (sm == 0.0) break;  // uniform
-            for (int p = 0; p < 11; p++) {
-                for (int q = p + 1; q < 12; q++) {
-                    const double apq = S.u.e.A[p * 12 + q];
-                    if (apq == 0.0 && sweep <= 3) continue;  // uniform: jacobi_rot would neither zero nor rotate
-                    const ctl::JacobiRot r = ctl::jacobi_rot(S.u.e.A[p * 12 + p], S.u.e.A[q * 12 + q], apq, sweep);
-                    if (!r.zero && !r.rotate) continue;
-                    wave_sync();
-                    if (r.zero) {
-                        if (lane == 0) {
-                            S.u.e.A[p * 12 + q] = 0.0;
-                            S.u.e.A[q * 12 + p] = 0.0;
+            for (int round = 0; round < 11; round++) {
+                if (lane < 6) {
+                    int p, q;
+                    ctl::rr12_pair(round, lane, p, q);
+                    const ctl::JacobiRot r = ctl::jacobi_rot(S.u.e.A[p * 12 + p], S.u.e.A[q * 12 + q], S.u.e.A[p * 12 + q], sweep);
+                    S.rot[3 * lane] = r.s;
+                    S.rot[3 * lane + 1] = r.tau;
+                    S.rot[3 * lane + 2] = r.h;
+                    S.rflag[lane] = r.zero ? 2 : (r.rotate ? 1 : 0);
+                }
+                wave_sync();
+                if (lane < 15) {  // block between pair i and pair j, i < j (processing order)
+                    int i = 0, e = lane;
+                    while (e >= 5 - i) {
+                        e -= 5 - i;
+                        i++;
+                    }
+                    const int j = i + 1 + e;
+                    const int fi = S.rflag[i], fj = S.rflag[j];
+                    if (fi == 1 || fj == 1) {
+                        int pi, qi, pj, qj;
+                        ctl::rr12_pair(round, i, pi, qi);
+                        ctl::rr12_pair(round, j, pj, qj);
+                        double b00 = S.u.e.A[pi * 12 + pj], b01 = S.u.e.A[pi * 12 + qj], b10 = S.u.e.A[qi * 12 + pj], b11 = S.u.e.A[qi * 12 + qj];
+                        if (fi == 1) {
+                            const double s_ = S.rot[3 * i], t_ = S.rot[3 * i + 1];
+                            ctl::jacobi_apply(b00, b10, s_, t_);
+                            ctl::jacobi_apply(b01, b11, s_, t_);
                         }
-                    } else if (lane < 12) {
-                        const int k = lane;
-                        if (k != p && k != q) {
-                            double x = S.u.e.A[k * 12 + p], y = S.u.e.A[k * 12 + q];
-                            ctl::jacobi_apply(x, y, r.s, r.tau);
-                            S.u.e.A[k * 12 + p] = x;
-                            S.u.e.A[p * 12 + k] = x;
-                            S.u.e.A[k * 12 + q] = y;
-                            S.u.e.A[q * 12 + k] = y;
-                        } else if (k == p) {
-                            S.u.e.A[p * 12 + p] -= r.h;
-                            S.u.e.A[q * 12 + q] += r.h;
-                            S.u.e.A[p * 12 + q] = 0.0;
-                            S.u.e.A[q * 12 + p] = 0.0;
+                        if (fj == 1) {
+                            const double s_ = S.rot[3 * j], t_ = S.rot[3 * j + 1];
+                            ctl::jacobi_apply(b00, b01, s_, t_);
+                            ctl::jacobi_apply(b10, b11, s_, t_);
                         }
+                        S.u.e.A[pi * 12 + pj] = b00;
+                        S.u.e.A[pj * 12 + pi] = b00;
+                        S.u.e.A[pi * 12 + qj] = b01;
+                        S.u.e.A[qj * 12 + pi] = b01;
+                        S.u.e.A[qi * 12 + pj] = b10;
+                        S.u.e.A[pj * 12 + qi] = b10;
+                        S.u.e.A[qi * 12 + qj] = b11;
+                        S.u.e.A[qj * 12 + qi] = b11;
+                    }
+                } else if (lane < 21) {  // the pair's own entries
+                    const int i = lane - 15;
+                    const int f = S.rflag[i];
+                    if (f) {
+                        int p, q;
+                        ctl::rr12_pair(round, i, p, q);
+                        if (f == 1) {
+                            const double h = S.rot[3 * i + 2];
+                            S.u.e.A[p * 12 + p] -= h;
+                            S.u.e.A[q * 12 + q] += h;
+                        }
+                        S.u.e.A[p * 12 + q] = 0.0;
+                        S.u.e.A[q * 12 + p] = 0.0;
+                    }
+                }
+                for (int t = lane - 21; t < 72; t += 64) {  // eigenvector columns: task = (pair, row k)
+                    if (t < 0) continue;
+                    const int i = t / 12, k = t % 12;
+                    if (S.rflag[i] == 1) {
+                        int p, q;
+                        ctl::rr12_pair(round, i, p, q);
                         double vx = S.u.e.V[k * 12 + p], vy = S.u.e.V[k * 12 + q];
-                        ctl::jacobi_apply(vx, vy, r.s, r.tau);
+                        ctl::jacobi_apply(vx, vy, S.rot[3 * i], S.rot[3 * i + 1]);
                         S.u.e.V[k * 12 + p] = vx;
                         S.u.e.V[k * 12 + q] = vy;
                     }
-                    wave_sync();
                 }
+                wave_sync();
             }
         }
         wave_sync();
@@ -584,7 +632,11 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
         PROF_MARK(7);
         // =========================================== PoseBA ===========================================
         // Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy (see the oracle for the statement of the loop).
-        // All lanes carry the same x / radius / cost; lane e < 28 owns one entry of the normal equations.
+        // All lanes carry the same x / radius / cost.  Lane = point writes its two (column-scaled) Jacobian rows and
+        // residuals to LDS; lane e < 34 owns one sequentially accumulated sum over those rows: e < 21 an entry of
+        // J^T J, 21..26 of J^T r, 27 the cost, 28..33 a squared column norm.  Every owner runs the same loop
+        // (acc += o[i0]*o[i1]; acc += o[i2]*o[i3]) with its own four offsets, so the 34 sums advance together.  The
+        // candidate point is evaluated WITH its Jacobian and normal equations, which an accepted step then keeps.
         double x[6], xc[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) x[i] = S.x[i];
@@ -593,8 +645,7 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
                 P->rvec0[i] = x[i];
                 P->tvec0[i] = x[3 + i];
             }
-        // entry owned by this lane: e < 21 -> H(a,b) with a <= b; 21..26 -> g(a); 27 -> cost; 28..33 -> column norm a
-        int ea = 0, eb = 0;
+        int i0 = 12, i1 = 12, i2 = 13, i3 = 13;  // lane 27 (and the idle lanes): the cost
         {
             int e = lane, a = 0;
             if (e < 21) {
@@ -602,95 +653,68 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
                     e -= 6 - a;
                     a++;
                 }
-                ea = a;
-                eb = a + e;
+                i0 = a;
+                i1 = a + e;
+                i2 = 6 + a;
+                i3 = 6 + a + e;
             } else if (e < 27) {
-                ea = eb = e - 21;
+                i0 = e - 21;
+                i1 = 12;
+                i2 = 6 + e - 21;
+                i3 = 13;
             } else if (e >= 28 && e < 34) {
-                ea = eb = e - 28;
+                i0 = i1 = e - 28;
+                i2 = i3 = 6 + e - 28;
             }
         }
         double scale[6] = {1, 1, 1, 1, 1, 1};
-        // evaluates residuals (+ Jacobian) at pose y; returns this lane's accumulated entry
-        auto eval = [&](const double* y, bool with_j, bool first) -> double {
+        auto eval_points = [&](const double* y) {  // rows of every point at pose y -> S.u.b.JR
             double R[9], dR[27];
-            ctl::angle_axis_rot(y, R, with_j ? dR : nullptr);
-            double acc = 0.0;
-            const double sa = scale[ea], sb = scale[eb];
-            for (int base = 0; base < n; base += 64) {
-                const int i = base + lane;
-                wave_sync();
-                if (i < n) {
-                    double r0, r1, j0[6], j1[6];
-                    point_residual(R, dR, y, cam.fx, cam.fy, cam.cx, cam.cy, S.X + 3 * i, S.OBS + 2 * i, r0, r1, j0, j1, with_j);
-                    double* o = S.u.b.JR + lane * kJStride;
-                    if (with_j) {
+            ctl::angle_axis_rot(y, R, dR);
+            wave_sync();
+            for (int i = lane; i < n; i += 64) {
+                double r0, r1, j0[6], j1[6];
+                point_residual(R, dR, y, cam.fx, cam.fy, cam.cx, cam.cy, S.X + 3 * i, S.OBS + 2 * i, r0, r1, j0, j1, true);
+                double* o = S.u.b.JR + i * kJStride;
 #pragma unroll
-                        for (int a = 0; a < 6; a++) {
-                            o[a] = j0[a];
-                            o[6 + a] = j1[a];
-                        }
-                    }
-                    o[12] = r0;
-                    o[13] = r1;
+                for (int a = 0; a < 6; a++) {
+                    o[a] = j0[a] * scale[a];
+                    o[6 + a] = j1[a] * scale[a];
                 }
-                wave_sync();
-                const int cnt = min(64, n - base);
-                if (lane < 21 && with_j) {
-                    for (int q = 0; q < cnt; q++) {
-                        const double* o = S.u.b.JR + q * kJStride;
-                        acc += (o[ea] * sa) * (o[eb] * sb);
-                        acc += (o[6 + ea] * sa) * (o[6 + eb] * sb);
-                    }
-                } else if (lane < 27 && with_j) {
-                    for (int q = 0; q < cnt; q++) {
-                        const double* o = S.u.b.JR + q * kJStride;
-                        acc += (o[ea] * sa) * o[12];
-                        acc += (o[6 + ea] * sa) * o[13];
-                    }
-                } else if (lane == 27) {
-                    for (int q = 0; q < cnt; q++) {
-                        const double* o = S.u.b.JR + q * kJStride;
-                        acc += o[12] * o[12];
-                        acc += o[13] * o[13];
-                    }
-                } else if (lane >= 28 && lane < 34 && first) {
-                    for (int q = 0; q < cnt; q++) {
-                        const double* o = S.u.b.JR + q * kJStride;
-                        acc += o[ea] * o[ea];
-                        acc += o[6 + ea] * o[6 + ea];
-                    }
+                o[12] = r0;
+                o[13] = r1;
+            }
+            wave_sync();
+        };
+        auto accumulate = [&]() -> double {
+            double acc = 0.0;
+            if (lane < 34) {
+                for (int q = 0; q < n; q++) {
+                    const double* o = S.u.b.JR + q * kJStride;
+                    acc += o[i0] * o[i1];
+                    acc += o[i2] * o[i3];
                 }
             }
             return acc;
         };
-        // first evaluation: cost and the Jacobi scaling (column norms); H and g need the scaling, so a second pass
-        double acc = eval(x, true, true);
-        wave_sync();
-        if (lane >= 27 && lane < 34) S.red[lane] = acc;
-        wave_sync();
-        double cost = 0.5 * S.red[27];
-#pragma unroll
-        for (int a = 0; a < 6; a++) scale[a] = 1.0 / (1.0 + ctm::sqrt64(S.red[28 + a]));
-        const double cost0 = cost;
-        int iter = 0;
-        bool live = ctl::finite64(cost);
         double H[36], g[6];
-        auto gather = [&](double v) {  // normal equations from the owning lanes to every lane
+        auto publish = [&](double v) {  // the owners' sums to LDS
             wave_sync();
-            if (lane < 28) S.red[lane] = v;
+            if (lane < 34) S.red[lane] = v;
             wave_sync();
+        };
+        auto take = [&](double* Ho, double* go) {  // ... and from there to every lane
             int e = 0;
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
                 for (int b = a; b < 6; b++) {
-                    H[a * 6 + b] = S.red[e];
-                    H[b * 6 + a] = S.red[e];
+                    Ho[a * 6 + b] = S.red[e];
+                    Ho[b * 6 + a] = S.red[e];
                     e++;
                 }
 #pragma unroll
-            for (int a = 0; a < 6; a++) g[a] = S.red[21 + a];
+            for (int a = 0; a < 6; a++) go[a] = S.red[21 + a];
         };
         auto gradient_max = [&]() {
             double m = 0.0;
@@ -701,9 +725,27 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
             }
             return m;
         };
+        // first evaluation with unit scaling: cost and the Jacobi scaling (column norms); then the rows are scaled in place
+        eval_points(x);
+        publish(accumulate());
+        double cost = 0.5 * S.red[27];
+#pragma unroll
+        for (int a = 0; a < 6; a++) scale[a] = 1.0 / (1.0 + ctm::sqrt64(S.red[28 + a]));
+        const double cost0 = cost;
+        int iter = 0;
+        bool live = ctl::finite64(cost);
         if (live) {
-            acc = eval(x, true, false);
-            gather(acc);
+            for (int i = lane; i < n; i += 64) {
+                double* o = S.u.b.JR + i * kJStride;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    o[a] = o[a] * scale[a];
+                    o[6 + a] = o[6 + a] * scale[a];
+                }
+            }
+            wave_sync();
+            publish(accumulate());
+            take(H, g);
             if (gradient_max() <= 1e-15) live = false;
         }
         double radius = 1e4, decrease_factor = 2.0;
@@ -749,10 +791,8 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
                 step2 += du * du;
                 x2 += x[a] * x[a];
             }
-            acc = eval(xc, false, false);
-            wave_sync();
-            if (lane == 27) S.red[27] = acc;
-            wave_sync();
+            eval_points(xc);
+            publish(accumulate());
             const double cost_c = 0.5 * S.red[27];
             const bool finite = ctl::finite64(cost_c);
             if (ctm::sqrt64(step2) <= 1e-10 * (ctm::sqrt64(x2) + 1e-10)) break;
@@ -762,9 +802,8 @@ __global__ __launch_bounds__(64) void k_pose(const ctag_frame_result* __restrict
             if (finite && rho > 1e-3) {
 #pragma unroll
                 for (int a = 0; a < 6; a++) x[a] = xc[a];
-                acc = eval(x, true, false);
-                gather(acc);
-                cost = 0.5 * S.red[27];
+                take(H, g);
+                cost = cost_c;
                 const double t = 2.0 * rho - 1.0;
                 double f = 1.0 - t * t * t;
                 if (f < 1.0 / 3.0) f = 1.0 / 3.0;
@@ -1021,7 +1060,12 @@ int ctag_pose_batch_device(ctag_handle* h, const ctag_frame_result* results_dev,
     hipLaunchKernelGGL(ctag::k_pose_offsets, dim3(1), dim3(256), 0, s, results_dev, n_frames, offsets_dev);
     if (n_frames > 0 && capacity > 0) {
         const int grid = std::min(capacity, 256 * 16);
-        hipLaunchKernelGGL(ctag::k_pose, dim3(grid), dim3(64), 0, s, results_dev, n_frames, offsets_dev, md, cam, poses_dev, capacity);
+        if (model->model_size * 8 <= ctag::kPoseSmallPts)
+            hipLaunchKernelGGL((ctag::k_pose<ctag::kPoseSmallPts, 2>), dim3(grid), dim3(64), 0, s, results_dev, n_frames, offsets_dev, md, cam,
+                               poses_dev, capacity);
+        else
+            hipLaunchKernelGGL((ctag::k_pose<ctag::kPoseMaxPts, 1>), dim3(grid), dim3(64), 0, s, results_dev, n_frames, offsets_dev, md, cam,
+                               poses_dev, capacity);
     }
     if (hipGetLastError() != hipSuccess) return CTAG_ERR_HIP;
     if (timing) {

@@ -1,7 +1,8 @@
 // ctag_demo.cpp -- the detection half of the reference's demo driver (main.cpp:28-41 read_from_image) on the HIP path:
 //   CylinderTag marker("CTag_2f12c.marker");  frame = imread(bmp) -> gray;  marker.detect(img_gray, markers, 5, true, 5);
 // Prints one line per marker: id, then "pos:id_left:id_right" per feature, then the first corner of every feature.
-// (estimatePose / drawAxis are the reference's CPU back end and GUI; they consume exactly this vector<MarkerInfo>.)
+// With a model and a camera file the pose half follows (main.cpp:33-34,40: loadModel, loadCamera, estimatePose) on the
+// GPU pose back end: one line per pose "pose <model index> rvec tvec".  drawAxis is the reference's GUI.
 #include <cstdio>
 #include <iostream>
 #include <string>
@@ -12,7 +13,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <dictionary.marker> <image.bmp> [adaptiveThresh=5] [cornerSubPix=1] [cornerSubPixDist=5]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <dictionary.marker> <image.bmp> [adaptiveThresh=5] [cornerSubPix=1] [cornerSubPixDist=5] [model.model cameraParams.yml]\n", argv[0]);
         return 2;
     }
     try {
@@ -29,6 +30,18 @@ int main(int argc, char** argv) {
             std::printf(" |");
             for (size_t j = 0; j < m.cornerLists.size(); j++) std::printf(" %.9g,%.9g", m.cornerLists[j][0].x, m.cornerLists[j][0].y);
             std::printf("\n");
+        }
+        if (argc > 7) {
+            std::vector<ModelInfo> model;
+            CamInfo camera;
+            marker.loadModel(argv[6], model);
+            marker.loadCamera(argv[7], camera);
+            std::vector<PoseInfo> pose;
+            marker.estimatePose(ctag_host::Mat(g.rows, g.cols, g.px.data()), markers, model, camera, pose, false);
+            std::printf("poses %zu\n", pose.size());
+            for (const PoseInfo& p : pose)
+                std::printf("pose %d rvec %.17g %.17g %.17g tvec %.17g %.17g %.17g\n", p.markerID, p.rvec[0], p.rvec[1], p.rvec[2], p.tvec[0],
+                            p.tvec[1], p.tvec[2]);
         }
     } catch (const std::string& s) {
         std::cerr << "error: " << s;

@@ -223,7 +223,7 @@ struct Epnp {
                 }
         }
         double V[144], w[12];
-        ctl::jacobi_eig<12>(MtM, V, w);
+        ctl::jacobi_eig_rr12(MtM, V, w);  // cvSVD of the symmetric M^T M: cyclic Jacobi, round-robin pair order
         int ord[12];
         ctl::sort_desc<12>(w, ord);
         // ut rows 11, 10, 9, 8 of cvSVD(MtM) = eigenvectors of the four smallest eigenvalues
@@ -601,6 +601,7 @@ int ctago_build_correspondences(const ctag_frame_result* r, int marker, const ct
         }
         if (j >= M.n_pos || F.pos < 0 || F.pos >= model->model_size) return CTAG_POSE_BAD_POS;
         const bool inner = ad < 3 && F.id_right != -1;  // :85
+        if (n + (inner ? 8 : 4) > model->model_size * 8 || n + (inner ? 8 : 4) > CTAG_POSE_MAX_POINTS) return CTAG_POSE_BAD_POS;
         const int ks[8] = {0, 1, 4, 5, 2, 3, 6, 7};
         for (int q = 0; q < (inner ? 8 : 4); q++) {
             const int k = ks[q];

@@ -100,3 +100,21 @@ def test_pose_edge_cases(env):
         assert not P[cap:need].view(np.uint8).any()  # surplus not computed
     # single-frame host entry point on a frame whose status is not OK: no records, no error
     assert len(env["det"].estimate_pose(recs[3], env["M"], env["cam"])) == 0
+
+
+def test_cpp_estimate_pose_demo(env):
+    """The C++ host layer with the reference's call sequence (main.cpp:31-40): CylinderTag marker(...); loadModel; loadCamera;
+    detect; estimatePose -- the printed poses equal the oracle's for every marker that has a model, in order, with
+    PoseInfo::markerID = model index."""
+    import subprocess
+    from ctag_testlib import ROOT
+    exe = os.path.join(ROOT, "cylindertag_amd", "_build", "ctag_demo")
+    out = subprocess.check_output([exe, os.path.join(GOLDEN, "CTag_2f12c.marker"), os.path.join(GOLDEN, "test.bmp"), "5", "1", "5",
+                                   MODEL_PATH, CAM_PATH], timeout=120).decode()
+    lines = [l.split() for l in out.splitlines() if l.startswith("pose ")]
+    res = env["det"].detect(read_bmp_gray(os.path.join(GOLDEN, "test.bmp")), 5, True, 5)
+    want = [p for p in env["po"].pose_frame(res, env["mv"], env["cam_o"]) if p["status"] != ca.capi.POSE_NO_MODEL]
+    assert "poses %d" % len(want) in out and len(lines) == len(want) == 5
+    for l, p in zip(lines, want):
+        assert int(l[1]) == p["model_index"]
+        assert [float(v) for v in l[3:6]] == list(p["rvec"]) and [float(v) for v in l[7:10]] == list(p["tvec"])
