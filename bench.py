@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--host-frames", type=int, default=1024,
                     help="frames of the host-memory (PCIe-inclusive) side measurement, 0 = skip; never `value`")
+    ap.add_argument("--pose-frames", type=int, default=1024,
+                    help="frames of the detect()+estimatePose side measurement on camera content, 0 = skip; never `value`")
     ap.add_argument("--size", default="1920x1080", help="frame size WxH; the headline metric is 1920x1080 (other sizes are side measurements)")
     ap.add_argument("--no-subpix", action="store_true")
     return ap.parse_args()
@@ -64,6 +66,65 @@ def host_stream_rate(det, frames_dev, m, subpix):
     return {"value": round(m / dt, 1), "unit": "frames/s", "frames": m, "host_gb_per_s": round(m * ROWS * COLS / dt / 1e9, 2),
             "note": "ctag_detect_batch_u8: pinned host frames in, host results out, upload of sub-chunk k+1 overlapped "
                     "with detection of sub-chunk k"}
+
+
+def pose_side(det, m, dev):
+    """Side measurement (never `value`; SURVEY.md 8(f) rank 2 / BASELINE config 5's estimatePose leg): camera content --
+    the 64-frame sequence derived from the reference's test.bmp (config 2's test.avi substitute, 5 physical markers in
+    view) tiled to m frames in HBM -- through detect() and then the GPU pose back end (EPnP + LM per marker against the
+    reference's CTag_2f12c.model / cameraParams.yml), everything device-resident.  The CPU pose oracle is timed beside it."""
+    import torch
+    import cylindertag_amd as ca
+    from cylindertag_amd import capi
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ctag_testlib import GOLDEN, read_bmp_gray
+    from pose_testlib import PoseOracle, make_camera, make_model_view, read_camera_yml, read_model_file
+    from sequences import avi_substitute
+    seq = avi_substitute(read_bmp_gray(os.path.join(GOLDEN, "test.bmp")))
+    m = max(len(seq), m // len(seq) * len(seq))
+    rows, cols = seq.shape[1:]
+    frames = torch.from_numpy(np.concatenate([seq] * (m // len(seq)))).to(dev)
+    model = ca.Model(os.path.join(GOLDEN, "CTag_2f12c.model"))
+    cam = ca.load_camera(os.path.join(GOLDEN, "cameraParams.yml"))
+    res = torch.zeros((m, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    off = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+    cap = m * 8
+    poses = torch.zeros(cap * ca.POSE_DT.itemsize, dtype=torch.uint8, device=dev)
+
+    def run():
+        det.detect_batch_device(frames.data_ptr(), m, rows, cols, cols, rows * cols, res.data_ptr(), 5, True, 5)
+        det.pose_batch_device(res.data_ptr(), m, model, cam, off.data_ptr(), poses.data_ptr(), cap)
+
+    run()
+    det.sync()
+    det.set_option(capi.OPT_TIMING, 1)
+    reps = 3
+    t0 = time.perf_counter()
+    pose_ms = 0.0
+    for _ in range(reps):
+        run()
+        pose_ms += det.pose_last_ms()
+    det.sync()
+    dt = (time.perf_counter() - t0) / reps
+    det.set_option(capi.OPT_TIMING, 0)
+    offs = off.cpu().numpy()
+    P = poses.cpu().numpy().view(ca.POSE_DT)[:offs[-1]]
+    ok = P[P["status"] == 0]
+    rms = np.sqrt(2 * ok["cost"] / np.maximum(ok["n_points"], 1))
+    # CPU pose oracle on the records of the first 64 frames (test infrastructure used as the timed baseline only)
+    K, dist = read_camera_yml(os.path.join(GOLDEN, "cameraParams.yml"))
+    mv = make_model_view(read_model_file(os.path.join(GOLDEN, "CTag_2f12c.model")))
+    po, cam_o = PoseOracle(), make_camera(K, dist)
+    recs = np.frombuffer(res[:64].cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    t0 = time.perf_counter()
+    ncpu = sum(len(po.pose_frame(r, mv, cam_o, i)) for i, r in enumerate(recs))
+    cpu_dt = time.perf_counter() - t0
+    return {"workload": "test.bmp-derived %d-frame sequence tiled to %d frames of %dx%d in HBM; detect(img,5,true,5) then "
+                        "estimatePose (EPnP + LM) with CTag_2f12c.model / cameraParams.yml" % (len(seq), m, cols, rows),
+            "detect_plus_pose_frames_per_s": round(m / dt, 1), "pose_kernel_ms": round(pose_ms / reps, 3),
+            "markers": int(offs[-1]), "poses_ok": int(len(ok)), "pose_markers_per_s": round(offs[-1] / (pose_ms / reps * 1e-3), 1),
+            "reprojection_rms_px_median": round(float(np.median(rms)), 4), "lm_iterations_mean": round(float(ok["iterations"].mean()), 2),
+            "cpu_pose_oracle_markers_per_s": round(ncpu / cpu_dt, 1), "cpu_cores": 1}
 
 
 def cpu_baseline(frames_host, state, fs, subpix):
@@ -200,11 +261,15 @@ def main():
                "roofline": roofline,
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
                "frames_ok": ok_frames, "markers_decoded_last_step": markers_found}
+        cpu_sample = frames[:min(args.cpu_frames, n)].cpu().numpy() if (world == 1 and args.cpu_frames > 0) else None
         if world == 1 and args.host_frames > 0:
             out["pcie_inclusive"] = host_stream_rate(det, frames, min(args.host_frames, n), subpix)
+        if world == 1 and args.pose_frames > 0 and (ROWS, COLS) == (1080, 1920):
+            del frames
+            out["pose_side"] = pose_side(det, args.pose_frames, dev)
+            frames = None
         if world == 1 and args.cpu_frames > 0:
-            m = min(args.cpu_frames, n)
-            out["cpu_baseline"] = cpu_baseline(frames[:m].cpu().numpy(), state, fs, subpix)
+            out["cpu_baseline"] = cpu_baseline(cpu_sample, state, fs, subpix)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
