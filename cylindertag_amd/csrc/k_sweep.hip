@@ -32,10 +32,13 @@ static inline int grid_for(int nframes, int per_frame) { return ((nframes + 7) /
 // Each lane owns 8 output pixels (one 16-byte source load per source row) and slides down a band of rows
 // keeping the four horizontal-pass rows in registers.
 // =====================================================================================================
-#ifndef CTAG_DEC_BAND
-#define CTAG_DEC_BAND 45
+// Band height: the host picks it so that a frame has a multiple of four bands (every 4-wave block full) of at most
+// kDecBandMax rows -- 135 rows for 1080p and 4K.  Taller bands re-read fewer prologue rows (6 source rows per band);
+// measured on 4096 1080p frames: 45 rows 2.35 ms, 90 (half-empty blocks) 2.58, 135 2.21, 180 2.49, 270 2.97.
+#ifndef CTAG_DEC_BAND_MAX
+#define CTAG_DEC_BAND_MAX 150
 #endif
-constexpr int kDecBand = CTAG_DEC_BAND;
+constexpr int kDecBandMax = CTAG_DEC_BAND_MAX;
 
 struct Raw18 {  // source pixels x0-1 .. x0+16 of one row
     uint32_t w0, w1, w2, w3;
@@ -131,17 +134,18 @@ __device__ __forceinline__ uint32_t vpass2(uint32_t qa, uint32_t qb, uint32_t qc
     return vround(v0, tail) | (vround(v1, tail) << 8);
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, int BAND>  // BAND: compile-time band height (0 = run-time band_rows_rt); the constant form is 5 % faster
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_decimate(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
-                                                  uint8_t* __restrict__ half, FrameGeom g, int nframes, int xblocks, int yblocks) {
+                                                  uint8_t* __restrict__ half, FrameGeom g, int nframes, int xblocks, int yblocks, int band_rows_rt) {
+    const int band_rows = BAND ? BAND : band_rows_rt;
     int frame, idx;
     if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
     const int bx = idx % xblocks, by = idx / xblocks;
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
     const int band = by * 4 + wy;
-    const int y_begin = band * kDecBand;
+    const int y_begin = band * band_rows;
     if (y_begin >= g.hrows) return;  // wave-uniform
-    const int y_end = min(y_begin + kDecBand, g.hrows);
+    const int y_end = min(y_begin + band_rows, g.hrows);
     const int hx0 = (bx * 64 + lane) * 8;
     const int x0 = hx0 * 2;
     const bool active = hx0 < g.hcols;
@@ -242,14 +246,21 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
     }
     const int lanes = (g.hcols + 7) / 8;
     const int xblocks = (lanes + 63) / 64;
-    const int bands = (g.hrows + kDecBand - 1) / kDecBand;
-    const int yblocks = (bands + 3) / 4;
+    const int bands = 4 * ((g.hrows + 4 * kDecBandMax - 1) / (4 * kDecBandMax));
+    const int band_rows = (g.hrows + bands - 1) / bands;
+    const int yblocks = bands / 4;
     const int grid = grid_for(nframes, xblocks * yblocks);
     const bool aligned = (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0;
-    if (aligned)
-        hipLaunchKernelGGL(k_decimate<true>, dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, yblocks);
+#define CTAG_DEC_LAUNCH(AL, B)                                                                                                       \
+    hipLaunchKernelGGL((k_decimate<AL, B>), dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, \
+                       yblocks, band_rows)
+    if (aligned && band_rows == 135)  // 1080p and 4K frames
+        CTAG_DEC_LAUNCH(true, 135);
+    else if (aligned)
+        CTAG_DEC_LAUNCH(true, 0);
     else
-        hipLaunchKernelGGL(k_decimate<false>, dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, yblocks);
+        CTAG_DEC_LAUNCH(false, 0);
+#undef CTAG_DEC_LAUNCH
     return hipGetLastError();
 }
 
@@ -1032,36 +1043,89 @@ __device__ __forceinline__ void seam_pixel(const uint16_t* __restrict__ limg, co
     }
 }
 
-// Horizontal seams: a thread takes 8 consecutive seam pixels with one 16-byte label load and leaves at once when they are
-// all background (nine out of ten are); vertical seams: a thread per pixel.
+// Horizontal seams: an item is 8 consecutive seam pixels behind one 16-byte label load (nine out of ten are all
+// background and need nothing else); vertical seams: an item is one pixel.  A thread takes kSeamItems items, 256 apart,
+// and requests all their labels before it looks at the first.  The foreground seam pixels found are compacted into an
+// LDS list and then handled one per lane: seam_pixel is a chain of dependent loads and atomics, and eight of them in a
+// row on the one lane whose group is foreground kept the other 63 lanes of its wave waiting.
+#ifndef CTAG_SEAM_ITEMS
+#define CTAG_SEAM_ITEMS 2
+#endif
+constexpr int kSeamItems = CTAG_SEAM_ITEMS;
+constexpr int kSeamList = 1024;  // foreground seam pixels per block held in LDS; the surplus is handled in place
 __global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, int nframes, int per_frame_blocks) {
     int frame, bidx;
     if (!map_block(blockIdx.x, per_frame_blocks, nframes, frame, bidx)) return;
+    __shared__ uint32_t s_list[kSeamList];  // x (12 bits) | y (12 bits) << 12 | horizontal << 24
+    __shared__ uint16_t s_lab[kSeamList];
+    __shared__ int s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
     const int hc8 = (g.hcols + 7) >> 3;
     const int nh = (g.tiles_y - 1) * hc8;      // 8-pixel groups on the lower side of horizontal seams
     const int nv = (g.tiles_x - 1) * g.hrows;  // pixels on the right side of vertical seams
-    const int i = bidx * 256 + threadIdx.x;
-    if (i >= nh + nv) return;
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     uint32_t* parent = P.parent + (size_t)frame * kPoolCap;
-    if (i < nh) {
-        const int sm = i / hc8;
-        const int x0 = (i - sm * hc8) * 8, y = (sm + 1) * kTileH;
-        const uint4 v = *reinterpret_cast<const uint4*>(limg + (size_t)y * g.lp + x0);  // lp is a multiple of 64: in bounds, aligned
-        if ((v.x | v.y | v.z | v.w) == 0u) return;
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint4 v[kSeamItems];
+    int px[kSeamItems], py[kSeamItems];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const unsigned c0 = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-            if (c0 && x0 + k < g.hcols) seam_pixel(limg, tbase, parent, g, x0 + k, y, true, c0);
+    for (int it = 0; it < kSeamItems; it++) {
+        const int i = (bidx * kSeamItems + it) * 256 + threadIdx.x;
+        v[it] = make_uint4(0u, 0u, 0u, 0u);
+        px[it] = -1;
+        py[it] = 0;
+        if (i < nh) {
+            const int sm = i / hc8;
+            px[it] = (i - sm * hc8) * 8;
+            py[it] = (sm + 1) * kTileH;
+            v[it] = *reinterpret_cast<const uint4*>(limg + (size_t)py[it] * g.lp + px[it]);  // lp is a multiple of 64: in bounds, aligned
+        } else if (i < nh + nv) {
+            const int j = i - nh;
+            const int sm = j / g.hrows;
+            py[it] = j - sm * g.hrows;
+            px[it] = -2 - (sm + 1) * kTileW;  // vertical item: x = -(px + 2)
+            v[it].x = limg[(size_t)py[it] * g.lp + (sm + 1) * kTileW];
         }
-    } else {
-        const int j = i - nh;
-        const int sm = j / g.hrows;
-        const int y = j - sm * g.hrows, x = (sm + 1) * kTileW;
-        const unsigned c0 = limg[(size_t)y * g.lp + x];
-        if (c0) seam_pixel(limg, tbase, parent, g, x, y, false, c0);
+    }
+    const bool packable = g.hcols <= 4096 && g.hrows <= 4096;
+#pragma unroll
+    for (int it = 0; it < kSeamItems; it++) {
+        if ((v[it].x | v[it].y | v[it].z | v[it].w) == 0u) continue;
+        if (px[it] >= 0) {
+            const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) cnt += (((w[k >> 1] >> (16 * (k & 1))) & 0xffffu) != 0u && px[it] + k < g.hcols) ? 1 : 0;
+            int slot = packable ? atomicAdd(&s_count, cnt) : kSeamList;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned c0 = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                if (c0 && px[it] + k < g.hcols) {
+                    if (slot < kSeamList) {
+                        s_list[slot] = (uint32_t)(px[it] + k) | ((uint32_t)py[it] << 12) | (1u << 24);
+                        s_lab[slot] = (uint16_t)c0;
+                    } else {
+                        seam_pixel(limg, tbase, parent, g, px[it] + k, py[it], true, c0);
+                    }
+                    slot++;
+                }
+            }
+        } else {
+            const int slot = packable ? atomicAdd(&s_count, 1) : kSeamList;
+            if (slot < kSeamList) {
+                s_list[slot] = (uint32_t)(-(px[it] + 2)) | ((uint32_t)py[it] << 12);
+                s_lab[slot] = (uint16_t)v[it].x;
+            } else {
+                seam_pixel(limg, tbase, parent, g, -(px[it] + 2), py[it], false, v[it].x);
+            }
+        }
+    }
+    __syncthreads();
+    const int n = min(s_count, kSeamList);
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const uint32_t e = s_list[k];
+        seam_pixel(limg, tbase, parent, g, (int)(e & 0xfffu), (int)((e >> 12) & 0xfffu), (e >> 24) != 0u, s_lab[k]);
     }
 }
 
@@ -1069,7 +1133,7 @@ hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s) {
     const FrameGeom& g = ws.g;
     const int n = (g.tiles_y - 1) * ((g.hcols + 7) >> 3) + (g.tiles_x - 1) * g.hrows;
     if (n <= 0) return hipSuccess;
-    const int per_frame = (n + 255) / 256;
+    const int per_frame = (n + 256 * kSeamItems - 1) / (256 * kSeamItems);
     hipLaunchKernelGGL(k_seam_merge, dim3(grid_for(nframes, per_frame)), dim3(256), 0, s, sweep_ptrs(ws), g, nframes, per_frame);
     return hipGetLastError();
 }
