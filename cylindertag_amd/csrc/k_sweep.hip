@@ -316,18 +316,19 @@ __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
         o = (o + bytes + 15) & ~(size_t)15;
         return at;
     };
-    const size_t stats = (size_t)kSlotCap * 6 * sizeof(int);
+    const size_t stats = (size_t)kSlotCap * 5 * sizeof(int);  // area, xmin, xmax, row mask (-> ymin, ymax), key
     const size_t ext = (size_t)L.ec * L.er * 2;
     const size_t thr = (size_t)L.tr * (kTileW + 8);  // per threshold-tile row: one threshold byte per tile column
     if (tw == 5) {
-        // Compact layout of the 5x5 front end (7 blocks per CU instead of 4).  Lifetimes: column extrema + tile extrema live
-        // until the thresholds exist, the run parents from S5 to the end of S8, the per-slot statistics from then on --
-        // the statistics overlay all three; the threshold bytes are dead before the run labels are first written.
+        // Compact layout of the 5x5 front end: 19,968 bytes, 8 blocks per CU.  Lifetimes: column extrema + tile extrema
+        // live until the thresholds exist (S3), the run parents from S5 to the end of S8, the per-slot statistics from
+        // then on -- all three share one region; the threshold bytes are dead before the run labels are first written.
         const size_t parent = (size_t)kRunCap * 4, vbuf = (size_t)2 * 8 * 352;
-        const size_t front = parent + vbuf + ext;
+        size_t front = vbuf + ((ext + 15) & ~(size_t)15);
+        front = front > parent ? front : parent;
         L.off_stats = take(front > stats ? front : stats);
         L.off_parent = L.off_stats;
-        L.off_region = L.off_parent + parent;
+        L.off_region = L.off_stats;
         L.off_ext = L.off_region + vbuf;
         L.off_mask = take((size_t)kTileH * kTileWords * 8);
         L.off_start = take((size_t)kTileH * kTileWords * 8);
@@ -353,6 +354,7 @@ __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
     L.total = o;
     return L;
 }
+static_assert(kTileH <= 32, "the per-slot row mask is one 32-bit word");
 size_t threshold_ccl_lds_bytes(int tw) { return ccl_layout(tw).total; }
 
 __device__ __forceinline__ uint64_t mask_le(int b) { return b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull); }
@@ -833,9 +835,8 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     int* st_area = reinterpret_cast<int*>(smem + L.off_stats);  // overlays buffers that are dead from here on (see ccl_layout)
     int* st_xmin = st_area + kSlotCap;
     int* st_xmax = st_xmin + kSlotCap;
-    int* st_ymin = st_xmax + kSlotCap;
-    int* st_ymax = st_ymin + kSlotCap;
-    int* st_key = st_ymax + kSlotCap;
+    unsigned* st_rows = reinterpret_cast<unsigned*>(st_xmax + kSlotCap);  // bit r: the component has a pixel in tile row r (kTileH <= 32)
+    int* st_key = reinterpret_cast<int*>(st_rows + kSlotCap);
     if (!overflow) {
         for (int i = tid; i < nruns; i += kCclThreads) {
             const unsigned r = lds_find(parent_s, (unsigned)i);
@@ -848,8 +849,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             st_area[i] = 0;
             st_xmin[i] = 0x7fffffff;
             st_xmax[i] = -1;
-            st_ymin[i] = 0x7fffffff;
-            st_ymax[i] = -1;
+            st_rows[i] = 0u;
             st_key[i] = 0x7fffffff;
         }
     }
@@ -874,8 +874,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             atomicAdd(&st_area[slot], len);
             atomicMin(&st_xmin[slot], gx0);
             atomicMax(&st_xmax[slot], gx1);
-            atomicMin(&st_ymin[slot], gy);
-            atomicMax(&st_ymax[slot], gy);
+            atomicOr(&st_rows[slot], 1u << r);
             atomicMin(&st_key[slot], (gy >> 1) * bcols + (gx0 >> 1));
         }
     }
@@ -938,9 +937,10 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             *reinterpret_cast<unsigned*>(q) = (unsigned)(base + i);        // parent
             *reinterpret_cast<int*>(q + 2 * ps) = st_area[i];               // area
             *reinterpret_cast<int*>(q + 3 * ps) = st_xmin[i];
-            *reinterpret_cast<int*>(q + 4 * ps) = st_ymin[i];
+            const unsigned rows = st_rows[i];  // never 0: a slot owns at least one run
+            *reinterpret_cast<int*>(q + 4 * ps) = ty0 + __ffs(rows) - 1;    // ymin
             *reinterpret_cast<int*>(q + 5 * ps) = st_xmax[i];
-            *reinterpret_cast<int*>(q + 6 * ps) = st_ymax[i];
+            *reinterpret_cast<int*>(q + 6 * ps) = ty0 + 31 - __clz(rows);   // ymax
             *reinterpret_cast<int*>(q + 7 * ps) = st_key[i];
             *reinterpret_cast<int*>(q + 8 * ps) = tile;                     // pool_tile
             *reinterpret_cast<int*>(q + 9 * ps) = -1;                       // member_head
