@@ -121,20 +121,23 @@ __device__ __forceinline__ void hpass(const Raw18& r, uint32_t q[4]) {
 // literal float evaluation the oracle uses).
 // Output columns at or beyond (hcols & ~7) are OpenCV's scalar row tail: integer FixedPtCast, (v + 2^21) >> 22, i.e.
 // round-half-UP of V/1024 -- `tail` switches the tie rule off for those (a lane's 8 columns are all body or all tail).
-__device__ __forceinline__ uint32_t vround(int V, bool tail) {
-    int r = (V + 512) >> 10;
-    if ((V & 1023) == 512 && !tail) r &= ~1;
-    return (uint32_t)min(max(r, 0), 255);
-}
-// two output pixels from packed rows: S1 = qb + qc and S2 = qa + qd stay inside int16 (|.| <= 19380)
-__device__ __forceinline__ uint32_t vpass2(uint32_t qa, uint32_t qb, uint32_t qc, uint32_t qd, bool tail) {
+// Round-half-even of V/1024 is (V + 511 + bit10(V)) >> 10 (remainder < 512: no carry; == 512: carries iff the quotient is
+// odd; > 512: carries), round-half-up is the same with the bit forced to 1 -- checked for every V in tests/test_oracle_cpu.py.
+// The shift, the saturation to 0..255 and the packing of two pixels are ONE gfx950 instruction, v_ashr_pk_u8_i32.  It
+// writes bits 15:0 of its destination only (measured: hipcc 7.2 forms it by itself from min(max(x >> 10, 0), 255) pairs and
+// then ORs the stale upper half into the neighbouring pixels), so the halves are gathered with v_perm_b32, which reads
+// nothing but the two valid bytes of each.
+__device__ __forceinline__ int vsum(int V, int tail) { return V + 511 + (((V >> 10) & 1) | tail); }
+// two output pixels from packed rows: S1 = qb + qc and S2 = qa + qd stay inside int16 (|.| <= 19380); result in bits 15:0
+__device__ __forceinline__ uint32_t vpass2(uint32_t qa, uint32_t qb, uint32_t qc, uint32_t qd, int tail) {
     const uint32_t s1 = pk_add_s16(qb, qc), s2 = pk_add_s16(qa, qd);
     const int v0 = 19 * (int)(short)(s1 & 0xffffu) - 3 * (int)(short)(s2 & 0xffffu);
     const int v1 = 19 * ((int)s1 >> 16) - 3 * ((int)s2 >> 16);
-    return vround(v0, tail) | (vround(v1, tail) << 8);
+    return (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(vsum(v0, tail), vsum(v1, tail), 10);
 }
+__device__ __forceinline__ uint32_t vpack4(uint32_t p01, uint32_t p23) { return __builtin_amdgcn_perm(p23, p01, 0x05040100u); }
 
-template <bool ALIGNED, int BAND>  // BAND: compile-time band height (0 = run-time band_rows_rt); the constant form is 5 % faster
+template <bool ALIGNED, int BAND, bool HAS_TAIL>  // BAND: compile-time band height (0 = run-time band_rows_rt); HAS_TAIL: hcols % 8 != 0
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_decimate(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
                                                   uint8_t* __restrict__ half, FrameGeom g, int nframes, int xblocks, int yblocks, int band_rows_rt) {
     const int band_rows = BAND ? BAND : band_rows_rt;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     const int hx0 = (bx * 64 + lane) * 8;
     const int x0 = hx0 * 2;
     const bool active = hx0 < g.hcols;
-    const bool tail = hx0 >= (g.hcols & ~7);
+    const int tail = (HAS_TAIL && hx0 >= (g.hcols & ~7)) ? 1 : 0;
     const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
     uint8_t* __restrict__ dst = half + ((size_t)frame * g.hrows) * g.hp;
     const int rmax = g.rows - 1;
@@ -169,8 +172,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     // two output rows per iteration: the four source rows of the NEXT iteration are requested before this iteration's
     // arithmetic, so every lane keeps 64 bytes in flight (the kernel is bound by memory latency x occupancy)
     auto emit = [&](int y, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
-        const uint32_t lo = vpass2(a[0], b[0], c[0], d[0], tail) | (vpass2(a[1], b[1], c[1], d[1], tail) << 16);
-        const uint32_t hi = vpass2(a[2], b[2], c[2], d[2], tail) | (vpass2(a[3], b[3], c[3], d[3], tail) << 16);
+        const uint32_t lo = vpack4(vpass2(a[0], b[0], c[0], d[0], tail), vpass2(a[1], b[1], c[1], d[1], tail));
+        const uint32_t hi = vpack4(vpass2(a[2], b[2], c[2], d[2], tail), vpass2(a[3], b[3], c[3], d[3], tail));
         if (active) *reinterpret_cast<uint2*>(dst + (size_t)y * g.hp + hx0) = make_uint2(lo, hi);
     };
     Raw18 n0 = load_row<ALIGNED>(rowp(2 * y_begin + 3), x0, g.cols, active, lane);
@@ -251,15 +254,16 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
     const int yblocks = bands / 4;
     const int grid = grid_for(nframes, xblocks * yblocks);
     const bool aligned = (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0;
-#define CTAG_DEC_LAUNCH(AL, B)                                                                                                       \
-    hipLaunchKernelGGL((k_decimate<AL, B>), dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, \
+#define CTAG_DEC_LAUNCH(AL, B, TL)                                                                                                         \
+    hipLaunchKernelGGL((k_decimate<AL, B, TL>), dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, \
                        yblocks, band_rows)
-    if (aligned && band_rows == 135)  // 1080p and 4K frames
-        CTAG_DEC_LAUNCH(true, 135);
+    const bool has_tail = (g.hcols & 7) != 0;
+    if (aligned && band_rows == 135 && !has_tail)  // 1080p and 4K frames
+        CTAG_DEC_LAUNCH(true, 135, false);
     else if (aligned)
-        CTAG_DEC_LAUNCH(true, 0);
+        CTAG_DEC_LAUNCH(true, 0, true);
     else
-        CTAG_DEC_LAUNCH(false, 0);
+        CTAG_DEC_LAUNCH(false, 0, true);
 #undef CTAG_DEC_LAUNCH
     return hipGetLastError();
 }
