@@ -138,9 +138,21 @@ def cpu_baseline(frames_host, state, fs, subpix):
     for i in range(n):
         orc.detect_fast(frames_host[i], state, fs, 5, subpix, 5)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "first %d frames of the same synthetic batch, CPU restatement of detect() "
-                      "(oracle/ctag_oracle.cpp, -O2 -ffp-contract=off), 1 thread, %.1f s" % (n, dt)}
+    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "first %d frames of the same synthetic batch, CPU restatement of detect() "
+                     "(oracle/ctag_oracle.cpp, -O2 -ffp-contract=off), 1 thread, %.1f s" % (n, dt)}
+    # frame-parallel on every host core (SURVEY.md 8(d) baseline (ii)): the same frames, one oracle call per frame, a thread
+    # per core (the calls run outside the GIL; results equal the single-thread ones)
+    from concurrent.futures import ThreadPoolExecutor
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if cores > 1:
+        with ThreadPoolExecutor(cores) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda f: orc.detect_fast(f, state, fs, 5, subpix, 5), list(frames_host)))
+            dt_all = time.perf_counter() - t0
+        out["all_cores"] = {"value": n / dt_all, "unit": "frames/s", "cores": cores,
+                            "sample": "the same %d frames, one thread per host core, %.1f s" % (n, dt_all)}
+    return out
 
 
 def main():
