@@ -567,6 +567,8 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     const int m_ng = recip16(ng);  // wave-uniform: one division instead of one per item
     uint2 pix[2][5];
     int it_cr[2] = {-1, -1}, it_g[2] = {0, 0};
+    bool dark = false;  // one of this thread's pixels INSIDE the tile is below 77
+    bool item_dark[2] = {false, false};  // ... one of the item's 5 x 8 pixels is
     if (tid < kTileH * kTileWords) mask_s[tid] = 0ull;  // rows / groups outside the frame stay background
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -604,10 +606,30 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             const uint2 mx = make_uint2((mxE0 | (mxO0 << 8)) & vm0, (mxE1 | (mxO1 << 8)) & vm1);
             *reinterpret_cast<uint2*>(vmin_s + cr * kVPitch + gq * 8) = mn;
             *reinterpret_cast<uint2*>(vmax_s + cr * kVPitch + gq * 8) = mx;
+            // tile rows / columns are multiples of 5 and 8, so an item lies wholly inside the tile or wholly in the ring
+            item_dark[q] = (lt4_bytes(mn.x, 0x4d4d4d4du) | lt4_bytes(mn.y, 0x4d4d4d4du)) != 0u;
+            if (tr0 + cr >= trs0 && tr0 + cr <= trs1 && gx >= tx0 && gx < tx0 + tw_eff) dark = dark || item_dark[q];
         }
+    }
+    {
+        const unsigned long long any = __ballot(dark);
+        if (lane == 0) misc_s[12 + wave] = any != 0ull ? 1 : 0;
     }
     CCL_SYNC();
     stamp(0);
+    // ---- bright tile: the reference caps the threshold at 0.3 (T <= 77 for every threshold tile, 0 on the frame border),
+    // so a tile whose pixels are all >= 77 has no foreground whatever its thresholds turn out to be: its labels are zero
+    // and it owns no component.  Exactly what the phases below would produce, without running them.
+    if ((misc_s[12] | misc_s[13] | misc_s[14] | misc_s[15]) == 0) {
+        uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+        constexpr int groups = kTileW / 8;
+        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
+            const int r = i / groups, gq = i - r * groups;
+            if (r < th_eff && gq * 8 < tw_eff) *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
+        return;
+    }
     // ---- per-threshold-tile min / max (corner_detector.cpp:42-53): 5 column extrema each
     {
         const int nc = tc1 - tc0 + 1;
@@ -631,7 +653,8 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             const int r = div_small(i, m_nc), c = i - r * nc;
             const int tr = trs0 + r, tc = tcs0 + c;
             int T = 0;
-            if (tr >= 1 && tr <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2) {
+            // a threshold tile whose own minimum is >= 77 has no pixel below any threshold (T <= 77): its T is never needed
+            if (tr >= 1 && tr <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2 && (ext_s[(tr - tr0) * L.ec + (tc - tc0)] & 0xff) < 77) {
                 int mn = 255, mx = 0;
 #pragma unroll
                 for (int dy = -1; dy <= 1; dy++)
@@ -664,7 +687,8 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
                     if (r0 + k < th_eff) {
-                        const unsigned bits = (lt4_bytes(pix[q][k].x, tt.x) | (lt4_bytes(pix[q][k].y, tt.y) << 4)) & keep;
+                        // an item without a pixel below 77 is background whatever its thresholds are
+                        const unsigned bits = item_dark[q] ? (lt4_bytes(pix[q][k].x, tt.x) | (lt4_bytes(pix[q][k].y, tt.y) << 4)) & keep : 0u;
                         mask_b[(r0 + k) * (kTileW / 8) + (cx >> 3)] = (uint8_t)bits;
                     }
                 }
@@ -889,9 +913,15 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     // ---- S11: per-pixel tile-local labels, 8 pixels (16 bytes) per lane
     {
         uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
-        constexpr int groups = kTileW / 8;
-        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
-            const int r = i / groups, gq = i - r * groups;
+        // A wave takes an 8-row x 8-group block (its stores are eight full 128-byte lines), not 64 consecutive groups of one
+        // or two rows: foreground is clustered, so most waves of a tile see background only and skip the per-segment path,
+        // whereas a row-major wave crosses a foreground stripe almost every time (8 % foreground groups, 99 % of the waves).
+        constexpr int groups = kTileW / 8, gblocks = groups / 8, rblocks = (kTileH + 7) / 8;
+        static_assert(groups % 8 == 0, "label blocks are 8 groups wide");
+        for (int i = tid; i < rblocks * gblocks * 64; i += kCclThreads) {
+            const int blk = i >> 6, l = i & 63;
+            const int by = blk / gblocks, bx = blk - by * gblocks;
+            const int r = by * 8 + (l >> 3), gq = bx * 8 + (l & 7);
             if (r >= th_eff || gq * 8 >= tw_eff) continue;
             const int item = r * kTileWords + (gq >> 3);
             const int b0 = (gq & 7) * 8;
