@@ -615,6 +615,41 @@ int ctago_build_correspondences(const ctag_frame_result* r, int marker, const ct
     return CTAG_POSE_OK;
 }
 
+// primitive probes for unit tests (tests/test_pose_cpu.py checks them against numpy.linalg)
+// op 0: jacobi_eig_rr12  in a[144]            out w[12] (unsorted), v[144] (eigenvectors as columns)
+// op 1: svd3             in a[9]              out U[9], s[3], V[9]
+// op 2: qr_solve<6,4>    in A[24], b[6]       out x[4]
+// op 3: chol6_solve      in H[36], g[6]       out x[6], ok
+// op 4: angle_axis_rot   in r[3]              out R[9], dR[27]
+// op 5: rodrigues        in R[9]              out r[3]
+// op 6: jacobi_eig<3>    in a[9]              out w[3], v[9]
+void ctago_linalg_probe(int op, const double* in, double* out) {
+    if (op == 0) {
+        double a[144];
+        for (int i = 0; i < 144; i++) a[i] = in[i];
+        ctl::jacobi_eig_rr12(a, out + 12, out);
+    } else if (op == 1) {
+        ctl::svd3(in, out, out + 9, out + 12);
+    } else if (op == 2) {
+        double A[24], b[6];
+        for (int i = 0; i < 24; i++) A[i] = in[i];
+        for (int i = 0; i < 6; i++) b[i] = in[24 + i];
+        ctl::qr_solve<6, 4>(A, b, out);
+    } else if (op == 3) {
+        double H[36];
+        for (int i = 0; i < 36; i++) H[i] = in[i];
+        out[6] = ctl::chol6_solve(H, in + 36, out) ? 1.0 : 0.0;
+    } else if (op == 4) {
+        ctl::angle_axis_rot(in, out, out + 9);
+    } else if (op == 5) {
+        ctl::rodrigues_from_matrix(in, out);
+    } else if (op == 6) {
+        double a[9];
+        for (int i = 0; i < 9; i++) a[i] = in[i];
+        ctl::jacobi_eig<3>(a, out + 3, out);
+    }
+}
+
 int ctago_pose_frame(const ctag_frame_result* r, const ctag_model_view* model, const ctag_camera* cam, int frame_index,
                      ctag_pose_rec* out) {
     if (r->status != CTAG_OK) return 0;

@@ -27,6 +27,8 @@ int ctago_pose_ba(const ctag_camera* cam, int n, const float* obj, const float* 
 /* the correspondence builder of PoseEstimator::PnPSolver (pose_estimation.cpp:72-95) */
 int ctago_build_correspondences(const ctag_frame_result* r, int marker, const ctag_model_view* model, int model_index, float* obj,
                                 float* img, int* n_out);
+/* probes of the shared dense linear algebra (cylindertag_amd/csrc/ctag_linalg.h); op codes in ctag_pose_oracle.cpp */
+void ctago_linalg_probe(int op, const double* in, double* out);
 /* all markers of one frame result: out[r->n_markers]; returns the number of records written */
 int ctago_pose_frame(const ctag_frame_result* r, const ctag_model_view* model, const ctag_camera* cam, int frame_index,
                      ctag_pose_rec* out);

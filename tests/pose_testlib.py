@@ -127,7 +127,15 @@ class PoseOracle:
         L.ctago_pose_ba.argtypes = [C.POINTER(Camera), C.c_int, pf, pf, pd, pd, pd, pd]
         L.ctago_build_correspondences.argtypes = [C.c_void_p, C.c_int, C.POINTER(ModelView), C.c_int, pf, pf,
                                                   C.POINTER(C.c_int)]
+        L.ctago_linalg_probe.argtypes = [C.c_int, pd, pd]
+        L.ctago_linalg_probe.restype = None
         L.ctago_pose_frame.argtypes = [C.c_void_p, C.POINTER(ModelView), C.POINTER(Camera), C.c_int, C.c_void_p]
+
+    def linalg(self, op, data, n_out):
+        data = np.ascontiguousarray(data, np.float64).ravel()
+        out = np.zeros(n_out, np.float64)
+        self.L.ctago_linalg_probe(op, data.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def undistort(self, cam, uv, with_P):
         uv = np.ascontiguousarray(uv, np.float32)

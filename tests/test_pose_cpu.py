@@ -59,6 +59,57 @@ def test_loader_errors(tmp_path):
     assert cam.n_dist == 4 and cam.K[4] == 1001.0 and abs(cam.dist[3] - 0.002) < 1e-9
 
 
+def test_shared_linear_algebra_against_numpy(env):
+    """ctag_linalg.h (shared by the kernel and the oracle like ctag_math.h) against numpy.linalg: the Jacobi eigen-solvers,
+    the 3x3 SVD, Householder least squares, the 6x6 Cholesky solve, the angle-axis rotation with its derivatives, Rodrigues."""
+    po = env["po"]
+    rng = np.random.default_rng(21)
+    for trial in range(30):
+        # EPnP-like 12x12 Gram matrices: eight well separated directions and a four-dimensional near-null space
+        B = rng.normal(size=(40, 12)) * np.concatenate([np.full(8, 1e3), rng.uniform(1e-3, 1.0, 4)])
+        Q, _ = np.linalg.qr(rng.normal(size=(12, 12)))
+        A = (B @ Q.T).T @ (B @ Q.T)
+        out = po.linalg(0, A, 12 + 144)
+        w, V = out[:12], out[12:].reshape(12, 12)
+        we, Ve = np.linalg.eigh(A)
+        order = np.argsort(w)
+        assert np.allclose(w[order], we, rtol=1e-9, atol=1e-9 * we[-1])
+        assert np.abs(V.T @ V - np.eye(12)).max() < 1e-12
+        assert np.abs(A @ V - V * w).max() < 1e-9 * we[-1]
+        # the null-space projector (what EPnP uses) agrees with LAPACK's
+        P1 = V[:, order[:4]] @ V[:, order[:4]].T
+        P2 = Ve[:, :4] @ Ve[:, :4].T
+        assert np.abs(P1 - P2).max() < 1e-6
+        M = rng.normal(size=(3, 3)) * rng.uniform(0.1, 100)
+        o = po.linalg(1, M, 21)
+        U, sv, Vv = o[:9].reshape(3, 3), o[9:12], o[12:].reshape(3, 3)
+        assert np.allclose(sv, np.linalg.svd(M, compute_uv=False), rtol=1e-12)
+        assert np.abs(U @ np.diag(sv) @ Vv.T - M).max() < 1e-12 * sv[0] and np.abs(U.T @ U - np.eye(3)).max() < 1e-12
+        S = M @ M.T
+        o = po.linalg(6, S, 12)
+        assert np.allclose(np.sort(o[:3]), np.linalg.eigvalsh(S), rtol=1e-10, atol=1e-12 * o[:3].max())
+        A64, b6 = rng.normal(size=(6, 4)), rng.normal(size=6)
+        x = po.linalg(2, np.concatenate([A64.ravel(), b6]), 4)
+        assert np.allclose(x, np.linalg.lstsq(A64, b6, rcond=None)[0], rtol=1e-10, atol=1e-12)
+        J = rng.normal(size=(20, 6))
+        H, g = J.T @ J, rng.normal(size=6)
+        o = po.linalg(3, np.concatenate([H.ravel(), g]), 7)
+        assert o[6] == 1.0 and np.allclose(o[:6], np.linalg.solve(H, g), rtol=1e-9)
+        r = rng.normal(size=3) * rng.choice([1e-9, 0.3, 2.0])
+        o = po.linalg(4, r, 36)
+        R, dR = o[:9].reshape(3, 3), o[9:].reshape(3, 3, 3)
+        assert np.abs(R - rodrigues(r)).max() < 1e-12
+        for k in range(3):
+            e = np.zeros(3)
+            e[k] = 1e-6
+            num = (rodrigues(r + e) - rodrigues(r - e)) / 2e-6
+            assert np.abs(dR[k] - num).max() < 1e-8, (trial, k)
+        if np.linalg.norm(r) > 1e-3:
+            back = po.linalg(5, rodrigues(r), 3)
+            assert np.abs(rodrigues(back) - rodrigues(r)).max() < 1e-12
+    assert po.linalg(3, np.concatenate([-np.eye(6).ravel(), np.ones(6)]), 7)[6] == 0.0  # not positive definite
+
+
 def test_undistort_inverts_the_distortion_model(env):
     """cv::undistortPoints' 5 fixed-point iterations invert cv::projectPoints' distortion to well below a pixel."""
     rng = np.random.default_rng(3)
