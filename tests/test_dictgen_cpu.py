@@ -1,0 +1,56 @@
+"""Dictionary generator (tools/dict_gen.py, restating CylinderTag_generator.m: SURVEY.md 8(f) rank 4) -- CPU tests.
+The reference's own dictionary is the known answer for the predicates."""
+import os
+import sys
+
+import numpy as np
+
+from ctag_testlib import GOLDEN, ROOT, read_marker_file
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import dict_gen as dg  # noqa: E402
+
+
+def test_reference_dictionary_satisfies_the_generator_predicates():
+    """CTag_2f12c.marker was produced by the reference generator: every code is legal (generator.m:17) and every cyclic
+    2-window is unique over the dictionary and its mirror image (testConflict, generator.m:288-334)."""
+    state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    assert state.shape == (41, 12) and fs == 2
+    assert all(dg.legal_code(int(c)) for c in state.ravel())
+    assert dg.test_conflict(state, fs)
+    # a duplicated window is detected: copy a pair of neighbours of row 0 into row 1
+    bad = state.copy()
+    bad[1, 3:5] = bad[0, 0:2]
+    assert not dg.test_conflict(bad, fs)
+    # ... and so is a window that equals the mirror image of another one
+    bad = state.copy()
+    bad[2, 5], bad[2, 6] = dg.invert_code(int(state[0, 1])), dg.invert_code(int(state[0, 0]))
+    assert not dg.test_conflict(bad, fs)
+
+
+def test_inverse_is_an_involution_and_matches_the_decoder_rule():
+    """inverse(): digits inverted and reversed (generator.m:182-196); the per-code rule is the one the decoder applies to a
+    reversed marker, (7 - c/8) + (7 - c%8)*8 (corner_detector.cpp match_dictionary)."""
+    for fs in (2, 3):
+        for v in np.random.RandomState(1).randint(0, 64 ** fs, 500):
+            assert dg.inverse_value(dg.inverse_value(int(v), fs), fs) == v
+    for c in range(64):
+        assert dg.invert_code(c) == (7 - c // 8) + (7 - c % 8) * 8
+        assert dg.legal_code(c) == dg.legal_code(dg.invert_code(c))
+
+
+def test_generated_dictionaries_are_legal_unique_and_loadable(tmp_path):
+    import cylindertag_amd as ca
+    for col, fs, num, seed in ((12, 2, 24, 3), (15, 2, 12, 4), (9, 3, 4, 5)):
+        code = dg.Generator(col, fs, seed=seed, node_budget=40000).generate(num)
+        assert code.shape == (num, col), (col, fs, code.shape)
+        assert all(dg.legal_code(int(c)) for c in code.ravel())
+        assert dg.test_conflict(code, fs)
+        path = tmp_path / ("gen_%dc%df.marker" % (col, fs))
+        dg.write_marker(str(path), code, fs)
+        state, rfs = ca.load_marker_file(str(path))  # the C ABI loader (CylinderTag::load_from_file)
+        assert rfs == fs and np.array_equal(state, code)
+    # same seed, same dictionary
+    a = dg.Generator(12, 2, seed=7).generate(6)
+    b = dg.Generator(12, 2, seed=7).generate(6)
+    assert np.array_equal(a, b)
