@@ -30,18 +30,21 @@ CTM_HD JacobiRot jacobi_rot(double app, double aqq, double apq, int sweep) {
         return r;
     }
     if (apq == 0.0) return r;
-    double h = aqq - app;
+    const double h = aqq - app;
     double t;
     if (ctm::fabs64(h) + g == ctm::fabs64(h)) {
         t = apq / h;
     } else {
-        const double theta = 0.5 * h / apq;
-        t = 1.0 / (ctm::fabs64(theta) + ctm::sqrt64(1.0 + theta * theta));
-        if (theta < 0.0) t = -t;
+        // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)) with theta = h / (2 apq), written without the division that
+        // forms theta: t = 2 apq / (h + sgn(h) sqrt(h^2 + 4 apq^2)) -- one square root and one division in sequence
+        // instead of division, square root, division (the chain is what a rotation costs on the GPU)
+        const double rad = ctm::sqrt64(h * h + 4.0 * (apq * apq));
+        t = (2.0 * apq) / (h < 0.0 ? h - rad : h + rad);
     }
-    const double c = 1.0 / ctm::sqrt64(1.0 + t * t);
-    r.s = t * c;
-    r.tau = r.s / (1.0 + c);
+    // c = 1 / sqrt(1 + t^2), s = t c, tau = s / (1 + c) = t / (sqrt(1 + t^2) + 1): the two divisions are independent
+    const double rt = ctm::sqrt64(1.0 + t * t);
+    r.s = t / rt;
+    r.tau = t / (rt + 1.0);
     r.h = t * apq;
     r.rotate = true;
     return r;
