@@ -274,14 +274,21 @@ def main():
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
                "frames_ok": ok_frames, "markers_decoded_last_step": markers_found}
         cpu_sample = frames[:min(args.cpu_frames, n)].cpu().numpy() if (world == 1 and args.cpu_frames > 0) else None
+        # side legs: a failure in one of them is reported in its place and never costs the headline line
+        def side(name, fn):
+            try:
+                out[name] = fn()
+            except Exception as e:  # noqa: BLE001
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
         if world == 1 and args.host_frames > 0:
-            out["pcie_inclusive"] = host_stream_rate(det, frames, min(args.host_frames, n), subpix)
+            side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
         if world == 1 and args.pose_frames > 0 and (ROWS, COLS) == (1080, 1920):
             del frames
-            out["pose_side"] = pose_side(det, args.pose_frames, dev)
             frames = None
+            side("pose_side", lambda: pose_side(det, args.pose_frames, dev))
         if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(cpu_sample, state, fs, subpix)
+            side("cpu_baseline", lambda: cpu_baseline(cpu_sample, state, fs, subpix))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
