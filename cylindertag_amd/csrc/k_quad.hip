@@ -949,7 +949,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
         const int x_min = cd.x_min, y_min = cd.y_min;
         const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
         const int C = pack_points(w, h);
-        const int w2 = (w + 1) & ~1;
         const int need = act ? pack_need(w, h) : 0;
         int off = 0;
 #pragma unroll
@@ -976,7 +975,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
         // (root entry + its member list built by k_resolve) so the pixel scan needs no gathers
         constexpr int kMaxKeys = 8;
         uint32_t mykey[kMaxKeys];
-        int nkeys = 0;
         bool many = false;
         {
             const int32_t* ptile = P.pool_tile + (size_t)frame * kPoolCap;
@@ -989,7 +987,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
                 if (e >= 0) {
                     const int t = ptile[e];
                     mykey[k] = ((uint32_t)t << 16) | (uint32_t)(e - tbase[t] + 1);
-                    nkeys = k + 1;
                     e = first_e ? P.member_head[(size_t)frame * kPoolCap + e] : mnext[e];
                     first_e = false;
                 }
