@@ -61,6 +61,13 @@ int ctago_detect_fast(const uint8_t* gray, int rows, int cols, ptrdiff_t row_str
                       int dict_rows, int dict_cols, int feature_size, int adaptive_thresh, int corner_subpix,
                       int subpix_dist, void* result);
 
+/* frame-parallel ctago_detect_fast over n frames (frame i at frames + i*frame_stride) on `threads` std::threads
+ * (<= 0: hardware_concurrency); results = n flat records.  Returns the number of threads used. */
+int ctago_detect_many(const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                      const int32_t* state, int dict_rows, int dict_cols, int feature_size, int adaptive_thresh,
+                      int corner_subpix, int subpix_dist, int threads, void* results);
+int ctago_hardware_concurrency(void);
+
 /* primitive probes for unit tests */
 void ctago_resize_half(const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, uint8_t* dst);
 void ctago_threshold(const uint8_t* half, int rows, int cols, int tw, uint8_t* dst);

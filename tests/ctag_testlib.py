@@ -71,9 +71,9 @@ def _ptr(a, t):
 
 
 class Oracle:
-    def __init__(self, libm=False):
+    def __init__(self, libm=False, path=None):
         name = "libctag_oracle_libm.so" if libm else "libctag_oracle.so"
-        path = os.path.join(ROOT, "oracle", "_build", name)
+        path = path or os.path.join(ROOT, "oracle", "_build", name)  # `path`: another build of the same source (asan, native)
         if not os.path.exists(path):
             build_oracle()
         L = self.L = C.CDLL(path)
@@ -96,6 +96,10 @@ class Oracle:
         L.ctago_detect_fast.restype = C.c_int
         L.ctago_detect_fast.argtypes = [_p_u8, C.c_int, C.c_int, C.c_ssize_t, _p_i32, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ctago_detect_many.restype = C.c_int
+        L.ctago_detect_many.argtypes = [_p_u8, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, _p_i32, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ctago_hardware_concurrency.restype = C.c_int
         L.ctago_resize_half.argtypes = [_p_u8, C.c_int, C.c_int, C.c_ssize_t, _p_u8]
         L.ctago_threshold.argtypes = [_p_u8, C.c_int, C.c_int, C.c_int, _p_u8]
         L.ctago_ccl.argtypes = [_p_u8, C.c_int, C.c_int, _p_i32, _p_i32, C.c_int]
@@ -160,6 +164,20 @@ class Oracle:
                                  _ptr(state, _p_i32), state.shape[0], state.shape[1], feature_size, adaptive_thresh,
                                  int(subpix), subpix_dist, res.ctypes.data)
         return res[0]
+
+    def detect_many(self, frames, state, feature_size, adaptive_thresh=5, subpix=True, subpix_dist=5, threads=0):
+        """n frames (n, rows, cols) through ctago_detect_many: a std::thread pool inside the oracle library (threads <= 0:
+        hardware_concurrency).  Returns (records, threads_used)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        n, rows, cols = frames.shape
+        res = np.zeros(n, RESULT_DT)
+        used = self.L.ctago_detect_many(_ptr(frames, _p_u8), n, rows, cols, frames.strides[1], frames.strides[0],
+                                        _ptr(state, _p_i32), state.shape[0], state.shape[1], feature_size, adaptive_thresh,
+                                        int(subpix), subpix_dist, threads, res.ctypes.data)
+        if used < 0:
+            raise RuntimeError("ctago_detect_many failed (%d)" % used)
+        return res, used
 
     # ---- primitives ----------------------------------------------------------------------------------
     def resize_half(self, gray):

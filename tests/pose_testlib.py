@@ -115,8 +115,8 @@ def project(K, dist, rvec, tvec, X, distort=True):
 
 
 class PoseOracle:
-    def __init__(self):
-        path = os.path.join(ROOT, "oracle", "_build", "libctag_pose_oracle.so")
+    def __init__(self, path=None):
+        path = path or os.path.join(ROOT, "oracle", "_build", "libctag_pose_oracle.so")
         if not os.path.exists(path):
             build_oracle()
         L = self.L = C.CDLL(path)
