@@ -6,13 +6,18 @@ a synthetic batch of 1920x1080 random-stripe frames, resident in HBM, one proces
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
 A "step" is one pass of the whole detect() path (resize -> threshold -> label -> quads -> features -> sub-pixel
-refine -> decode) over one batch of frames per GPU; frames are independent, so each rank owns its own shard of
-the job (weak scaling) and the only collective is the final RCCL all-gather of the result records.
-Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
-  roofline      the threshold+label sweep (2*W*H algorithmic bytes per frame) against 8 TB/s HBM,
-                timed with HIP events on the library's own stream
-  cpu_baseline  the CPU restatement (oracle/, "port") timed on the host cores on a bounded sample of the batch
-PyTorch is used only for device memory, synchronisation and torch.distributed.
+refine -> decode) over the job's batch of frames.  Frames are independent, so with N GPUs every rank owns a contiguous
+shard of the SAME 4096-frame batch (BASELINE config 4: strong scaling; `--scaling weak` gives every GPU its own 4096)
+and the only collective is the final gather of the marker lists: the library's ctag_gather (packed shards, RCCL called
+from the C ABI, include/ctag_gather.h), pipelined against the next step's detection.
+Prints ONE JSON line on rank 0 (contract in the task statement), with extra objects:
+  roofline        the threshold+label sweep (2*W*H algorithmic bytes per frame) against 8 TB/s HBM,
+                  timed with HIP events on the library's own stream
+  cpu_baseline    the CPU restatement (oracle/, "port") timed on the host cores on a bounded sample of the batch
+  parity          the GPU records of the timed configuration compared byte for byte with the oracle's records of the
+                  same frames (the ones the cpu_baseline leg computes anyway); a mismatch makes the exit code 1
+  results_sha256  hash of the (gathered) result list in frame order: equal for N = 1, 2, 4, 8 in strong scaling
+PyTorch is used only for device memory, synchronisation and the torch.distributed bootstrap.
 """
 import argparse
 import ctypes
@@ -37,10 +42,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (BASELINE config 3: 4096)")
+    ap.add_argument("--frames", type=int, default=4096, help="frames of the job's batch per step (BASELINE config 3: 4096); per GPU with --scaling weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the same --frames batch sharded over the GPUs (BASELINE config 4), weak = --frames per GPU")
     ap.add_argument("--chunk", type=int, default=4096, help="frames per pipeline pass (workspace size)")
     ap.add_argument("--markers", type=int, default=4)
-    ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the one-thread CPU baseline (0 = skip CPU legs and parity)")
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=8, help="all-cores CPU baseline: frames per hardware thread")
     ap.add_argument("--host-frames", type=int, default=1024,
                     help="frames of the host-memory (PCIe-inclusive) side measurement, 0 = skip; never `value`")
     ap.add_argument("--pose-frames", type=int, default=1024,
@@ -127,32 +135,70 @@ def pose_side(det, m, dev):
             "cpu_pose_oracle_markers_per_s": round(ncpu / cpu_dt, 1), "cpu_cores": 1}
 
 
-def cpu_baseline(frames_host, state, fs, subpix):
-    """Times the CPU restatement of detect() (oracle, kind 'port'), single thread, on the given frames."""
+def _native_oracle():
+    """The timed baseline build of the oracle (-O3 -march=native -ffp-contract=off), compiled ON THIS HOST
+    (native code must not travel between machines); falls back to the portable -O2 checker build when g++ is missing."""
+    import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from ctag_testlib import Oracle  # the oracle is test infrastructure: used here only as the timed CPU baseline
-    orc = Oracle()
-    n = frames_host.shape[0]
+    from ctag_testlib import Oracle  # the oracle is test infrastructure: used here only as the timed CPU baseline / checker
+    path = os.path.join(ROOT, "oracle", "_native", "libctag_oracle.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        return Oracle(path=path), "-O3 -march=native -ffp-contract=off, built on this host"
+    except Exception as e:  # noqa: BLE001
+        return Oracle(), "-O2 -ffp-contract=off (portable build; native build failed: %s)" % type(e).__name__
+
+
+def cpu_baseline(frames_dev, n_one, per_thread, state, fs, subpix):
+    """Times the CPU restatement of detect() (oracle, kind 'port') on this host: one thread on the first n_one frames, then
+    frame-parallel on every hardware thread (std::thread pool inside the oracle library, >= per_thread frames per
+    thread).  Returns (json object, oracle records of the frames it ran) -- the records feed the parity check."""
+    orc, build = _native_oracle()
+    hw = int(orc.L.ctago_hardware_concurrency()) or (os.cpu_count() or 1)
+    n_all = min(int(frames_dev.shape[0]), max(n_one, per_thread * hw))
+    frames_host = frames_dev[:n_all].cpu().numpy()
+    n_one = min(n_one, n_all)
     orc.detect_fast(frames_host[0], state, fs, 5, subpix, 5)  # warm
     t0 = time.perf_counter()
-    for i in range(n):
-        orc.detect_fast(frames_host[i], state, fs, 5, subpix, 5)
+    rec_one, _ = orc.detect_many(frames_host[:n_one], state, fs, 5, subpix, 5, threads=1)
     dt = time.perf_counter() - t0
-    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    out = {"value": n_one / dt, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "first %d frames of the same synthetic batch, CPU restatement of detect() "
-                     "(oracle/ctag_oracle.cpp, -O2 -ffp-contract=off), 1 thread, %.1f s" % (n, dt)}
-    # frame-parallel on every host core (SURVEY.md 8(d) baseline (ii)): the same frames, one oracle call per frame, a thread
-    # per core (the calls run outside the GIL; results equal the single-thread ones)
-    from concurrent.futures import ThreadPoolExecutor
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    if cores > 1:
-        with ThreadPoolExecutor(cores) as ex:
+                     "(oracle/ctag_oracle.cpp, %s), 1 thread, %.1f s" % (n_one, build, dt)}
+    records = rec_one
+    if hw > 1:
+        runs = []
+        for _ in range(2):  # twice: the figure has to be stable
             t0 = time.perf_counter()
-            list(ex.map(lambda f: orc.detect_fast(f, state, fs, 5, subpix, 5), list(frames_host)))
-            dt_all = time.perf_counter() - t0
-        out["all_cores"] = {"value": n / dt_all, "unit": "frames/s", "cores": cores,
-                            "sample": "the same %d frames, one thread per host core, %.1f s" % (n, dt_all)}
-    return out
+            rec_all, used = orc.detect_many(frames_host, state, fs, 5, subpix, 5, threads=hw)
+            runs.append(n_all / (time.perf_counter() - t0))
+        if rec_all[:n_one].tobytes() != rec_one.tobytes():
+            raise AssertionError("frame-parallel oracle records differ from the one-thread ones")
+        out["all_cores"] = {"value": max(runs), "unit": "frames/s", "cores": used, "hardware_concurrency": hw,
+                            "runs_frames_per_s": [round(r, 1) for r in runs],
+                            "sample": "first %d frames (%.1f per thread), ctago_detect_many: std::thread pool inside the oracle library"
+                                      % (n_all, n_all / used)}
+        records = rec_all
+    return out, records
+
+
+def latency_side(det, state, fs):
+    """Side measurement (never `value`): the reference's actual use -- one frame per call (main.cpp:52-59) -- on the
+    reference's test.bmp through ctag_detect_u8 (host frame in, host record out)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ctag_testlib import GOLDEN, read_bmp_gray
+    img = read_bmp_gray(os.path.join(GOLDEN, "test.bmp"))
+    for _ in range(20):
+        det.detect(img, 5, True, 5)
+    ts = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        det.detect(img, 5, True, 5)
+        ts.append(time.perf_counter() - t0)
+    ts = np.sort(np.array(ts)) * 1e3
+    return {"workload": "test.bmp 1920x1200, ctag_detect_u8(img,5,true,5), pageable host frame in, host record out, 200 calls",
+            "latency_ms_median": round(float(ts[len(ts) // 2]), 4), "latency_ms_p10": round(float(ts[len(ts) // 10]), 4),
+            "latency_ms_p90": round(float(ts[len(ts) * 9 // 10]), 4)}
 
 
 def main():
@@ -160,9 +206,11 @@ def main():
     args = parse_args()
     COLS, ROWS = (int(v) for v in args.size.lower().split("x"))
     ALGO_BYTES_PER_FRAME = 2 * ROWS * COLS
+    import hashlib
     import torch
     import cylindertag_amd as ca
     from cylindertag_amd import capi
+    from cylindertag_amd.dist import CommGather, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -184,33 +232,67 @@ def main():
 
     state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
     det = ca.Detector(state, fs, device=local_rank)
-    det.set_option(capi.OPT_MAX_CHUNK, args.chunk)
-    n = args.frames
     subpix = not args.no_subpix
 
-    # ---- synthetic shard of this rank, generated on the device (frames [rank*n, (rank+1)*n) of the job)
-    frames = torch.empty((n, ROWS, COLS), dtype=torch.uint8, device=dev)
-    det.synth_frames_device(frames.data_ptr(), rank * n, n, ROWS, COLS, COLS, ROWS * COLS, markers=args.markers)
-    # two result buffers: the gather of step k (RCCL, its own stream) overlaps the detection of step k+1
-    result_bufs = [torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
-    results = result_bufs[0]
-    from cylindertag_amd.dist import gather_results_async
-    pending = []
+    # ---- the job: n_total frames per step; this rank owns frames [lo, hi) of it
+    strong = args.scaling == "strong" or world == 1
+    n_total = args.frames if strong else args.frames * world
+    lo, hi = shard_range(n_total, rank, world)
+    n = hi - lo
+    chunk = max(1, min(args.chunk, n))
+    det.set_option(capi.OPT_MAX_CHUNK, chunk)
+    frames = torch.empty((max(n, 1), ROWS, COLS), dtype=torch.uint8, device=dev)
+    det.synth_frames_device(frames.data_ptr(), lo, n, ROWS, COLS, COLS, ROWS * COLS, markers=args.markers)
+    rec_bytes = ca.RESULT_DT.itemsize
+    local_bufs = [torch.zeros((max(n, 1), rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    gather_impl, comm, gathered = "none (1 GPU)", None, None
+    if world > 1:
+        # the path's only exchange: final marker lists.  The library's own RCCL gather (packed shards); should its
+        # communicator fail to come up, torch.distributed's all_gather of the fixed records (also RCCL) takes over and the
+        # line says so.
+        gathered = [torch.zeros((n_total, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        try:
+            comm = CommGather(det, dist)
+            gather_impl = "ctag_gather (C ABI -> ncclAllGather of packed shards)"
+        except Exception as e:  # noqa: BLE001
+            comm = None
+            gather_impl = "torch.distributed.all_gather_into_tensor of fixed records (ctag_comm_init failed: %s)" % e
+        flags = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        if int(flags.item()) == 0 and comm is not None:  # some rank fell back: all ranks must take the same path
+            comm.close()
+            comm = None
+            gather_impl = "torch.distributed.all_gather_into_tensor of fixed records (another rank's ctag_comm_init failed)"
+        if comm is None and n * world != n_total:
+            raise SystemExit("the torch.distributed fallback gather needs equal shards")
     step_no = [0]
+    pending = []  # gathers begun and not yet ended: (index of the gathered buffer)
+
+    def finish_pending():
+        while pending:
+            k = pending.pop(0)
+            if comm is not None:
+                comm.end(gathered[k % 2])
 
     def step():
-        buf = result_bufs[step_no[0] % len(result_bufs)]
+        k = step_no[0]
         step_no[0] += 1
-        if len(pending) == len(result_bufs):
-            pending.pop(0).wait()  # the gather that read this buffer two steps ago
+        buf = local_bufs[k % len(local_bufs)]
         det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, buf.data_ptr(), 5, subpix, 5)
         if world > 1:
-            det.sync()  # results are produced on the library's stream
-            pending.append(gather_results_async(buf, world * n, dist))  # the path's only exchange: final marker lists (RCCL all-gather)
+            if comm is not None:
+                finish_pending()            # sizes of step k-1 are in (its detection ended while step k was being enqueued)
+                comm.begin(buf[:n], n_total)  # pack + size exchange of step k behind its detection, on the gather stream
+                pending.append(k)
+            else:
+                det.sync()
+                dist.all_gather_into_tensor(gathered[k % 2].view(-1), buf[:n].reshape(-1))
 
     def fence():
-        while pending:
-            pending.pop(0).wait()
+        finish_pending()
+        if comm is not None:
+            comm.wait()
+        det.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -218,16 +300,20 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # Per-kernel device time: HIP events recorded by the library on ITS stream around every kernel of the timed steps
-    # themselves (torch.cuda.Event would only see torch's current stream).  Reading them back costs one event
-    # synchronisation per chunk, which is inside the timed region.
-    det.set_option(capi.OPT_TIMING, 1)
+    # Per-kernel device time: HIP events recorded by the library on ITS stream around every kernel (torch.cuda.Event
+    # would only see torch's current stream).  At N = 1 they bracket the kernels of the timed steps themselves (reading
+    # them back costs one event synchronisation per chunk, inside the timed region); at N > 1 that synchronisation would
+    # serialise the detect / gather pipeline, so the timed steps run without it and ONE extra untimed step collects them.
+    timed_with_events = world == 1
     acc = {k: 0.0 for k in ca.STAGE_NAMES}
+    if timed_with_events:
+        det.set_option(capi.OPT_TIMING, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for k, v in det.timings().items():
-            acc[k] += v
+        if timed_with_events:
+            for k, v in det.timings().items():
+                acc[k] += v
     fence()
     dt = time.perf_counter() - t0
     det.set_option(capi.OPT_TIMING, 0)
@@ -235,45 +321,60 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    stage_ms = {k: v / max(1, args.steps) for k, v in acc.items()}  # per step (n frames)
-    launches = (n + args.chunk - 1) // args.chunk
+    last = step_no[0] - 1
+    if timed_with_events:
+        stage_ms = {k: v / max(1, args.steps) for k, v in acc.items()}  # per step (n frames)
+    else:
+        det.set_option(capi.OPT_TIMING, 1)
+        det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, local_bufs[(last + 1) % 2].data_ptr(), 5, subpix, 5)
+        det.sync()
+        stage_ms = det.timings()
+        det.set_option(capi.OPT_TIMING, 0)
+    launches = (n + chunk - 1) // chunk
 
-    # ---- sanity on the outcome of the last step
-    results = result_bufs[(step_no[0] - 1) % len(result_bufs)]
-    res = np.frombuffer(results.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    # ---- outcome of the last step: the job's result list in frame order (gathered when N > 1)
+    final = gathered[last % 2] if world > 1 else local_bufs[0][:n]
+    res = np.frombuffer(final.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
     ok_frames = int((res["status"] == 0).sum())
     markers_found = int(res["n_markers"].sum())
+    sha = hashlib.sha256(res.tobytes()).hexdigest()
+    rc = 0
 
     if rank == 0:
         sweep_ms = sum(stage_ms[k] for k in SWEEP_STAGES)
         achieved = ALGO_BYTES_PER_FRAME * n / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))  # per-round PMC passes; latest round wins
         tpath = cands[-1] if cands else ""
         if os.path.exists(tpath) and (ROWS, COLS) == (1080, 1920):  # the PMC passes were collected on the 1080p workload
             try:
-                traffic = json.load(open(tpath)).get("sweep_bytes_per_frame") * min(n, args.chunk)  # measured per frame
+                traffic = json.load(open(tpath)).get("sweep_bytes_per_frame") * min(n, chunk)  # measured per frame
+                traffic_source = "replayed from %s (separate rocprofv3 --pmc passes; not collected in this run)" % os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": "threshold+label sweep = " + "+".join("k_" + k for k in SWEEP_STAGES),
-                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * min(n, args.chunk),
+                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * min(n, chunk),
                     "avg_launch_ms": round(sweep_ms / launches, 4), "launches_per_step": launches,
-                    "frames_per_launch": min(n, args.chunk)}
-        out = {"metric": "frames/sec detect() %dx%d" % (COLS, ROWS), "value": round(world * n * args.steps / dt, 2),
+                    "frames_per_launch": min(n, chunk),
+                    "timing": "HIP events on the library's stream, " + ("timed steps" if timed_with_events else "one extra untimed step on rank 0 (N > 1)")}
+        out = {"metric": "frames/sec detect() %dx%d" % (COLS, ROWS), "value": round(n_total * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "synthetic %dx%d random-stripe frames," % (COLS, ROWS) + " %d per GPU per step, %d planted "
+               "config": {"workload": "synthetic %dx%d random-stripe frames," % (COLS, ROWS) + " %d per step over %d GPU(s), %d planted "
                                       "CTag_2f12c markers each, detect(img,5,%s,5), inputs resident in HBM"
-                                      % (n, args.markers, "true" if subpix else "false"),
-                          "frames_per_gpu": n, "chunk": args.chunk, "parallelism": "frames sharded, dp%d" % world},
+                                      % (n_total, world, args.markers, "true" if subpix else "false"),
+                          "frames_per_step": n_total, "frames_per_gpu": n, "chunk": chunk, "parallelism": "frames sharded, dp%d" % world,
+                          "gather": gather_impl},
                "roofline": roofline,
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
-               "frames_ok": ok_frames, "markers_decoded_last_step": markers_found}
-        cpu_sample = frames[:min(args.cpu_frames, n)].cpu().numpy() if (world == 1 and args.cpu_frames > 0) else None
+               "frames_ok": ok_frames, "markers_decoded_last_step": markers_found, "results_sha256": sha}
+        if comm is not None:
+            lb, pb = det.gather_last_bytes()
+            out["config"]["gather_bytes"] = {"packed_local": lb, "padded_per_rank": pb, "fixed_records_per_rank": n * rec_bytes}
         # side legs: a failure in one of them is reported in its place and never costs the headline line
         def side(name, fn):
             try:
@@ -281,22 +382,45 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+        oracle_records = [None]
+
+        def cpu_leg():
+            obj, recs = cpu_baseline(frames, min(args.cpu_frames, n), args.cpu_frames_per_thread, state, fs, subpix)
+            oracle_records[0] = recs
+            return obj
+
+        if world == 1 and args.cpu_frames > 0:
+            side("cpu_baseline", cpu_leg)
+            recs = oracle_records[0]
+            if recs is not None:  # parity of the timed configuration itself (chunk %d): GPU records vs oracle records, byte for byte
+                bad = [int(f) for f in range(len(recs)) if recs[f].tobytes() != res[f].tobytes()]
+                out["parity"] = {"frames_checked": len(recs), "mismatches": len(bad), "first_mismatching_frames": bad[:8],
+                                 "bar": "byte-identical ctag_frame_result records (ids, order, float corners)"}
+                if bad:
+                    rc = 1
+            else:
+                out["parity"] = {"frames_checked": 0, "mismatches": None, "note": "cpu_baseline leg failed"}
+                rc = 1
+        else:
+            out["cpu_baseline"] = None
+            out["parity"] = None
         if world == 1 and args.host_frames > 0:
             side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
+        if world == 1:
+            side("single_frame_latency", lambda: latency_side(det, state, fs))
         if world == 1 and args.pose_frames > 0 and (ROWS, COLS) == (1080, 1920):
             del frames
             frames = None
             side("pose_side", lambda: pose_side(det, args.pose_frames, dev))
-        if world == 1 and args.cpu_frames > 0:
-            side("cpu_baseline", lambda: cpu_baseline(cpu_sample, state, fs, subpix))
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
     det.close()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

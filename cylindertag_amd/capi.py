@@ -31,7 +31,12 @@ EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", 
 # ... and include/ctag_pose.h
 POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag_model_get_view", "ctag_camera_load",
                 "ctag_pose_batch_device", "ctag_estimate_pose", "ctag_pose_last_ms"]
-EXPORTS = EXPORTS + POSE_EXPORTS
+# ... and include/ctag_gather.h
+GATHER_EXPORTS = ["ctag_shard_range", "ctag_packed_capacity", "ctag_pack_results", "ctag_unpack_results", "ctag_comm_unique_id",
+                  "ctag_comm_init", "ctag_comm_attach", "ctag_comm_destroy", "ctag_comm_last_error", "ctag_gather_begin",
+                  "ctag_gather_end", "ctag_gather_wait", "ctag_gather", "ctag_gather_last_bytes"]
+EXPORTS = EXPORTS + POSE_EXPORTS + GATHER_EXPORTS
+COMM_ID_BYTES = 128
 
 POSE_DT = np.dtype([("status", "<i4"), ("model_index", "<i4"), ("frame", "<i4"), ("marker", "<i4"),
                     ("n_points", "<i4"), ("iterations", "<i4"), ("rvec", "<f8", (3,)), ("tvec", "<f8", (3,)),
@@ -141,6 +146,35 @@ def load_library():
     L.ctag_estimate_pose.argtypes = [vp, vp, vp, C.POINTER(CameraC), vp]
     L.ctag_pose_last_ms.restype = C.c_float
     L.ctag_pose_last_ms.argtypes = [vp]
+    u64p = C.POINTER(C.c_uint64)
+    L.ctag_shard_range.restype = C.c_int
+    L.ctag_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ctag_packed_capacity.restype = C.c_size_t
+    L.ctag_packed_capacity.argtypes = [C.c_int]
+    L.ctag_pack_results.restype = C.c_int
+    L.ctag_pack_results.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, u64p]
+    L.ctag_unpack_results.restype = C.c_int
+    L.ctag_unpack_results.argtypes = [vp, vp, C.c_int, vp]
+    L.ctag_comm_unique_id.restype = C.c_int
+    L.ctag_comm_unique_id.argtypes = [vp]
+    L.ctag_comm_init.restype = C.c_int
+    L.ctag_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.ctag_comm_attach.restype = C.c_int
+    L.ctag_comm_attach.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.ctag_comm_destroy.restype = C.c_int
+    L.ctag_comm_destroy.argtypes = [vp]
+    L.ctag_comm_last_error.restype = C.c_char_p
+    L.ctag_comm_last_error.argtypes = [vp]
+    L.ctag_gather_begin.restype = C.c_int
+    L.ctag_gather_begin.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.ctag_gather_end.restype = C.c_int
+    L.ctag_gather_end.argtypes = [vp, vp]
+    L.ctag_gather_wait.restype = C.c_int
+    L.ctag_gather_wait.argtypes = [vp]
+    L.ctag_gather.restype = C.c_int
+    L.ctag_gather.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.ctag_gather_last_bytes.restype = C.c_int
+    L.ctag_gather_last_bytes.argtypes = [vp, u64p, u64p]
     _lib = L
     return L
 
@@ -150,6 +184,27 @@ def _strerror(status):
         return load_library().ctag_strerror(status).decode()
     except Exception:  # pragma: no cover
         return "ctag error"
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 bytes rank 0 hands to the other ranks."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    st = load_library().ctag_comm_unique_id(buf)
+    if st != 0:
+        raise CtagError(st, "ctag_comm_unique_id (RCCL not loadable?)")
+    return bytes(buf)
+
+
+def shard_range(n_total, rank, world):
+    lo, hi = C.c_int(), C.c_int()
+    st = load_library().ctag_shard_range(n_total, rank, world, C.byref(lo), C.byref(hi))
+    if st != 0:
+        raise CtagError(st, "ctag_shard_range")
+    return lo.value, hi.value
+
+
+def packed_capacity(n):
+    return int(load_library().ctag_packed_capacity(n))
 
 
 def load_marker_file(path):
@@ -362,6 +417,43 @@ class Detector:
                                              markers)
         if st != 0:
             raise CtagError(st, "ctag_synth_frames_device")
+
+    # ---- multi-GPU gather (include/ctag_gather.h); pointers are plain integers
+    def _gcheck(self, st, what):
+        if st != 0:
+            raise CtagError(st, "%s: %s" % (what, self.L.ctag_comm_last_error(self.h).decode()))
+
+    def pack_results(self, results_ptr, n, packed_ptr, capacity):
+        nbytes = C.c_uint64()
+        self._gcheck(self.L.ctag_pack_results(self.h, results_ptr, n, packed_ptr, capacity, C.byref(nbytes)), "ctag_pack_results")
+        return int(nbytes.value)
+
+    def unpack_results(self, packed_ptr, n, out_ptr):
+        self._gcheck(self.L.ctag_unpack_results(self.h, packed_ptr, n, out_ptr), "ctag_unpack_results")
+
+    def comm_init(self, id_bytes, rank, world):
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        self._gcheck(self.L.ctag_comm_init(self.h, buf, rank, world), "ctag_comm_init")
+
+    def comm_destroy(self):
+        self.L.ctag_comm_destroy(self.h)
+
+    def gather_begin(self, local_ptr, n_local, n_total):
+        self._gcheck(self.L.ctag_gather_begin(self.h, local_ptr, n_local, n_total), "ctag_gather_begin")
+
+    def gather_end(self, out_ptr):
+        self._gcheck(self.L.ctag_gather_end(self.h, out_ptr), "ctag_gather_end")
+
+    def gather_wait(self):
+        self._gcheck(self.L.ctag_gather_wait(self.h), "ctag_gather_wait")
+
+    def gather(self, local_ptr, n_local, n_total, out_ptr):
+        self._gcheck(self.L.ctag_gather(self.h, local_ptr, n_local, n_total, out_ptr), "ctag_gather")
+
+    def gather_last_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.ctag_gather_last_bytes(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     # ---- pose back end (include/ctag_pose.h)
     def estimate_pose(self, result, model, camera):

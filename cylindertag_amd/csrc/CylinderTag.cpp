@@ -173,13 +173,19 @@ void CylinderTag::loadCamera(const std::string& path, CamInfo& camera) {
 #endif
 }
 
-static void flatten(const std::vector<MarkerInfo>& markers, ctag_frame_result& r) {
+// markers[first...] -> one flat record; returns the index of the first marker that did not fit (records hold at most
+// CTAG_MAX_MARKERS markers / CTAG_MAX_FEATURES features: estimatePose walks a longer list in several records, nothing
+// is dropped).  A single marker with more features than a record holds cannot come from detect() (the reference's
+// father[100], corner_detector.h:143) and is reported.
+static size_t flatten(const std::vector<MarkerInfo>& markers, size_t first, ctag_frame_result& r) {
     std::memset(&r, 0, sizeof(r));
     r.status = CTAG_OK;
     int nf = 0;
-    for (size_t m = 0; m < markers.size() && m < CTAG_MAX_MARKERS; m++) {
+    size_t m = first;
+    for (; m < markers.size() && r.n_markers < CTAG_MAX_MARKERS; m++) {
         const MarkerInfo& mi = markers[m];
         const int n = (int)mi.cornerLists.size();
+        if (n > CTAG_MAX_FEATURES) throw std::string("estimatePose, a marker with more than 100 features\n");
         if (nf + n > CTAG_MAX_FEATURES) break;
         ctag_marker_rec& M = r.markers[r.n_markers++];
         M.marker_id = mi.markerID;
@@ -200,6 +206,7 @@ static void flatten(const std::vector<MarkerInfo>& markers, ctag_frame_result& r
         nf += n;
     }
     r.n_features = nf;
+    return m;
 }
 
 // reference: CylinderTag::estimatePose, CylinderTag.cpp:198-209 (+ PoseEstimator::PnPSolver / PoseBA)
@@ -243,12 +250,20 @@ void CylinderTag::estimatePose(const Mat& img, std::vector<MarkerInfo> markers, 
     cam.n_dist = camera.distCoeffs.size() > 14 ? 14 : (int)camera.distCoeffs.size();
     for (int i = 0; i < cam.n_dist; i++) cam.dist[i] = camera.distCoeffs[(size_t)i];
 #endif
-    ctag_frame_result res;
-    flatten(markers, res);
-    std::vector<ctag_pose_rec> rec((size_t)res.n_markers);
-    const int st = ctag_estimate_pose(h_, &res, model, &cam, rec.data());
+    std::vector<ctag_pose_rec> rec;
+    for (size_t first = 0; first < markers.size();) {  // any number of markers: one record (<= 100 markers / features) at a time
+        ctag_frame_result res;
+        const size_t next = flatten(markers, first, res);
+        const size_t at = rec.size();
+        rec.resize(at + (size_t)res.n_markers);
+        const int st = ctag_estimate_pose(h_, &res, model, &cam, rec.data() + at);
+        if (st != CTAG_OK) {
+            ctag_model_free(model);
+            throw __FUNCTION__ + std::string(", ") + ctag_strerror(st) + "\n";
+        }
+        first = next;
+    }
     ctag_model_free(model);
-    if (st != CTAG_OK) throw __FUNCTION__ + std::string(", ") + ctag_strerror(st) + "\n";
     for (const ctag_pose_rec& p : rec) {
         if (p.status == CTAG_POSE_NO_MODEL) continue;  // pose.erase(remove_if(markerID == -1)), CylinderTag.cpp:206-208
         if (p.status != CTAG_POSE_OK)  // cv::solvePnP throws on < 4 points; an out-of-model position is UB in the reference

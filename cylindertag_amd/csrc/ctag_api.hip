@@ -41,7 +41,10 @@ struct ctag_handle {
     int max_chunk = 1024;
     bool timing = false;
     bool keep_pre = false;
-    hipEvent_t ev[CTAG_NUM_STAGES + 1] = {};
+    // timing (CTAG_OPT_TIMING): one set of CTAG_NUM_STAGES + 1 events per chunk of a public call, read back ONCE after the
+    // call's last chunk has been enqueued (a read-back per chunk would serialise the upload / detect overlap being measured)
+    std::vector<hipEvent_t> ev;
+    int ev_sets_used = 0;
     float stage_ms[CTAG_NUM_STAGES] = {};
     // staging for host-memory entry points: two slabs of `host_sub` frames, filled on copy_stream while the
     // other slab is being processed on `stream`
@@ -59,12 +62,19 @@ struct ctag_handle {
     // state of the pose back end (k_pose.hip), created on first use
     void* pose_state = nullptr;
     void (*pose_state_free)(void*) = nullptr;
+    // state of the multi-GPU gather layer (ctag_gather.hip), created on first use
+    void* gather_state = nullptr;
+    void (*gather_state_free)(void*) = nullptr;
 };
 
 namespace ctag {
 void** handle_pose_slot(ctag_handle* h, void (*free_fn)(void*)) {
     h->pose_state_free = free_fn;
     return &h->pose_state;
+}
+void** handle_gather_slot(ctag_handle* h, void (*free_fn)(void*)) {
+    h->gather_state_free = free_fn;
+    return &h->gather_state;
 }
 bool handle_timing(const ctag_handle* h) { return h->timing; }
 int handle_device(const ctag_handle* h) { return h->device; }
@@ -254,7 +264,18 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
     HIP_TRY(hipMemsetAsync(ws.frame_ncomp, 0, (size_t)n * 4, s));
     HIP_TRY(hipMemsetAsync(ws.frame_flags, 0, (size_t)n * 4, s));
     int st = 0;
-    auto mark = [&](int i) -> hipError_t { return h->timing ? hipEventRecord(h->ev[i], s) : hipSuccess; };
+    hipEvent_t* evs = nullptr;
+    if (h->timing) {
+        const size_t need = (size_t)(h->ev_sets_used + 1) * (CTAG_NUM_STAGES + 1);
+        while (h->ev.size() < need) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        evs = h->ev.data() + (size_t)h->ev_sets_used * (CTAG_NUM_STAGES + 1);
+        h->ev_sets_used++;
+    }
+    auto mark = [&](int i) -> hipError_t { return evs ? hipEventRecord(evs[i], s) : hipSuccess; };
     HIP_TRY(mark(0));
     HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s));
     HIP_TRY(mark(++st));
@@ -280,13 +301,23 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
     return CTAG_OK;
 }
 
+// public entry points call begin_timings() before their first chunk and collect_timings() after their last
+static void begin_timings(ctag_handle* h) {
+    h->ev_sets_used = 0;
+    for (int i = 0; i < CTAG_NUM_STAGES; i++) h->stage_ms[i] = 0.f;
+}
 static int collect_timings(ctag_handle* h) {
-    if (!h->timing) return CTAG_OK;
-    HIP_TRY(hipEventSynchronize(h->ev[CTAG_NUM_STAGES]));
-    for (int i = 0; i < CTAG_NUM_STAGES; i++) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-        h->stage_ms[i] += ms;
+    const int sets = h->ev_sets_used;
+    h->ev_sets_used = 0;
+    if (!h->timing || sets == 0) return CTAG_OK;
+    HIP_TRY(hipEventSynchronize(h->ev[(size_t)sets * (CTAG_NUM_STAGES + 1) - 1]));
+    for (int k = 0; k < sets; k++) {
+        const hipEvent_t* evs = h->ev.data() + (size_t)k * (CTAG_NUM_STAGES + 1);
+        for (int i = 0; i < CTAG_NUM_STAGES; i++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, evs[i], evs[i + 1]));
+            h->stage_ms[i] += ms;
+        }
     }
     return CTAG_OK;
 }
@@ -301,15 +332,10 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
     const int wr = ensure_workspace(h, rows, cols, adaptive_thresh, std::max(chunk, h->ws_rows == rows && h->ws_cols == cols ? h->ws_cap : 0));
     if (wr != CTAG_OK) return wr;
     DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict};
-    for (int i = 0; i < CTAG_NUM_STAGES; i++) h->stage_ms[i] = 0.f;
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int m = std::min(chunk, n - f0);
         const int r = run_chunk(h, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0);
         if (r != CTAG_OK) return r;
-        if (h->timing) {
-            const int t = collect_timings(h);
-            if (t != CTAG_OK) return t;
-        }
     }
     return CTAG_OK;
 }
@@ -412,7 +438,6 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
         ok = hipMalloc(reinterpret_cast<void**>(&h->d_pick_table), tab.size()) == hipSuccess &&
              hipMemcpy(h->d_pick_table, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
-    for (int i = 0; ok && i <= CTAG_NUM_STAGES; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     if (!ok) {
         ctag_destroy(h);
         return CTAG_ERR_HIP;
@@ -428,6 +453,7 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
 void ctag_destroy(ctag_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->d_dict) (void)hipFree(h->d_dict);
@@ -436,6 +462,7 @@ void ctag_destroy(ctag_handle* h) {
     if (h->d_results) (void)hipFree(h->d_results);
     if (h->d_synth) (void)hipFree(h->d_synth);
     if (h->pose_state && h->pose_state_free) h->pose_state_free(h->pose_state);
+    if (h->gather_state && h->gather_state_free) h->gather_state_free(h->gather_state);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
@@ -508,16 +535,25 @@ int ctag_sync(ctag_handle* h) {
 int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
                              int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev) {
     if (!h || !out_dev) return CTAG_ERR_ARG;
-    return detect_device_impl(h, frames_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev);
+    begin_timings(h);
+    const int r = detect_device_impl(h, frames_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev);
+    if (r != CTAG_OK) {
+        h->ev_sets_used = 0;
+        return r;
+    }
+    return collect_timings(h);  // with CTAG_OPT_TIMING the call waits for its last chunk; otherwise it returns at once
 }
 
-int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
-                         int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out) {
-    if (!h || !out) return CTAG_ERR_ARG;
-    const int rc = check_args(h, frames, n, rows, cols, row_stride, adaptive_thresh, subpix_dist);
-    if (rc != CTAG_OK) return rc;
-    if (n == 0) return CTAG_OK;
-    HIP_TRY(hipSetDevice(h->device));
+// both streams idle: every exit of the host-batch path that leaves copies or kernels in flight goes through here, and so does
+// every reallocation of the staging slabs (an upload still running on copy_stream must not lose its destination)
+static int quiesce(ctag_handle* h) {
+    if (h->copy_stream) HIP_TRY(hipStreamSynchronize(h->copy_stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CTAG_OK;
+}
+
+static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                                int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out) {
     // Frames stream through two device slabs: while slab k is processed on the compute stream, slab k+1 is filled over
     // PCIe on the copy stream (main.cpp:29,36,52-54 feed one frame at a time; this is the batched equivalent).  The
     // copies only overlap when `frames` is pinned (ctag_host_alloc / hipHostRegister); pageable memory still works.
@@ -525,7 +561,7 @@ int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows,
     const ptrdiff_t dstride = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;  // packed, 16-byte aligned rows on the device
     const size_t dframe = (size_t)dstride * rows;
     if (h->d_frames_bytes < dframe * sub * 2) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (quiesce(h) != CTAG_OK) return CTAG_ERR_HIP;
         if (h->d_frames) HIP_TRY(hipFree(h->d_frames));
         h->d_frames = nullptr;
         h->d_frames_bytes = 0;
@@ -533,7 +569,7 @@ int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows,
         h->d_frames_bytes = dframe * sub * 2;
     }
     if (h->d_results_count < (size_t)sub * 2) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (quiesce(h) != CTAG_OK) return CTAG_ERR_HIP;
         if (h->d_results) HIP_TRY(hipFree(h->d_results));
         h->d_results = nullptr;
         h->d_results_count = 0;
@@ -580,6 +616,26 @@ int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows,
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return CTAG_OK;
+}
+
+int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                         int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out) {
+    if (!h || !out) return CTAG_ERR_ARG;
+    const int rc = check_args(h, frames, n, rows, cols, row_stride, adaptive_thresh, subpix_dist);
+    if (rc != CTAG_OK) return rc;
+    if (n == 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    begin_timings(h);
+    const int r = detect_batch_u8_impl(h, frames, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out);
+    if (r != CTAG_OK) {  // uploads / kernels may still be in flight: nothing may outlive this call (the caller frees `frames`)
+        h->ev_sets_used = 0;
+        char keep[sizeof(h->last_error)];
+        std::memcpy(keep, h->last_error, sizeof(keep));
+        (void)quiesce(h);
+        std::memcpy(h->last_error, keep, sizeof(keep));
+        return r;
+    }
+    return collect_timings(h);
 }
 
 void* ctag_host_alloc(size_t bytes) {

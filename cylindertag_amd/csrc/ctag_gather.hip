@@ -1,0 +1,512 @@
+// ctag_gather.hip -- implementation of include/ctag_gather.h: frame shards, packed result shards and the one
+// collective of the path: all-gather of the detected marker lists over RCCL.
+//
+// The reference has no counterpart (single process); the record layout that is packed is the
+// flattened `vector<MarkerInfo>` of a frame (include/ctag_types.h <- /root/reference/header/corner_detector.h:16-22).
+// RCCL is bound with dlopen at first use -- no link-time dependency, and a process that already holds a librccl.so.1
+// (PyTorch's) shares it instead of loading a second runtime.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only; every entry point is resolved at run time
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/ctag_gather.h"
+#include "ctag_internal.h"
+
+namespace {
+
+constexpr int kMaxWorld = 64;
+constexpr int kHeadBytes = 16;                      // shard header, and the per-frame head {status, n_markers, n_features, flags}
+constexpr int kRecWords = sizeof(ctag_frame_result) / 4;
+constexpr int kMarkerWords = sizeof(ctag_marker_rec) / 4;
+constexpr int kFeatureWords = sizeof(ctag_feature_rec) / 4;
+constexpr int kMarkersOffWords = offsetof(ctag_frame_result, markers) / 4;
+constexpr int kFeaturesOffWords = offsetof(ctag_frame_result, features) / 4;
+static_assert(sizeof(ctag_frame_result) % 16 == 0 && kMarkersOffWords == 4, "record head is 16 bytes");
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    char err[256] = {0};
+};
+
+Rccl* rccl() {
+    static Rccl R;
+    if (R.lib || R.err[0]) return &R;
+    const char* env = std::getenv("CTAG_RCCL_LIB");
+    if (env && *env) R.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);  // the one this process already holds
+    if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!R.lib) R.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!R.lib) {
+        std::snprintf(R.err, sizeof(R.err), "cannot load librccl.so.1: %s", dlerror());
+        return &R;
+    }
+    R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(dlsym(R.lib, "ncclGetUniqueId"));
+    R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.lib, "ncclCommInitRank"));
+    R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));
+    R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.lib, "ncclAllGather"));
+    R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) {
+        std::snprintf(R.err, sizeof(R.err), "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather");
+        R.lib = nullptr;
+    }
+    return &R;
+}
+
+struct GatherState {
+    int device = 0;
+    hipStream_t gstream = nullptr;   // pack, collectives and unpack run here, beside the detection stream
+    hipEvent_t ev_main = nullptr, ev_packed = nullptr, ev_sizes = nullptr, ev_done = nullptr;
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    int rank = 0, world = 1;
+    unsigned char* d_packed = nullptr;
+    size_t packed_cap = 0;
+    unsigned char* d_gathered = nullptr;
+    size_t gathered_cap = 0;
+    uint64_t* d_off = nullptr;       // per-frame payload offsets of the work on the gather stream (pack: n+1, unpack: n_total + world)
+    size_t off_cap = 0;
+    uint64_t* d_off_main = nullptr;  // the same for the stand-alone ctag_pack_results / ctag_unpack_results (handle's main stream)
+    size_t off_main_cap = 0;
+    uint64_t* d_sizes = nullptr;     // [world] packed size of every rank
+    uint64_t* h_sizes = nullptr;     // pinned copy
+    int n_local = 0, n_total = 0;
+    bool in_flight = false;
+    uint64_t last_local = 0, last_padded = 0;
+    char err[256] = {0};
+};
+
+void gather_state_free(void* p) {
+    GatherState* g = static_cast<GatherState*>(p);
+    (void)hipSetDevice(g->device);
+    if (g->gstream) (void)hipStreamSynchronize(g->gstream);
+    if (g->comm && g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
+    if (g->d_packed) (void)hipFree(g->d_packed);
+    if (g->d_gathered) (void)hipFree(g->d_gathered);
+    if (g->d_off) (void)hipFree(g->d_off);
+    if (g->d_off_main) (void)hipFree(g->d_off_main);
+    if (g->d_sizes) (void)hipFree(g->d_sizes);
+    if (g->h_sizes) (void)hipHostFree(g->h_sizes);
+    for (hipEvent_t e : {g->ev_main, g->ev_packed, g->ev_sizes, g->ev_done})
+        if (e) (void)hipEventDestroy(e);
+    if (g->gstream) (void)hipStreamDestroy(g->gstream);
+    delete g;
+}
+
+GatherState* gather_state(ctag_handle* h) {
+    void** slot = ctag::handle_gather_slot(h, gather_state_free);
+    if (!*slot) {
+        GatherState* g = new (std::nothrow) GatherState();
+        if (!g) return nullptr;
+        g->device = ctag::handle_device(h);
+        bool ok = hipSetDevice(g->device) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&g->gstream, hipStreamNonBlocking) == hipSuccess;
+        for (hipEvent_t* e : {&g->ev_main, &g->ev_packed, &g->ev_sizes, &g->ev_done})
+            ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&g->d_sizes), kMaxWorld * sizeof(uint64_t)) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g->h_sizes), kMaxWorld * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+        if (!ok) {
+            gather_state_free(g);
+            return nullptr;
+        }
+        *slot = g;
+    }
+    return static_cast<GatherState*>(*slot);
+}
+
+#define G_HIP(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            std::snprintf(g->err, sizeof(g->err), "%s: %s", #expr, hipGetErrorString(e__));      \
+            return CTAG_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+#define G_NCCL(expr)                                                                                                    \
+    do {                                                                                                                \
+        ncclResult_t r__ = (expr);                                                                                      \
+        if (r__ != ncclSuccess) {                                                                                       \
+            std::snprintf(g->err, sizeof(g->err), "%s: %s", #expr, R->GetErrorString ? R->GetErrorString(r__) : "RCCL error"); \
+            return CTAG_ERR_HIP;                                                                                        \
+        }                                                                                                               \
+    } while (0)
+
+int grow(GatherState* g, unsigned char** p, size_t* cap, size_t need) {
+    if (*cap >= need) return CTAG_OK;
+    G_HIP(hipDeviceSynchronize());  // rare: a buffer grows; nothing on either stream may still use the old one
+    if (*p) G_HIP(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 2 + 4096;
+    G_HIP(hipMalloc(reinterpret_cast<void**>(p), want));
+    *cap = want;
+    return CTAG_OK;
+}
+int grow_off(GatherState* g, uint64_t** off, size_t* off_cap, size_t entries) {
+    size_t cap = *off_cap * sizeof(uint64_t);
+    unsigned char* p = reinterpret_cast<unsigned char*>(*off);
+    const int r = grow(g, &p, &cap, entries * sizeof(uint64_t));
+    *off = reinterpret_cast<uint64_t*>(p);
+    *off_cap = cap / sizeof(uint64_t);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+struct Segments {  // unpack: one packed shard per rank inside the gathered buffer
+    int world;
+    int lo[kMaxWorld];       // first frame of the shard
+    int n[kMaxWorld];        // frames in the shard
+    uint64_t base[kMaxWorld];  // byte offset of the shard in the gathered buffer
+    uint64_t off0[kMaxWorld];  // first entry of the shard's offsets in `off`
+};
+
+__device__ inline uint32_t payload_bytes(int nm, int nf) {
+    nm = min(max(nm, 0), CTAG_MAX_MARKERS);
+    nf = min(max(nf, 0), CTAG_MAX_FEATURES);
+    return (uint32_t)nm * (uint32_t)sizeof(ctag_marker_rec) + (uint32_t)nf * (uint32_t)sizeof(ctag_feature_rec);
+}
+
+// exclusive scan of the per-frame payload sizes by ONE block; heads come either from fixed records (stride = record) or from a
+// packed frame table (stride = 16 B).  Optionally copies the heads into a packed frame table and writes the shard header.
+__device__ void scan_heads(const unsigned char* heads, size_t stride, int n, uint64_t* off, unsigned char* table_out) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int f0 = 0; f0 < n; f0 += blockDim.x) {
+        const int f = f0 + threadIdx.x;
+        uint64_t v = 0;
+        if (f < n) {
+            const int4 hd = *reinterpret_cast<const int4*>(heads + (size_t)f * stride);
+            v = payload_bytes(hd.y, hd.z);
+            if (table_out) *reinterpret_cast<int4*>(table_out + kHeadBytes + (size_t)f * kHeadBytes) = hd;
+        }
+        uint64_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry;
+        for (int w = 0; w < wave; w++) before += wave_sum[w];
+        if (f < n) off[f] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = carry;
+            for (int w = 0; w < nwaves; w++) t += wave_sum[w];
+            carry = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_pack_scan(const ctag_frame_result* res, int n, uint64_t* off, unsigned char* packed, uint64_t* size_out) {
+    scan_heads(reinterpret_cast<const unsigned char*>(res), sizeof(ctag_frame_result), n, off, packed);
+    if (threadIdx.x == 0) {
+        const uint64_t total = (uint64_t)kHeadBytes + (uint64_t)n * kHeadBytes + off[n];
+        int32_t* hd = reinterpret_cast<int32_t*>(packed);
+        hd[0] = n;
+        hd[1] = 0;
+        *reinterpret_cast<uint64_t*>(hd + 2) = total;
+        if (size_out) *size_out = total;
+    }
+}
+
+__global__ __launch_bounds__(128) void k_pack(const ctag_frame_result* res, int n, const uint64_t* off, unsigned char* packed) {
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(res + f);
+        const int nm = min(max((int)src[1], 0), CTAG_MAX_MARKERS), nf = min(max((int)src[2], 0), CTAG_MAX_FEATURES);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(packed + kHeadBytes + (size_t)n * kHeadBytes + off[f]);
+        const int mw = nm * kMarkerWords, fw = nf * kFeatureWords;
+        for (int i = threadIdx.x; i < mw; i += blockDim.x) dst[i] = src[kMarkersOffWords + i];
+        for (int i = threadIdx.x; i < fw; i += blockDim.x) dst[mw + i] = src[kFeaturesOffWords + i];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_unpack_scan(const unsigned char* gathered, Segments S, uint64_t* off) {
+    const int r = blockIdx.x;
+    scan_heads(gathered + S.base[r] + kHeadBytes, kHeadBytes, S.n[r], off + S.off0[r], nullptr);
+}
+
+__global__ __launch_bounds__(256) void k_unpack(const unsigned char* gathered, Segments S, const uint64_t* off, ctag_frame_result* out) {
+    const int r = blockIdx.y;
+    const int n = S.n[r];
+    const unsigned char* shard = gathered + S.base[r];
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        const uint32_t* head = reinterpret_cast<const uint32_t*>(shard + kHeadBytes + (size_t)f * kHeadBytes);
+        const int nm = min(max((int)head[1], 0), CTAG_MAX_MARKERS), nf = min(max((int)head[2], 0), CTAG_MAX_FEATURES);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(shard + kHeadBytes + (size_t)n * kHeadBytes + off[S.off0[r] + f]);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + S.lo[r] + f);
+        const int mw = nm * kMarkerWords, fw = nf * kFeatureWords;
+        for (int i = threadIdx.x; i < kRecWords; i += blockDim.x) {
+            uint32_t v = 0;
+            if (i < kMarkersOffWords) v = head[i];
+            else if (i < kFeaturesOffWords) v = (i - kMarkersOffWords) < mw ? src[i - kMarkersOffWords] : 0u;
+            else v = (i - kFeaturesOffWords) < fw ? src[mw + i - kFeaturesOffWords] : 0u;
+            dst[i] = v;
+        }
+    }
+}
+
+int enqueue_pack(GatherState* g, bool main_stream, const ctag_frame_result* results_dev, int n, unsigned char* packed, uint64_t* size_dev, hipStream_t s) {
+    uint64_t** off = main_stream ? &g->d_off_main : &g->d_off;
+    const int r = grow_off(g, off, main_stream ? &g->off_main_cap : &g->off_cap, (size_t)n + 1 + kMaxWorld);
+    if (r != CTAG_OK) return r;
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, s, results_dev, n, *off, packed, size_dev);
+    if (n > 0) hipLaunchKernelGGL(k_pack, dim3(std::min(n, 65535)), dim3(128), 0, s, results_dev, n, *off, packed);
+    G_HIP(hipGetLastError());
+    return CTAG_OK;
+}
+
+int enqueue_unpack(GatherState* g, bool main_stream, const unsigned char* gathered, const Segments& S, int n_total, ctag_frame_result* out, hipStream_t s) {
+    uint64_t** offp = main_stream ? &g->d_off_main : &g->d_off;
+    const int r = grow_off(g, offp, main_stream ? &g->off_main_cap : &g->off_cap, (size_t)n_total + 1 + kMaxWorld);
+    if (r != CTAG_OK) return r;
+    uint64_t* d_off = *offp;
+    int nmax = 0;
+    for (int k = 0; k < S.world; k++) nmax = std::max(nmax, S.n[k]);
+    hipLaunchKernelGGL(k_unpack_scan, dim3(S.world), dim3(1024), 0, s, gathered, S, d_off);
+    if (nmax > 0) hipLaunchKernelGGL(k_unpack, dim3(std::min(nmax, 65535), S.world), dim3(256), 0, s, gathered, S, d_off, out);
+    G_HIP(hipGetLastError());
+    return CTAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctag_shard_range(int n_total, int rank, int world, int* lo, int* hi) {
+    if (n_total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return CTAG_ERR_ARG;
+    const int base = n_total / world, rem = n_total % world;
+    *lo = rank * base + std::min(rank, rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+    return CTAG_OK;
+}
+
+size_t ctag_packed_capacity(int n_frames) {
+    if (n_frames < 0) return 0;
+    return (size_t)kHeadBytes + (size_t)n_frames * (kHeadBytes + CTAG_MAX_MARKERS * sizeof(ctag_marker_rec) + CTAG_MAX_FEATURES * sizeof(ctag_feature_rec));
+}
+
+int ctag_pack_results(ctag_handle* h, const ctag_frame_result* results_dev, int n, void* packed_dev, size_t capacity, uint64_t* packed_bytes_host) {
+    if (!h || n < 0 || (n > 0 && !results_dev) || !packed_dev || capacity < ctag_packed_capacity(n)) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    G_HIP(hipSetDevice(g->device));
+    hipStream_t s = static_cast<hipStream_t>(ctag_stream(h));
+    const int r = enqueue_pack(g, true, results_dev, n, static_cast<unsigned char*>(packed_dev), packed_bytes_host ? g->d_sizes : nullptr, s);
+    if (r != CTAG_OK) return r;
+    if (packed_bytes_host) {
+        G_HIP(hipMemcpyAsync(g->h_sizes, g->d_sizes, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        G_HIP(hipStreamSynchronize(s));
+        *packed_bytes_host = g->h_sizes[0];
+    }
+    return CTAG_OK;
+}
+
+int ctag_unpack_results(ctag_handle* h, const void* packed_dev, int n, ctag_frame_result* out_dev) {
+    if (!h || n < 0 || !packed_dev || (n > 0 && !out_dev)) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    G_HIP(hipSetDevice(g->device));
+    Segments S{};
+    S.world = 1;
+    S.n[0] = n;
+    return enqueue_unpack(g, true, static_cast<const unsigned char*>(packed_dev), S, n, out_dev, static_cast<hipStream_t>(ctag_stream(h)));
+}
+
+int ctag_comm_unique_id(void* id_bytes) {
+    if (!id_bytes) return CTAG_ERR_ARG;
+    Rccl* R = rccl();
+    if (!R->lib) return CTAG_ERR_HIP;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return CTAG_ERR_HIP;
+    static_assert(sizeof(id) == CTAG_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    std::memcpy(id_bytes, &id, sizeof(id));
+    return CTAG_OK;
+}
+
+int ctag_comm_destroy(ctag_handle* h) {
+    if (!h) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    if (g->comm) {
+        (void)hipSetDevice(g->device);
+        (void)hipStreamSynchronize(g->gstream);
+        if (g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
+    }
+    g->comm = nullptr;
+    g->own_comm = false;
+    g->rank = 0;
+    g->world = 1;
+    g->in_flight = false;
+    return CTAG_OK;
+}
+
+int ctag_comm_init(ctag_handle* h, const void* id_bytes, int rank, int world) {
+    if (!h || !id_bytes || world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    Rccl* R = rccl();
+    if (!R->lib) {
+        std::snprintf(g->err, sizeof(g->err), "%s", R->err);
+        return CTAG_ERR_HIP;
+    }
+    (void)ctag_comm_destroy(h);
+    G_HIP(hipSetDevice(g->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    G_NCCL(R->CommInitRank(&g->comm, world, id, rank));
+    g->own_comm = true;
+    g->rank = rank;
+    g->world = world;
+    return CTAG_OK;
+}
+
+int ctag_comm_attach(ctag_handle* h, void* nccl_comm, int rank, int world) {
+    if (!h || !nccl_comm || world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    Rccl* R = rccl();
+    if (!R->lib) {
+        std::snprintf(g->err, sizeof(g->err), "%s", R->err);
+        return CTAG_ERR_HIP;
+    }
+    (void)ctag_comm_destroy(h);
+    g->comm = static_cast<ncclComm_t>(nccl_comm);
+    g->own_comm = false;
+    g->rank = rank;
+    g->world = world;
+    return CTAG_OK;
+}
+
+const char* ctag_comm_last_error(ctag_handle* h) {
+    if (!h) return "";
+    GatherState* g = gather_state(h);
+    return g ? g->err : "";
+}
+
+int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_local, int n_total) {
+    if (!h || n_local < 0 || n_total < n_local || (n_local > 0 && !local_dev)) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    if (g->in_flight) return CTAG_ERR_ARG;
+    int lo = 0, hi = 0;
+    (void)ctag_shard_range(n_total, g->rank, g->world, &lo, &hi);
+    if (hi - lo != n_local) {
+        std::snprintf(g->err, sizeof(g->err), "rank %d of %d owns %d of %d frames, got n_local = %d", g->rank, g->world, hi - lo, n_total, n_local);
+        return CTAG_ERR_ARG;
+    }
+    Rccl* R = rccl();
+    if (g->world > 1 && (!g->comm || !R->lib)) {
+        std::snprintf(g->err, sizeof(g->err), "no communicator: call ctag_comm_init / ctag_comm_attach first");
+        return CTAG_ERR_ARG;
+    }
+    G_HIP(hipSetDevice(g->device));
+    hipStream_t main_s = static_cast<hipStream_t>(ctag_stream(h));
+    const int n_max = (n_total + g->world - 1) / g->world;
+    int r = grow(g, &g->d_packed, &g->packed_cap, ctag_packed_capacity(n_max));
+    if (r != CTAG_OK) return r;
+    // the gather stream picks up behind the detection already enqueued on the main stream
+    G_HIP(hipEventRecord(g->ev_main, main_s));
+    G_HIP(hipStreamWaitEvent(g->gstream, g->ev_main, 0));
+    r = enqueue_pack(g, false, local_dev, n_local, g->d_packed, g->d_sizes + g->rank, g->gstream);
+    if (r != CTAG_OK) return r;
+    // local_dev may be overwritten by whatever the caller enqueues next on the main stream: order it behind the pack
+    G_HIP(hipEventRecord(g->ev_packed, g->gstream));
+    G_HIP(hipStreamWaitEvent(main_s, g->ev_packed, 0));
+    if (g->comm) G_NCCL(R->AllGather(g->d_sizes + g->rank, g->d_sizes, 1, ncclUint64, g->comm, g->gstream));
+    G_HIP(hipMemcpyAsync(g->h_sizes, g->d_sizes, sizeof(uint64_t) * g->world, hipMemcpyDeviceToHost, g->gstream));
+    G_HIP(hipEventRecord(g->ev_sizes, g->gstream));
+    g->n_local = n_local;
+    g->n_total = n_total;
+    g->in_flight = true;
+    return CTAG_OK;
+}
+
+int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
+    if (!h || !out_dev) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    if (!g->in_flight) return CTAG_ERR_ARG;
+    g->in_flight = false;
+    Rccl* R = rccl();
+    G_HIP(hipSetDevice(g->device));
+    G_HIP(hipEventSynchronize(g->ev_sizes));  // the only host wait of the exchange: world x 8 bytes
+    uint64_t width = 0;
+    for (int r = 0; r < g->world; r++) {
+        if (g->h_sizes[r] > ctag_packed_capacity((g->n_total + g->world - 1) / g->world)) {
+            std::snprintf(g->err, sizeof(g->err), "rank %d reports a packed shard of %llu bytes", r, (unsigned long long)g->h_sizes[r]);
+            return CTAG_ERR_ARG;
+        }
+        width = std::max(width, g->h_sizes[r]);
+    }
+    width = (width + 255) & ~(uint64_t)255;
+    g->last_local = g->h_sizes[g->rank];
+    g->last_padded = width;
+    Segments S{};
+    S.world = g->world;
+    uint64_t off0 = 0;
+    for (int r = 0; r < g->world; r++) {
+        int lo = 0, hi = 0;
+        (void)ctag_shard_range(g->n_total, r, g->world, &lo, &hi);
+        S.lo[r] = lo;
+        S.n[r] = hi - lo;
+        S.base[r] = (uint64_t)r * width;
+        S.off0[r] = off0;
+        off0 += (uint64_t)(hi - lo) + 1;
+    }
+    const unsigned char* gathered = g->d_packed;
+    if (g->comm) {
+        const int rc = grow(g, &g->d_gathered, &g->gathered_cap, (size_t)width * g->world);
+        if (rc != CTAG_OK) return rc;
+        G_NCCL(R->AllGather(g->d_packed, g->d_gathered, (size_t)width, ncclUint8, g->comm, g->gstream));
+        gathered = g->d_gathered;
+    }
+    const int rc = enqueue_unpack(g, false, gathered, S, g->n_total, out_dev, g->gstream);
+    if (rc != CTAG_OK) return rc;
+    G_HIP(hipEventRecord(g->ev_done, g->gstream));
+    return CTAG_OK;
+}
+
+int ctag_gather_wait(ctag_handle* h) {
+    if (!h) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    G_HIP(hipSetDevice(g->device));
+    G_HIP(hipStreamSynchronize(g->gstream));
+    return CTAG_OK;
+}
+
+int ctag_gather(ctag_handle* h, const ctag_frame_result* local_dev, int n_local, int n_total, ctag_frame_result* out_dev) {
+    int r = ctag_gather_begin(h, local_dev, n_local, n_total);
+    if (r != CTAG_OK) return r;
+    r = ctag_gather_end(h, out_dev);
+    if (r != CTAG_OK) return r;
+    return ctag_gather_wait(h);
+}
+
+int ctag_gather_last_bytes(ctag_handle* h, uint64_t* local_bytes, uint64_t* padded_bytes) {
+    if (!h) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    if (local_bytes) *local_bytes = g->last_local;
+    if (padded_bytes) *padded_bytes = g->last_padded;
+    return CTAG_OK;
+}
+
+}  // extern "C"

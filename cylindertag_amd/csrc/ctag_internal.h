@@ -163,6 +163,8 @@ void build_pick_table(uint8_t* table);  // kPickN*20*10 bytes
 
 // accessors of the opaque handle for the pose back end (k_pose.hip)
 void** handle_pose_slot(struct ::ctag_handle* h, void (*free_fn)(void*));
+// ... and for the multi-GPU gather layer (ctag_gather.hip)
+void** handle_gather_slot(struct ::ctag_handle* h, void (*free_fn)(void*));
 bool handle_timing(const struct ::ctag_handle* h);
 int handle_device(const struct ::ctag_handle* h);
 

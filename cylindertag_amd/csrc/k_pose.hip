@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void k_pose_offsets(const ctag_frame_result* _
     const int per = (n_frames + 255) / 256;
     const int f0 = tid * per, f1 = min(f0 + per, n_frames);
     int32_t s = 0;
-    for (int f = f0; f < f1; f++) s += (res[f].status == CTAG_OK) ? res[f].n_markers : 0;
+    // a corrupted record cannot make the work list (or a reader of FR.markers[]) run past the record's arrays
+    auto count = [&](int f) -> int32_t { return res[f].status == CTAG_OK ? min(max(res[f].n_markers, 0), CTAG_MAX_MARKERS) : 0; };
+    for (int f = f0; f < f1; f++) s += count(f);
     part[tid] = s;
     __syncthreads();
     if (tid == 0) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void k_pose_offsets(const ctag_frame_result* _
     int32_t run = part[tid];
     for (int f = f0; f < f1; f++) {
         offsets[f] = run;
-        run += (res[f].status == CTAG_OK) ? res[f].n_markers : 0;
+        run += count(f);
     }
 }
 
@@ -218,6 +220,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         int status = mi < 0 ? CTAG_POSE_NO_MODEL : CTAG_POSE_OK;
         int n = 0;
         const int nf = M.n_features;
+        // a marker that points outside the frame's feature array (hand-built or corrupted record) is rejected, never read
+        if (status == CTAG_POSE_OK && (M.first_feature < 0 || nf < 0 || M.first_feature > CTAG_MAX_FEATURES - nf)) status = CTAG_POSE_BAD_POS;
         if (status == CTAG_POSE_OK) {
             const float* __restrict__ corners = model.corners + (size_t)mi * model.model_size * 24;
             for (int j = 0; j < nf; j++) {

@@ -1,59 +1,124 @@
-"""Multi-GPU plumbing: one process per GPU, frames sharded contiguously, one all-gather of the result records.
+"""Multi-GPU plumbing around include/ctag_gather.h: one process per GPU, frames sharded contiguously, ONE exchange at the
+end -- the gather of the detected marker lists (north_star).
 
 Frames are independent (the reference clears all per-frame state, CylinderTag.cpp:73-76), so the data path has no
-collective; the only exchange is the final gather of marker lists (north_star).  backend "nccl" is RCCL on ROCm;
-the same code runs on "gloo" CPU tensors, which is how the CPU test-suite covers it."""
+collective.  On GPUs the gather is the library's own (`ctag_gather*`: pack kernel -> ncclAllGather of the packed sizes ->
+ncclAllGather of the packed shards -> unpack kernel, RCCL called directly from the C ABI); `CommGather` below only
+bootstraps its communicator through torch.distributed.  The numpy functions restate the packed-shard format on the
+host: they are what the world_size-2 gloo tests run (no GPU there), and the GPU tests check the kernels against them."""
 import numpy as np
+
+HEAD = 16  # shard header, and the head {status, n_markers, n_features, flags} of a record
+MAX_MARKERS = MAX_FEATURES = 100
+MARKER_BYTES, FEATURE_BYTES, RECORD_BYTES = 16, 100, 11616
+_MARKERS_OFF, _FEATURES_OFF = HEAD, HEAD + MAX_MARKERS * MARKER_BYTES
 
 
 def shard_range(n_frames, rank, world):
-    """Contiguous frame range [lo, hi) owned by `rank` (first ranks take the remainder)."""
+    """Contiguous frame range [lo, hi) owned by `rank` (first ranks take the remainder) == ctag_shard_range."""
     base, rem = divmod(n_frames, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class _Gather:
-    """Handle of one (possibly still running) gather: wait() returns the [n_total, record_bytes] tensor in frame order."""
+def _as_bytes(records):
+    a = np.ascontiguousarray(records)
+    a = a.view(np.uint8).reshape(-1, RECORD_BYTES)
+    return a
 
-    def __init__(self, out, work, counts, width, local):
-        self.out, self.work, self.counts, self.width, self.local = out, work, counts, width, local
+
+def pack_records(records):
+    """n fixed records (any array whose rows are the 11 616 record bytes) -> packed shard (uint8 array), the layout of
+    include/ctag_gather.h: header {n, 0, total_bytes}, n record heads, then per frame its used marker and feature records."""
+    a = _as_bytes(records)
+    n = a.shape[0]
+    heads = a[:, :HEAD].copy().view(np.int32).reshape(n, 4)
+    nm = np.clip(heads[:, 1], 0, MAX_MARKERS)
+    nf = np.clip(heads[:, 2], 0, MAX_FEATURES)
+    parts = [np.zeros(HEAD, np.uint8), heads.view(np.uint8).ravel()]
+    for f in range(n):
+        parts.append(a[f, _MARKERS_OFF:_MARKERS_OFF + int(nm[f]) * MARKER_BYTES])
+        parts.append(a[f, _FEATURES_OFF:_FEATURES_OFF + int(nf[f]) * FEATURE_BYTES])
+    out = np.concatenate(parts)
+    hd = out[:HEAD].view(np.int32)
+    hd[0] = n
+    out[8:16].view(np.int64)[0] = out.size
+    return out
+
+
+def unpack_records(packed, n=None):
+    """packed shard -> uint8 array [n, 11 616] of fixed records (unused bytes zero, as the detector writes them)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    n_in = int(packed[:4].view(np.int32)[0])
+    n = n_in if n is None else n
+    assert n == n_in, "shard holds %d frames, expected %d" % (n_in, n)
+    heads = packed[HEAD:HEAD + n * HEAD].view(np.int32).reshape(n, 4)
+    out = np.zeros((n, RECORD_BYTES), np.uint8)
+    p = HEAD + n * HEAD
+    for f in range(n):
+        nm, nf = int(np.clip(heads[f, 1], 0, MAX_MARKERS)), int(np.clip(heads[f, 2], 0, MAX_FEATURES))
+        out[f, :HEAD] = heads[f].view(np.uint8)
+        out[f, _MARKERS_OFF:_MARKERS_OFF + nm * MARKER_BYTES] = packed[p:p + nm * MARKER_BYTES]
+        p += nm * MARKER_BYTES
+        out[f, _FEATURES_OFF:_FEATURES_OFF + nf * FEATURE_BYTES] = packed[p:p + nf * FEATURE_BYTES]
+        p += nf * FEATURE_BYTES
+    assert p == int(packed[8:16].view(np.int64)[0]), "packed size mismatch"
+    return out
+
+
+def gather_records(local, n_total, dist=None, stats=None):
+    """Host form of ctag_gather (same protocol, torch.distributed collectives on CPU tensors -- the gloo tests): `local` =
+    this rank's records; returns uint8 [n_total, 11 616], identical on every rank.  `stats` (dict) receives the byte counts."""
+    import torch
+    a = _as_bytes(local)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return unpack_records(pack_records(a))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(n_total, rank, world)
+    assert hi - lo == a.shape[0], "rank %d owns frames [%d, %d), got %d records" % (rank, lo, hi, a.shape[0])
+    packed = pack_records(a)
+    sizes = torch.zeros(world, dtype=torch.int64)
+    dist.all_gather_into_tensor(sizes, torch.tensor([packed.size], dtype=torch.int64))  # exchange 1: world x 8 bytes
+    width = (int(sizes.max()) + 255) & ~255
+    send = torch.zeros(width, dtype=torch.uint8)
+    send[:packed.size] = torch.from_numpy(packed)
+    recv = torch.empty(world * width, dtype=torch.uint8)
+    dist.all_gather_into_tensor(recv, send)                                              # exchange 2: the packed shards
+    if stats is not None:
+        stats.update(local_bytes=int(packed.size), padded_bytes=width, fixed_record_bytes=a.shape[0] * RECORD_BYTES)
+    buf = recv.numpy()
+    parts = []
+    for r in range(world):
+        rlo, rhi = shard_range(n_total, r, world)
+        parts.append(unpack_records(buf[r * width:r * width + int(sizes[r])], rhi - rlo))
+    return np.concatenate(parts, 0)
+
+
+class CommGather:
+    """The library's RCCL gather (include/ctag_gather.h) for one Detector: __init__ bootstraps the communicator (rank 0's
+    ncclUniqueId travels through the already-initialised torch.distributed group, the only thing torch does here);
+    begin/end/wait map 1:1 onto ctag_gather_begin/_end/_wait."""
+
+    def __init__(self, det, dist):
+        import torch
+        from . import capi
+        self.det, self.rank, self.world = det, dist.get_rank(), dist.get_world_size()
+        ident = [capi.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        det.comm_init(ident[0], self.rank, self.world)
+        torch.cuda.synchronize()
+
+    def begin(self, local, n_total):
+        self.det.gather_begin(local.data_ptr(), local.shape[0], n_total)
+
+    def end(self, out):
+        self.det.gather_end(out.data_ptr())
 
     def wait(self):
-        import torch
-        if self.work is None:
-            return self.local
-        self.work.wait()
-        if self.out.is_cuda:  # nccl: wait() only orders the current stream behind the collective
-            torch.cuda.current_stream(self.out.device).synchronize()
-        parts = [self.out[r * self.width:r * self.width + (hi - lo)] for r, (lo, hi) in enumerate(self.counts)]
-        return torch.cat(parts, 0)
+        self.det.gather_wait()
 
-
-def gather_results_async(local, n_total, dist=None):
-    """Starts the all-gather of per-rank result records (torch uint8 tensor [n_local, record_bytes]) and returns a
-    handle; the collective runs while the caller enqueues the next batch.  `local` must stay untouched until wait().
-
-    Ranks may own different counts (shard_range); shards are padded to the largest one for the collective and
-    trimmed afterwards."""
-    import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return _Gather(None, None, None, 0, local)
-    world = dist.get_world_size()
-    counts = [shard_range(n_total, r, world) for r in range(world)]
-    width = max(hi - lo for lo, hi in counts)
-    padded = local
-    if local.shape[0] < width:
-        pad = torch.zeros((width - local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
-        padded = torch.cat([local, pad], 0)
-    out = torch.empty((world * width, local.shape[1]), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(out, padded.contiguous(), async_op=True)
-    return _Gather(out, work, counts, width, local)
-
-
-def gather_results(local, n_total, dist=None):
-    """Blocking form: returns a tensor [n_total, record_bytes] identical on every rank."""
-    return gather_results_async(local, n_total, dist).wait()
+    def close(self):
+        self.det.comm_destroy()
 
 
 def records_from_tensor(t, dtype):

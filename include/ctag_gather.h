@@ -1,0 +1,80 @@
+/* ctag_gather.h -- C ABI of the multi-GPU step (libctag_hip.so): frame shards and the final gather of marker lists.
+ *
+ * The reference is a single-process program (no collective anywhere); north_star adds the
+ * only exchange there is: "a batch of independent frames shards trivially across the 8 GPUs of one node with RCCL
+ * over xGMI only for the final gather of detected marker lists" (SURVEY.md 8(e)).  One process per GPU, one
+ * ctag_handle each; frames are split into contiguous ranges (ctag_shard_range) and every rank ends up with the
+ * result records of ALL frames in frame order, byte-identical to a one-GPU run.
+ *
+ * What travels is not the fixed 11 616-byte record per frame but a packed shard ("counts + used
+ * records"): per frame the 16-byte record head (status, n_markers, n_features, flags) followed by its n_markers marker
+ * records and n_features feature records.  Exchange = ncclAllGather of the packed sizes, then ONE ncclAllGather of the
+ * packed shards padded to the largest, then an unpack kernel that rebuilds the fixed records.
+ *
+ * RCCL is bound at run time (dlopen of the librccl.so.1 the process already holds, e.g. the one PyTorch loaded, else
+ * the system one; CTAG_RCCL_LIB overrides): the library has no link-time dependency on it and single-GPU users never
+ * load it.  A C++ host (the reference is C++, main.cpp:44-60) needs nothing but this header; INTEGRATION.md shows
+ * the loop.
+ */
+#ifndef CTAG_GATHER_H
+#define CTAG_GATHER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ctag.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Contiguous frame range [*lo, *hi) of `rank` when n_total frames are split over `world` ranks; the first
+ * n_total % world ranks own one frame more.  Pure function, no GPU. */
+int ctag_shard_range(int n_total, int rank, int world, int* lo, int* hi);
+
+/* ---- packed shards ------------------------------------------------------------------------------------
+ * Layout of a packed shard of n frames (all little-endian, 4-byte aligned):
+ *   int32 n_frames, int32 reserved(0), int64 total_bytes                                   16 B
+ *   n_frames x { int32 status, n_markers, n_features; uint32 flags }                        16 B each
+ *   per frame, in order: its n_markers marker records (ctag_marker_rec, 16 B each), then its n_features feature records
+ *   (ctag_feature_rec, 100 B each)
+ * Records of frames whose status is not CTAG_OK carry no payload (n_markers = n_features = 0 there). */
+size_t ctag_packed_capacity(int n_frames); /* worst-case bytes of a packed shard */
+/* device records -> packed shard in device memory (capacity >= ctag_packed_capacity(n)); enqueued on the handle's
+ * stream.  If packed_bytes_host is not NULL the call waits and stores the shard's size there. */
+int ctag_pack_results(ctag_handle* h, const ctag_frame_result* results_dev, int n, void* packed_dev, size_t capacity,
+                      uint64_t* packed_bytes_host);
+/* packed shard -> n fixed records in device memory (bytes a record does not use are zero, as the detector writes them) */
+int ctag_unpack_results(ctag_handle* h, const void* packed_dev, int n, ctag_frame_result* out_dev);
+
+/* ---- communicator --------------------------------------------------------------------------------------
+ * ctag_comm_unique_id: ncclGetUniqueId (rank 0 calls it and hands the 128 bytes to the other ranks by any means).
+ * ctag_comm_init: ncclCommInitRank on the handle's device; collective over all ranks.
+ * ctag_comm_attach: use a communicator the caller owns (ncclComm_t passed as void*); it is not destroyed here. */
+#define CTAG_COMM_ID_BYTES 128
+int ctag_comm_unique_id(void* id_bytes);
+int ctag_comm_init(ctag_handle* h, const void* id_bytes, int rank, int world);
+int ctag_comm_attach(ctag_handle* h, void* nccl_comm, int rank, int world);
+int ctag_comm_destroy(ctag_handle* h);
+/* text of the last failure of the gather layer on this handle (RCCL / dlopen message), "" if none */
+const char* ctag_comm_last_error(ctag_handle* h);
+
+/* ---- the gather ------------------------------------------------------------------------------------------
+ * local_dev: this rank's n_local = hi - lo records (ctag_shard_range(n_total, rank, world)), device memory, produced on
+ * the handle's stream.  out_dev: n_total records, device memory, identical on every rank afterwards.
+ *
+ * Two-phase form, so that the host never idles the GPU: _begin enqueues (on the handle's gather stream, ordered after
+ * the work already enqueued on the handle's main stream) pack + all-gather of the sizes + their download; the caller
+ * may now enqueue the NEXT batch's detection; _end waits for the sizes only, then enqueues the payload all-gather and
+ * the unpack and returns; _wait blocks until out_dev is complete.  ctag_gather = the three in a row.
+ * One gather may be in flight per handle. */
+int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_local, int n_total);
+int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev);
+int ctag_gather_wait(ctag_handle* h);
+int ctag_gather(ctag_handle* h, const ctag_frame_result* local_dev, int n_local, int n_total, ctag_frame_result* out_dev);
+/* bytes this rank contributed / the padded per-rank width of the last payload all-gather (introspection for the bench) */
+int ctag_gather_last_bytes(ctag_handle* h, uint64_t* local_bytes, uint64_t* padded_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

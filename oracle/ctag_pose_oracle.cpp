@@ -15,6 +15,7 @@
 // cameraParams.yml every decoded marker gets a sub-pixel reprojection RMS.
 #include "ctag_pose_oracle.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -591,6 +592,9 @@ int ctago_build_correspondences(const ctag_frame_result* r, int marker, const ct
     const int nf = M.n_features;
     const float* corners = model->corners + (size_t)model_index * model->model_size * 8 * 3;
     int n = 0;
+    *n_out = 0;
+    // a record whose marker points outside the frame's feature array (hand-built or corrupted input) is rejected, never read
+    if (M.first_feature < 0 || nf < 0 || M.first_feature > CTAG_MAX_FEATURES - nf) return CTAG_POSE_BAD_POS;
     for (int j = 0; j < nf; j++) {
         const ctag_feature_rec& F = r->features[M.first_feature + j];
         const int d = F.id_left - F.id_right;
@@ -653,7 +657,8 @@ void ctago_linalg_probe(int op, const double* in, double* out) {
 int ctago_pose_frame(const ctag_frame_result* r, const ctag_model_view* model, const ctag_camera* cam, int frame_index,
                      ctag_pose_rec* out) {
     if (r->status != CTAG_OK) return 0;
-    for (int m = 0; m < r->n_markers; m++) {
+    const int n_markers = std::min(std::max(r->n_markers, 0), CTAG_MAX_MARKERS);  // as k_pose_offsets clamps it
+    for (int m = 0; m < n_markers; m++) {
         ctag_pose_rec& P = out[m];
         std::memset(&P, 0, sizeof(P));
         P.frame = frame_index;
@@ -680,7 +685,7 @@ int ctago_pose_frame(const ctag_frame_result* r, const ctag_model_view* model, c
         }
         P.iterations = ctago_pose_ba(cam, n, obj, img, P.rvec, P.tvec, &P.cost0, &P.cost);
     }
-    return r->n_markers;
+    return n_markers;
 }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ from ctag_testlib import GOLDEN, ROOT, read_marker_file
 
 def test_library_exports_every_declared_symbol():
     ca.build()
-    hdr = open(os.path.join(ROOT, "include", "ctag.h")).read() + open(os.path.join(ROOT, "include", "ctag_pose.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("ctag.h", "ctag_pose.h", "ctag_gather.h"))
     declared = set(re.findall(r"\b(ctag_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(capi.EXPORTS)
     L = capi.load_library()

@@ -282,13 +282,14 @@ def test_batch_equals_single_and_is_repeatable(detector, dictionary):
         assert a[k].tobytes() == detector.detect(frames[k]).tobytes()
 
 
-def test_streamed_host_batch(detector, dictionary):
+def test_streamed_host_batch(detector, oracle, dictionary):
     """ctag_detect_batch_u8 streams sub-chunks through two device slabs (upload of k+1 overlapping detection of k): the
-    results equal the single-pass ones for pinned and pageable frame memory, odd sub-chunk counts and strided rows."""
+    records equal the ORACLE's for pinned and pageable frame memory, odd sub-chunk counts and strided rows."""
     state, fs = dictionary
     n = 7
     frames = np.stack([ca.synth_frame_host(state, 300 + f)[0] for f in range(n)])
-    want = detector.detect_batch(frames)
+    want = np.array([oracle.detect_fast(f, state, fs) for f in frames])
+    assert (want["status"] == 0).all() and want["n_markers"].sum() >= 2 * n
     pinned = ca.pinned_empty(frames.shape, np.uint8)
     pinned[...] = frames
     res = ca.pinned_empty((n,), ca.RESULT_DT)
@@ -307,7 +308,17 @@ def test_streamed_host_batch(detector, dictionary):
         st = detector.L.ctag_detect_batch_u8(detector.h, view.ctypes.data, n, view.shape[1], view.shape[2], view.strides[1],
                                              view.strides[0], 5, 1, 5, r.ctypes.data)
         assert st == 0 and r.tobytes() == want.tobytes()
+        # per-stage timers accumulate over the sub-chunks of one call (they used to report the last sub-chunk only)
+        detector.set_option(capi.OPT_HOST_SUBCHUNK, 2)
+        detector.set_option(capi.OPT_TIMING, 1)
+        assert detector.detect_batch(pinned, out=res).tobytes() == want.tobytes()
+        t4 = detector.timings()
+        detector.set_option(capi.OPT_HOST_SUBCHUNK, 128)
+        detector.detect_batch(pinned, out=res)
+        t1 = detector.timings()
+        assert all(v > 0 for v in t4.values()) and sum(t4.values()) > 0.5 * sum(t1.values())
     finally:
+        detector.set_option(capi.OPT_TIMING, 0)
         detector.set_option(capi.OPT_HOST_SUBCHUNK, 128)
 
 
@@ -378,6 +389,89 @@ def test_full_size_batch_properties(detector, oracle, dictionary):
     flagged = [int(f) for f in np.nonzero(a["flags"])[0][:4]]
     for f in sorted(set(list(range(0, n, 16)) + [17, 255, 511] + flagged)):
         assert_same_record(a[f], oracle.detect_fast(frames[f].cpu().numpy(), state, fs), "synthetic frame %d" % f)
+
+
+def test_bench_config_chunk4096(detector, oracle, dictionary):
+    """The configuration the headline number is quoted on (bench.py: 4096 device-generated 1080p frames, ONE pass with
+    CTAG_OPT_MAX_CHUNK = 4096, a 14 GB workspace): its records equal the chunk-1024 run byte for byte, and 72 sampled frames
+    (first, last, every 64th, flagged ones) equal the oracle."""
+    import torch
+    state, fs = dictionary
+    n, rows, cols = 4096, 1080, 1920
+    frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+    detector.synth_frames_device(frames.data_ptr(), 0, n, rows, cols, cols, rows * cols)
+    out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    try:
+        detector.set_option(capi.OPT_MAX_CHUNK, 4096)
+        detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr())
+        detector.sync()
+        big = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+        out.zero_()
+        detector.set_option(capi.OPT_MAX_CHUNK, 1024)
+        detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr())
+        detector.sync()
+        small = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    finally:
+        detector.set_option(capi.OPT_MAX_CHUNK, 1024)
+    assert big.tobytes() == small.tobytes()
+    assert (big["status"] == 0).all() and ((big["flags"] & ~np.uint32(4)) == 0).all()
+    flagged = [int(f) for f in np.nonzero(big["flags"])[0][:4]]
+    sample = sorted(set(list(range(0, n, 64)) + [1, 1023, 1024, 2047, 3071, 4094, 4095] + flagged))
+    assert len(sample) >= 64
+    host = {f: frames[f].cpu().numpy() for f in sample}
+    del frames
+    for f in sample:
+        assert_same_record(big[f], oracle.detect_fast(host[f], state, fs), "chunk-4096 frame %d" % f)
+
+
+def test_packed_shards_and_rccl_gather_single_rank(detector, dictionary):
+    """include/ctag_gather.h on one GPU: k_pack / k_unpack equal the host restatement of the packed-shard format
+    (cylindertag_amd/dist.py) on real detector records, and ctag_gather with a world-1 RCCL communicator (ncclCommInitRank +
+    two ncclAllGather calls through the dlopen'ed librccl) returns the input list."""
+    import torch
+    from cylindertag_amd.dist import pack_records, unpack_records
+    state, fs = dictionary
+    n, rows, cols = 96, 1080, 1920
+    frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+    detector.synth_frames_device(frames.data_ptr(), 40, n, rows, cols, cols, rows * cols)
+    frames[5] = 180      # "No corner detected!"
+    frames[6] = 0
+    frames[7, 500:560, 900:930] = 10
+    rec = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, rec.data_ptr())
+    detector.sync()
+    host = rec.cpu().numpy()
+    assert len(set(host.view(ca.RESULT_DT).ravel()["status"])) >= 2
+    cap = capi.packed_capacity(n)
+    packed = torch.full((cap,), 0xAB, dtype=torch.uint8, device="cuda")
+    nbytes = detector.pack_results(rec.data_ptr(), n, packed.data_ptr(), cap)
+    want = pack_records(host)
+    assert nbytes == want.size and (packed[:nbytes].cpu().numpy() == want).all()
+    back = torch.full((n, ca.RESULT_DT.itemsize), 0xCD, dtype=torch.uint8, device="cuda")
+    detector.unpack_results(packed.data_ptr(), n, back.data_ptr())
+    detector.sync()
+    assert (back.cpu().numpy() == host).all() and (unpack_records(want) == host).all()
+    # empty shard
+    assert detector.pack_results(rec.data_ptr(), 0, packed.data_ptr(), cap) == 16
+    # the collective path: world 1
+    detector.comm_init(capi.comm_unique_id(), 0, 1)
+    try:
+        out = torch.full((n, ca.RESULT_DT.itemsize), 0xEE, dtype=torch.uint8, device="cuda")
+        detector.gather(rec.data_ptr(), n, n, out.data_ptr())
+        assert (out.cpu().numpy() == host).all()
+        lb, pb = detector.gather_last_bytes()
+        assert lb == want.size and pb >= lb and pb < n * ca.RESULT_DT.itemsize // 2
+        # two-phase form with the next detection enqueued in between
+        out.fill_(0x11)
+        detector.gather_begin(rec.data_ptr(), n, n)
+        rec2 = torch.zeros_like(rec)
+        detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, rec2.data_ptr())
+        detector.gather_end(out.data_ptr())
+        detector.gather_wait()
+        detector.sync()
+        assert (out.cpu().numpy() == host).all() and (rec2.cpu().numpy() == host).all()
+    finally:
+        detector.comm_destroy()
 
 
 def test_cpp_cylindertag_class_demo(oracle, dictionary, test_bmp):

@@ -1,5 +1,7 @@
-"""world_size-2 gloo test of the multi-GPU plumbing (cylindertag_amd/dist.py): contiguous frame shards, one
-all-gather of result records, byte-identical to the single-process list in frame order."""
+"""world_size-2 gloo tests of the multi-GPU protocol (include/ctag_gather.h, host form in cylindertag_amd/dist.py):
+contiguous frame shards, packed shards (record heads + used marker / feature records), all-gather of the sizes then of
+the padded shards, byte-identical to the single-process list in frame order.  The records are
+the committed golden DETECTOR records (tests/golden/golden_v1.npz), not synthetic byte patterns."""
 import os
 import socket
 import sys
@@ -8,6 +10,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_NPZ = os.path.join(ROOT, "tests", "golden", "golden_v1.npz")
 
 
 def _free_port():
@@ -18,90 +21,79 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, rec_bytes, ret):
-    import torch
+def _golden_records(n_total):
+    """n_total records in a fixed order: the 64 sequence records, test.bmp, the 8 synthetic ones, plus early-return records."""
+    g = np.load(GOLDEN_NPZ)
+    recs = np.concatenate([g["seq_results"], g["bmp_result"], g["synth_results"]])
+    extra = np.zeros(3, recs.dtype)
+    extra["status"] = [1, 2, -3]     # "No corner detected!", "No feature detected!", CTAG_ERR_LIMIT
+    extra["flags"] = [0, 0, 8]
+    recs = np.concatenate([recs, extra])
+    reps = (n_total + len(recs) - 1) // len(recs)
+    return np.concatenate([recs] * reps)[:n_total]
+
+
+def _worker(rank, world, port, n_total, ret):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
-    from cylindertag_amd.dist import gather_results, shard_range
+    from cylindertag_amd.dist import gather_records, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(n_total, rank, world)
-    # every frame's record is a deterministic function of its global index (stands in for the detector output)
-    local = torch.stack([torch.full((rec_bytes,), (f * 7 + 3) % 251, dtype=torch.uint8) for f in range(lo, hi)]) if hi > lo \
-        else torch.zeros((0, rec_bytes), dtype=torch.uint8)
-    out = gather_results(local, n_total, dist)
-    ret[rank] = out.numpy().copy()
+    local = _golden_records(n_total)[lo:hi]  # stands in for this rank's detector output: the records of ITS frames
+    stats = {}
+    out = gather_records(local, n_total, dist, stats)
+    ret[rank] = (out.copy(), stats)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [8, 7, 1])
-def test_gather_two_ranks_matches_single_process(n_total):
+@pytest.mark.parametrize("n_total", [64, 76, 7, 1])
+def test_gather_two_ranks_equals_the_golden_list(n_total):
     import torch.multiprocessing as mp
-    world, rec = 2, 64
+    world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
-    procs = [mp.Process(target=_worker, args=(r, world, port, n_total, rec, ret)) for r in range(world)]
+    procs = [mp.Process(target=_worker, args=(r, world, port, n_total, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    want = np.stack([np.full((rec,), (f * 7 + 3) % 251, np.uint8) for f in range(n_total)])
+    want = _golden_records(n_total)
+    want_bytes = np.ascontiguousarray(want).view(np.uint8).reshape(n_total, -1)
     for r in range(world):
-        assert ret[r].shape == want.shape and (ret[r] == want).all()
+        got, stats = ret[r]
+        assert got.shape == want_bytes.shape and (got == want_bytes).all()
+        assert got.view(want.dtype).ravel().tobytes() == want.tobytes()
+        if n_total >= 64:  # what travels is a fraction of the fixed 11 616-byte records (SURVEY.md 8(e): counts + used records)
+            assert stats["padded_bytes"] * 2 < stats["fixed_record_bytes"]
 
 
-def _worker_pipelined(rank, world, port, n_local, rec_bytes, steps, ret):
-    """bench.py's N>1 step loop: two result buffers, the gather of step k in flight while step k+1 is produced."""
-    import torch
-    import torch.distributed as dist
-    sys.path.insert(0, ROOT)
-    from cylindertag_amd.dist import gather_results_async
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    bufs = [torch.zeros((n_local, rec_bytes), dtype=torch.uint8) for _ in range(2)]
-    pending, got = [], []
-    for k in range(steps):
-        buf = bufs[k % 2]
-        if len(pending) == 2:
-            got.append(pending.pop(0).wait().numpy().copy())
-        for f in range(n_local):  # "detection" of step k: record = f(global frame index, step)
-            buf[f] = (rank * n_local + f) * 5 + k * 17 + 1
-        pending.append(gather_results_async(buf, world * n_local, dist))
-    while pending:
-        got.append(pending.pop(0).wait().numpy().copy())
-    ret[rank] = np.stack(got)
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_pipelined_gathers_two_ranks():
-    import torch.multiprocessing as mp
-    world, n_local, rec, steps = 2, 3, 32, 5
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = _free_port()
-    procs = [mp.Process(target=_worker_pipelined, args=(r, world, port, n_local, rec, steps, ret)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    want = np.stack([np.stack([np.full((rec,), (f * 5 + k * 17 + 1) % 256, np.uint8) for f in range(world * n_local)])
-                     for k in range(steps)])
-    for r in range(world):
-        assert ret[r].shape == want.shape and (ret[r] == want).all()
+def test_pack_unpack_round_trip_and_layout():
+    from cylindertag_amd.dist import HEAD, pack_records, unpack_records
+    recs = _golden_records(76)
+    packed = pack_records(recs)
+    n = len(recs)
+    assert packed[:4].view(np.int32)[0] == n and packed[8:16].view(np.int64)[0] == packed.size
+    heads = packed[HEAD:HEAD + 16 * n].view(np.int32).reshape(n, 4)
+    assert (heads[:, 0] == recs["status"]).all() and (heads[:, 1] == recs["n_markers"]).all() and (heads[:, 2] == recs["n_features"]).all()
+    assert packed.size == HEAD + 16 * n + int((16 * recs["n_markers"] + 100 * recs["n_features"]).sum())
+    back = unpack_records(packed)
+    assert back.view(recs.dtype).ravel().tobytes() == recs.tobytes()
+    # an empty shard is a bare header
+    assert pack_records(recs[:0]).size == HEAD and unpack_records(pack_records(recs[:0])).shape == (0, recs.dtype.itemsize)
 
 
 def test_shard_ranges_cover_all_frames():
     from cylindertag_amd.dist import shard_range
+    from cylindertag_amd import capi
     for n in (0, 1, 7, 4096, 4099):
         for world in (1, 2, 4, 8):
             spans = [shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+            assert spans == [capi.shard_range(n, r, world) for r in range(world)]  # the C ABI's rule (ctag_shard_range)
