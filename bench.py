@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=4096, help="frames per pipeline pass (workspace size)")
     ap.add_argument("--markers", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the one-thread CPU baseline (0 = skip CPU legs and parity)")
-    ap.add_argument("--cpu-frames-per-thread", type=int, default=8, help="all-cores CPU baseline: frames per hardware thread")
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=32, help="all-cores CPU baseline: frames per hardware thread")
     ap.add_argument("--host-frames", type=int, default=1024,
                     help="frames of the host-memory (PCIe-inclusive) side measurement, 0 = skip; never `value`")
     ap.add_argument("--pose-frames", type=int, default=1024,
@@ -149,13 +149,32 @@ def _native_oracle():
         return Oracle(), "-O2 -ffp-contract=off (portable build; native build failed: %s)" % type(e).__name__
 
 
+def _cpu_quota():
+    """CPUs the container may actually use: cgroup v2 cpu.max / v1 cfs quota (the GPU box grants 16 of its host's 256
+    hardware threads; threads beyond the quota only get throttled).  None = unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(frames_dev, n_one, per_thread, state, fs, subpix):
     """Times the CPU restatement of detect() (oracle, kind 'port') on this host: one thread on the first n_one frames, then
     frame-parallel on every hardware thread (std::thread pool inside the oracle library, >= per_thread frames per
     thread).  Returns (json object, oracle records of the frames it ran) -- the records feed the parity check."""
     orc, build = _native_oracle()
     hw = int(orc.L.ctago_hardware_concurrency()) or (os.cpu_count() or 1)
-    n_all = min(int(frames_dev.shape[0]), max(n_one, per_thread * hw))
+    hw = min(hw, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else hw
+    quota = _cpu_quota()
+    threads = max(1, min(hw, int(quota + 0.5))) if quota else hw  # more threads than granted CPUs only get throttled
+    n_all = min(int(frames_dev.shape[0]), max(n_one, per_thread * threads))
     frames_host = frames_dev[:n_all].cpu().numpy()
     n_one = min(n_one, n_all)
     orc.detect_fast(frames_host[0], state, fs, 5, subpix, 5)  # warm
@@ -166,15 +185,16 @@ def cpu_baseline(frames_dev, n_one, per_thread, state, fs, subpix):
            "sample": "first %d frames of the same synthetic batch, CPU restatement of detect() "
                      "(oracle/ctag_oracle.cpp, %s), 1 thread, %.1f s" % (n_one, build, dt)}
     records = rec_one
-    if hw > 1:
+    if threads > 1:
         runs = []
         for _ in range(2):  # twice: the figure has to be stable
             t0 = time.perf_counter()
-            rec_all, used = orc.detect_many(frames_host, state, fs, 5, subpix, 5, threads=hw)
+            rec_all, used = orc.detect_many(frames_host, state, fs, 5, subpix, 5, threads=threads)
             runs.append(n_all / (time.perf_counter() - t0))
         if rec_all[:n_one].tobytes() != rec_one.tobytes():
             raise AssertionError("frame-parallel oracle records differ from the one-thread ones")
         out["all_cores"] = {"value": max(runs), "unit": "frames/s", "cores": used, "hardware_concurrency": hw,
+                            "cgroup_cpu_quota": quota,
                             "runs_frames_per_s": [round(r, 1) for r in runs],
                             "sample": "first %d frames (%.1f per thread), ctago_detect_many: std::thread pool inside the oracle library"
                                       % (n_all, n_all / used)}

@@ -437,6 +437,7 @@ def test_packed_shards_and_rccl_gather_single_rank(detector, dictionary):
     frames[5] = 180      # "No corner detected!"
     frames[6] = 0
     frames[7, 500:560, 900:930] = 10
+    torch.cuda.synchronize()  # torch's stream wrote the three frames; the detector runs on the library's own stream
     rec = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
     detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, rec.data_ptr())
     detector.sync()
