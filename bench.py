@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=4096, help="frames per pipeline pass (workspace size)")
     ap.add_argument("--markers", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=384, help="sample size of the one-thread CPU baseline (0 = skip CPU legs and parity)")
-    ap.add_argument("--cpu-frames-per-thread", type=int, default=32, help="all-cores CPU baseline: frames per hardware thread")
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=128, help="all-cores CPU baseline: frames per hardware thread")
     ap.add_argument("--host-frames", type=int, default=1024,
                     help="frames of the host-memory (PCIe-inclusive) side measurement, 0 = skip; never `value`")
     ap.add_argument("--pose-frames", type=int, default=1024,
