@@ -55,6 +55,7 @@ def parse_args():
                     help="frames of the detect()+estimatePose side measurement on camera content, 0 = skip; never `value`")
     ap.add_argument("--size", default="1920x1080", help="frame size WxH; the headline metric is 1920x1080 (other sizes are side measurements)")
     ap.add_argument("--no-subpix", action="store_true")
+    ap.add_argument("--latency-calls", type=int, default=200, help="single-frame ctag_detect_u8 calls of the latency side measurement, 0 = skip")
     return ap.parse_args()
 
 
@@ -202,7 +203,7 @@ def cpu_baseline(frames_dev, n_one, per_thread, state, fs, subpix):
     return out, records
 
 
-def latency_side(det, state, fs):
+def latency_side(det, state, fs, calls=200):
     """Side measurement (never `value`): the reference's actual use -- one frame per call (main.cpp:52-59) -- on the
     reference's test.bmp through ctag_detect_u8 (host frame in, host record out)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -211,12 +212,12 @@ def latency_side(det, state, fs):
     for _ in range(20):
         det.detect(img, 5, True, 5)
     ts = []
-    for _ in range(200):
+    for _ in range(calls):
         t0 = time.perf_counter()
         det.detect(img, 5, True, 5)
         ts.append(time.perf_counter() - t0)
     ts = np.sort(np.array(ts)) * 1e3
-    return {"workload": "test.bmp 1920x1200, ctag_detect_u8(img,5,true,5), pageable host frame in, host record out, 200 calls",
+    return {"workload": "test.bmp 1920x1200, ctag_detect_u8(img,5,true,5), pageable host frame in, host record out, %d calls" % calls,
             "latency_ms_median": round(float(ts[len(ts) // 2]), 4), "latency_ms_p10": round(float(ts[len(ts) // 10]), 4),
             "latency_ms_p90": round(float(ts[len(ts) * 9 // 10]), 4)}
 
@@ -426,8 +427,8 @@ def main():
             out["parity"] = None
         if world == 1 and args.host_frames > 0:
             side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
-        if world == 1:
-            side("single_frame_latency", lambda: latency_side(det, state, fs))
+        if world == 1 and args.latency_calls > 0:
+            side("single_frame_latency", lambda: latency_side(det, state, fs, args.latency_calls))
         if world == 1 and args.pose_frames > 0 and (ROWS, COLS) == (1080, 1920):
             del frames
             frames = None

@@ -1,0 +1,137 @@
+// ctag_refine.h -- the per-sample normal search of edgeRefine (/root/reference/corner_detector.cpp:623-657), in two
+// forms that return THE SAME BITS:
+//
+//   search_exact   the reference's arithmetic, expression by expression: pixel = ((int)(x0 + m*nx), (int)(y0 + m*ny)) in
+//                  double, running sums Mn += weight*n, Mcount += weight in step order.
+//   search_fast    the same result from cheaper instructions (k_edge_refine is bound by vector-instruction ISSUE, an FP64
+//                  add / mul / convert costing twice an integer one, profiles/r02_*_pmc_instmix.json):
+//                  * pixel coordinates walk a 32.32 fixed-point progression X += D (two 32-bit integer adds per axis and
+//                    step, the integer part IS the pixel index) instead of 2 FP64 multiplies, 3 FP64 adds and 2 converts.
+//                    The walk may be off by < 2^-26 px; a coordinate that comes within 2^-22 px of an integer (where
+//                    truncation could differ from the double expression) is detected with one v_min3_u32 per step and
+//                    the sample is redone by search_exact (probability ~5e-5 per sample, and ALWAYS the same answer);
+//                  * the running sums are exact in double (every weight is a float square, a multiple of 2^-39 <= 1; 65
+//                    steps at most), hence independent of order and grouping:  with prefix sums P_k = w_0 + ... + w_k and
+//                    Q = P_0 + ... + P_K,   Mcount = P_K   and   Mn = sum (k/4 - range) w_k = (range + 1/4) P_K - Q/4
+//                    -- two FP64 adds per step instead of a multiply, two adds and the increment of n.
+//                  Preconditions (else the caller uses search_exact): every fetched pixel is inside the image
+//                  (`interior`), subpix <= kFastMaxSubpix.
+// tests/test_refine_cpu.py checks the two against each other bit for bit on random and adversarial inputs (through the
+// oracle library's probe), and the GPU parity tests check the kernel against the oracle, which keeps the literal loop.
+#pragma once
+#include <stdint.h>
+
+#include "ctag_math.h"
+
+#if defined(__HIPCC__)
+#define CTR_UNROLL _Pragma("unroll")
+#else
+#define CTR_UNROLL
+#endif
+
+namespace ctr {
+
+constexpr int kFastMaxSubpix = 8;            // exactness bound of the prefix-sum form: 8*8+1 = 65 steps
+constexpr uint32_t kGuard = 1u << 10;        // 2^-22 px on either side of an integer, in 2^-32 px units
+
+CTM_HD float unit(unsigned u8) { return (float)u8 * (float)(1.0 / 255); }  // convertTo(CV_32F, 1/255), CylinderTag.cpp:101
+
+// Reference arithmetic.  `px(x, y)` returns the pixel (0..255) at in-image integer coordinates.  Every pixel on the normal is
+// fetched once: the point at n-1 is the point the step 8 earlier read at n+1 (same double expression, same pixel), kept in an
+// 8-deep ring.  A step whose two pixels are not both inside the image, or whose gradient has the wrong sign, contributes
+// weight +0.0, which leaves the running sums bit-identical to skipping it.
+template <class Px>
+CTM_HD void search_exact(double x0, double y0, double nx, double ny, int subpix, int rows, int cols, Px&& px, double& Mn_out, double& Mcount_out) {
+    const double range = subpix;
+    const int nsteps = 8 * subpix + 1;
+    auto sample = [&](double m) -> float {  // pixel / 255 at (x0, y0) + m * normal, -1 outside the image
+        const int x = (int)(x0 + m * nx);
+        const int y = (int)(y0 + m * ny);
+        const bool in = ((unsigned)x < (unsigned)cols) & ((unsigned)y < (unsigned)rows);
+        const float g = unit(px(in ? x : 0, in ? y : 0));
+        return in ? g : -1.f;
+    };
+    float ring[8];
+    double m = -range - 1;  // all offsets are multiples of 0.25: exact
+CTR_UNROLL
+    for (int u = 0; u < 8; u++) {
+        ring[u] = sample(m);
+        m += 0.25;
+    }
+    double n = -range, Mn = 0, Mcount = 0;  // m == n + 1 from here on
+    for (int st0 = 0; st0 < nsteps; st0 += 8) {
+CTR_UNROLL
+        for (int u = 0; u < 8; u++) {
+            if (st0 + u < nsteps) {
+                const float g1 = sample(m);
+                const float g2 = ring[u];
+                const bool use = (g1 >= 0.f) & (g2 >= 0.f) & !(g1 < g2);
+                const double weight = use ? (double)((g2 - g1) * (g2 - g1)) : 0.0;
+                Mn += weight * n;
+                Mcount += weight;
+                ring[u] = g1;
+                m += 0.25;
+                n += 0.25;
+            }
+        }
+    }
+    Mn_out = Mn;
+    Mcount_out = Mcount;
+}
+
+// true when every pixel the search of this sample touches lies at least one pixel inside the image (so no bounds test is
+// needed per pixel and a coordinate in (-1, 0), which truncates to 0, cannot occur)
+CTM_HD bool interior(double x0, double y0, double nx, double ny, int subpix, int rows, int cols) {
+    const double r = (double)subpix + 1.0;
+    const double xa = x0 - r * nx, xb = x0 + r * nx, ya = y0 - r * ny, yb = y0 + r * ny;
+    const double xlo = xa < xb ? xa : xb, xhi = xa < xb ? xb : xa, ylo = ya < yb ? ya : yb, yhi = ya < yb ? yb : ya;
+    return xlo >= 2.0 && ylo >= 2.0 && xhi <= (double)(cols - 3) && yhi <= (double)(rows - 3);
+}
+
+// Fast form; returns false when a coordinate came too close to an integer (the caller then runs search_exact).
+// Requires interior(...) and subpix <= kFastMaxSubpix.
+template <class Px>
+CTM_HD bool search_fast(double x0, double y0, double nx, double ny, int subpix, Px&& px, double& Mn_out, double& Mcount_out) {
+    const double range = subpix;
+    const int nsteps = 8 * subpix + 1;
+    const double two32 = 4294967296.0;
+    // start point (m = -range - 1) and step (1/4 of the normal) in 32.32 fixed point, biased by +kGuard so that the low word
+    // of a coordinate within kGuard of an integer reads < 2*kGuard
+    uint64_t X = (uint64_t)(int64_t)((x0 - (range + 1) * nx) * two32) + kGuard;
+    uint64_t Y = (uint64_t)(int64_t)((y0 - (range + 1) * ny) * two32) + kGuard;
+    const uint64_t DX = (uint64_t)(int64_t)(nx * (0.25 * two32));
+    const uint64_t DY = (uint64_t)(int64_t)(ny * (0.25 * two32));
+    uint32_t gmin = 0xffffffffu;
+    auto fetch = [&]() -> float {
+        const uint32_t xl = (uint32_t)X, yl = (uint32_t)Y;
+        gmin = gmin < xl ? gmin : xl;
+        gmin = gmin < yl ? gmin : yl;
+        const float g = unit(px((int)(uint32_t)(X >> 32), (int)(uint32_t)(Y >> 32)));
+        X += DX;
+        Y += DY;
+        return g;
+    };
+    float ring[8];
+CTR_UNROLL
+    for (int u = 0; u < 8; u++) ring[u] = fetch();
+    double P = 0, Q = 0;
+    for (int st0 = 0; st0 < nsteps; st0 += 8) {
+CTR_UNROLL
+        for (int u = 0; u < 8; u++) {
+            if (st0 + u < nsteps) {
+                const float g1 = fetch();
+                const float g2 = ring[u];
+                const float d = g2 - g1;
+                const float w = (g1 < g2) ? 0.f : d * d;
+                P += (double)w;
+                Q += P;
+                ring[u] = g1;
+            }
+        }
+    }
+    Mcount_out = P;
+    Mn_out = (range + 0.25) * P - 0.25 * Q;
+    return gmin >= 2u * kGuard;
+}
+
+}  // namespace ctr

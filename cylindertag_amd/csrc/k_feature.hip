@@ -13,6 +13,7 @@
 //       and replays the reference's order-dependent max / second-max bookkeeping afterwards.
 #include "ctag_internal.h"
 #include "ctag_math.h"
+#include "ctag_refine.h"
 
 namespace ctag {
 
@@ -312,7 +313,12 @@ struct RefinePtrs {
     const FeatureDev* feat1;
     FeatureDev* feat2;
 };
-constexpr int kRefineThreads = 128;
+constexpr int kRefineSamples = 128;               // samples of an edge searched per pass (the reference's minimum sample count, :615)
+constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: waves 0-1 edge e, waves 2-3 edge e + 1
+#ifndef CTAG_REFINE_REGION
+#define CTAG_REFINE_REGION 15872                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 32 KB per block)
+#endif
+constexpr int kRefineRegion = CTAG_REFINE_REGION;
 
 __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
@@ -320,12 +326,17 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
     // 16 columns of per-sample values: rows 0-3 x of edge 0-3, 4-7 y, 8-11 weight towards the next corner, 12-15 towards the
     // last one (0 for a sample without an edge point).  The odd row length puts the 16 rows on 16 different LDS bank
     // pairs: the accumulation reads one element of up to 9 rows per instruction.
-    __shared__ double s_v[16][kRefineThreads + 1];
-    double (*s_bx)[kRefineThreads + 1] = s_v, (*s_by)[kRefineThreads + 1] = s_v + 4;
+    __shared__ double s_v[16][kRefineSamples + 1];
+    double (*s_bx)[kRefineSamples + 1] = s_v, (*s_by)[kRefineSamples + 1] = s_v + 4;
     __shared__ double s_nrm[4][2];                // unit normal of each edge
     __shared__ double s_one;
     __shared__ double s_acc[48];
     __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
+    // The pixels the searches of this quad can touch -- the bounding box of its corners grown by the search length --
+    // staged once with coalesced row loads: the 4 x 128 x 49 scattered byte loads of the searches then gather from LDS
+    // instead of going through the texture-address path, which was as busy as the vector ALUs (70 % TA busy,
+    // profiles/r02_before_pmc_instmix.json).  A box that does not fit stays in global memory (uniform per block).
+    __shared__ __attribute__((aligned(16))) uint8_t s_reg[kRefineRegion];
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
     if (P.status[frame] != CTAG_OK) return;
@@ -334,11 +345,11 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
     const int tid = threadIdx.x;
     const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi;
     const uint8_t* __restrict__ img = P.frames + (ptrdiff_t)frame * P.frame_stride;
-    const float k255 = (float)(1.0 / 255);
     const uint32_t rs = (uint32_t)P.row_stride;
     const int off = quad * 4;
     __shared__ float s_cx[4], s_cy[4];
     __shared__ int s_ns[4];
+    __shared__ int s_box[4];  // x0, y0 of the staged box, its pitch, its rows (0 = not staged)
     if (tid < 4) {
         s_cx[tid] = F->c[2 * (off + tid)];
         s_cy[tid] = F->c[2 * (off + tid) + 1];
@@ -356,12 +367,59 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
         s_nrm[tid][1] = ny / mag;
         if (tid == 0) s_one = 1.0;
     }
+    if (tid == 64) {  // the box: corners +- (search length + 2), clipped to the image; columns from a multiple of 4
+        const float m = (float)(subpix + 3);
+        const float fx0 = fminf(fminf(s_cx[0], s_cx[1]), fminf(s_cx[2], s_cx[3])) - m, fx1 = fmaxf(fmaxf(s_cx[0], s_cx[1]), fmaxf(s_cx[2], s_cx[3])) + m;
+        const float fy0 = fminf(fminf(s_cy[0], s_cy[1]), fminf(s_cy[2], s_cy[3])) - m, fy1 = fmaxf(fmaxf(s_cy[0], s_cy[1]), fmaxf(s_cy[2], s_cy[3])) + m;
+        int staged = 0, bx0 = 0, by0 = 0, pitch = 4;
+        // (a corner far outside the image cannot come out of detect(); the comparisons also reject NaN)
+        if (fx0 > -1e6f && fx1 < 1e6f && fy0 > -1e6f && fy1 < 1e6f) {
+            bx0 = max((int)floorf(fx0), 0) & ~3;
+            by0 = max((int)floorf(fy0), 0);
+            const int bx1 = min((int)floorf(fx1) + 1, cols - 1), by1 = min((int)floorf(fy1) + 1, rows - 1);
+            if (bx1 >= bx0 && by1 >= by0) {
+                pitch = (bx1 - bx0 + 4) & ~3;
+                if (((pitch >> 2) & 1) == 0) pitch += 4;  // odd number of banks per row: a column of pixels spreads over the banks
+                staged = (long long)pitch * (by1 - by0 + 1) <= kRefineRegion ? by1 - by0 + 1 : 0;
+            }
+        }
+        s_box[0] = bx0;
+        s_box[1] = by0;
+        s_box[2] = pitch;
+        s_box[3] = staged;  // rows staged, 0 = the box stays in global memory
+    }
     __syncthreads();
+    const int box_x0 = s_box[0], box_y0 = s_box[1], box_pitch = s_box[2], box_rows = s_box[3];
+    const bool staged = box_rows > 0;
+    if (staged) {
+        // rows of the box, 4 bytes per lane: aligned words when the frame's rows allow it, bytes otherwise
+        const int wpr = box_pitch >> 2;  // words per row
+        const int nwords = wpr * box_rows;
+        const bool aligned = ((rs & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(img) & 3u) == 0u);
+        for (int i = tid; i < nwords; i += kRefineThreads) {
+            const int r = i / wpr, c4 = (i - r * wpr) * 4;
+            const int gx = box_x0 + c4;
+            const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx;
+            uint32_t v;
+            if (aligned && gx + 3 < cols) {
+                v = *reinterpret_cast<const uint32_t*>(src);
+            } else {
+                v = 0;
+                for (int k = 0; k < 4; k++)
+                    if (gx + k < cols) v |= (uint32_t)src[k] << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = v;
+        }
+        __syncthreads();
+    }
+    const uint32_t lds_bias = (uint32_t)(-(box_y0 * box_pitch + box_x0));  // (y - y0) * pitch + (x - x0) = y * pitch + x + bias
+    const int half = tid >> 7, st = tid & (kRefineSamples - 1);
     const int max_ns = max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3]));
-    for (int sbase = 0; sbase < max_ns; sbase += kRefineThreads) {
-        const int s = sbase + tid;
+    for (int sbase = 0; sbase < max_ns; sbase += kRefineSamples) {
+        const int s = sbase + st;
 #pragma nounroll
-        for (int edge = 0; edge < 4; edge++) {  // rolled on purpose: one copy of the search loop keeps the kernel at 5+ waves per SIMD
+        for (int epair = 0; epair < 2; epair++) {  // rolled on purpose: one copy of the search loops
+            const int edge = 2 * epair + half;
             const int a = edge, b = (edge + 1) & 3;
             const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
             const int nsamples = s_ns[edge];
@@ -372,47 +430,20 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                 alpha = (15.0 + s) / (nsamples + 30);
                 const double x0 = alpha * ax + (1 - alpha) * bx;
                 const double y0 = alpha * ay + (1 - alpha) * by;
+                // the normal search of this sample (:623-657): ctag_refine.h -- the fast form where every pixel of the search is
+                // inside the image, the reference's own arithmetic otherwise or when the fast form declines
                 double Mn = 0, Mcount = 0;
-                const double range = subpix;
-                // The reference's loop (:627-649) reads, at every step n = -range, -range+0.25, ..., +range, the pixels at
-                // offsets n+1 and n-1 along the normal.  The point at n-1 is the point the step 8 earlier read at n+1
-                // (same double arithmetic, hence the same pixel), so every pixel is fetched once and kept in an 8-deep
-                // register ring: the kernel is bound by these scattered byte loads.  A step whose two pixels are not both
-                // inside the image, or whose gradient has the wrong sign, contributes weight +0.0, which leaves the
-                // running sums bit-identical to skipping it.  Pixel offsets are 32-bit (checked by the API).
-                const int nsteps = 8 * subpix + 1;
-                auto sample = [&](double m) -> float {  // pixel / 255 at x0 + m * normal, -1 outside the image
-                    const int x = (int)(x0 + m * nx);
-                    const int y = (int)(y0 + m * ny);
-                    const bool in = ((unsigned)x < (unsigned)cols) & ((unsigned)y < (unsigned)rows);
-                    const uint32_t o = in ? __umul24((unsigned)y, rs) + (unsigned)x : 0u;
-                    const float g = (float)img[o] * k255;
-                    return in ? g : -1.f;
-                };
-                float ring[8];
-                double m = -range - 1;  // all offsets are multiples of 0.25: exact
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    ring[u] = sample(m);
-                    m += 0.25;
-                }
-                double n = -range;  // m == n + 1 from here on
-                for (int st0 = 0; st0 < nsteps; st0 += 8) {
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (st0 + u < nsteps) {
-                            const float g1 = sample(m);
-                            const float g2 = ring[u];
-                            const bool use = (g1 >= 0.f) & (g2 >= 0.f) & !(g1 < g2);
-                            const double weight = use ? (double)((g2 - g1) * (g2 - g1)) : 0.0;
-                            Mn += weight * n;
-                            Mcount += weight;
-                            ring[u] = g1;
-                            m += 0.25;
-                            n += 0.25;
-                        }
+                auto px = [&](int x, int y) -> unsigned { return img[__umul24((unsigned)y, rs) + (unsigned)x]; };  // 32-bit pixel offsets (checked by the API)
+                bool done = false;
+                if (subpix <= ctr::kFastMaxSubpix && ctr::interior(x0, y0, nx, ny, subpix, rows, cols)) {
+                    if (staged) {
+                        auto px_lds = [&](int x, int y) -> unsigned { return s_reg[__umul24((unsigned)y, (unsigned)box_pitch) + (unsigned)x + lds_bias]; };
+                        done = ctr::search_fast(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount);
+                    } else {
+                        done = ctr::search_fast(x0, y0, nx, ny, subpix, px, Mn, Mcount);
                     }
                 }
+                if (!done) ctr::search_exact(x0, y0, nx, ny, subpix, rows, cols, px, Mn, Mcount);
                 if (Mcount != 0) {
                     const double n0 = Mn / Mcount;
                     bestx = x0 + n0 * nx;
@@ -420,10 +451,10 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                     ok = true;
                 }
             }
-            s_bx[edge][tid] = bestx;  // 0 when !ok
-            s_by[edge][tid] = besty;
-            s_v[8 + edge][tid] = ok ? 1 - alpha : 0.0;
-            s_v[12 + edge][tid] = ok ? alpha : 0.0;
+            s_bx[edge][st] = bestx;  // 0 when !ok
+            s_by[edge][st] = besty;
+            s_v[8 + edge][st] = ok ? 1 - alpha : 0.0;
+            s_v[12 + edge][st] = ok ? alpha : 0.0;
         }
         __syncthreads();
         if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
@@ -436,7 +467,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
             const int sa = which == 5 ? 0 : 1, sb = (which >= 2 && which <= 4) ? 1 : 0;
             const double* pw = s_v[8 + 4 * pass + edge];
             double acc = s_acc[tid];
-            const int cntS = min(kRefineThreads, s_ns[edge] - sbase);
+            const int cntS = min(kRefineSamples, s_ns[edge] - sbase);
 #pragma unroll 8
             for (int k = 0; k < cntS; k++) acc += (pa[k * sa] * pb[k * sb]) * pw[k];
             s_acc[tid] = acc;

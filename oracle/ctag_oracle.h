@@ -68,6 +68,10 @@ int ctago_detect_many(const uint8_t* frames, int n, int rows, int cols, ptrdiff_
                       int corner_subpix, int subpix_dist, int threads, void* results);
 int ctago_hardware_concurrency(void);
 
+/* probe of the PRODUCT header cylindertag_amd/csrc/ctag_refine.h on the host (see ctag_oracle.cpp) */
+void ctago_refine_probe(const uint8_t* img, int rows, int cols, ptrdiff_t stride, int subpix, int n, const double* xy_nxny,
+                        double* exact, double* fast, double* lit, int32_t* flag);
+
 /* primitive probes for unit tests */
 void ctago_resize_half(const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, uint8_t* dst);
 void ctago_threshold(const uint8_t* half, int rows, int cols, int tw, uint8_t* dst);
