@@ -28,6 +28,14 @@
 #else
 #define CTR_UNROLL
 #endif
+// On the device the coordinate walk is kept as ONE serial chain of 64-bit adds: left alone, the optimiser turns the eight
+// unrolled positions of a group into eight induction variables of their own (2 x 8 extra 64-bit adds per group and ~90
+// more registers, which halves the occupancy).  An empty asm that "modifies" the value is the barrier.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CTR_SERIAL(x) asm volatile("" : "+v"(x))
+#else
+#define CTR_SERIAL(x) ((void)0)
+#endif
 
 namespace ctr {
 
@@ -90,15 +98,19 @@ CTM_HD bool interior(double x0, double y0, double nx, double ny, int subpix, int
 
 // Fast form; returns false when a coordinate came too close to an integer (the caller then runs search_exact).
 // Requires interior(...) and subpix <= kFastMaxSubpix.
-template <class Px>
-CTM_HD bool search_fast(double x0, double y0, double nx, double ny, int subpix, Px&& px, double& Mn_out, double& Mcount_out) {
+// `px` is called with coordinates relative to (org_x, org_y) (the origin of a staged box; exact: an integer offset of the
+// integer part).
+// SUBPIX > 0: the window is a compile-time constant (the group loop unrolls completely and the pixel ring becomes register
+// renaming); SUBPIX == 0: `subpix` at run time.
+template <int SUBPIX = 0, class Px>
+CTM_HD bool search_fast(double x0, double y0, double nx, double ny, int subpix_rt, Px&& px, double& Mn_out, double& Mcount_out, int org_x = 0, int org_y = 0) {
+    const int subpix = SUBPIX > 0 ? SUBPIX : subpix_rt;
     const double range = subpix;
-    const int nsteps = 8 * subpix + 1;
     const double two32 = 4294967296.0;
     // start point (m = -range - 1) and step (1/4 of the normal) in 32.32 fixed point, biased by +kGuard so that the low word
     // of a coordinate within kGuard of an integer reads < 2*kGuard
-    uint64_t X = (uint64_t)(int64_t)((x0 - (range + 1) * nx) * two32) + kGuard;
-    uint64_t Y = (uint64_t)(int64_t)((y0 - (range + 1) * ny) * two32) + kGuard;
+    uint64_t X = (uint64_t)(int64_t)((x0 - (range + 1) * nx) * two32) + kGuard - ((uint64_t)(uint32_t)org_x << 32);
+    uint64_t Y = (uint64_t)(int64_t)((y0 - (range + 1) * ny) * two32) + kGuard - ((uint64_t)(uint32_t)org_y << 32);
     const uint64_t DX = (uint64_t)(int64_t)(nx * (0.25 * two32));
     const uint64_t DY = (uint64_t)(int64_t)(ny * (0.25 * two32));
     uint32_t gmin = 0xffffffffu;
@@ -109,26 +121,38 @@ CTM_HD bool search_fast(double x0, double y0, double nx, double ny, int subpix, 
         const float g = unit(px((int)(uint32_t)(X >> 32), (int)(uint32_t)(Y >> 32)));
         X += DX;
         Y += DY;
+        CTR_SERIAL(X);
+        CTR_SERIAL(Y);
         return g;
     };
     float ring[8];
 CTR_UNROLL
     for (int u = 0; u < 8; u++) ring[u] = fetch();
     double P = 0, Q = 0;
-    for (int st0 = 0; st0 < nsteps; st0 += 8) {
+    auto step = [&](float g1, float g2) {
+        // weight (g2 - g1)^2 when !(g1 < g2), else the step is skipped (:643-645): with d = g2 - g1 that is min(d, 0)^2
+        // (d > 0 -> 0 * 0 = +0, d <= 0 -> d * d), one instruction less than compare + select
+        const float d = g2 - g1;
+        const float dn = d < 0.f ? d : 0.f;
+        P += (double)(dn * dn);
+        Q += P;
+    };
+    // nsteps = 8 * subpix + 1: subpix groups of eight steps whose eight pixels are requested together (their addresses do
+    // not depend on the data), then the last step
+#if defined(__HIPCC__)
+#pragma unroll SUBPIX > 0 ? SUBPIX : 1
+#endif
+    for (int it = 0; it < subpix; it++) {
+        float g[8];
+CTR_UNROLL
+        for (int u = 0; u < 8; u++) g[u] = fetch();
 CTR_UNROLL
         for (int u = 0; u < 8; u++) {
-            if (st0 + u < nsteps) {
-                const float g1 = fetch();
-                const float g2 = ring[u];
-                const float d = g2 - g1;
-                const float w = (g1 < g2) ? 0.f : d * d;
-                P += (double)w;
-                Q += P;
-                ring[u] = g1;
-            }
+            step(g[u], ring[u]);
+            ring[u] = g[u];
         }
     }
+    step(fetch(), ring[0]);
     Mcount_out = P;
     Mn_out = (range + 0.25) * P - 0.25 * Q;
     return gmin >= 2u * kGuard;

@@ -316,7 +316,7 @@ struct RefinePtrs {
 constexpr int kRefineSamples = 128;               // samples of an edge searched per pass (the reference's minimum sample count, :615)
 constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: waves 0-1 edge e, waves 2-3 edge e + 1
 #ifndef CTAG_REFINE_REGION
-#define CTAG_REFINE_REGION 15872                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 32 KB per block)
+#define CTAG_REFINE_REGION 22528                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
 #endif
 constexpr int kRefineRegion = CTAG_REFINE_REGION;
 
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
             if (bx1 >= bx0 && by1 >= by0) {
                 pitch = (bx1 - bx0 + 4) & ~3;
                 if (((pitch >> 2) & 1) == 0) pitch += 4;  // odd number of banks per row: a column of pixels spreads over the banks
-                staged = (long long)pitch * (by1 - by0 + 1) <= kRefineRegion ? by1 - by0 + 1 : 0;
+                staged = ((long long)pitch * (by1 - by0 + 1) <= kRefineRegion && (pitch >> 2) <= kRefineThreads) ? by1 - by0 + 1 : 0;
             }
         }
         s_box[0] = bx0;
@@ -392,27 +392,36 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
     const int box_x0 = s_box[0], box_y0 = s_box[1], box_pitch = s_box[2], box_rows = s_box[3];
     const bool staged = box_rows > 0;
     if (staged) {
-        // rows of the box, 4 bytes per lane: aligned words when the frame's rows allow it, bytes otherwise
-        const int wpr = box_pitch >> 2;  // words per row
-        const int nwords = wpr * box_rows;
+        // rows of the box, 4 bytes per lane: aligned words when the frame's rows allow it, bytes otherwise.  A thread keeps its
+        // column and walks down the rows, four rows requested before the first is stored (the loads of a row-major loop with
+        // a division per word were issued and awaited one at a time: staging a large box then cost more than it saved).
+        const int wpr = box_pitch >> 2;              // words per row
+        const int rpp = kRefineThreads / wpr;        // rows per pass (>= 1: a staged box is at most kRefineThreads words wide)
         const bool aligned = ((rs & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(img) & 3u) == 0u);
-        for (int i = tid; i < nwords; i += kRefineThreads) {
-            const int r = i / wpr, c4 = (i - r * wpr) * 4;
-            const int gx = box_x0 + c4;
-            const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx;
-            uint32_t v;
-            if (aligned && gx + 3 < cols) {
-                v = *reinterpret_cast<const uint32_t*>(src);
-            } else {
-                v = 0;
+        const int r0 = tid / wpr, c4 = (tid - r0 * wpr) * 4;
+        const int gx = box_x0 + c4;
+        if (rpp > 0 && r0 < rpp) {
+            const bool word_ok = aligned && gx + 3 < cols;
+            auto load = [&](int r) -> uint32_t {
+                const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx;
+                if (word_ok) return *reinterpret_cast<const uint32_t*>(src);
+                uint32_t v = 0;
                 for (int k = 0; k < 4; k++)
                     if (gx + k < cols) v |= (uint32_t)src[k] << (8 * k);
+                return v;
+            };
+            int r = r0;
+            for (; r + 3 * rpp < box_rows; r += 4 * rpp) {
+                const uint32_t v0 = load(r), v1 = load(r + rpp), v2 = load(r + 2 * rpp), v3 = load(r + 3 * rpp);
+                *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = v0;
+                *reinterpret_cast<uint32_t*>(s_reg + (r + rpp) * box_pitch + c4) = v1;
+                *reinterpret_cast<uint32_t*>(s_reg + (r + 2 * rpp) * box_pitch + c4) = v2;
+                *reinterpret_cast<uint32_t*>(s_reg + (r + 3 * rpp) * box_pitch + c4) = v3;
             }
-            *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = v;
+            for (; r < box_rows; r += rpp) *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = load(r);
         }
         __syncthreads();
     }
-    const uint32_t lds_bias = (uint32_t)(-(box_y0 * box_pitch + box_x0));  // (y - y0) * pitch + (x - x0) = y * pitch + x + bias
     const int half = tid >> 7, st = tid & (kRefineSamples - 1);
     const int max_ns = max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3]));
     for (int sbase = 0; sbase < max_ns; sbase += kRefineSamples) {
@@ -436,9 +445,10 @@ __global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, in
                 auto px = [&](int x, int y) -> unsigned { return img[__umul24((unsigned)y, rs) + (unsigned)x]; };  // 32-bit pixel offsets (checked by the API)
                 bool done = false;
                 if (subpix <= ctr::kFastMaxSubpix && ctr::interior(x0, y0, nx, ny, subpix, rows, cols)) {
-                    if (staged) {
-                        auto px_lds = [&](int x, int y) -> unsigned { return s_reg[__umul24((unsigned)y, (unsigned)box_pitch) + (unsigned)x + lds_bias]; };
-                        done = ctr::search_fast(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount);
+                    if (staged) {  // the walk runs in box coordinates: the address is one multiply-add
+                        auto px_lds = [&](int x, int y) -> unsigned { return s_reg[__umul24((unsigned)y, (unsigned)box_pitch) + (unsigned)x]; };
+                        done = subpix == 5 ? ctr::search_fast<5>(x0, y0, nx, ny, 5, px_lds, Mn, Mcount, box_x0, box_y0)  // main.cpp:39,57
+                                           : ctr::search_fast<0>(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount, box_x0, box_y0);
                     } else {
                         done = ctr::search_fast(x0, y0, nx, ny, subpix, px, Mn, Mcount);
                     }
