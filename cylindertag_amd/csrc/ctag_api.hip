@@ -100,6 +100,7 @@ static FrameGeom make_geom(int rows, int cols, int tw) {
     g.tiles_x = (g.hcols + kTileW - 1) / kTileW;
     g.tiles_y = (g.hrows + kTileH - 1) / kTileH;
     g.max_area = (int)std::round(0.01 * g.hcols * g.hrows);  // corner_detector.cpp:88
+    g.pool_cap = std::max(kPoolCapMin, 256 * g.tiles_x * g.tiles_y);
     return g;
 }
 
@@ -157,7 +158,9 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_tbase = take(F * tiles * 4);
     const size_t o_ncomp = take(F * 4);
     const size_t o_flags = take(F * 4);
-    const size_t pool = F * kPoolCap * 4;
+    const size_t o_ovfc = take(256);
+    const size_t o_ovfl = take(F * tiles * 4);
+    const size_t pool = F * (size_t)g.pool_cap * 4;
     const size_t o_parent = take(pool), o_root = take(pool), o_area = take(pool), o_xmin = take(pool), o_ymin = take(pool),
                  o_xmax = take(pool), o_ymax = take(pool), o_key = take(pool), o_ptile = take(pool), o_mhead = take(pool), o_mnext = take(pool);
     const size_t o_ncand = take(F * 4);
@@ -192,6 +195,8 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.tile_base = reinterpret_cast<int32_t*>(b + o_tbase);
     W.frame_ncomp = reinterpret_cast<int32_t*>(b + o_ncomp);
     W.frame_flags = reinterpret_cast<uint32_t*>(b + o_flags);
+    W.ovf_count = reinterpret_cast<int32_t*>(b + o_ovfc);
+    W.ovf_list = reinterpret_cast<int32_t*>(b + o_ovfl);
     W.parent = reinterpret_cast<uint32_t*>(b + o_parent);
     W.root_of = reinterpret_cast<int32_t*>(b + o_root);
     W.area = reinterpret_cast<int32_t*>(b + o_area);
@@ -374,7 +379,9 @@ __global__ void k_label_roots(const uint16_t* labels, const int32_t* tile_base, 
     if (x >= g.hcols || y >= g.hrows) return;
     const unsigned l = labels[(size_t)y * g.lp + x];
     int v = 0;
-    if (l) v = 1 + root_of[tile_base[(y / kTileH) * g.tiles_x + (x / kTileW)] + (int)l - 1];
+    const int tile = (y / kTileH) * g.tiles_x + (x / kTileW);
+    if (l & 0x8000u) v = -(1 + tile * 32768 + (int)(l & 0x7fffu));  // an unpublished speck of the second CCL pass: a private negative id
+    else if (l) v = 1 + root_of[tile_base[tile] + (int)l - 1];
     out[(size_t)y * g.hcols + x] = v;
 }
 
@@ -676,7 +683,7 @@ long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t cap
                 if (hipMalloc(reinterpret_cast<void**>(&tmp), n * 4) != hipSuccess) return -2;
                 hipLaunchKernelGGL(k_label_roots, dim3((g.hcols + 255) / 256, g.hrows), dim3(256), 0, h->stream,
                                    W.labels + (size_t)frame * g.hrows * g.lp, W.tile_base + (size_t)frame * g.tiles_x * g.tiles_y,
-                                   W.root_of + (size_t)frame * kPoolCap, tmp, g);
+                                   W.root_of + (size_t)frame * g.pool_cap, tmp, g);
                 const bool ok = hipStreamSynchronize(h->stream) == hipSuccess && d2h(dst, tmp, n * 4);
                 (void)hipFree(tmp);
                 if (!ok) return -2;

@@ -25,9 +25,9 @@ namespace ctag {
 constexpr int kTileW = 320;             // 5 x 64-bit mask words per tile row
 constexpr int kTileH = 30;
 constexpr int kTileWords = kTileW / 64;
-constexpr int kRunCap = 2048;           // max row-runs per tile handled in LDS
-constexpr int kSlotCap = 640;           // max tile-local components per tile
-constexpr int kPoolCap = 8192;          // max tile-local components per frame (global pool)
+constexpr int kRunCap = 2048;           // row-runs per tile the first CCL pass holds in LDS; a tile with more takes the second pass
+constexpr int kSlotCap = 128;           // tile-local components a tile publishes in the first CCL pass; a tile with more takes the second pass
+constexpr int kPoolCapMin = 8192;       // tile-local components per frame (global pool): max(this, 256 per CCL tile), FrameGeom::pool_cap
 constexpr int kCandCap = 2048;          // max area-filtered candidates per frame
 constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range [1, 32]
 
@@ -78,6 +78,7 @@ struct FrameGeom {
     int trows, tcols;          // threshold tile grid
     int tiles_x, tiles_y;      // CCL tile grid
     int max_area;              // round(0.01*hcols*hrows)
+    int pool_cap;              // component pool entries per frame
 };
 
 // Per-chunk device workspace (structure of arrays; one allocation, carved by Workspace::layout()).
@@ -88,8 +89,10 @@ struct Workspace {
     uint16_t* labels = nullptr;     // [F][hrows][lp]   tile-local label (0 = background)
     int32_t* tile_base = nullptr;   // [F][tiles]       pool offset of each tile's local components
     int32_t* frame_ncomp = nullptr; // [F]              pool fill
+    int32_t* ovf_count = nullptr;   // [1]              tiles handed to the second CCL pass (k_threshold_ccl_big) ...
+    int32_t* ovf_list = nullptr;    // [F * tiles]      ... as frame * tiles + tile
     uint32_t* frame_flags = nullptr;// [F]
-    // component pool, [F][kPoolCap] each
+    // component pool, [F][g.pool_cap] each
     uint32_t* parent = nullptr;
     int32_t* root_of = nullptr;
     int32_t* area = nullptr;

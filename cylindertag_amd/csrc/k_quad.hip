@@ -42,9 +42,9 @@ struct QuadPtrs {
     float* line_fit;       // [F][kLineCap][4]
     CandAux* cand_aux;     // [F][kCandCap]
     const uint8_t* pick_table;  // [kPickN][20][10] cv::RNG initial samples of fitLine2D for every point count < kPickN
-    const int32_t* pool_tile;    // [F][kPoolCap]
-    const int32_t* member_head;  // [F][kPoolCap]
-    const int32_t* member_next;  // [F][kPoolCap]
+    const int32_t* pool_tile;    // [F][pool_cap]
+    const int32_t* member_head;  // [F][pool_cap]
+    const int32_t* member_next;  // [F][pool_cap]
     int32_t* npacks;       // [F]
     uint32_t* packs;       // [F][kCandCap] first candidate | count << 16
     unsigned long long* stamps;  // developer aid (CTAG_QUAD_STAMPS=1): cycles per phase of k_quad_edges, else null
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
     const int nc = P.ncand[frame];
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
-    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * kPoolCap;
+    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
     for (int ci = item & 3; ci < nc; ci += 4) {
         __syncthreads();
         stamp(-1);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
                 if (x < w) {
                     const int gx = x_min + x;
                     const unsigned l = lrow[gx];
-                    if (l) fg = rootof[tbase[trow + gx / kTileW] + (int)l - 1] == cd.root;
+                    if (l && l < 0x8000u) fg = rootof[tbase[trow + gx / kTileW] + (int)l - 1] == cd.root;  // bit 15: an unpublished speck (k_threshold_ccl_big)
                     if (fg) {
                         if (top[x] == 0xffff) top[x] = (uint16_t)y;
                         bot[x] = (uint16_t)y;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
 // K6p: greedy packing of a frame's candidates (in candidate order) into waves of <= 8 components whose LDS needs
 // sum to <= kPackWords.  Oversize components are skipped here; k_quad_edges<true> takes them.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes) {
+__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack) {
     const int frame = blockIdx.x * 64 + threadIdx.x;
     if (frame >= nframes) return;
     const int nc = P.ncand[frame];
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes) {
         const Candidate c = cand[i];
         const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
         const bool big = pack_big(c.x_min, c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
-        if (cnt > 0 && (big || cnt == kSG || words + need > kPackWords)) {  // packs hold consecutive candidates
+        if (cnt > 0 && (big || cnt == max_per_pack || words + need > kPackWords)) {  // packs hold consecutive candidates
             packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
             cnt = 0;
             words = 0;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
     const int npk = P.npacks[frame];
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
-    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * kPoolCap;
+    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
 
     unsigned long long t_prev = 0;
     auto stamp = [&](int phase) {  // developer aid: wave-level cycles per phase (the sub-groups reconverge between phases)
@@ -977,8 +977,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
         uint32_t mykey[kMaxKeys];
         bool many = false;
         {
-            const int32_t* ptile = P.pool_tile + (size_t)frame * kPoolCap;
-            const int32_t* mnext = P.member_next + (size_t)frame * kPoolCap;
+            const int32_t* ptile = P.pool_tile + (size_t)frame * g.pool_cap;
+            const int32_t* mnext = P.member_next + (size_t)frame * g.pool_cap;
             int e = cd.root;
             bool first_e = true;
 #pragma unroll
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
                 if (e >= 0) {
                     const int t = ptile[e];
                     mykey[k] = ((uint32_t)t << 16) | (uint32_t)(e - tbase[t] + 1);
-                    e = first_e ? P.member_head[(size_t)frame * kPoolCap + e] : mnext[e];
+                    e = first_e ? P.member_head[(size_t)frame * g.pool_cap + e] : mnext[e];
                     first_e = false;
                 }
             }
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WA
                     for (int k = 0; k < kMaxKeys; k++) r = r || (key == mykey[k]);
                     return r;
                 }
-                return rootof[tbase[tile] + (int)l - 1] == cd.root;
+                return l < 0x8000u && rootof[tbase[tile] + (int)l - 1] == cd.root;  // bit 15: an unpublished speck, never a candidate
             };
             auto fg_of = [&](const uint4& v, unsigned la, unsigned lb, bool over, int tile, unsigned valid) {
                 const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
@@ -1635,8 +1635,12 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     }
     (void)hipMemsetAsync(ws.line_count, 0, sizeof(int32_t) * (size_t)nframes, s);
     (void)hipMemsetAsync(ws.clp_used, 0, sizeof(int32_t) * (size_t)nframes, s);
-    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes);
-    hipLaunchKernelGGL(k_quad_edges_packed, dim3(32, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    static const int pack_max_env = getenv("CTAG_PACK_MAX") ? atoi(getenv("CTAG_PACK_MAX")) : 0;
+    const int pack_max = pack_max_env > 0 ? std::min(pack_max_env, kSG) : kSG;
+    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes, pack_max);
+    static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
+    const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
+    hipLaunchKernelGGL(k_quad_edges_packed, dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(4 * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 342;  // block columns per frame; a column loops when a frame has more edge triples

@@ -295,12 +295,14 @@ struct SweepPtrs {
     int32_t* member_next;
     int32_t* ncand;
     Candidate* cand;
+    int32_t* ovf_count;    // tiles the LDS-sized pass could not finish (too many runs / components, or the frame's pool filled up) ...
+    int32_t* ovf_list;     // ... as frame * tiles_per_frame + tile: k_threshold_ccl_big takes them
     unsigned long long* stamps;  // developer aid (CTAG_CCL_STAMPS=1): cycles per phase of k_threshold_ccl, else null
     size_t pool_stride;    // bytes between consecutive pool arrays (parent, root_of, area, xmin, ymin, xmax, ymax, key, pool_tile, member_head, member_next)
 };
 static SweepPtrs sweep_ptrs(const Workspace& ws) {
     return SweepPtrs{ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
-                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand, nullptr,
+                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand, ws.ovf_count, ws.ovf_list, nullptr,
                      (size_t)(reinterpret_cast<const char*>(ws.root_of) - reinterpret_cast<const char*>(ws.parent))};
 }
 
@@ -308,9 +310,9 @@ struct CclLdsLayout {
     int rp, rh;       // half-res staging region pitch / rows
     int ec, er;       // extrema grid (with ring)
     int tc, tr;       // threshold grid (tiles overlapping the CCL tile)
-    size_t off_region, off_ext, off_thr, off_mask, off_start, off_runbase, off_parent, off_lab, off_misc, off_stats, total;
+    size_t off_region, off_ext, off_thr, off_mask, off_start, off_runbase, off_parent, off_lab, off_misc, off_stats, off_final, total;
 };
-__host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
+__host__ __device__ inline CclLdsLayout ccl_layout(int tw, int run_cap = kRunCap, int slot_cap = kSlotCap, bool big = false) {
     CclLdsLayout L;
     // a tile starts at an arbitrary offset inside a threshold tile: span <= tile + 2*(tw-1) + 2*tw (ring)
     L.rp = ((kTileW + 4 * tw + 32) + 15) & ~15;
@@ -325,14 +327,14 @@ __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
         o = (o + bytes + 15) & ~(size_t)15;
         return at;
     };
-    const size_t stats = (size_t)kSlotCap * 5 * sizeof(int);  // area, xmin, xmax, row mask (-> ymin, ymax), key
+    const size_t stats = (size_t)slot_cap * 5 * sizeof(int);  // area, xmin, xmax, row mask (-> ymin, ymax), key
     const size_t ext = (size_t)L.ec * L.er * 2;
     const size_t thr = (size_t)L.tr * (kTileW + 8);  // per threshold-tile row: one threshold byte per tile column
     if (tw == 5) {
         // Compact layout of the 5x5 front end: 19,968 bytes, 8 blocks per CU.  Lifetimes: column extrema + tile extrema
         // live until the thresholds exist (S3), the run parents from S5 to the end of S8, the per-slot statistics from
         // then on -- all three share one region; the threshold bytes are dead before the run labels are first written.
-        const size_t parent = (size_t)kRunCap * 4, vbuf = (size_t)2 * 8 * 352;
+        const size_t parent = (size_t)run_cap * 4, vbuf = (size_t)2 * 8 * 352;
         size_t front = vbuf + ((ext + 15) & ~(size_t)15);
         front = front > parent ? front : parent;
         L.off_stats = take(front > stats ? front : stats);
@@ -342,10 +344,11 @@ __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
         L.off_mask = take((size_t)kTileH * kTileWords * 8);
         L.off_start = take((size_t)kTileH * kTileWords * 8);
         L.off_runbase = take(((size_t)kTileH * kTileWords + 1) * 4);
-        const size_t lab = (size_t)kRunCap * 2;
+        const size_t lab = (size_t)run_cap * 2;
         L.off_lab = take(lab > thr ? lab : thr);
         L.off_thr = L.off_lab;
         L.off_misc = take(64);
+        L.off_final = take(big ? (size_t)slot_cap * 2 : 0);
         L.total = o;
         return L;
     }
@@ -357,9 +360,10 @@ __host__ __device__ inline CclLdsLayout ccl_layout(int tw) {
     L.off_mask = take((size_t)kTileH * kTileWords * 8);
     L.off_start = take((size_t)kTileH * kTileWords * 8);
     L.off_runbase = take(((size_t)kTileH * kTileWords + 1) * 4);
-    L.off_parent = take((size_t)kRunCap * 4);
-    L.off_lab = take((size_t)kRunCap * 2);
+    L.off_parent = take((size_t)run_cap * 4);
+    L.off_lab = take((size_t)run_cap * 2);
     L.off_misc = take(64);
+    L.off_final = take(big ? (size_t)slot_cap * 2 : 0);
     L.total = o;
     return L;
 }
@@ -509,14 +513,19 @@ __device__ __forceinline__ int div_small(int n, int m16) { return (int)(((unsign
 __device__ __forceinline__ int recip16(int d) { return (65536 + d - 1) / d; }
 constexpr int kVPitch = 352;  // column extrema per threshold-tile row: 5 + 320 + 5 columns from an 8-aligned start
 
-template <int TWC>
-__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One 320x30 tile.  RUNCAP / SLOTCAP: row runs / components of the tile held in LDS.  BIG = false is the pass every tile
+// takes first (2048 runs, 640 components, 8 tiles per CU); a tile that does not fit -- dense speckle, fine texture -- or
+// whose components no longer fit the frame's pool is handed on through the overflow list instead of failing the frame, and
+// k_threshold_ccl_big runs the same code on it with BIG = true: caps that hold ANY 320x30 tile (160 runs per row), one
+// tile per CU, and only the components that can matter are published -- area >= 30 (corner_detector.cpp:88) or touching
+// the tile border (they may grow by seam merging); the other specks keep a label of their own with bit 15 set, which no
+// later stage ever looks up.
+template <int TWC, int RUNCAP, int SLOTCAP, bool BIG>
+__device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P, const FrameGeom& g, int frame0, int tile0) {
     const int tw = TWC ? TWC : g.tw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per_frame = g.tiles_x * g.tiles_y;
 
-    const CclLdsLayout L = ccl_layout(tw);
+    const CclLdsLayout L = ccl_layout(tw, RUNCAP, SLOTCAP, BIG);
     uint8_t* hr_s = smem + L.off_region;
     uint16_t* ext_s = reinterpret_cast<uint16_t*>(smem + L.off_ext);
     uint8_t* thr_s = smem + L.off_thr;  // [tile row][x - tx0], pitch kTileW + 8
@@ -527,9 +536,6 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     uint16_t* lab_s = reinterpret_cast<uint16_t*>(smem + L.off_lab);
     int* misc_s = reinterpret_cast<int*>(smem + L.off_misc);
 
-    // one tile per block; blocks b and b+8 share an XCD, so a frame's tiles stay on one XCD (map_block)
-    int frame0, tile0;
-    if (!map_block(blockIdx.x, per_frame, nframes, frame0, tile0)) return;
     const TileRegion T = tile_region(frame0, tile0, g, tw);
 
     // developer aid: per-phase cycles are kept in registers and flushed once per tile (a global atomic per stamp would
@@ -812,8 +818,19 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     int nruns;
     const int rb = block_excl_scan(nruns_mine, misc_s, nruns);
     if (tid < kTileH * kTileWords) runbase_s[tid] = rb;
-    bool overflow = nruns > kRunCap;
-    for (int i = tid; i < min(nruns, kRunCap); i += kCclThreads) parent_s[i] = (unsigned)i;
+    // a tile this pass cannot hold goes to the overflow list (BIG: cannot happen, the caps cover every tile)
+    auto hand_over = [&]() {
+        if (tid == 0) {
+            if (BIG) {
+                atomicOr(&P.frame_flags[T.frame], CTAG_FLAG_POOL_OVERFLOW);
+                P.tile_base[(size_t)T.frame * g.tiles_x * g.tiles_y + T.tile] = 0;
+            } else {
+                P.ovf_list[atomicAdd(P.ovf_count, 1)] = T.frame * (g.tiles_x * g.tiles_y) + T.tile;
+            }
+        }
+    };
+    bool overflow = nruns > RUNCAP;
+    for (int i = tid; i < min(nruns, RUNCAP); i += kCclThreads) parent_s[i] = (unsigned)i;
     CCL_SYNC();
     auto runid = [&](int item, int b) -> int { return runbase_s[item] + __popcll(start_s[item] & mask_le(b)) - 1; };
 
@@ -848,52 +865,60 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     int nslots = 0;
     {
         int roots_mine = 0;
-        const int i0 = tid * (kRunCap / kCclThreads);
+        const int i0 = tid * (RUNCAP / kCclThreads);
         if (!overflow && i0 < nruns) {
-            for (int k = 0; k < kRunCap / kCclThreads; k++) {
+            for (int k = 0; k < RUNCAP / kCclThreads; k++) {
                 const int i = i0 + k;
                 if (i < nruns && parent_s[i] == (unsigned)i) roots_mine++;
             }
         }
         int s = block_excl_scan(roots_mine, misc_s, nslots);
         if (!overflow && i0 < nruns) {
-            for (int k = 0; k < kRunCap / kCclThreads; k++) {
+            for (int k = 0; k < RUNCAP / kCclThreads; k++) {
                 const int i = i0 + k;
                 if (i < nruns && parent_s[i] == (unsigned)i) lab_s[i] = (uint16_t)(s++);
             }
         }
     }
-    if (nslots > kSlotCap) overflow = true;
+    if (nslots > SLOTCAP) overflow = true;
     CCL_SYNC();
+    if (overflow) {  // block-uniform: the tile does not fit this pass
+        hand_over();
+        return;
+    }
     int* st_area = reinterpret_cast<int*>(smem + L.off_stats);  // overlays buffers that are dead from here on (see ccl_layout)
-    int* st_xmin = st_area + kSlotCap;
-    int* st_xmax = st_xmin + kSlotCap;
-    unsigned* st_rows = reinterpret_cast<unsigned*>(st_xmax + kSlotCap);  // bit r: the component has a pixel in tile row r (kTileH <= 32)
-    int* st_key = reinterpret_cast<int*>(st_rows + kSlotCap);
-    if (!overflow) {
-        for (int i = tid; i < nruns; i += kCclThreads) {
-            const unsigned r = lds_find(parent_s, (unsigned)i);
-            if (r != (unsigned)i) lab_s[i] = lab_s[r];
-        }
+    int* st_xmin = st_area + SLOTCAP;
+    int* st_xmax = st_xmin + SLOTCAP;
+    unsigned* st_rows = reinterpret_cast<unsigned*>(st_xmax + SLOTCAP);  // bit r: the component has a pixel in tile row r (kTileH <= 32)
+    int* st_key = reinterpret_cast<int*>(st_rows + SLOTCAP);
+    for (int i = tid; i < nruns; i += kCclThreads) {
+        const unsigned r = lds_find(parent_s, (unsigned)i);
+        if (r != (unsigned)i) lab_s[i] = lab_s[r];
     }
     CCL_SYNC();  // the statistics below overlay the run parents
-    if (!overflow) {
-        for (int i = tid; i < nslots; i += kCclThreads) {
-            st_area[i] = 0;
-            st_xmin[i] = 0x7fffffff;
-            st_xmax[i] = -1;
-            st_rows[i] = 0u;
-            st_key[i] = 0x7fffffff;
-        }
+    for (int i = tid; i < nslots; i += kCclThreads) {
+        st_area[i] = 0;
+        st_xmin[i] = 0x7fffffff;
+        st_xmax[i] = -1;
+        st_rows[i] = 0u;
+        st_key[i] = 0x7fffffff;
     }
     CCL_SYNC();
-    // pool slots for this tile: the returning atomic is issued now and its result is first used after the label stores
+    // pool entries for this tile.  The first pass cannot run out: it publishes at most SLOTCAP entries per tile and the pool
+    // holds twice that for every tile (FrameGeom::pool_cap); the second pass takes what is left and fails the frame when
+    // that is not enough (more than ~256 components per tile that are large or touch a tile border, frame-wide).  The
+    // returning atomic is issued now and its result first used after the label stores.
+    auto reserve = [&](int n) -> int {  // one lane
+        if (n <= 0) return 0;
+        const int at = atomicAdd(&P.frame_ncomp[frame], n);
+        return at + n <= g.pool_cap ? at : -1;
+    };
     int base_reg = 0;
-    if (tid == 0 && !overflow && nslots > 0) base_reg = atomicAdd(&P.frame_ncomp[frame], nslots);
+    if (!BIG && tid == 0) base_reg = reserve(nslots);
     stamp(6);
     // ---- S9: per-slot stats from run segments (area, bbox, first 2x2 block in block-raster order)
     const int bcols = (g.hcols + 1) >> 1;
-    if (!overflow && tid < kTileH * kTileWords) {
+    if (tid < kTileH * kTileWords) {
         const int r = tid / kTileWords, w = tid - r * kTileWords;
         uint64_t cur = mask_s[tid];
         while (cur) {
@@ -912,6 +937,36 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
         }
     }
     stamp(7);
+    int npub = nslots;
+    uint16_t* final_s = reinterpret_cast<uint16_t*>(smem + L.off_final);  // BIG: slot -> label (published: 1.., culled: 0x8000 | k)
+    if (BIG) {
+        // ---- cull: a component of fewer than 30 pixels that does not touch the tile border can neither pass the area filter
+        // (corner_detector.cpp:88) nor merge with anything: it is not published (its pixels keep a private label)
+        CCL_SYNC();  // S9's LDS atomics are done
+        constexpr int per = (SLOTCAP + kCclThreads - 1) / kCclThreads;
+        const int i0 = tid * per;
+        auto keep = [&](int i) -> bool {
+            const unsigned rows = st_rows[i];
+            const bool border = st_xmin[i] == tx0 || st_xmax[i] == tx0 + tw_eff - 1 || (rows & 1u) != 0u || ((rows >> (th_eff - 1)) & 1u) != 0u;
+            return border || st_area[i] >= 30;
+        };
+        int mine = 0;
+        for (int k = 0; k < per; k++)
+            if (i0 + k < nslots && keep(i0 + k)) mine++;
+        int pub = block_excl_scan(mine, misc_s, npub);
+        for (int k = 0; k < per; k++) {
+            const int i = i0 + k;
+            if (i < nslots) {
+                const bool kp = keep(i);
+                final_s[i] = kp ? (uint16_t)(pub + 1) : (uint16_t)(0x8000u | (unsigned)(i - pub));  // i - pub = culled slots before i: < 2^15
+                pub += kp ? 1 : 0;
+            }
+        }
+        CCL_SYNC();
+        for (int i = tid; i < nruns; i += kCclThreads) lab_s[i] = final_s[lab_s[i]];
+        if (tid == 0) base_reg = reserve(npub);
+        CCL_SYNC();
+    }
     // ---- S11: per-pixel tile-local labels, 8 pixels (16 bytes) per lane
     {
         uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
@@ -927,7 +982,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             if (r >= th_eff || gq * 8 >= tw_eff) continue;
             const int item = r * kTileWords + (gq >> 3);
             const int b0 = (gq & 7) * 8;
-            const unsigned byte = overflow ? 0u : (unsigned)((mask_s[item] >> b0) & 0xff);
+            const unsigned byte = (unsigned)((mask_s[item] >> b0) & 0xff);
             uint32_t o[4] = {0, 0, 0, 0};
             if (byte) {
                 // one run-id lookup per run segment of the group (a run's pixels share its label), then a select per pixel
@@ -937,7 +992,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
                     const int sb = __ffs(rest) - 1;
                     const unsigned inv = ~(rest >> sb);
                     const int len = __ffs(inv) - 1;  // rest >> sb has at most 8 significant bits, so inv != 0
-                    const uint32_t lab = (uint32_t)lab_s[runid(item, b0 + sb)] + 1u;
+                    const uint32_t lab = (uint32_t)lab_s[runid(item, b0 + sb)] + (BIG ? 0u : 1u);
                     const unsigned seg = ((1u << len) - 1u) << sb;
 #pragma unroll
                     for (int k = 0; k < 8; k++) lab8[k] = ((seg >> k) & 1u) ? lab : lab8[k];
@@ -951,29 +1006,28 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     }
     stamp(8);
     // ---- S10: publish the tile's components in the frame pool
-    if (tid == 0) {
-        int ovf = overflow ? 1 : 0;
-        if (!ovf && nslots > 0 && base_reg + nslots > kPoolCap) ovf = 1;
-        misc_s[8] = ovf;
-        misc_s[9] = base_reg;
-    }
+    if (tid == 0) misc_s[9] = base_reg;
     CCL_SYNC();  // also orders the S9 LDS atomics before the reads below
-    overflow = misc_s[8] != 0;
     const int base = misc_s[9];
-    if (overflow) {
-        if (tid == 0) {
-            atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
-            P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
-        }
-    } else {
-        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
-        const size_t pool0 = (size_t)frame * kPoolCap;
+    if (base < 0) {  // second pass only: the frame's pool is exhausted
+        hand_over();
+        return;
+    }
+    if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
+    {
+        const size_t pool0 = (size_t)frame * g.pool_cap;
         for (int i = tid; i < nslots; i += kCclThreads) {
-            const size_t gidx = pool0 + base + i;
+            int at = i;
+            if (BIG) {
+                const unsigned f = final_s[i];
+                if (f & 0x8000u) continue;
+                at = (int)f - 1;
+            }
+            const size_t gidx = pool0 + base + at;
             // the pool arrays are carved back to back at a fixed stride: one base pointer instead of nine
             char* q = reinterpret_cast<char*>(P.parent + gidx);
             const size_t ps = P.pool_stride;
-            *reinterpret_cast<unsigned*>(q) = (unsigned)(base + i);        // parent
+            *reinterpret_cast<unsigned*>(q) = (unsigned)(base + at);       // parent
             *reinterpret_cast<int*>(q + 2 * ps) = st_area[i];               // area
             *reinterpret_cast<int*>(q + 3 * ps) = st_xmin[i];
             const unsigned rows = st_rows[i];  // never 0: a slot owns at least one run
@@ -985,6 +1039,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
             *reinterpret_cast<int*>(q + 9 * ps) = -1;                       // member_head
         }
     }
+    (void)npub;
     stamp(9);
     if (P.stamps && tid == 0) {
 #pragma unroll
@@ -996,6 +1051,31 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, Fram
     }
   }
 }
+
+template <int TWC>
+__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // one tile per block; blocks b and b+8 share an XCD, so a frame's tiles stay on one XCD (map_block)
+    int frame0, tile0;
+    if (!map_block(blockIdx.x, g.tiles_x * g.tiles_y, nframes, frame0, tile0)) return;
+    ccl_tile<TWC, kRunCap, kSlotCap, false>(smem, P, g, frame0, tile0);
+}
+
+// second pass over the tiles of the overflow list (usually none: the blocks read the count and leave)
+constexpr int kRunCapBig = 4864;   // >= 160 runs per row x 30 rows, a multiple of the block size
+constexpr int kSlotCapBig = 2560;  // >= 160 x 15 isolated pixels
+template <int TWC>
+__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl_big(SweepPtrs P, FrameGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int count = *P.ovf_count, per_frame = g.tiles_x * g.tiles_y;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int e = P.ovf_list[i];
+        ccl_tile<TWC, kRunCapBig, kSlotCapBig, true>(smem, P, g, e / per_frame, e % per_frame);
+        __syncthreads();
+    }
+}
+static_assert(2 * kSlotCap <= 256, "FrameGeom::pool_cap = 256 entries per tile holds two first passes");
+static_assert(kRunCapBig % kCclThreads == 0 && kRunCapBig >= (kTileW / 2) * kTileH && kSlotCapBig >= (kTileW / 2) * ((kTileH + 1) / 2), "second-pass caps hold any tile");
 
 hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s) {
     const FrameGeom& g = ws.g;
@@ -1009,12 +1089,19 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s)
         (void)hipMemsetAsync(d_stamps, 0, 16 * 8, s);
         P.stamps = d_stamps;
     }
+    (void)hipMemsetAsync(ws.ovf_count, 0, sizeof(int32_t), s);
+    const size_t lds_big = ccl_layout(g.tw, kRunCapBig, kSlotCapBig, true).total;
+    const int grid_big = 1024;  // persistent: loops over the overflow list
     if (g.tw == 5) {
         hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl_big<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+        hipLaunchKernelGGL(k_threshold_ccl_big<5>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g);
     } else {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl_big<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+        hipLaunchKernelGGL(k_threshold_ccl_big<0>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g);
     }
     if (want_stamps) {
         unsigned long long h[16];
@@ -1105,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_seam_merge(SweepPtrs P, FrameGeom g, in
     const int nv = (g.tiles_x - 1) * g.hrows;  // pixels on the right side of vertical seams
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
-    uint32_t* parent = P.parent + (size_t)frame * kPoolCap;
+    uint32_t* parent = P.parent + (size_t)frame * g.pool_cap;
     uint4 v[kSeamItems];
     int px[kSeamItems], py[kSeamItems];
 #pragma unroll
@@ -1180,11 +1267,11 @@ hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s) {
 // =====================================================================================================
 // K4: flatten every pool entry to its root and fold its stats into the root.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_resolve(SweepPtrs P, int nframes, int per_frame_blocks) {
+__global__ __launch_bounds__(256) void k_resolve(SweepPtrs P, int nframes, int per_frame_blocks, int pool_cap) {
     int frame, bidx;
     if (!map_block(blockIdx.x, per_frame_blocks, nframes, frame, bidx)) return;
-    const int n = min(P.frame_ncomp[frame], kPoolCap);
-    const size_t pool0 = (size_t)frame * kPoolCap;
+    const int n = min(P.frame_ncomp[frame], pool_cap);
+    const size_t pool0 = (size_t)frame * pool_cap;
     for (int i = bidx * 256 + threadIdx.x; i < n; i += per_frame_blocks * 256) {
         const unsigned r = g_find(P.parent + pool0, (unsigned)i);
         P.root_of[pool0 + i] = (int)r;
@@ -1201,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_resolve(SweepPtrs P, int nframes, int p
 }
 hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s) {
     const int per_frame = 2;
-    hipLaunchKernelGGL(k_resolve, dim3(grid_for(nframes, per_frame)), dim3(256), 0, s, sweep_ptrs(ws), nframes, per_frame);
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(nframes, per_frame)), dim3(256), 0, s, sweep_ptrs(ws), nframes, per_frame, ws.g.pool_cap);
     return hipGetLastError();
 }
 
@@ -1217,8 +1304,8 @@ __global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, in
     if (frame >= nframes) return;
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    const int n = min(P.frame_ncomp[frame], kPoolCap);
-    const size_t pool0 = (size_t)frame * kPoolCap;
+    const int n = min(P.frame_ncomp[frame], g.pool_cap);
+    const size_t pool0 = (size_t)frame * g.pool_cap;
     for (int i = threadIdx.x; i < n; i += 256) {
         if (P.root_of[pool0 + i] == i) {
             const int a = P.area[pool0 + i];

@@ -268,6 +268,59 @@ def test_components_across_tile_seams(detector, oracle, dictionary):
     assert_same_record(r, o["result"], "seam stress")
 
 
+def _stage_check(detector, oracle, state, fs, img, what):
+    o = oracle.detect(img, state, fs)
+    r = detector.detect(img)
+    lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+    assert ((lab != 0) == (o["binary"] > 0)).all(), what
+    pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
+    assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1])), what  # same partition
+    cand = detector.debug(0, capi.DBG_CANDIDATES)
+    assert cand.shape[0] == o["candidates"].shape[0] and (cand[:, 0:7] == o["candidates"][:, 1:8]).all(), what
+    assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes(), what
+    assert_same_record(r, o["result"], what)
+    return o, r, lab
+
+
+def test_dense_speckle_and_texture_take_the_second_ccl_pass(detector, oracle, dictionary):
+    """Frames the reference labels without complaint but whose 320x30 CCL tiles do not fit the first pass's LDS caps (2048 row
+    runs, 640 components) or whose specks would fill the frame's component pool: dark sensor noise (about half of the
+    pixels below the local mid level), a noise band beside real markers, a lattice of dots.  Such tiles go through the
+    overflow list to k_threshold_ccl_big; the frame must come out exactly as the oracle's, never as CTAG_ERR_LIMIT."""
+    state, fs = dictionary
+    rng = np.random.RandomState(41)
+    detector.set_option(capi.OPT_KEEP_PREMARKERS, 1)
+    try:
+        # 1. dark sensor noise: every tile overflows the run cap
+        dark = np.clip(rng.normal(22, 7, (540, 960)), 0, 255).astype(np.uint8)
+        o, r, lab = _stage_check(detector, oracle, state, fs, dark, "dark noise")
+        assert r["flags"] == 0 and (lab < 0).sum() > 100  # unpublished specks got private labels
+        runs = (np.diff((o["binary"] > 0).astype(np.int8), axis=1, prepend=0) == 1)[:30, :320].sum()
+        assert runs > 2048  # the first tile really exceeds the first pass
+        # 2. a marker frame with a band of dark noise (640 x 60 and more): the markers elsewhere are still decoded
+        frame, truth = ca.synth_frame_host(state, 11)
+        band = frame.copy()
+        band[300:420, 200:1500] = np.clip(rng.normal(25, 8, (120, 1300)), 0, 255).astype(np.uint8)
+        o, r, lab = _stage_check(detector, oracle, state, fs, band, "noise band beside markers")
+        assert r["status"] == 0 and r["flags"] == 0 and r["n_markers"] >= 2
+        # 3. a lattice of 2x2 half-res dots around the markers of a 1080p frame: ~600 specks per tile fit the first pass, but
+        # 54 tiles of them do not fit the frame's component pool -> the tiles that find it full are handed over and the
+        # second pass publishes only what can matter
+        dots, truth = ca.synth_frame_host(state, 12)
+        dots = dots.copy()
+        yy, xx = np.mgrid[0:1080, 0:1920]
+        lattice = ((yy % 8) < 4) & ((xx % 8) < 4)
+        for k in range(truth["n_markers"]):
+            c = truth["corners"][k].reshape(4, 2)
+            x0, y0, x1, y1 = c[:, 0].min() - 24, c[:, 1].min() - 24, c[:, 0].max() + 24, c[:, 1].max() + 24
+            lattice &= ~((xx >= x0) & (xx <= x1) & (yy >= y0) & (yy <= y1))
+        dots[lattice] = 15
+        o, r, lab = _stage_check(detector, oracle, state, fs, dots, "dot lattice")
+        assert r["status"] == 0 and r["flags"] == 0 and r["n_markers"] >= 2 and len(o["areas"]) - 1 > 13824
+    finally:
+        detector.set_option(capi.OPT_KEEP_PREMARKERS, 0)
+
+
 def test_batch_equals_single_and_is_repeatable(detector, dictionary):
     state, fs = dictionary
     frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
