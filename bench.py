@@ -136,6 +136,81 @@ def pose_side(det, m, dev):
             "cpu_pose_oracle_markers_per_s": round(ncpu / cpu_dt, 1), "cpu_cores": 1}
 
 
+def pose_side_3d(det, state, m, dev, frames_cap):
+    """Side measurement for frame sizes other than 1080p (BASELINE config 5: 3840x2160): ray-cast cylinders with PLANTED
+    poses (ctag_synth3d_*: printed strips on cylinders, pinhole camera) -> detect(img,5,true,5) -> estimatePose on the GPU
+    with the objects' 3-D corner lists, everything device-resident; the recovered poses are compared with the planted ones."""
+    import torch
+    import cylindertag_amd as ca
+    from cylindertag_amd import capi
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pose_testlib import PoseOracle, make_camera, make_model_view, rodrigues
+    m = max(1, min(m, frames_cap))
+    f = 5200.0 * COLS / 3840.0
+    K = np.array([[f, 0, COLS / 2.0], [0, f, ROWS / 2.0], [0, 0, 1]])
+    model, corners = ca.synth3d_model(state)
+    cam = ca.make_camera(K, np.zeros(5))
+    frames = torch.empty((m, ROWS, COLS), dtype=torch.uint8, device=dev)
+    det.synth3d_frames_device(frames.data_ptr(), 0, m, ROWS, COLS, COLS, ROWS * COLS, K)
+    res = torch.zeros((m, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    off = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+    cap = m * 8
+    poses = torch.zeros(cap * ca.POSE_DT.itemsize, dtype=torch.uint8, device=dev)
+
+    def run():
+        det.detect_batch_device(frames.data_ptr(), m, ROWS, COLS, COLS, ROWS * COLS, res.data_ptr(), 5, True, 5)
+        det.pose_batch_device(res.data_ptr(), m, model, cam, off.data_ptr(), poses.data_ptr(), cap)
+
+    run()
+    det.sync()
+    det.set_option(capi.OPT_TIMING, 1)
+    reps, pose_ms = 3, 0.0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+        pose_ms += det.pose_last_ms()
+    det.sync()
+    dt = (time.perf_counter() - t0) / reps
+    det.set_option(capi.OPT_TIMING, 0)
+    offs = off.cpu().numpy()
+    P = poses.cpu().numpy().view(ca.POSE_DT)[:offs[-1]]
+    recs = np.frombuffer(res.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    ok = P[P["status"] == 0]
+    # planted poses of the first frames (the host layout: no rendering needed beyond a 1-row image)
+    ang, rel = [], []
+    for fr in range(min(m, 64)):
+        truth = ca.synth3d_frame_host(state, fr, K, rows=ROWS, cols=COLS)[1] if fr < 2 else None
+        if truth is None:
+            break
+        for p in P[offs[fr]:offs[fr + 1]]:
+            if p["status"] != 0:
+                continue
+            k = [i for i in range(truth["n_markers"]) if truth["dict_row"][i] == p["model_index"]]
+            if not k:
+                continue
+            R, Rt = rodrigues(p["rvec"]), truth["R"][k[0]].reshape(3, 3)
+            ang.append(float(np.degrees(np.arccos(np.clip((np.trace(R.T @ Rt) - 1) / 2, -1, 1)))))
+            rel.append(float(np.linalg.norm(p["tvec"] - truth["t"][k[0]]) / np.linalg.norm(truth["t"][k[0]])))
+    ids = np.arange(state.shape[0], dtype=np.int32)
+    mv = make_model_view({"ids": ids, "size": state.shape[1], "base": np.zeros((len(ids), 3), np.float32),
+                          "axis": np.zeros((len(ids), 3), np.float32), "corners": corners})
+    po, cam_o = PoseOracle(), make_camera(K, np.zeros(5))
+    t0 = time.perf_counter()
+    want = [po.pose_frame(r, mv, cam_o, i) for i, r in enumerate(recs[:min(m, 64)])]
+    cpu_dt = time.perf_counter() - t0
+    ncpu = sum(len(w) for w in want)
+    same = np.concatenate(want).tobytes() == P[:ncpu].tobytes() if ncpu else True
+    rms = np.sqrt(2 * ok["cost"] / np.maximum(ok["n_points"], 1))
+    return {"workload": "%d ray-cast %dx%d frames of 4 cylinders with planted poses in HBM; detect(img,5,true,5) then estimatePose (EPnP + LM) "
+                        "with the objects' 3-D corner lists" % (m, COLS, ROWS),
+            "detect_plus_pose_frames_per_s": round(m / dt, 1), "pose_kernel_ms": round(pose_ms / reps, 3), "markers": int(offs[-1]),
+            "poses_ok": int(len(ok)), "reprojection_rms_px_median": round(float(np.median(rms)), 4) if len(ok) else None,
+            "planted_pose_error": {"poses_compared": len(ang), "rotation_deg_max": round(max(ang), 4) if ang else None,
+                                   "translation_rel_max": round(max(rel), 6) if rel else None},
+            "gpu_poses_equal_cpu_pose_oracle": bool(same), "cpu_pose_oracle_markers_per_s": round(ncpu / cpu_dt, 1) if cpu_dt > 0 else None,
+            "cpu_cores": 1}
+
+
 def _native_oracle():
     """The timed baseline build of the oracle (-O3 -march=native -ffp-contract=off), compiled ON THIS HOST
     (native code must not travel between machines); falls back to the portable -O2 checker build when g++ is missing."""
@@ -429,10 +504,13 @@ def main():
             side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
         if world == 1 and args.latency_calls > 0:
             side("single_frame_latency", lambda: latency_side(det, state, fs, args.latency_calls))
-        if world == 1 and args.pose_frames > 0 and (ROWS, COLS) == (1080, 1920):
+        if world == 1 and args.pose_frames > 0:
             del frames
             frames = None
-            side("pose_side", lambda: pose_side(det, args.pose_frames, dev))
+            if (ROWS, COLS) == (1080, 1920):
+                side("pose_side", lambda: pose_side(det, args.pose_frames, dev))
+            else:
+                side("pose_side", lambda: pose_side_3d(det, state, args.pose_frames, dev, 256))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -15,6 +15,8 @@ FEATURE_DT = np.dtype([("pos", "<i4"), ("id", "<i4"), ("id_left", "<i4"), ("id_r
 MARKER_DT = np.dtype([("marker_id", "<i4"), ("first_feature", "<i4"), ("n_features", "<i4"), ("n_pos", "<i4")])
 RESULT_DT = np.dtype([("status", "<i4"), ("n_markers", "<i4"), ("n_features", "<i4"), ("flags", "<u4"),
                       ("markers", MARKER_DT, (MAX_MARKERS,)), ("features", FEATURE_DT, (MAX_FEATURES,))])
+TRUTH3D_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("_pad", "<i4", (1,)), ("R", "<f8", (8, 9)), ("t", "<f8", (8, 3)),
+                       ("radius", "<f8", (8,))])
 TRUTH_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("strip_len", "<f4", (8,)),
                      ("corners", "<f4", (8, 8))])
 STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates", "quad", "features", "edge_refine",
@@ -27,7 +29,8 @@ DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURE
 EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
            "ctag_detect_batch_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
            "ctag_stage_name", "ctag_strerror", "ctag_version", "ctag_debug_fetch", "ctag_math_probe",
-           "ctag_synth_frames_device", "ctag_synth_frame_host", "ctag_synth_layout_truth"]
+           "ctag_synth_frames_device", "ctag_synth_frame_host", "ctag_synth_layout_truth", "ctag_synth3d_frames_device",
+           "ctag_synth3d_frame_host", "ctag_synth3d_model"]
 # ... and include/ctag_pose.h
 POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag_model_get_view", "ctag_camera_load",
                 "ctag_pose_batch_device", "ctag_estimate_pose", "ctag_pose_last_ms"]
@@ -130,6 +133,14 @@ def load_library():
                                         C.c_int, vp]
     L.ctag_synth_layout_truth.restype = C.c_int
     L.ctag_synth_layout_truth.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp]
+    L.ctag_synth3d_frames_device.restype = C.c_int
+    L.ctag_synth3d_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_uint64, C.c_int,
+                                             C.c_double, C.c_double, C.c_double, C.c_double]
+    L.ctag_synth3d_frame_host.restype = C.c_int
+    L.ctag_synth3d_frame_host.argtypes = [i32p, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_uint64, C.c_int, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, vp]
+    L.ctag_synth3d_model.restype = C.c_int
+    L.ctag_synth3d_model.argtypes = [i32p, C.c_int, C.c_int, vp]
     L.ctag_model_load.restype = C.c_int
     L.ctag_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.ctag_model_create.restype = C.c_int
@@ -300,6 +311,31 @@ def synth_frame_host(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, 
     return img, truth[0]
 
 
+def synth3d_frame_host(state, frame_index, K, rows=2160, cols=3840, seed=SYNTH_SEED, markers=4):
+    """Host rendering of frame `frame_index` of the 3-D scene (cylinders with planted poses, camera matrix K) -> (image, truth)."""
+    L = load_library()
+    state = np.ascontiguousarray(state, dtype=np.int32)
+    img = np.zeros((rows, cols), np.uint8)
+    truth = np.zeros(1, TRUTH3D_DT)
+    K = np.asarray(K, np.float64)
+    st = L.ctag_synth3d_frame_host(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1], img.ctypes.data, frame_index,
+                                   rows, cols, img.strides[0], seed, markers, K[0, 0], K[1, 1], K[0, 2], K[1, 2], truth.ctypes.data)
+    if st != 0:
+        raise CtagError(st, "ctag_synth3d_frame_host")
+    return img, truth[0]
+
+
+def synth3d_model(state):
+    """3-D corner lists of the synthetic cylinders, one model per dictionary row (marker id = row) -> Model."""
+    L = load_library()
+    state = np.ascontiguousarray(state, dtype=np.int32)
+    corners = np.zeros((state.shape[0], state.shape[1] * 8, 3), np.float32)
+    st = L.ctag_synth3d_model(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1], corners.ctypes.data)
+    if st != 0:
+        raise CtagError(st, "ctag_synth3d_model")
+    return Model(ids=np.arange(state.shape[0], dtype=np.int32), corners=corners, model_size=state.shape[1]), corners
+
+
 def synth_truth(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, markers=4):
     """Planted markers (dictionary rows, strip corners) of synthetic frame `frame_index`, without rendering."""
     L = load_library()
@@ -417,6 +453,13 @@ class Detector:
                                              markers)
         if st != 0:
             raise CtagError(st, "ctag_synth_frames_device")
+
+    def synth3d_frames_device(self, frames_ptr, first, n, rows, cols, row_stride, frame_stride, K, seed=SYNTH_SEED, markers=4):
+        K = np.asarray(K, np.float64)
+        st = self.L.ctag_synth3d_frames_device(self.h, frames_ptr, first, n, rows, cols, row_stride, frame_stride, seed, markers,
+                                               K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        if st != 0:
+            raise CtagError(st, "ctag_synth3d_frames_device")
 
     # ---- multi-GPU gather (include/ctag_gather.h); pointers are plain integers
     def _gcheck(self, st, what):

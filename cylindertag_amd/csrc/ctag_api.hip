@@ -778,8 +778,9 @@ int ctag_math_probe(ctag_handle* h, int op, int n, const double* a, const double
     return CTAG_OK;
 }
 
-int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride,
-                             ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame) {
+// renders frames [first_frame, first_frame + n) of a synthetic scene into device memory; layouts are computed on the host
+static int synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                               uint64_t seed, int markers_per_frame, bool scene3d, double fx, double fy, double cx, double cy) {
     if (!h || !frames_dev || n < 0 || rows < 1 || cols < 1 || row_stride < cols) return CTAG_ERR_ARG;
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
@@ -793,8 +794,12 @@ int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_fram
     std::vector<ctag_synth::Frame> lay(step);
     for (int f0 = 0; f0 < n; f0 += step) {
         const int m = std::min(step, n - f0);
-        for (int i = 0; i < m; i++)
-            ctag_synth::layout(h->dict.data(), h->dict_rows, h->dict_cols, seed, first_frame + f0 + i, rows, cols, markers_per_frame, &lay[i], nullptr);
+        for (int i = 0; i < m; i++) {
+            if (scene3d)
+                ctag_synth::layout3d(h->dict.data(), h->dict_rows, h->dict_cols, seed, first_frame + f0 + i, rows, cols, markers_per_frame, fx, fy, cx, cy, &lay[i], nullptr);
+            else
+                ctag_synth::layout(h->dict.data(), h->dict_rows, h->dict_cols, seed, first_frame + f0 + i, rows, cols, markers_per_frame, &lay[i], nullptr);
+        }
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipMemcpy(h->d_synth, lay.data(), sizeof(ctag_synth::Frame) * m, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_synth, dim3((cols + 255) / 256, rows, m), dim3(256), 0, h->stream, h->d_synth, frames_dev + (ptrdiff_t)f0 * frame_stride, rows,
@@ -802,6 +807,44 @@ int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_fram
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return CTAG_OK;
+}
+
+int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride,
+                             ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame) {
+    return synth_frames_device(h, frames_dev, first_frame, n, rows, cols, row_stride, frame_stride, seed, markers_per_frame, false, 1, 1, 0, 0);
+}
+
+int ctag_synth3d_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride,
+                               ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame, double fx, double fy, double cx, double cy) {
+    if (!(fx > 0) || !(fy > 0)) return CTAG_ERR_ARG;
+    return synth_frames_device(h, frames_dev, first_frame, n, rows, cols, row_stride, frame_stride, seed, markers_per_frame, true, fx, fy, cx, cy);
+}
+
+int ctag_synth3d_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows, int cols, ptrdiff_t row_stride,
+                            uint64_t seed, int markers_per_frame, double fx, double fy, double cx, double cy, ctag_synth3d_truth* truth) {
+    if (!state || !frame || rows < 1 || cols < 1 || row_stride < cols || dict_rows < 1 || dict_cols < 1 || !(fx > 0) || !(fy > 0)) return CTAG_ERR_ARG;
+    ctag_synth::Frame F;
+    ctag_synth::Truth3D T;
+    ctag_synth::layout3d(state, dict_rows, dict_cols, seed, frame_index, rows, cols, markers_per_frame, fx, fy, cx, cy, &F, &T);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) frame[(ptrdiff_t)y * row_stride + x] = ctag_synth::pixel(F, x, y, rows, cols);
+    if (truth) {
+        std::memset(truth, 0, sizeof(*truth));
+        truth->n_markers = T.n;
+        for (int k = 0; k < T.n && k < 8; k++) {
+            truth->dict_row[k] = T.dict_row[k];
+            for (int i = 0; i < 9; i++) truth->R[k][i] = T.R[k][i];
+            for (int i = 0; i < 3; i++) truth->t[k][i] = T.t[k][i];
+            truth->radius[k] = T.radius[k];
+        }
+    }
+    return CTAG_OK;
+}
+
+int ctag_synth3d_model(const int32_t* state, int dict_rows, int dict_cols, float* corners) {
+    if (!state || !corners || dict_rows < 1 || dict_cols < 1 || dict_cols > ctag_synth::kMaxCols) return CTAG_ERR_ARG;
+    for (int r = 0; r < dict_rows; r++) ctag_synth::model_corners(state, dict_cols, r, corners + (size_t)r * dict_cols * 24);
     return CTAG_OK;
 }
 

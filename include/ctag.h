@@ -116,6 +116,26 @@ int ctag_synth_frame_host(const int32_t* state, int dict_rows, int dict_cols, ui
 int ctag_synth_layout_truth(const int32_t* state, int dict_rows, int dict_cols, int frame_index, int rows, int cols, uint64_t seed,
                      int markers_per_frame, ctag_synth_truth* truth);
 
+/* ---- synthetic 3-D scenes (BASELINE config 5: detect() + estimatePose with known answers) ---------------------
+ * The same strips printed on cylinders (strip height 60 mm, a radius fixed per dictionary row) in front of a pinhole
+ * camera (fx, fy, cx, cy; no distortion), every marker with a planted rigid pose; the image is ray-cast.
+ * ctag_synth3d_model gives the objects' 3-D corner lists -- the `.model` of CylinderTag.cpp:168-188 for them:
+ * corners[row][feature*8 + k][3] in mm, corner order as detect() emits it -- ready for ctag_model_create with
+ * marker ids 0..dict_rows-1. */
+typedef struct ctag_synth3d_truth {
+    int32_t n_markers;
+    int32_t dict_row[8];
+    double R[8][9];    /* object -> camera rotation, row-major */
+    double t[8][3];    /* mm */
+    double radius[8];  /* mm */
+} ctag_synth3d_truth;
+int ctag_synth3d_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride,
+                               ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame, double fx, double fy, double cx, double cy);
+int ctag_synth3d_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows, int cols,
+                            ptrdiff_t row_stride, uint64_t seed, int markers_per_frame, double fx, double fy, double cx, double cy,
+                            ctag_synth3d_truth* truth);
+int ctag_synth3d_model(const int32_t* state, int dict_rows, int dict_cols, float* corners);
+
 #ifdef __cplusplus
 }
 #endif

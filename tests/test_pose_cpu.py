@@ -269,3 +269,43 @@ def test_reference_scene_gets_subpixel_poses(env):
         assert 200 < p["tvec"][2] < 1200  # millimetres in front of the camera
         # EPnP is already close: BA moves the pose by millimetres
         assert np.abs(p["tvec"] - p["tvec0"]).max() < 5.0
+
+
+def _pose_errors(p, truth, ids):
+    """(rotation error in degrees, translation error relative to the distance) of pose record p against the planted pose."""
+    k = [i for i in range(truth["n_markers"]) if truth["dict_row"][i] == ids[p["model_index"]]][0]
+    R, Rt = rodrigues(p["rvec"]), truth["R"][k].reshape(3, 3)
+    ang = np.degrees(np.arccos(np.clip((np.trace(R.T @ Rt) - 1) / 2, -1, 1)))
+    return ang, np.linalg.norm(p["tvec"] - truth["t"][k]) / np.linalg.norm(truth["t"][k])
+
+
+def test_planted_3d_poses_are_recovered_end_to_end():
+    """Known answers for the whole chain (BASELINE config 5): cylinders with printed strips are ray-cast under planted rigid
+    poses (ctag_synth3d_*), the oracle's detect() finds and decodes them, and estimatePose with the objects' 3-D corner lists
+    (ctag_synth3d_model: detect()'s corner order, CylinderTag.cpp:168-188) returns the planted poses -- which pins the
+    detector's corner order, the correspondence builder (pose_estimation.cpp:72-95) and EPnP + LM together."""
+    state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    orc, po = Oracle(), PoseOracle()
+    rows, cols = 1080, 1920
+    K = np.array([[2600.0, 0, 960.0], [0, 2600.0, 540.0], [0, 0, 1]])
+    M, corners = ca.synth3d_model(state)
+    ids = np.arange(state.shape[0], dtype=np.int32)
+    mv = make_model_view({"ids": ids, "size": state.shape[1], "base": np.zeros((len(ids), 3), np.float32),
+                          "axis": np.zeros((len(ids), 3), np.float32), "corners": corners})
+    assert (M.view()["corners"] == corners).all()
+    cam = make_camera(K, np.zeros(5))
+    npose = 0
+    for f in (0, 1, 2):
+        img, truth = ca.synth3d_frame_host(state, f, K, rows=rows, cols=cols)
+        res = orc.detect_fast(img, state, fs)
+        assert res["status"] == 0
+        planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
+        found = sorted(int(m["marker_id"]) for m in res["markers"][:res["n_markers"]])
+        assert set(found) <= set(planted) and len(found) >= len(planted) - 1
+        for p in po.pose_frame(res, mv, cam):
+            assert p["status"] == 0 and p["n_points"] >= 40
+            ang, rel = _pose_errors(p, truth, ids)
+            rms = np.sqrt(2 * p["cost"] / p["n_points"])
+            assert ang < 0.15 and rel < 1e-3 and rms < 0.3, (f, ang, rel, rms)
+            npose += 1
+    assert npose >= 10

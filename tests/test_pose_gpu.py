@@ -118,3 +118,57 @@ def test_cpp_estimate_pose_demo(env):
     for l, p in zip(lines, want):
         assert int(l[1]) == p["model_index"]
         assert [float(v) for v in l[3:6]] == list(p["rvec"]) and [float(v) for v in l[7:10]] == list(p["tvec"])
+
+
+def test_config5_4k_detect_plus_pose_known_answers(env):
+    """BASELINE config 5 end to end on the GPU at 3840x2160: ray-cast cylinders with planted poses (rendered on the device,
+    identical to the host rendering), detect(img,5,true,5), ctag_pose_batch_device with the objects' 3-D corner lists --
+    pose records byte-identical to the CPU pose oracle on the oracle's detection records, and the planted poses recovered."""
+    import torch
+    from ctag_testlib import Oracle
+    from pose_testlib import rodrigues
+    det = env["det"]
+    state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    rows, cols, n = 2160, 3840, 6
+    K = np.array([[5200.0, 0, 1920.0], [0, 5200.0, 1080.0], [0, 0, 1]])
+    M, corners = ca.synth3d_model(state)
+    ids = np.arange(state.shape[0], dtype=np.int32)
+    mv = make_model_view({"ids": ids, "size": state.shape[1], "base": np.zeros((len(ids), 3), np.float32),
+                          "axis": np.zeros((len(ids), 3), np.float32), "corners": corners})
+    cam_c, cam_o = ca.make_camera(K, np.zeros(5)), make_camera(K, np.zeros(5))
+    frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+    det.synth3d_frames_device(frames.data_ptr(), 0, n, rows, cols, cols, rows * cols, K)
+    host0, truth0 = ca.synth3d_frame_host(state, 0, K)
+    assert (frames[0].cpu().numpy() == host0).all()
+    res = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    det.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, res.data_ptr(), 5, True, 5)
+    off = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    poses = torch.zeros(n * 8 * ca.POSE_DT.itemsize, dtype=torch.uint8, device="cuda")
+    det.pose_batch_device(res.data_ptr(), n, M, cam_c, off.data_ptr(), poses.data_ptr(), n * 8)
+    det.sync()
+    recs = np.frombuffer(res.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    offs = off.cpu().numpy()
+    P = np.frombuffer(poses.cpu().numpy().tobytes(), dtype=ca.POSE_DT)[:offs[-1]]
+    orc = Oracle()
+    for f in (0, n - 1):  # detection parity at 4K on two frames (the oracle takes ~1 s per 4K frame)
+        want = orc.detect_fast(frames[f].cpu().numpy(), state, fs)
+        assert recs[f].tobytes() == want.tobytes(), "4K detection record %d" % f
+    want_p = np.concatenate([env["po"].pose_frame(recs[f], mv, cam_o, f) for f in range(n)])
+    assert_pose_parity(P, want_p, "config 5 poses")
+    assert P.tobytes() == want_p.tobytes()
+    nposes = 0
+    for f in range(n):
+        img_f, truth = (host0, truth0) if f == 0 else ca.synth3d_frame_host(state, f, K)  # the planted poses (and the host rendering)
+        assert (frames[f].cpu().numpy() == img_f).all()
+        planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
+        found = sorted(int(m["marker_id"]) for m in recs[f]["markers"][:recs[f]["n_markers"]])
+        assert set(found) <= set(planted) and len(found) >= len(planted) - 1, f
+        for p in P[offs[f]:offs[f + 1]]:
+            assert p["status"] == 0
+            k = [i for i in range(truth["n_markers"]) if truth["dict_row"][i] == ids[p["model_index"]]][0]
+            R, Rt = rodrigues(p["rvec"]), truth["R"][k].reshape(3, 3)
+            ang = np.degrees(np.arccos(np.clip((np.trace(R.T @ Rt) - 1) / 2, -1, 1)))
+            rel = np.linalg.norm(p["tvec"] - truth["t"][k]) / np.linalg.norm(truth["t"][k])
+            assert ang < 0.1 and rel < 5e-4 and np.sqrt(2 * p["cost"] / p["n_points"]) < 0.3, (f, ang, rel)
+            nposes += 1
+    assert nposes >= 4 * n - 4
