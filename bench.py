@@ -211,6 +211,34 @@ def pose_side_3d(det, state, m, dev, frames_cap):
             "cpu_cores": 1}
 
 
+ISSUE_KERNELS = {"edge_refine": "ctag::k_edge_refine", "welsch": "ctag::k_welsch", "quad_edges": "ctag::k_quad_edges_packed",
+                 "threshold_ccl": "ctag::k_threshold_ccl<5>"}
+
+
+def issue_rooflines(stage_ms, n_frames):
+    """Vector-instruction ISSUE roofline of the kernels that are not memory-bound (86 % of the step): wave-instructions of the
+    kernel -- counted by rocprofv3 PMC passes, replayed from profiles/r*_pmc_instmix.json like roofline.traffic -- priced at
+    the SIMD's peak issue rate (2 cycles per wave64 instruction, 4 for FP64 add / mul / fma: MI355X_MICROARCH.md) on 1024
+    SIMDs at 2.4 GHz, against the kernel's time measured in THIS run."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instmix.json")))
+    if not cands or (ROWS, COLS) != (1080, 1920):
+        return None
+    prof = json.load(open(cands[-1]))
+    out = {"source": "instruction counts replayed from %s (rocprofv3 --pmc, 1024-frame pass); times from this run's HIP events" % os.path.relpath(cands[-1], ROOT),
+           "model": "issue_bound_ms = (2 * (VALU - FP64) + 4 * FP64 wave-instructions) / (1024 SIMDs * 2.4 GHz): the SIMDs' peak issue rate", "kernels": {}}
+    for stage, kname in ISSUE_KERNELS.items():
+        e = prof["kernels"].get(kname)
+        if not e or stage_ms.get(stage, 0) <= 0:
+            continue
+        per_frame = e["issue_model"]["issue_cycles"] / 1024.0
+        bound_ms = per_frame * n_frames / (1024 * 2.4e9) * 1e3
+        out["kernels"]["k_" + stage if not stage.startswith("quad") else "k_quad_edges_packed"] = {
+            "achieved_ms": round(stage_ms[stage], 3), "issue_bound_ms": round(bound_ms, 3), "frac": round(bound_ms / stage_ms[stage], 4),
+            "valu_wave_instructions_per_frame": round(e["wave_instructions"]["valu"] / 1024.0, 1), "fp64_share_of_valu": e["fp64_share_of_valu"]}
+    return out
+
+
 def _native_oracle():
     """The timed baseline build of the oracle (-O3 -march=native -ffp-contract=off), compiled ON THIS HOST
     (native code must not travel between machines); falls back to the portable -O2 checker build when g++ is missing."""
@@ -427,6 +455,8 @@ def main():
         stage_ms = det.timings()
         det.set_option(capi.OPT_TIMING, 0)
     launches = (n + chunk - 1) // chunk
+    stage_ms = dict(stage_ms)
+    stage_ms["quad"] = sum(stage_ms[k] for k in capi.QUAD_STAGES)  # a4 edgeExtraction: the six kernels of the quad stage
 
     # ---- outcome of the last step: the job's result list in frame order (gathered when N > 1)
     final = gathered[last % 2] if world > 1 else local_bufs[0][:n]
@@ -466,6 +496,7 @@ def main():
                           "frames_per_step": n_total, "frames_per_gpu": n, "chunk": chunk, "parallelism": "frames sharded, dp%d" % world,
                           "gather": gather_impl},
                "roofline": roofline,
+               "issue_roofline": issue_rooflines(stage_ms, n),
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
                "frames_ok": ok_frames, "markers_decoded_last_step": markers_found, "results_sha256": sha}
         if comm is not None:

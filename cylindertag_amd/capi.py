@@ -19,8 +19,9 @@ TRUTH3D_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("_pad",
                        ("radius", "<f8", (8,))])
 TRUTH_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("strip_len", "<f4", (8,)),
                      ("corners", "<f4", (8, 8))])
-STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates", "quad", "features", "edge_refine",
-               "markers"]
+STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates", "quad_pack", "quad_edges", "quad_edges_big",
+               "line_sort", "welsch", "quad_final", "features", "edge_refine", "markers"]
+QUAD_STAGES = ["quad_pack", "quad_edges", "quad_edges_big", "line_sort", "welsch", "quad_final"]  # a4: edgeExtraction
 
 OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK = 1, 2, 3, 4
 DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS = range(1, 9)

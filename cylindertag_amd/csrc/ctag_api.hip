@@ -80,8 +80,8 @@ bool handle_timing(const ctag_handle* h) { return h->timing; }
 int handle_device(const ctag_handle* h) { return h->device; }
 }  // namespace ctag
 
-static const char* kStageNames[CTAG_NUM_STAGES] = {"decimate", "threshold_ccl", "seam_merge", "resolve", "candidates",
-                                                    "quad",     "features",      "edge_refine", "markers"};
+static const char* kStageNames[CTAG_NUM_STAGES] = {"decimate",  "threshold_ccl", "seam_merge", "resolve", "candidates", "quad_pack", "quad_edges", "quad_edges_big",
+                                                    "line_sort", "welsch",        "quad_final", "features", "edge_refine", "markers"};
 
 // ---------------------------------------------------------------------------------------------------
 // workspace
@@ -292,7 +292,8 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
     HIP_TRY(mark(++st));
     HIP_TRY(launch_candidates(n, ws, s));
     HIP_TRY(mark(++st));
-    HIP_TRY(launch_quads(n, ws, s));
+    HIP_TRY(launch_quads(n, ws, s, evs ? evs + st + 1 : nullptr));  // records one event after each of its first five kernels
+    st += 5;
     HIP_TRY(mark(++st));
     HIP_TRY(launch_features(n, ws, p, s));
     HIP_TRY(mark(++st));

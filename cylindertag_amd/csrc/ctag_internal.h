@@ -154,7 +154,7 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s)
 hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s);
-hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s);
+hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEvent_t* ev5 = nullptr);  // ev5: 5 events, one after each kernel but the last
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s);

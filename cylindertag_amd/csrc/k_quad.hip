@@ -1623,7 +1623,11 @@ __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int 
     }
 }
 
-hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
+hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEvent_t* ev5) {
+    int evi = 0;
+    auto mark = [&]() {
+        if (ev5) (void)hipEventRecord(ev5[evi++], s);
+    };
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
                ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, nullptr};
     static unsigned long long* d_stamps = nullptr;
@@ -1638,13 +1642,18 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s) {
     static const int pack_max_env = getenv("CTAG_PACK_MAX") ? atoi(getenv("CTAG_PACK_MAX")) : 0;
     const int pack_max = pack_max_env > 0 ? std::min(pack_max_env, kSG) : kSG;
     hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes, pack_max);
+    mark();
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
     hipLaunchKernelGGL(k_quad_edges_packed, dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    mark();
     hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(4 * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
+    mark();
     static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 342;  // block columns per frame; a column loops when a frame has more edge triples
     hipLaunchKernelGGL(k_welsch, dim3(welsch_gx, nframes), dim3(64), 0, s, P, nframes);
+    mark();
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {
         unsigned long long h[16];

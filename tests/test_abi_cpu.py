@@ -76,7 +76,7 @@ def test_synthetic_generator_is_deterministic_and_planted(dictionary):
 def test_strerror_messages_mirror_reference_text():
     L = capi.load_library()
     assert L.ctag_strerror(1) == b"No corner detected!" and L.ctag_strerror(2) == b"No feature detected!"
-    assert [L.ctag_stage_name(i).decode() for i in range(9)] == ca.STAGE_NAMES
+    assert [L.ctag_stage_name(i).decode() for i in range(len(ca.STAGE_NAMES))] == ca.STAGE_NAMES and L.ctag_stage_name(len(ca.STAGE_NAMES)) == b""
 
 
 def test_cpp_host_layer_builds_and_keeps_reference_interface():

@@ -3,9 +3,10 @@
 
 Per kernel of the detect() path (mean over its launches in the profiled bench pass of 1024 frames): wave-instruction counts by
 unit and by type, FP64 share, VALU-busy and stall fractions, LDS bank-conflict rate, TA busy, and the VALU ISSUE model the
-bench's `issue_roofline` uses:  issue_cycles = 4 * (VALU - FP64) + 8 * FP64 wave-instructions (one wave's vector instruction
-holds its SIMD's issue port for 4 cycles, an FP64 add / mul / fma / cvt for 8: MI355X_MICROARCH.md "vector-instruction ISSUE
-cost", DESIGN.md 5); issue_bound_ms = issue_cycles / (1024 SIMDs * clock)."""
+bench's `issue_roofline` uses:  issue_cycles = 2 * (VALU - FP64) + 4 * FP64 wave-instructions -- the PEAK rate of a SIMD with
+two or more waves to pick from (a wave64 FP32 / integer instruction every 2 cycles, "v_fma_f32 (wave64) 2 cyc (SIMD-32)" in
+MI355X_MICROARCH.md; FP64 add / mul / fma at half that, 78.6 vs 157.3 TFLOP/s); one wave alone issues at half of it.
+issue_bound_ms = issue_cycles / (1024 SIMDs * 2.4 GHz)."""
 import collections
 import csv
 import glob
@@ -45,7 +46,7 @@ def main(tag, dirs):
         if valu < 1e4:
             continue
         f64 = g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")
-        issue_cycles = 4.0 * (valu - f64) + 8.0 * f64
+        issue_cycles = 2.0 * (valu - f64) + 4.0 * f64
         e = {"launch_ms_profiled": round(sum(dur[k]) / len(dur[k]), 4), "waves": g("SQ_WAVES"),
              "wave_instructions": {"valu": valu, "salu": g("SQ_INSTS_SALU"), "lds": g("SQ_INSTS_LDS"), "vmem_rd": g("SQ_INSTS_VMEM_RD"),
                                    "vmem_wr": g("SQ_INSTS_VMEM_WR")},

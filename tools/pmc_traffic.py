@@ -17,8 +17,9 @@ def main(fetch_dir, write_dir, frames_per_launch, tag):
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     detail, total = {}, 0.0
     for k in SWEEP:
-        fk = [v for name, vals in fe.items() if k in name for v in vals]
-        wk = [v for name, vals in wr.items() if k in name for v in vals]
+        base = lambda name: name.split("(")[0].split("<")[0].replace("void ", "").replace("ctag::", "")  # noqa: E731  (k_threshold_ccl, not ..._big)
+        fk = [v for name, vals in fe.items() if base(name) == k for v in vals]
+        wk = [v for name, vals in wr.items() if base(name) == k for v in vals]
         if not fk or not wk:
             continue
         fetch = sum(fk) / len(fk) * 1024.0
