@@ -114,3 +114,14 @@ def test_cpp_bmp_reader_matches_python_reader(test_bmp, tmp_path):
     b, g, rr = bgr[..., 0].astype(np.int64), bgr[..., 1].astype(np.int64), bgr[..., 2].astype(np.int64)
     assert (out.reshape(5, 7) == ((b * 1868 + g * 9617 + rr * 4899 + 8192) >> 14)).all()
     assert f(str(tmp_path / "missing.bmp").encode(), None, None, None, 0) == -1
+
+
+def test_opencv_branch_of_the_cpp_layer_passes_the_compiler():
+    """COMPILE CHECK ONLY (pins nothing about OpenCV): the -DCTAG_WITH_OPENCV branch of CylinderTag.{h,cpp} -- cv::Mat in
+    detect(), cv::Mat camera / pose members, cv::Mat1i dictionary: the drop-in build of INTEGRATION.md option A -- goes through
+    g++'s syntax and type checks against a declaration-only stand-in for <opencv2/core.hpp> (tests/opencv_decl_stub), because
+    this image has no OpenCV; without this the branch had never seen a compiler."""
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DCTAG_WITH_OPENCV", "-I" + os.path.join(ROOT, "tests", "opencv_decl_stub"),
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "cylindertag_amd", "csrc", "CylinderTag.cpp")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]

@@ -13,7 +13,7 @@ import dict_gen as dg  # noqa: E402
 
 def test_reference_dictionary_satisfies_the_generator_predicates():
     """CTag_2f12c.marker was produced by the reference generator: every code is legal (generator.m:17) and every cyclic
-    2-window is unique over the dictionary and its mirror image (testConflict, generator.m:288-334)."""
+    2-window is unique over the dictionary and its mirror image (testConflict, generator.m:247-286)."""
     state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
     assert state.shape == (41, 12) and fs == 2
     assert all(dg.legal_code(int(c)) for c in state.ravel())
@@ -54,3 +54,29 @@ def test_generated_dictionaries_are_legal_unique_and_loadable(tmp_path):
     a = dg.Generator(12, 2, seed=7).generate(6)
     b = dg.Generator(12, 2, seed=7).generate(6)
     assert np.array_equal(a, b)
+
+
+def test_strip_writer_round_trip_through_the_oracle(oracle, tmp_path):
+    """plot_tag / draw (generator.m:208-245): a dictionary row written as a printable strip (BMP) is read back and decoded by
+    detect() to exactly that row with all 12 columns; the gap centres follow the generator's quadratic (draw :227-241)."""
+    from ctag_testlib import read_bmp_gray, result_markers
+    state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    # known answers of block_pos: cross ratio (l0 + l1)(l2 + l1) / (l1 l3) of the column's edge = the id's cross ratio
+    for hid in range(8):
+        L, p = 1200.0, dg.block_pos(hid, 1200.0)
+        l0, l1, l2 = p - 0.1 * L, 0.2 * L, L - p - 0.1 * L
+        cr = (l0 + l1) * (l2 + l1) / (l1 * L)
+        assert abs(cr - dg.DECODER[hid][0]) < 1e-9 and (p > 0.5 * L) == bool(dg.DECODER[hid][1])
+    for row in (0, 17, 40):
+        path = str(tmp_path / ("cy%d.bmp" % (row + 1)))
+        dg.write_strip_bmp(path, state[row], tag_length=400, ratio=15, margin=(150, 260))
+        img = read_bmp_gray(path)
+        assert img.shape == (400 + 300, 480 + 520) and img.min() == 0 and img.max() == 255
+        res = oracle.detect_fast(img, state, fs)
+        ms = result_markers(res)
+        assert len(ms) == 1 and ms[0]["marker_id"] == row and sorted(ms[0]["pos"]) == list(range(12))
+        by_pos = dict(zip(ms[0]["pos"], ms[0]["id"]))
+        inv = [dg.invert_code(int(c)) for c in state[row]]
+        assert all(by_pos[p] in (int(state[row][p]), inv[p]) for p in range(12))
+    # the reference layout itself (no margin): tag_length x 1.5 * tag_length / ratio * columns, generator.m:212
+    assert dg.render_strip(state[0]).shape == (1200, 1440)

@@ -33,3 +33,22 @@ def test_generated_dictionary_round_trip():
         exact += planted == found
     assert exact >= int(0.85 * n)
     det.close()
+
+
+def test_written_strip_decodes_through_the_cpp_reader_and_the_hip_path(tmp_path):
+    """Rank 4 end to end: tools/dict_gen.py writes a dictionary row as a printable strip (plot_tag / draw, generator.m:208-245,
+    plus paper margin) -> the C++ BMP reader (ctag_io) -> CylinderTag::detect on the GPU (ctag_demo) -> the written row."""
+    import subprocess
+    from ctag_testlib import GOLDEN, ROOT, read_marker_file
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dict_gen as dg
+    state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
+    exe = os.path.join(ROOT, "cylindertag_amd", "_build", "ctag_demo")
+    for row in (3, 29):
+        path = str(tmp_path / ("cy%d.bmp" % (row + 1)))
+        dg.write_strip_bmp(path, state[row], tag_length=400, ratio=15, margin=(150, 260))
+        out = subprocess.check_output([exe, os.path.join(GOLDEN, "CTag_2f12c.marker"), path], timeout=120).decode()
+        lines = [l for l in out.splitlines() if l.startswith("id ")]
+        assert out.splitlines()[0] == "markers 1" and len(lines) == 1
+        toks = lines[0].split("|")[0].split()
+        assert int(toks[1]) == row and int(toks[3]) == 12
