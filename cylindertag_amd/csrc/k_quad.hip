@@ -236,9 +236,11 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
 }
 // the packed kernel takes every component whose working set fits the wave's LDS budget (the silhouette scan walks a wide
 // box in passes of 128 columns); the rest are "big" and go to k_quad_edges<true>
-__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h) {
+// big_points: in latency mode (a few frames per call) components with a long boundary also go there -- a whole wave per
+// component instead of 8 lanes shortens the critical path of the call; 0x7fffffff otherwise
+__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points) {
     (void)x_min;
-    return pack_need(w, h) > kPackWords;
+    return pack_need(w, h) > kPackWords || pack_points(w, h) > big_points;
 }
 
 struct CornerPre {
@@ -248,7 +250,7 @@ struct CornerPre {
 // BIG = false: components whose working set fits the LDS budget (LDS-typed pointers, the common case);
 // BIG = true: the rare oversize components, same code on a global scratch slot.
 template <bool BIG>
-__global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGeom g, int nframes) {
+__global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGeom g, int nframes, int big_points, int bcols) {
     __shared__ uint32_t s_mem[kQuadLdsWords];
     __shared__ unsigned long long s_sum[2];
     __shared__ int s_i[16];
@@ -268,15 +270,15 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
         }
     };
     // Persistent blocks: block b owns global scratch slot b for the whole launch and walks the (frame, column) items
-    // b, b + gridDim.x, ...; column c of a frame takes that frame's candidates c, c + 4, ...  (a slot per component would
+    // b, b + gridDim.x, ...; column c of a frame takes that frame's candidates c, c + bcols, ...  (a slot per component would
     // run out on a batch with many oversize components)
-    for (int item = blockIdx.x; item < 4 * nframes; item += gridDim.x) {
-    const int frame = item >> 2;
+    for (int item = blockIdx.x; item < bcols * nframes; item += gridDim.x) {
+    const int frame = item / bcols;
     const int nc = P.ncand[frame];
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
-    for (int ci = item & 3; ci < nc; ci += 4) {
+    for (int ci = item - frame * bcols; ci < nc; ci += bcols) {
         __syncthreads();
         stamp(-1);
         const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
         const int C = min(2 * (w + h), w * h) + 1;
         const int w2 = (w + 1) & ~1;
         const size_t need = (size_t)(w2) + 2 * (size_t)h + 3 * (size_t)C + 72;
-        if (BIG != pack_big(x_min, w, h)) continue;  // block-uniform: k_quad_edges_packed owns the rest
+        if (BIG != pack_big(x_min, w, h, big_points)) continue;  // block-uniform: k_quad_edges_packed owns the rest
         uint32_t* mem = s_mem;
         if (BIG) {
             const int slot = blockIdx.x;
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
 // K6p: greedy packing of a frame's candidates (in candidate order) into waves of <= 8 components whose LDS needs
 // sum to <= kPackWords.  Oversize components are skipped here; k_quad_edges<true> takes them.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack) {
+__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points) {
     const int frame = blockIdx.x * 64 + threadIdx.x;
     if (frame >= nframes) return;
     const int nc = P.ncand[frame];
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
     for (int i = 0; i < nc; i++) {
         const Candidate c = cand[i];
         const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
-        const bool big = pack_big(c.x_min, c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
+        const bool big = pack_big(c.x_min, c.x_max - c.x_min + 1, c.y_max - c.y_min + 1, big_points);
         if (cnt > 0 && (big || cnt == max_per_pack || words + need > kPackWords)) {  // packs hold consecutive candidates
             packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
             cnt = 0;
@@ -1641,13 +1643,17 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     (void)hipMemsetAsync(ws.clp_used, 0, sizeof(int32_t) * (size_t)nframes, s);
     static const int pack_max_env = getenv("CTAG_PACK_MAX") ? atoi(getenv("CTAG_PACK_MAX")) : 0;
     const int pack_max = pack_max_env > 0 ? std::min(pack_max_env, kSG) : kSG;
-    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes, pack_max);
+    static const int big_env = getenv("CTAG_BIG_POINTS") ? atoi(getenv("CTAG_BIG_POINTS")) : 0;
+    const int big_points = big_env > 0 ? big_env : 0x7fffffff;
+    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes, pack_max, big_points);
     mark();
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
     hipLaunchKernelGGL(k_quad_edges_packed, dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
     mark();
-    hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(4 * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes);
+    static const int bcols_env = getenv("CTAG_BIG_COLS") ? atoi(getenv("CTAG_BIG_COLS")) : 0;
+    const int bcols = bcols_env > 0 ? bcols_env : 4;
+    hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(bcols * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes, big_points, bcols);
     mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     mark();
