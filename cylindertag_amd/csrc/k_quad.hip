@@ -96,7 +96,7 @@ struct CvRng {
 #define CTAG_WCAP 16
 #endif
 #ifndef CTAG_WUNROLL
-#define CTAG_WUNROLL 1
+#define CTAG_WUNROLL 2
 #endif
 #define CTAG_PRAGMA_(x) _Pragma(#x)
 #define CTAG_PRAGMA(x) CTAG_PRAGMA_(x)
@@ -226,7 +226,12 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
 #ifndef CTAG_PACK_WAVES
 #define CTAG_PACK_WAVES 2
 #endif
-constexpr int kPackWords = CTAG_PACK_WORDS;  // LDS words shared by the up to 8 components of a wave
+constexpr int kPackWords = CTAG_PACK_WORDS;  // LDS words shared by the up to 8 components of a wave (large configuration)
+// Two builds of the packed kernel.  The kernel is bound by dependent LDS round trips (24 % of the issue roof at 2 waves per
+// SIMD), so for frames of 1080p class -- boundaries of ~150 points, a pack of 5 components in 10 KB -- the small configuration
+// runs 4 waves per SIMD (128 VGPRs, 61 of them spilled to scratch: still 6.8 -> 6.2 ms per 4096 frames); 4K frames have
+// components four times the size and keep the large one (same-box A/B: 8.4 vs 7.9 ms per 1024 frames with the small one).
+constexpr int kPackWordsSmall = 2560, kPackWavesSmall = 4;
 constexpr int kSG = 8;
 __host__ __device__ __forceinline__ int pack_points(int w, int h) { return min(2 * (w + h), w * h) + 1; }
 // LDS words one component needs in the packed kernel: silhouette arrays + boundary list + stack / ping-pong list
@@ -238,9 +243,9 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
 // box in passes of 128 columns); the rest are "big" and go to k_quad_edges<true>
 // big_points: in latency mode (a few frames per call) components with a long boundary also go there -- a whole wave per
 // component instead of 8 lanes shortens the critical path of the call; 0x7fffffff otherwise
-__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points) {
+__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points, int pack_words) {
     (void)x_min;
-    return pack_need(w, h) > kPackWords || pack_points(w, h) > big_points;
+    return pack_need(w, h) > pack_words || pack_points(w, h) > big_points;
 }
 
 struct CornerPre {
@@ -250,7 +255,7 @@ struct CornerPre {
 // BIG = false: components whose working set fits the LDS budget (LDS-typed pointers, the common case);
 // BIG = true: the rare oversize components, same code on a global scratch slot.
 template <bool BIG>
-__global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGeom g, int nframes, int big_points, int bcols) {
+__global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGeom g, int nframes, int big_points, int bcols, int pack_words) {
     __shared__ uint32_t s_mem[kQuadLdsWords];
     __shared__ unsigned long long s_sum[2];
     __shared__ int s_i[16];
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
         const int C = min(2 * (w + h), w * h) + 1;
         const int w2 = (w + 1) & ~1;
         const size_t need = (size_t)(w2) + 2 * (size_t)h + 3 * (size_t)C + 72;
-        if (BIG != pack_big(x_min, w, h, big_points)) continue;  // block-uniform: k_quad_edges_packed owns the rest
+        if (BIG != pack_big(x_min, w, h, big_points, pack_words)) continue;  // block-uniform: k_quad_edges_packed owns the rest
         uint32_t* mem = s_mem;
         if (BIG) {
             const int slot = blockIdx.x;
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
 // K6p: greedy packing of a frame's candidates (in candidate order) into waves of <= 8 components whose LDS needs
 // sum to <= kPackWords.  Oversize components are skipped here; k_quad_edges<true> takes them.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points) {
+__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words) {
     const int frame = blockIdx.x * 64 + threadIdx.x;
     if (frame >= nframes) return;
     const int nc = P.ncand[frame];
@@ -768,8 +773,8 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
     for (int i = 0; i < nc; i++) {
         const Candidate c = cand[i];
         const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
-        const bool big = pack_big(c.x_min, c.x_max - c.x_min + 1, c.y_max - c.y_min + 1, big_points);
-        if (cnt > 0 && (big || cnt == max_per_pack || words + need > kPackWords)) {  // packs hold consecutive candidates
+        const bool big = pack_big(c.x_min, c.x_max - c.x_min + 1, c.y_max - c.y_min + 1, big_points, pack_words);
+        if (cnt > 0 && (big || cnt == max_per_pack || words + need > pack_words)) {  // packs hold consecutive candidates
             packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
             cnt = 0;
             words = 0;
@@ -920,8 +925,9 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
 // Every lane of a sub-group executes the serial control flow redundantly (uniform within the sub-group), so no
 // broadcasts are needed; loops over pixels / boundary points are strided over the 8 lanes.
 // =====================================================================================================
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_PACK_WAVES, CTAG_PACK_WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes) {
-    __shared__ uint32_t s_mem[kPackWords];
+template <int WORDS, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes) {
+    __shared__ uint32_t s_mem[WORDS];
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
     const int lane = threadIdx.x, sub = lane >> 3, sl = lane & 7, lane0 = lane & ~7;
@@ -1526,7 +1532,10 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int f
     }
 }
 
-__global__ __launch_bounds__(64) void k_welsch(QuadPtrs P, int nframes) {
+#ifndef CTAG_WELSCH_WAVES
+#define CTAG_WELSCH_WAVES 5
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes) {
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
@@ -1645,15 +1654,20 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     const int pack_max = pack_max_env > 0 ? std::min(pack_max_env, kSG) : kSG;
     static const int big_env = getenv("CTAG_BIG_POINTS") ? atoi(getenv("CTAG_BIG_POINTS")) : 0;
     const int big_points = big_env > 0 ? big_env : 0x7fffffff;
-    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes, pack_max, big_points);
+    const bool small_cfg = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;  // up to 1920x1200 frames
+    const int pack_words = small_cfg ? kPackWordsSmall : kPackWords;
+    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words);
     mark();
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
-    hipLaunchKernelGGL(k_quad_edges_packed, dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    if (small_cfg)
+        hipLaunchKernelGGL((k_quad_edges_packed<kPackWordsSmall, kPackWavesSmall>), dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    else
+        hipLaunchKernelGGL((k_quad_edges_packed<kPackWords, CTAG_PACK_WAVES>), dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
     mark();
     static const int bcols_env = getenv("CTAG_BIG_COLS") ? atoi(getenv("CTAG_BIG_COLS")) : 0;
     const int bcols = bcols_env > 0 ? bcols_env : 4;
-    hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(bcols * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes, big_points, bcols);
+    hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(bcols * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes, big_points, bcols, pack_words);
     mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     mark();
