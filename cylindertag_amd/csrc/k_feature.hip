@@ -320,7 +320,12 @@ constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: wa
 #endif
 constexpr int kRefineRegion = CTAG_REFINE_REGION;
 
-__global__ __launch_bounds__(kRefineThreads) void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
+#ifdef CTAG_REFINE_WAVES
+__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(CTAG_REFINE_WAVES, CTAG_REFINE_WAVES)))
+#else
+__global__ __launch_bounds__(kRefineThreads)
+#endif
+void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
     // 16 columns of per-sample values: rows 0-3 x of edge 0-3, 4-7 y, 8-11 weight towards the next corner, 12-15 towards the

@@ -1113,7 +1113,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 note(fg_of(v, labA0, labB0, over0, trow + tcol0, valid0), y, top0, bot0, seen0, gxf - x_min);
                 if (ld_ok1) note(fg_of(v1, labA1, labB1, over1, trow + tcol1, valid1), y, top1, bot1, seen1, gxf + 64 - x_min);
             };
-            // 4 label rows in flight per lane: the scan is bound by latency, not by bytes
+            // label rows in flight per lane (the scan is bound by latency, not by bytes): 4 in the large configuration, 2 in the
+            // small one, whose 128-register budget the eight row registers of the deeper pipeline would spill
+            if constexpr (WAVES >= 4) {
+                uint4 r0 = load_row(0), r1 = load_row(1);
+                uint4 s0 = load_row1(0), s1 = load_row1(1);
+                for (int y = 0; y < h; y += 2) {
+                    process_row(r0, s0, y);
+                    r0 = load_row(y + 2);
+                    s0 = load_row1(y + 2);
+                    if (y + 1 < h) process_row(r1, s1, y + 1);
+                    r1 = load_row(y + 3);
+                    s1 = load_row1(y + 3);
+                }
+            } else {
             uint4 r0 = load_row(0), r1 = load_row(1), r2 = load_row(2), r3 = load_row(3);
             uint4 s0 = load_row1(0), s1 = load_row1(1), s2 = load_row1(2), s3 = load_row1(3);
             for (int y = 0; y < h; y += 4) {
@@ -1129,6 +1142,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 if (y + 3 < h) process_row(r3, s3, y + 3);
                 r3 = load_row(y + 7);
                 s3 = load_row1(y + 7);
+            }
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
