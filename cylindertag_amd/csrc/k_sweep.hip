@@ -1053,7 +1053,12 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
 }
 
 template <int TWC>
-__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
+#ifdef CTAG_CCL_WAVES
+__global__ __launch_bounds__(kCclThreads) __attribute__((amdgpu_waves_per_eu(CTAG_CCL_WAVES, CTAG_CCL_WAVES)))
+#else
+__global__ __launch_bounds__(kCclThreads)
+#endif
+void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // one tile per block; blocks b and b+8 share an XCD, so a frame's tiles stay on one XCD (map_block)
     int frame0, tile0;
