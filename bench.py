@@ -345,17 +345,24 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the detection path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())  # identity on a node with one GPU per rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm.  CTAG_BENCH_BACKEND=gloo is a developer aid: it lets N ranks share ONE GPU (RCCL refuses that),
+        # which exercises the sharding / double-buffering / hashing logic of this file; the gather then goes through host memory
+        backend = os.environ.get("CTAG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
-    det = ca.Detector(state, fs, device=local_rank)
+    det = ca.Detector(state, fs, device=dev_index)
     subpix = not args.no_subpix
 
     # ---- the job: n_total frames per step; this rank owns frames [lo, hi) of it
@@ -375,13 +382,16 @@ def main():
         # communicator fail to come up, torch.distributed's all_gather of the fixed records (also RCCL) takes over and the
         # line says so.
         gathered = [torch.zeros((n_total, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host_gather = dist.get_backend() != "nccl"
         try:
+            if host_gather:
+                raise RuntimeError("backend %s: no RCCL communicator" % dist.get_backend())
             comm = CommGather(det, dist)
             gather_impl = "ctag_gather (C ABI -> ncclAllGather of packed shards)"
         except Exception as e:  # noqa: BLE001
             comm = None
             gather_impl = "torch.distributed.all_gather_into_tensor of fixed records (ctag_comm_init failed: %s)" % e
-        flags = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        flags = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cpu" if host_gather else dev)
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)
         if int(flags.item()) == 0 and comm is not None:  # some rank fell back: all ranks must take the same path
             comm.close()
@@ -410,7 +420,12 @@ def main():
                 pending.append(k)
             else:
                 det.sync()
-                dist.all_gather_into_tensor(gathered[k % 2].view(-1), buf[:n].reshape(-1))
+                if host_gather:  # developer aid (gloo): through host memory
+                    out_h = torch.empty((n_total, rec_bytes), dtype=torch.uint8)
+                    dist.all_gather_into_tensor(out_h.view(-1), buf[:n].cpu().reshape(-1))
+                    gathered[k % 2].copy_(out_h)
+                else:
+                    dist.all_gather_into_tensor(gathered[k % 2].view(-1), buf[:n].reshape(-1))
 
     def fence():
         finish_pending()
@@ -442,7 +457,7 @@ def main():
     dt = time.perf_counter() - t0
     det.set_option(capi.OPT_TIMING, 0)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     last = step_no[0] - 1

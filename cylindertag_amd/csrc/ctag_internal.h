@@ -25,7 +25,10 @@ namespace ctag {
 constexpr int kTileW = 320;             // 5 x 64-bit mask words per tile row
 constexpr int kTileH = 30;
 constexpr int kTileWords = kTileW / 64;
-constexpr int kRunCap = 2048;           // row-runs per tile the first CCL pass holds in LDS; a tile with more takes the second pass
+#ifndef CTAG_RUN_CAP
+#define CTAG_RUN_CAP 2048
+#endif
+constexpr int kRunCap = CTAG_RUN_CAP;           // row-runs per tile the first CCL pass holds in LDS; a tile with more takes the second pass
 constexpr int kSlotCap = 128;           // tile-local components a tile publishes in the first CCL pass; a tile with more takes the second pass
 constexpr int kPoolCapMin = 8192;       // tile-local components per frame (global pool): max(this, 256 per CCL tile), FrameGeom::pool_cap
 constexpr int kCandCap = 2048;          // max area-filtered candidates per frame
