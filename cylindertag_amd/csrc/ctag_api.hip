@@ -59,6 +59,21 @@ struct ctag_handle {
     size_t d_synth_count = 0;
     int last_chunk_frames = 0;
     char last_error[256] = {0};
+    // hipGraph cache of the per-chunk kernel chain (CTAG_OPT_GRAPH): a chunk with the same pointers, sizes and parameters is
+    // replayed with one hipGraphLaunch instead of ~25 launches / memsets -- what a stream of single frames (main.cpp:52-59)
+    // and the small per-GPU shards of a multi-GPU job repeat thousands of times
+    struct GraphEntry {
+        const void* frames = nullptr;
+        void* out = nullptr;
+        const void* ws_base = nullptr;
+        int n = 0, rows = 0, cols = 0, tw = 0, subpix = 0, dist = 0, keep_pre = 0;
+        ptrdiff_t row_stride = 0, frame_stride = 0;
+        hipGraphExec_t exec = nullptr;
+        uint64_t last_use = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    int use_graph = 0;   // CTAG_OPT_GRAPH; back to 0 after a capture failed once (the direct path takes over for good)
     // state of the pose back end (k_pose.hip), created on first use
     void* pose_state = nullptr;
     void (*pose_state_free)(void*) = nullptr;
@@ -130,6 +145,8 @@ static void build_resize_tables(int src, int dst, std::vector<int32_t>& ofs, std
     }
 }
 
+static void drop_graphs(ctag_handle* h);
+
 static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int frames) {
     if (h->ws.base && h->ws_rows == rows && h->ws_cols == cols && h->ws_cap >= frames) {
         h->ws.g = make_geom(rows, cols, tw);
@@ -139,6 +156,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     }
     if (h->ws.base) {
         HIP_TRY(hipStreamSynchronize(h->stream));
+        drop_graphs(h);  // they hold pointers into the old workspace
         HIP_TRY(hipFree(h->ws.base));
         h->ws = Workspace{};
     }
@@ -261,25 +279,14 @@ static int check_args(ctag_handle* h, const void* frames, int n, int rows, int c
     return CTAG_OK;
 }
 
-// enqueue the whole pipeline for `n` device-resident frames (n <= workspace capacity)
-static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
-                     ctag_frame_result* out_dev) {
+// enqueue the whole pipeline for `n` device-resident frames (n <= workspace capacity); evs: CTAG_NUM_STAGES + 1 timing events or null
+static int enqueue_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
+                         ctag_frame_result* out_dev, hipEvent_t* evs) {
     const Workspace& ws = h->ws;
     hipStream_t s = h->stream;
     HIP_TRY(hipMemsetAsync(ws.frame_ncomp, 0, (size_t)n * 4, s));
     HIP_TRY(hipMemsetAsync(ws.frame_flags, 0, (size_t)n * 4, s));
     int st = 0;
-    hipEvent_t* evs = nullptr;
-    if (h->timing) {
-        const size_t need = (size_t)(h->ev_sets_used + 1) * (CTAG_NUM_STAGES + 1);
-        while (h->ev.size() < need) {
-            hipEvent_t e = nullptr;
-            HIP_TRY(hipEventCreate(&e));
-            h->ev.push_back(e);
-        }
-        evs = h->ev.data() + (size_t)h->ev_sets_used * (CTAG_NUM_STAGES + 1);
-        h->ev_sets_used++;
-    }
     auto mark = [&](int i) -> hipError_t { return evs ? hipEventRecord(evs[i], s) : hipSuccess; };
     HIP_TRY(mark(0));
     HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s));
@@ -303,8 +310,92 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
     if (!h->keep_pre) wtmp.premarkers = nullptr;
     HIP_TRY(launch_markers(n, wtmp, p, out_dev, s));
     HIP_TRY(mark(++st));
-    h->last_chunk_frames = n;
     return CTAG_OK;
+}
+
+static void drop_graphs(ctag_handle* h) {
+    for (auto& g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+// replay (or first capture) the chunk as a hipGraph; any failure disables the graph path for this handle and the caller
+// falls back to direct launches -- results are the same either way
+static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
+                            ctag_frame_result* out_dev) {
+    constexpr size_t kMaxGraphs = 8;
+    ctag_handle::GraphEntry* hit = nullptr;
+    for (auto& g : h->graphs)
+        if (g.frames == frames_dev && g.out == out_dev && g.ws_base == h->ws.base && g.n == n && g.rows == h->ws.g.rows && g.cols == h->ws.g.cols &&
+            g.tw == p.adaptive_thresh && g.subpix == p.corner_subpix && g.dist == p.subpix_dist && g.keep_pre == (h->keep_pre ? 1 : 0) &&
+            g.row_stride == row_stride && g.frame_stride == frame_stride)
+            hit = &g;
+    if (!hit) {
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) != hipSuccess) return false;
+        const int r = enqueue_chunk(h, frames_dev, n, row_stride, frame_stride, p, out_dev, nullptr);
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (r != CTAG_OK || e != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            return false;
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess || !exec) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (h->graphs.size() >= kMaxGraphs) {  // evict the least recently used
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); i++)
+                if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+            (void)hipGraphExecDestroy(h->graphs[lru].exec);
+            h->graphs.erase(h->graphs.begin() + (ptrdiff_t)lru);
+        }
+        ctag_handle::GraphEntry g;
+        g.frames = frames_dev;
+        g.out = out_dev;
+        g.ws_base = h->ws.base;
+        g.n = n;
+        g.rows = h->ws.g.rows;
+        g.cols = h->ws.g.cols;
+        g.tw = p.adaptive_thresh;
+        g.subpix = p.corner_subpix;
+        g.dist = p.subpix_dist;
+        g.keep_pre = h->keep_pre ? 1 : 0;
+        g.row_stride = row_stride;
+        g.frame_stride = frame_stride;
+        g.exec = exec;
+        h->graphs.push_back(g);
+        hit = &h->graphs.back();
+    }
+    hit->last_use = ++h->graph_clock;
+    return hipGraphLaunch(hit->exec, h->stream) == hipSuccess;
+}
+
+static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
+                     ctag_frame_result* out_dev) {
+    h->last_chunk_frames = n;
+    hipEvent_t* evs = nullptr;
+    if (h->timing) {
+        const size_t need = (size_t)(h->ev_sets_used + 1) * (CTAG_NUM_STAGES + 1);
+        while (h->ev.size() < need) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        evs = h->ev.data() + (size_t)h->ev_sets_used * (CTAG_NUM_STAGES + 1);
+        h->ev_sets_used++;
+    }
+    static const bool stamps = getenv("CTAG_CCL_STAMPS") != nullptr || getenv("CTAG_QUAD_STAMPS") != nullptr;  // developer aids that synchronise inside the chain
+    if (!evs && h->use_graph && !stamps) {
+        if (run_chunk_graph(h, frames_dev, n, row_stride, frame_stride, p, out_dev)) return CTAG_OK;
+        h->use_graph = 0;  // capture / instantiate / launch failed: direct launches from now on
+        drop_graphs(h);
+    }
+    return enqueue_chunk(h, frames_dev, n, row_stride, frame_stride, p, out_dev, evs);
 }
 
 // public entry points call begin_timings() before their first chunk and collect_timings() after their last
@@ -463,6 +554,7 @@ void ctag_destroy(ctag_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->d_dict) (void)hipFree(h->d_dict);
     if (h->d_pick_table) (void)hipFree(h->d_pick_table);
@@ -517,6 +609,10 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
             return CTAG_OK;
         case CTAG_OPT_TIMING: h->timing = value != 0; return CTAG_OK;
         case CTAG_OPT_KEEP_PREMARKERS: h->keep_pre = value != 0; return CTAG_OK;
+        case CTAG_OPT_GRAPH:
+            h->use_graph = value != 0;
+            if (!h->use_graph) drop_graphs(h);
+            return CTAG_OK;
         case CTAG_OPT_HOST_SUBCHUNK:
             if (value < 1 || value > (1 << 20)) return CTAG_ERR_ARG;
             h->host_sub = (int)value;

@@ -71,6 +71,8 @@ void* ctag_stream(ctag_handle* h);
 #define CTAG_OPT_TIMING 2         /* 1: bracket every kernel with HIP events (ctag_get_timings) */
 #define CTAG_OPT_KEEP_PREMARKERS 3 /* 1: keep the markers before decoding for ctag_debug_fetch */
 #define CTAG_OPT_HOST_SUBCHUNK 4   /* frames per upload/detect pipeline step of ctag_detect_batch_u8; default 128 */
+#define CTAG_OPT_GRAPH 5           /* 1: replay a chunk whose pointers / sizes / parameters repeat as one hipGraph launch; default 0 (measured: no gain,
+                                      the chain is not launch-bound -- DESIGN.md 10) */
 int ctag_set_option(ctag_handle* h, int option, int64_t value);
 
 /* Per-stage device time of the LAST ctag_detect_batch_* call, milliseconds measured with HIP events on

@@ -335,6 +335,35 @@ def test_batch_equals_single_and_is_repeatable(detector, dictionary):
         assert a[k].tobytes() == detector.detect(frames[k]).tobytes()
 
 
+def test_graph_replay_option_gives_identical_records(detector, dictionary):
+    """CTAG_OPT_GRAPH: the per-chunk kernel chain captured once and replayed as a hipGraph (off by default: no measured gain)
+    returns the same bytes, across repeated calls, changing inputs behind the same pointers, and a changed batch size."""
+    import torch
+    state, fs = dictionary
+    n, rows, cols = 24, 1080, 1920
+    frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+    detector.synth_frames_device(frames.data_ptr(), 900, n, rows, cols, cols, rows * cols)
+    out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+
+    def run(m):
+        out.zero_()
+        torch.cuda.synchronize()
+        detector.detect_batch_device(frames.data_ptr(), m, rows, cols, cols, rows * cols, out.data_ptr())
+        detector.sync()
+        return out[:m].cpu().numpy().tobytes()
+
+    want24, want7 = run(24), run(7)
+    detector.set_option(capi.OPT_GRAPH, 1)
+    try:
+        assert run(24) == want24 and run(24) == want24 and run(7) == want7 and run(24) == want24
+        detector.synth_frames_device(frames.data_ptr(), 950, n, rows, cols, cols, rows * cols)  # new content, same pointers
+        got = run(24)
+        detector.set_option(capi.OPT_GRAPH, 0)
+        assert got == run(24) and got != want24
+    finally:
+        detector.set_option(capi.OPT_GRAPH, 0)
+
+
 def test_streamed_host_batch(detector, oracle, dictionary):
     """ctag_detect_batch_u8 streams sub-chunks through two device slabs (upload of k+1 overlapping detection of k): the
     records equal the ORACLE's for pinned and pageable frame memory, odd sub-chunk counts and strided rows."""
