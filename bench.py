@@ -306,6 +306,26 @@ def cpu_baseline(frames_dev, n_one, per_thread, state, fs, subpix):
     return out, records
 
 
+def opencv_stage_probe(frames_host):
+    """BASELINE.md's optional stage-level sanity baseline: if an OpenCV build is importable on this host, time its own
+    resize(INTER_CUBIC, 1/2) + connectedComponentsWithStats(8, CCL_BBDT) -- the two OpenCV primitives of the sweep
+    (CylinderTag.cpp:79, corner_detector.cpp:82) -- on a few frames of the batch and say which version; otherwise say so.
+    (This image and the GPU box have no OpenCV: the probe reports its absence.)"""
+    try:
+        import cv2
+    except Exception as e:  # noqa: BLE001
+        return {"available": False, "note": "no OpenCV importable on this host (%s): stage-level OpenCV baseline not measured" % type(e).__name__}
+    n = min(16, len(frames_host))
+    t0 = time.perf_counter()
+    for f in frames_host[:n]:
+        half = cv2.resize(f, (f.shape[1] // 2, f.shape[0] // 2), 0.5, 0.5, cv2.INTER_CUBIC)
+        binary = ((half.astype(np.float32) * np.float32(1.0 / 255)) < 0.3).astype(np.uint8) * 255  # stand-in mask: the threshold is the reference's own code
+        cv2.connectedComponentsWithStats(binary, 8, cv2.CV_32S, cv2.CCL_BBDT)
+    dt = time.perf_counter() - t0
+    return {"available": True, "version": cv2.__version__, "threads": cv2.getNumThreads(), "frames": n,
+            "resize_plus_ccl_frames_per_s": round(n / dt, 1), "note": "OpenCV resize INTER_CUBIC + connectedComponentsWithStats(8, CCL_BBDT) only"}
+
+
 def latency_side(det, state, fs, calls=200):
     """Side measurement (never `value`): the reference's actual use -- one frame per call (main.cpp:52-59) -- on the
     reference's test.bmp through ctag_detect_u8 (host frame in, host record out)."""
@@ -546,6 +566,8 @@ def main():
         else:
             out["cpu_baseline"] = None
             out["parity"] = None
+        if world == 1 and args.cpu_frames > 0 and frames is not None:
+            side("opencv_stage_probe", lambda: opencv_stage_probe(frames[:16].cpu().numpy()))
         if world == 1 and args.host_frames > 0:
             side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
         if world == 1 and args.latency_calls > 0:
