@@ -193,7 +193,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_lsort = take(F * kLineCap * 4);
     const size_t o_lfit = take(F * kLineCap * 16);
     const size_t o_aux = take(F * kCandCap * sizeof(CandAux));
-    const size_t o_npk = take(F * 4), o_pk = take(F * kCandCap * 4);
+    const size_t o_npk = take(F * 4), o_pk = take(F * kCandCap * 4), o_pord = take(F * kCandCap * 2);
     const size_t o_der = take(F * kCandCap * 48);
     const size_t o_qidx = take(F * kCandCap * 4);
     const size_t o_nq = take(F * 4), o_nf = take(F * 4), o_st = take(F * 4);
@@ -240,6 +240,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.cand_aux = reinterpret_cast<CandAux*>(b + o_aux);
     W.npacks = reinterpret_cast<int32_t*>(b + o_npk);
     W.packs = reinterpret_cast<uint32_t*>(b + o_pk);
+    W.pack_order = reinterpret_cast<uint16_t*>(b + o_pord);
     W.pick_table = h->d_pick_table;
     W.quad_derived = b + o_der;
     W.quad_index = reinterpret_cast<int32_t*>(b + o_qidx);
@@ -284,8 +285,7 @@ static int enqueue_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdi
                          ctag_frame_result* out_dev, hipEvent_t* evs) {
     const Workspace& ws = h->ws;
     hipStream_t s = h->stream;
-    HIP_TRY(hipMemsetAsync(ws.frame_ncomp, 0, (size_t)n * 4, s));
-    HIP_TRY(hipMemsetAsync(ws.frame_flags, 0, (size_t)n * 4, s));
+    HIP_TRY(launch_zero_counters(n, ws, s));
     int st = 0;
     auto mark = [&](int i) -> hipError_t { return evs ? hipEventRecord(evs[i], s) : hipSuccess; };
     HIP_TRY(mark(0));

@@ -122,6 +122,7 @@ struct Workspace {
     CandAux* cand_aux = nullptr;    // [F][kCandCap]
     int32_t* npacks = nullptr;      // [F]
     uint32_t* packs = nullptr;      // [F][kCandCap]
+    uint16_t* pack_order = nullptr; // [F][kCandCap]
     const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
     // features
     void* quad_derived = nullptr;   // [F][kCandCap] x 48 B (K7 scratch)
@@ -152,6 +153,7 @@ struct DetectParams {
 };
 
 // kernel launchers (each enqueues on `s`, returns hipGetLastError())
+hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s);  // frame_ncomp, frame_flags, line_count, clp_used, ovf_count
 hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s);

@@ -46,7 +46,8 @@ struct QuadPtrs {
     const int32_t* member_head;  // [F][pool_cap]
     const int32_t* member_next;  // [F][pool_cap]
     int32_t* npacks;       // [F]
-    uint32_t* packs;       // [F][kCandCap] first candidate | count << 16
+    uint32_t* packs;       // [F][kCandCap] first entry of pack_order | count << 16, longest first
+    uint16_t* pack_order;  // [F][kCandCap] candidate indices by descending boundary capacity
     unsigned long long* stamps;  // developer aid (CTAG_QUAD_STAMPS=1): cycles per phase of k_quad_edges, else null
 };
 
@@ -760,32 +761,58 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
 
 
 // =====================================================================================================
-// K6p: greedy packing of a frame's candidates (in candidate order) into waves of <= 8 components whose LDS needs
-// sum to <= kPackWords.  Oversize components are skipped here; k_quad_edges<true> takes them.
+// K6p: packs of a frame's candidates for k_quad_edges_packed: <= 8 components whose LDS needs sum to <= pack_words per wave.
+// Candidates are ranked by boundary capacity, LONGEST FIRST, and packed in that order: a pack's 8-lane sub-groups run in
+// lockstep, so its time is its longest component's -- components of similar length share a wave -- and the packs come out
+// longest first, which is the order the kernel dispatches them in across the whole batch (the long ones used to start
+// anywhere and were the kernel's tail: a 150-point boundary is ~0.3 ms of dependent LDS round trips).
+// One block per frame; rank sort in LDS like k_candidates.  Oversize components are skipped; k_quad_edges<true> takes them.
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words) {
-    const int frame = blockIdx.x * 64 + threadIdx.x;
+    __shared__ int s_key[kCandCap];
+    __shared__ uint16_t s_ord[kCandCap];
+    const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    const int nc = P.ncand[frame];
+    const int nc = min(P.ncand[frame], kCandCap);
     const Candidate* cand = P.cand + (size_t)frame * kCandCap;
-    uint32_t* packs = P.packs + (size_t)frame * kCandCap;
-    int np = 0, first = -1, cnt = 0, words = 0;
-    for (int i = 0; i < nc; i++) {
+    uint16_t* order = P.pack_order + (size_t)frame * kCandCap;
+    for (int i = threadIdx.x; i < nc; i += 64) {
         const Candidate c = cand[i];
-        const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
-        const bool big = pack_big(c.x_min, c.x_max - c.x_min + 1, c.y_max - c.y_min + 1, big_points, pack_words);
-        if (cnt > 0 && (big || cnt == max_per_pack || words + need > pack_words)) {  // packs hold consecutive candidates
-            packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
-            cnt = 0;
-            words = 0;
-        }
-        if (big) continue;
-        if (cnt == 0) first = i;
-        cnt++;
-        words += need;
+        const int w = c.x_max - c.x_min + 1, h = c.y_max - c.y_min + 1;
+        s_key[i] = pack_big(c.x_min, w, h, big_points, pack_words) ? -1 : pack_points(w, h);  // -1: not packed, sorts last
     }
-    if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
-    P.npacks[frame] = np;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += 64) {
+        const int ki = s_key[i];
+        int rank = 0;
+        for (int j = 0; j < nc; j++) {
+            const int kj = s_key[j];
+            rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+        }
+        s_ord[rank] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += 64) order[i] = s_ord[i];
+    if (threadIdx.x == 0) {
+        uint32_t* packs = P.packs + (size_t)frame * kCandCap;
+        int np = 0, first = -1, cnt = 0, words = 0;
+        for (int r = 0; r < nc; r++) {
+            const int i = s_ord[r];
+            if (s_key[i] < 0) break;  // the rest is oversize
+            const Candidate c = cand[i];
+            const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
+            if (cnt > 0 && (cnt == max_per_pack || words + need > pack_words)) {  // a pack = consecutive entries of `order`
+                packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
+                cnt = 0;
+                words = 0;
+            }
+            if (cnt == 0) first = r;
+            cnt++;
+            words += need;
+        }
+        if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
+        P.npacks[frame] = np;
+    }
 }
 
 // wave-level ordering point for the 8-lane sub-groups (no s_barrier: the sub-groups of a wave run in lockstep;
@@ -928,7 +955,7 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
 template <int WORDS, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes) {
     __shared__ uint32_t s_mem[WORDS];
-    const int frame = blockIdx.y;
+    const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int lane = threadIdx.x, sub = lane >> 3, sl = lane & 7, lane0 = lane & ~7;
     const int npk = P.npacks[frame];
@@ -944,15 +971,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             t_prev = t;
         }
     };
-    // a frame's packs fill block columns 0..npk-1 only and blockIdx.x % 8 picks the XCD, so the column is rotated by
-    // the frame index: otherwise the low XCDs carry twice the work of the high ones
-    for (int pk = (blockIdx.x + frame) % gridDim.x; pk < npk; pk += gridDim.x) {
+    // blockIdx.x (the fast dispatch index) is the frame, blockIdx.y the pack rank: the longest packs of ALL frames start first
+    for (int pk = blockIdx.y; pk < npk; pk += gridDim.y) {
         __syncthreads();  // single-wave workgroup: the previous pack is done with s_mem
         stamp(-1);
         const uint32_t pw = P.packs[(size_t)frame * kCandCap + pk];
         const int first = (int)(pw & 0xffffu), cnt = (int)(pw >> 16);
         const bool act = sub < cnt;
-        const int ci = first + (act ? sub : 0);
+        const int ci = P.pack_order[(size_t)frame * kCandCap + first + (act ? sub : 0)];
         const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
         const int x_min = cd.x_min, y_min = cd.y_min;
         const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
@@ -1550,11 +1576,15 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int f
 #define CTAG_WELSCH_WAVES 5
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes) {
-    const int frame = blockIdx.y;
+    // Longest first across the WHOLE batch: blockIdx.x (the fast dispatch index) is the frame, blockIdx.y the rank of the
+    // edge triple in the frame's list sorted by descending point count.  The longest triples of all frames are dispatched
+    // first and the kernel drains on the short ones: a long triple runs ~0.3 ms as a lone wave, and with the triple rank on
+    // the fast index some of them started last and WERE the kernel's tail.  Consecutive frames fall on consecutive XCDs, so
+    // the load stays balanced without the column rotation the other layout needed.
+    const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
-    // the column is rotated by the frame index so the busy blocks of consecutive frames land on different XCDs
-    for (int first = (int)((blockIdx.x + frame) % gridDim.x) * 3; first < L; first += gridDim.x * 3) {
+    for (int first = (int)blockIdx.y * 3; first < L; first += gridDim.y * 3) {
         welsch_three(P, frame, first, L);
         __syncthreads();
     }
@@ -1654,7 +1684,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         if (ev5) (void)hipEventRecord(ev5[evi++], s);
     };
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, nullptr};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
@@ -1662,22 +1692,20 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         (void)hipMemsetAsync(d_stamps, 0, 16 * 8, s);
         P.stamps = d_stamps;
     }
-    (void)hipMemsetAsync(ws.line_count, 0, sizeof(int32_t) * (size_t)nframes, s);
-    (void)hipMemsetAsync(ws.clp_used, 0, sizeof(int32_t) * (size_t)nframes, s);
     static const int pack_max_env = getenv("CTAG_PACK_MAX") ? atoi(getenv("CTAG_PACK_MAX")) : 0;
     const int pack_max = pack_max_env > 0 ? std::min(pack_max_env, kSG) : kSG;
     static const int big_env = getenv("CTAG_BIG_POINTS") ? atoi(getenv("CTAG_BIG_POINTS")) : 0;
     const int big_points = big_env > 0 ? big_env : 0x7fffffff;
     const bool small_cfg = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;  // up to 1920x1200 frames
     const int pack_words = small_cfg ? kPackWordsSmall : kPackWords;
-    hipLaunchKernelGGL(k_pack, dim3((nframes + 63) / 64), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words);
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words);
     mark();
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
     if (small_cfg)
-        hipLaunchKernelGGL((k_quad_edges_packed<kPackWordsSmall, kPackWavesSmall>), dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
+        hipLaunchKernelGGL((k_quad_edges_packed<kPackWordsSmall, kPackWavesSmall>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes);
     else
-        hipLaunchKernelGGL((k_quad_edges_packed<kPackWords, CTAG_PACK_WAVES>), dim3(pack_gx, nframes), dim3(64), 0, s, P, ws.g, nframes);
+        hipLaunchKernelGGL((k_quad_edges_packed<kPackWords, CTAG_PACK_WAVES>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes);
     mark();
     static const int bcols_env = getenv("CTAG_BIG_COLS") ? atoi(getenv("CTAG_BIG_COLS")) : 0;
     const int bcols = bcols_env > 0 ? bcols_env : 4;
@@ -1686,7 +1714,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     mark();
     static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 342;  // block columns per frame; a column loops when a frame has more edge triples
-    hipLaunchKernelGGL(k_welsch, dim3(welsch_gx, nframes), dim3(64), 0, s, P, nframes);
+    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx), dim3(64), 0, s, P, nframes);
     mark();
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {

@@ -1094,7 +1094,6 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s)
         (void)hipMemsetAsync(d_stamps, 0, 16 * 8, s);
         P.stamps = d_stamps;
     }
-    (void)hipMemsetAsync(ws.ovf_count, 0, sizeof(int32_t), s);
     const size_t lds_big = ccl_layout(g.tw, kRunCapBig, kSlotCapBig, true).total;
     const int grid_big = 1024;  // persistent: loops over the overflow list
     if (g.tw == 5) {
@@ -1291,6 +1290,23 @@ __global__ __launch_bounds__(256) void k_resolve(SweepPtrs P, int nframes, int p
         }
     }
 }
+// the per-chunk counters, zeroed by ONE kernel at the head of the chain (five hipMemsetAsync calls before; as memset nodes of a
+// captured hipGraph they did not take effect on replay under ROCm 7.0, CTAG_OPT_GRAPH)
+__global__ __launch_bounds__(256) void k_zero_counters(int32_t* a, uint32_t* b, int32_t* c, int32_t* d, int32_t* one, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        a[i] = 0;
+        b[i] = 0u;
+        c[i] = 0;
+        d[i] = 0;
+    }
+    if (i == 0) *one = 0;
+}
+hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_counters, dim3((nframes + 255) / 256), dim3(256), 0, s, ws.frame_ncomp, ws.frame_flags, ws.line_count, ws.clp_used, ws.ovf_count, nframes);
+    return hipGetLastError();
+}
+
 hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s) {
     const int per_frame = 2;
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(nframes, per_frame)), dim3(256), 0, s, sweep_ptrs(ws), nframes, per_frame, ws.g.pool_cap);
