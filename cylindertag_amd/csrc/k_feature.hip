@@ -624,13 +624,17 @@ __device__ void feature_ids(float* C, int direction, int& ID_left, int& ID_right
 }
 
 __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int feature_size, int drows, int dcols) {
-    __shared__ FeatureDev s_feat[CTAG_MAX_FEATURES];
+    // the features as K8 left them and, later, the records built from them share one region (records are built from registers):
+    // with the coverage table in bytes the block needs 19.6 KB instead of 31.6 KB of LDS -- 8 frames per CU instead of 5
+    __shared__ __attribute__((aligned(16))) unsigned char s_fr[CTAG_MAX_FEATURES * sizeof(ctag_feature_rec)];
+    static_assert(sizeof(ctag_feature_rec) >= sizeof(FeatureDev), "records overlay the features");
+    FeatureDev* s_feat = reinterpret_cast<FeatureDev*>(s_fr);
+    ctag_feature_rec* s_rec = reinterpret_cast<ctag_feature_rec*>(s_fr);
     __shared__ int s_father[CTAG_MAX_FEATURES];
     __shared__ int s_group[CTAG_MAX_FEATURES];   // marker index of each feature
     __shared__ int s_order[CTAG_MAX_FEATURES];   // features grouped by marker, in marker order, sorted
     __shared__ int s_mfirst[CTAG_MAX_FEATURES + 1];
-    __shared__ ctag_feature_rec s_rec[CTAG_MAX_FEATURES];
-    __shared__ short s_cov[2 * kMaxDictCells];   // coverage per (dir, row, col)
+    __shared__ uint8_t s_cov[2 * kMaxDictCells];  // coverage per (dir, row, col): at most CTAG_MAX_CODE_POS
     __shared__ int s_code[CTAG_MAX_CODE_POS];
     __shared__ int s_misc[8];
     __shared__ unsigned long long s_pair[CTAG_MAX_FEATURES][2];
@@ -786,10 +790,21 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     // ---- featureExtraction (lane per feature slot).  ID_left / ID_right persist from one feature to the next when no
     // cross-ratio band matches, so each lane reports "matched value or carry" and thread 0 replays the carry.
     constexpr int kCarry = -99;
-    for (int k = tid; k < nf; k += 64) {
-        const FeatureDev& F = s_feat[s_order[k]];
+    static_assert(CTAG_MAX_FEATURES <= 128, "two feature slots per lane");
+    FeatureDev Fk[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int k = tid + 64 * q;
+        if (k < nf) Fk[q] = s_feat[s_order[k]];
+    }
+    __syncthreads();  // every feature is in registers: the region becomes the records
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int k = tid + 64 * q;
+        if (k >= nf) continue;
+        const FeatureDev& F = Fk[q];
         ctag_feature_rec& R = s_rec[k];
-        for (int q = 0; q < 16; q++) R.corners[q] = F.c[q];
+        for (int c = 0; c < 16; c++) R.corners[c] = F.c[c];
         R.center[0] = F.center[0];
         R.center[1] = F.center[1];
         R.edge_length = (dist2p(P2{F.c[0], F.c[1]}, P2{F.c[2], F.c[3]}) + dist2p(P2{F.c[8], F.c[9]}, P2{F.c[10], F.c[11]}) / 2);
@@ -899,7 +914,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
                         if (c >= 0 && (int)row[c] == ((7 - cd / 8) + (7 - cd % 8) * 8)) cov++;
                     }
                 }
-                s_cov[h] = (short)cov;
+                s_cov[h] = (uint8_t)cov;
                 lane_max = max(lane_max, cov);
                 if (++j == dcols) {
                     j = 0;
