@@ -1713,7 +1713,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     mark();
-    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 342;  // block columns per frame; a column loops when a frame has more edge triples
+    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 144;  // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144: fewer empty blocks, 6.74 -> 6.59 ms)
     hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx), dim3(64), 0, s, P, nframes);
     mark();
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
