@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <cstdlib>
 
 #include "../../include/ctag_gather.h"
 #include "ctag_internal.h"
@@ -38,9 +39,13 @@ struct Rccl {
     char err[256] = {0};
 };
 
-Rccl* rccl() {
+Rccl* rccl_bind();
+Rccl* rccl() {  // bound once per process, also when handles live on several host threads
+    static Rccl* const R = rccl_bind();
+    return R;
+}
+Rccl* rccl_bind() {
     static Rccl R;
-    if (R.lib || R.err[0]) return &R;
     const char* env = std::getenv("CTAG_RCCL_LIB");
     if (env && *env) R.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
     if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);  // the one this process already holds

@@ -1096,15 +1096,25 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s)
     }
     const size_t lds_big = ccl_layout(g.tw, kRunCapBig, kSlotCapBig, true).total;
     const int grid_big = 1024;  // persistent: loops over the overflow list
+    // kernels that ask for more than 64 KB of dynamic LDS need the attribute raised (per device; it only ever grows)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= 64 ? 0 : dev;
+    auto want_lds = [dev](const void* fn, size_t bytes, size_t* have) {
+        if (bytes > 64 * 1024 && bytes > have[dev]) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            have[dev] = bytes;
+        }
+    };
+    static size_t have_big5[64] = {0}, have_big0[64] = {0}, have_0[64] = {0};
     if (g.tw == 5) {
         hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl_big<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+        want_lds(reinterpret_cast<const void*>(k_threshold_ccl_big<5>), lds_big, have_big5);
         hipLaunchKernelGGL(k_threshold_ccl_big<5>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g);
     } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        want_lds(reinterpret_cast<const void*>(k_threshold_ccl<0>), lds, have_0);
         hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_threshold_ccl_big<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+        want_lds(reinterpret_cast<const void*>(k_threshold_ccl_big<0>), lds_big, have_big0);
         hipLaunchKernelGGL(k_threshold_ccl_big<0>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g);
     }
     if (want_stamps) {
