@@ -1,0 +1,48 @@
+"""bench.py itself, on the GPU box: the one-GPU line carries the objects the contract asks for and verifies what it times, and
+the N > 1 logic (shards, double-buffered gathers, the hash of the gathered list) gives the same result list as N = 1 -- run
+with two ranks sharing the one GPU through the developer backend (RCCL refuses two ranks on one device, so the gather goes
+through gloo and host memory there; the RCCL gather itself is covered by test_packed_shards_and_rccl_gather_single_rank)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from ctag_testlib import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _line(out):
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+def test_one_gpu_line_and_two_rank_hash():
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "192", "--host-frames", "0",
+            "--pose-frames", "0", "--latency-calls", "0"]
+    p = subprocess.run(base + ["--cpu-frames", "24", "--cpu-frames-per-thread", "2"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    one = _line(p.stdout)
+    assert one["n_gpus"] == 1 and one["unit"] == "frames/s" and one["frames_ok"] == 192
+    assert one["parity"]["mismatches"] == 0 and one["parity"]["frames_checked"] >= 24
+    assert one["roofline"]["bound"] == "hbm" and 0.0 < one["roofline"]["frac"] < 1.0 and one["roofline"]["traffic_source"]
+    assert one["cpu_baseline"]["kind"] == "port" and one["cpu_baseline"]["cores"] == 1 and one["cpu_baseline"]["value"] > 0
+    assert set(one["issue_roofline"]["kernels"]) >= {"k_edge_refine", "k_welsch", "k_quad_edges_packed"}
+    env = dict(os.environ, CTAG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + base[1:] + ["--gpus", "2", "--cpu-frames", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    two = _line(p.stdout)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["frames_per_gpu"] == 96 and two["frames_ok"] == 192
+    assert two["results_sha256"] == one["results_sha256"]  # the gathered list equals the one-GPU list
