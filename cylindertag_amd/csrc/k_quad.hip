@@ -1572,6 +1572,9 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int f
     }
 }
 
+#ifndef CTAG_WELSCH_PRIO_RANKS
+#define CTAG_WELSCH_PRIO_RANKS 16
+#endif
 #ifndef CTAG_WELSCH_WAVES
 #define CTAG_WELSCH_WAVES 5
 #endif
@@ -1584,6 +1587,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
+    // the first ranks are the long edges: their waves are the kernel's critical path, so they get issue priority over the short
+    // ones they share a SIMD with (s_setprio; the bulk fills the slots they leave)
+    if (blockIdx.y < (unsigned)CTAG_WELSCH_PRIO_RANKS) __builtin_amdgcn_s_setprio(3);
     for (int first = (int)blockIdx.y * 3; first < L; first += gridDim.y * 3) {
         welsch_three(P, frame, first, L);
         __syncthreads();
