@@ -80,3 +80,22 @@ def test_strip_writer_round_trip_through_the_oracle(oracle, tmp_path):
         assert all(by_pos[p] in (int(state[row][p]), inv[p]) for p in range(12))
     # the reference layout itself (no margin): tag_length x 1.5 * tag_length / ratio * columns, generator.m:212
     assert dg.render_strip(state[0]).shape == (1200, 1440)
+
+
+def test_other_dictionary_shapes_15c3f_18c4f(oracle):
+    """The dictionary shapes the reference's README lists beside 2f12c (15 columns / 3-feature windows, 18 / 4): fixtures written by
+    tools/dict_gen.py (seed 3; `python tools/dict_gen.py 15 3 24 ... 3`) satisfy the generator predicates, and synthetic frames planted
+    with them decode only to planted rows (feature_size 3 and 4 paths of markerDecoder, corner_detector.cpp:1215)."""
+    import cylindertag_amd as ca
+    for name, shape, fs in (("CTag_3f15c_gen.marker", (24, 15), 3), ("CTag_4f18c_gen.marker", (24, 18), 4)):
+        state, got_fs = read_marker_file(os.path.join(GOLDEN, name))
+        assert state.shape == shape and got_fs == fs and all(dg.legal_code(int(c)) for c in state.ravel()) and dg.test_conflict(state, fs)
+        exact = 0
+        for f in range(4):
+            img, truth = ca.synth_frame_host(state, 100 + f)
+            res = oracle.detect_fast(img, state, fs)
+            planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
+            found = sorted(int(m["marker_id"]) for m in res["markers"][:res["n_markers"]])
+            assert res["status"] == 0 and set(found) <= set(planted) and len(found) >= 2
+            exact += planted == found
+        assert exact >= 1

@@ -52,3 +52,20 @@ def test_written_strip_decodes_through_the_cpp_reader_and_the_hip_path(tmp_path)
         assert out.splitlines()[0] == "markers 1" and len(lines) == 1
         toks = lines[0].split("|")[0].split()
         assert int(toks[1]) == row and int(toks[3]) == 12
+
+
+@pytest.mark.parametrize("name,fs", [("CTag_3f15c_gen.marker", 3), ("CTag_4f18c_gen.marker", 4)])
+def test_other_dictionary_shapes_match_the_oracle(name, fs):
+    """15-column / 3-feature and 18-column / 4-feature dictionaries (README of the reference) through the HIP path: records
+    byte-identical to the oracle's on planted frames, and the pose back end's 160-point model variant accepts an 18-column model."""
+    from ctag_testlib import GOLDEN, read_marker_file
+    state, got_fs = read_marker_file(os.path.join(GOLDEN, name))
+    assert got_fs == fs
+    det, orc = ca.Detector(state, fs, device=0), Oracle()
+    frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
+    got = det.detect_batch(frames)
+    for f in range(6):
+        want = orc.detect_fast(frames[f], state, fs)
+        assert got[f].tobytes() == want.tobytes(), (name, f)
+    assert int(got["n_markers"].sum()) >= 12
+    det.close()
