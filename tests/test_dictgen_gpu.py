@@ -68,4 +68,27 @@ def test_other_dictionary_shapes_match_the_oracle(name, fs):
         want = orc.detect_fast(frames[f], state, fs)
         assert got[f].tobytes() == want.tobytes(), (name, f)
     assert int(got["n_markers"].sum()) >= 12
+    # the same dictionary on cylinders with planted poses: the pose kernel's large point set (18 columns x 8 corners = 144 > 96)
+    from pose_testlib import PoseOracle, make_camera, make_model_view, rodrigues
+    K = np.array([[2600.0, 0, 960.0], [0, 2600.0, 540.0], [0, 0, 1]])
+    M, corners = ca.synth3d_model(state)
+    ids = np.arange(state.shape[0], dtype=np.int32)
+    mv = make_model_view({"ids": ids, "size": state.shape[1], "base": np.zeros((len(ids), 3), np.float32),
+                          "axis": np.zeros((len(ids), 3), np.float32), "corners": corners})
+    img, truth = ca.synth3d_frame_host(state, 1, K, rows=1080, cols=1920)
+    rec = det.detect(img)
+    assert rec.tobytes() == orc.detect_fast(img, state, fs).tobytes()
+    poses = det.estimate_pose(rec, M, ca.make_camera(K, np.zeros(5)))
+    want = PoseOracle().pose_frame(rec, mv, make_camera(K, np.zeros(5)))
+    assert poses.tobytes() == want.tobytes() and len(poses) >= 2
+    good = 0
+    for p in poses:  # a strip of 15-18 columns wraps up to 2.2 rad of its cylinder: the reference's gap rounding (:1223-1224) can misplace
+        # the foreshortened end columns, which shows as a large reprojection error; the well-placed markers must give the planted pose
+        if p["status"] != 0 or np.sqrt(2 * p["cost"] / p["n_points"]) > 0.5:
+            continue
+        k = [i for i in range(truth["n_markers"]) if truth["dict_row"][i] == p["model_index"]][0]
+        R, Rt = rodrigues(p["rvec"]), truth["R"][k].reshape(3, 3)
+        assert np.degrees(np.arccos(np.clip((np.trace(R.T @ Rt) - 1) / 2, -1, 1))) < 0.5
+        good += 1
+    assert good >= 2
     det.close()
