@@ -316,7 +316,7 @@ struct RefinePtrs {
 constexpr int kRefineSamples = 128;               // samples of an edge searched per pass (the reference's minimum sample count, :615)
 constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: waves 0-1 edge e, waves 2-3 edge e + 1
 #ifndef CTAG_REFINE_REGION
-#define CTAG_REFINE_REGION 22528                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
+#define CTAG_REFINE_REGION 21504                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
 #endif
 constexpr int kRefineRegion = CTAG_REFINE_REGION;
 
@@ -331,10 +331,11 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // 16 columns of per-sample values: rows 0-3 x of edge 0-3, 4-7 y, 8-11 weight towards the next corner, 12-15 towards the
     // last one (0 for a sample without an edge point).  The odd row length puts the 16 rows on 16 different LDS bank
     // pairs: the accumulation reads one element of up to 9 rows per instruction.
-    __shared__ double s_v[16][kRefineSamples + 1];
+    // row 16 holds ones: the factors "1" of the sums Mx = (x * 1) * w, N = (1 * 1) * w are read like any other column, so that
+    // every lane of the accumulation walks three unit-stride columns (immediate offsets, no address arithmetic in the loop)
+    __shared__ double s_v[17][kRefineSamples + 1];
     double (*s_bx)[kRefineSamples + 1] = s_v, (*s_by)[kRefineSamples + 1] = s_v + 4;
     __shared__ double s_nrm[4][2];                // unit normal of each edge
-    __shared__ double s_one;
     __shared__ double s_acc[48];
     __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
     // The pixels the searches of this quad can touch -- the bounding box of its corners grown by the search length --
@@ -360,6 +361,7 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         s_cy[tid] = F->c[2 * (off + tid) + 1];
     }
     if (tid < 48) s_acc[tid] = 0.0;
+    if (tid < kRefineSamples + 1) s_v[16][tid] = 1.0;
     __syncthreads();
     if (tid < 4) {  // :609-615
         const int a = tid, b = (tid + 1) & 3;
@@ -370,7 +372,6 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         s_ns[tid] = (int)ns_d;
         s_nrm[tid][0] = nx / mag;
         s_nrm[tid][1] = ny / mag;
-        if (tid == 0) s_one = 1.0;
     }
     if (tid == 64) {  // the box: corners +- (search length + 2), clipped to the image; columns from a multiple of 4
         const float m = (float)(subpix + 3);
@@ -477,14 +478,17 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
             // edge point has x = y = w = 0 and adds +0.0, which equals the reference skipping it
             const int edge = tid / 12, r = tid - edge * 12;
             const int pass = r / 6, which = r - pass * 6;
-            const double* pa = (which == 0 || which == 2 || which == 3) ? s_bx[edge] : (which == 5 ? &s_one : s_by[edge]);
-            const double* pb = which == 2 ? s_bx[edge] : ((which == 3 || which == 4) ? s_by[edge] : &s_one);
-            const int sa = which == 5 ? 0 : 1, sb = (which >= 2 && which <= 4) ? 1 : 0;
+            const double* pa = (which == 0 || which == 2 || which == 3) ? s_bx[edge] : (which == 5 ? s_v[16] : s_by[edge]);
+            const double* pb = which == 2 ? s_bx[edge] : ((which == 3 || which == 4) ? s_by[edge] : s_v[16]);
             const double* pw = s_v[8 + 4 * pass + edge];
             double acc = s_acc[tid];
             const int cntS = min(kRefineSamples, s_ns[edge] - sbase);
-#pragma unroll 8
-            for (int k = 0; k < cntS; k++) acc += (pa[k * sa] * pb[k * sb]) * pw[k];
+            int k = 0;
+            for (; k + 16 <= cntS; k += 16) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc += (pa[k + u] * pb[k + u]) * pw[k + u];
+            }
+            for (; k < cntS; k++) acc += (pa[k] * pb[k]) * pw[k];
             s_acc[tid] = acc;
         }
         __syncthreads();
