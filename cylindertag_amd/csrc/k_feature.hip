@@ -341,7 +341,7 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // The pixels the searches of this quad can touch -- the bounding box of its corners grown by the search length --
     // staged once with coalesced row loads: the 4 x 128 x 49 scattered byte loads of the searches then gather from LDS
     // instead of going through the texture-address path, which was as busy as the vector ALUs (70 % TA busy,
-    // profiles/r02_before_pmc_instmix.json).  A box that does not fit stays in global memory (uniform per block).
+    // profiles/r02a_before_round2_work_instmix.json).  A box that does not fit stays in global memory (uniform per block).
     __shared__ __attribute__((aligned(16))) uint8_t s_reg[kRefineRegion];
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
