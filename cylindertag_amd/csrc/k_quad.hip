@@ -280,13 +280,15 @@ __global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGe
     // run out on a batch with many oversize components)
     for (int item = blockIdx.x; item < bcols * nframes; item += gridDim.x) {
     const int frame = item / bcols;
-    const int nc = P.ncand[frame];
+    const int nc = min(P.ncand[frame], kCandCap);
+    const int nbig = BIG ? (P.npacks[frame] >> 16) : nc;  // BIG: only the oversize tail of k_pack's order
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
-    for (int ci = item - frame * bcols; ci < nc; ci += bcols) {
+    for (int rk = nc - nbig + (item - frame * bcols); rk < nc; rk += bcols) {
         __syncthreads();
         stamp(-1);
+        const int ci = BIG ? (int)P.pack_order[(size_t)frame * kCandCap + rk] : rk;
         const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
         const int x_min = cd.x_min, y_min = cd.y_min;
         const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
@@ -811,7 +813,9 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
             words += need;
         }
         if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
-        P.npacks[frame] = np;
+        int nbig = 0;  // the oversize components sort last: entries [nc - nbig, nc) of `order`, k_quad_edges<true> walks only those
+        for (int r = nc - 1; r >= 0 && s_key[s_ord[r]] < 0; r--) nbig++;
+        P.npacks[frame] = np | (nbig << 16);
     }
 }
 
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int lane = threadIdx.x, sub = lane >> 3, sl = lane & 7, lane0 = lane & ~7;
-    const int npk = P.npacks[frame];
+    const int npk = P.npacks[frame] & 0xffff;
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
