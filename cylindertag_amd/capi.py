@@ -23,7 +23,7 @@ STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates
                "line_sort", "welsch", "quad_final", "features", "edge_refine", "markers"]
 QUAD_STAGES = ["quad_pack", "quad_edges", "quad_edges_big", "line_sort", "welsch", "quad_final"]  # a4: edgeExtraction
 
-OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH = 1, 2, 3, 4, 5
+OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OPT_WAVE_POINTS = 1, 2, 3, 4, 5, 6
 DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS = range(1, 9)
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)

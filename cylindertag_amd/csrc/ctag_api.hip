@@ -32,6 +32,8 @@ using namespace ctag;
 struct ctag_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;          // side branch of the chain in few-frame calls (launch_quads), joined by events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<int32_t> dict;
     int32_t* d_dict = nullptr;
     uint8_t* d_pick_table = nullptr;
@@ -39,6 +41,7 @@ struct ctag_handle {
     Workspace ws;
     int ws_rows = 0, ws_cols = 0, ws_tw = 0, ws_cap = 0;
     int max_chunk = 1024;
+    int wave_points = 0;  // CTAG_OPT_WAVE_POINTS
     bool timing = false;
     bool keep_pre = false;
     // timing (CTAG_OPT_TIMING): one set of CTAG_NUM_STAGES + 1 events per chunk of a public call, read back ONCE after the
@@ -151,6 +154,10 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     if (h->ws.base && h->ws_rows == rows && h->ws_cols == cols && h->ws_cap >= frames) {
         h->ws.g = make_geom(rows, cols, tw);
         h->ws.pick_table = h->d_pick_table;
+        h->ws.aux_stream = h->aux_stream;
+        h->ws.wave_points = h->wave_points;
+        h->ws.ev_fork = h->ev_fork;
+        h->ws.ev_join = h->ev_join;
         h->ws_tw = tw;
         return CTAG_OK;
     }
@@ -184,9 +191,6 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_ncand = take(F * 4);
     const size_t o_cand = take(F * kCandCap * sizeof(Candidate));
     const size_t o_quads = take(F * kCandCap * sizeof(QuadOut));
-    const size_t scratch_words = (size_t)4 * kQuadScratchPoints + 2048;
-    const size_t o_scratch = take((size_t)kQuadScratchSlots * scratch_words * 4);
-    const size_t o_scr_used = take(4);
     const size_t o_lcount = take(F * 4), o_clused = take(F * 4);
     const size_t o_clpool = take(F * kClPool * 4);
     const size_t o_ldesc = take(F * kLineCap * sizeof(LineDesc));
@@ -229,8 +233,6 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.ncand = reinterpret_cast<int32_t*>(b + o_ncand);
     W.cand = reinterpret_cast<Candidate*>(b + o_cand);
     W.quads = reinterpret_cast<QuadOut*>(b + o_quads);
-    W.quad_scratch = reinterpret_cast<uint32_t*>(b + o_scratch);
-    W.quad_scratch_used = reinterpret_cast<int32_t*>(b + o_scr_used);
     W.line_count = reinterpret_cast<int32_t*>(b + o_lcount);
     W.clp_used = reinterpret_cast<int32_t*>(b + o_clused);
     W.cl_pool = reinterpret_cast<uint32_t*>(b + o_clpool);
@@ -242,6 +244,10 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.packs = reinterpret_cast<uint32_t*>(b + o_pk);
     W.pack_order = reinterpret_cast<uint16_t*>(b + o_pord);
     W.pick_table = h->d_pick_table;
+    W.aux_stream = h->aux_stream;
+    W.wave_points = h->wave_points;
+    W.ev_fork = h->ev_fork;
+    W.ev_join = h->ev_join;
     W.quad_derived = b + o_der;
     W.quad_index = reinterpret_cast<int32_t*>(b + o_qidx);
     W.nquads = reinterpret_cast<int32_t*>(b + o_nq);
@@ -529,6 +535,9 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
     h->feature_size = feature_size;
     bool ok = hipSetDevice(device_id) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_dict), h->dict.size() * 4) == hipSuccess;
     ok = ok && hipMemcpy(h->d_dict, h->dict.data(), h->dict.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
@@ -569,7 +578,10 @@ void ctag_destroy(ctag_handle* h) {
         if (h->ev_copied[i]) (void)hipEventDestroy(h->ev_copied[i]);
         if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
     }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -612,6 +624,11 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
         case CTAG_OPT_GRAPH:
             h->use_graph = value != 0;
             if (!h->use_graph) drop_graphs(h);
+            return CTAG_OK;
+        case CTAG_OPT_WAVE_POINTS:
+            if (value < 0 || value > 0x7fffffff) return CTAG_ERR_ARG;
+            h->wave_points = (int)value;
+            drop_graphs(h);  // a captured chain holds the old value
             return CTAG_OK;
         case CTAG_OPT_HOST_SUBCHUNK:
             if (value < 1 || value > (1 << 20)) return CTAG_ERR_ARG;

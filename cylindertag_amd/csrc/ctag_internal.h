@@ -35,9 +35,6 @@ constexpr int kCandCap = 2048;          // max area-filtered candidates per fram
 constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range [1, 32]
 
 // ---- K6 limits ----------------------------------------------------------------------------------------------
-constexpr int kQuadLdsPoints = 1024;    // boundary points held in LDS; larger components use global scratch
-constexpr int kQuadScratchSlots = 1024; // global scratch slots = persistent blocks of the oversize-component kernel (139 KB each)
-constexpr int kQuadScratchPoints = 8192;  // >= 2*(1920+1080)+4: worst-case silhouette of a 4K frame at half-res
 constexpr int kLineCap = 4 * kCandCap;     // fitted edges per frame (4 per candidate that survives the RDP split)
 constexpr int kClPool = 262144;           // edge-cluster points per frame (a candidate reserves its boundary capacity + 64)
 constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table
@@ -111,8 +108,6 @@ struct Workspace {
     int32_t* ncand = nullptr;       // [F]
     Candidate* cand = nullptr;      // [F][kCandCap]
     QuadOut* quads = nullptr;       // [F][kCandCap]
-    uint32_t* quad_scratch = nullptr;   // [kQuadScratchSlots][...]
-    int32_t* quad_scratch_used = nullptr;
     int32_t* line_count = nullptr;  // [F]
     int32_t* clp_used = nullptr;    // [F]
     uint32_t* cl_pool = nullptr;    // [F][kClPool]
@@ -124,6 +119,9 @@ struct Workspace {
     uint32_t* packs = nullptr;      // [F][kCandCap]
     uint16_t* pack_order = nullptr; // [F][kCandCap]
     const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
+    hipStream_t aux_stream = nullptr;     // owned by the handle: side branch for few-frame calls (launch_quads)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int wave_points = 0;                  // CTAG_OPT_WAVE_POINTS (0 = automatic)
     // features
     void* quad_derived = nullptr;   // [F][kCandCap] x 48 B (K7 scratch)
     int32_t* quad_index = nullptr;  // [F][kCandCap]

@@ -18,11 +18,6 @@
 
 namespace ctag {
 
-constexpr int kQuadThreads = 64;   // one wave per component: the serial phases are latency-bound, so more resident
-                                    // components per CU beat more lanes per component
-constexpr int kQuadWaves = kQuadThreads / 64;
-constexpr int kQuadLdsWords = 3072;  // 12 KB of per-component working storage in LDS
-
 struct QuadPtrs {
     const uint16_t* labels;
     const int32_t* tile_base;
@@ -30,8 +25,6 @@ struct QuadPtrs {
     const int32_t* ncand;
     const Candidate* cand;
     QuadOut* quads;
-    uint32_t* scratch;
-    int32_t* scratch_used;
     uint32_t* frame_flags;
     // edge clusters handed from k_quad_edges to k_welsch / k_quad_final
     int32_t* line_count;   // [F]
@@ -234,6 +227,10 @@ constexpr int kPackWords = CTAG_PACK_WORDS;  // LDS words shared by the up to 8 
 // components four times the size and keep the large one (same-box A/B: 8.4 vs 7.9 ms per 1024 frames with the small one).
 constexpr int kPackWordsSmall = 2560, kPackWavesSmall = 4;
 constexpr int kSG = 8;
+constexpr int kWaveWords = 8192;      // LDS words of the common whole-wave build (32 KB: five components per CU)
+constexpr int kWaveWordsMax = 36864;  // ... of the build for the longest boundaries (144 KB: one per CU)
+constexpr int kLatencyFrames = 4;     // calls with at most this many frames are tuned for the latency of the call
+constexpr int kLatencyBigPoints = 96; // ... there, components with a boundary capacity above this get a wave of their own
 __host__ __device__ __forceinline__ int pack_points(int w, int h) { return min(2 * (w + h), w * h) + 1; }
 // LDS words one component needs in the packed kernel: silhouette arrays + boundary list + stack / ping-pong list
 __host__ __device__ __forceinline__ int pack_need(int w, int h) {
@@ -241,7 +238,7 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
     return ((w + 1) & ~1) + 2 * h + 2 * C + 4;
 }
 // the packed kernel takes every component whose working set fits the wave's LDS budget (the silhouette scan walks a wide
-// box in passes of 128 columns); the rest are "big" and go to k_quad_edges<true>
+// box in passes of 128 columns); the rest are "big" and get a wave of their own (k_quad_edges_packed<64, ...>)
 // big_points: in latency mode (a few frames per call) components with a long boundary also go there -- a whole wave per
 // component instead of 8 lanes shortens the critical path of the call; 0x7fffffff otherwise
 __host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points, int pack_words) {
@@ -253,522 +250,13 @@ struct CornerPre {
     float x, y, dis, ang;
 };
 
-// BIG = false: components whose working set fits the LDS budget (LDS-typed pointers, the common case);
-// BIG = true: the rare oversize components, same code on a global scratch slot.
-template <bool BIG>
-__global__ __launch_bounds__(kQuadThreads) void k_quad_edges(QuadPtrs P, FrameGeom g, int nframes, int big_points, int bcols, int pack_words) {
-    __shared__ uint32_t s_mem[kQuadLdsWords];
-    __shared__ unsigned long long s_sum[2];
-    __shared__ int s_i[16];
-    __shared__ float s_redf[kQuadWaves];
-    __shared__ int s_redi[kQuadWaves];
-    __shared__ int s_cl_off[5];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr size_t kScratchWords = (size_t)4 * kQuadScratchPoints + 2048;
-
-    unsigned long long t_prev = 0;
-    auto stamp = [&](int phase) {
-        if (P.stamps && tid == 0) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (phase >= 0) atomicAdd(&P.stamps[phase], t - t_prev);
-            t_prev = t;
-        }
-    };
-    // Persistent blocks: block b owns global scratch slot b for the whole launch and walks the (frame, column) items
-    // b, b + gridDim.x, ...; column c of a frame takes that frame's candidates c, c + bcols, ...  (a slot per component would
-    // run out on a batch with many oversize components)
-    for (int item = blockIdx.x; item < bcols * nframes; item += gridDim.x) {
-    const int frame = item / bcols;
-    const int nc = min(P.ncand[frame], kCandCap);
-    const int nbig = BIG ? (P.npacks[frame] >> 16) : nc;  // BIG: only the oversize tail of k_pack's order
-    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
-    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
-    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
-    for (int rk = nc - nbig + (item - frame * bcols); rk < nc; rk += bcols) {
-        __syncthreads();
-        stamp(-1);
-        const int ci = BIG ? (int)P.pack_order[(size_t)frame * kCandCap + rk] : rk;
-        const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
-        const int x_min = cd.x_min, y_min = cd.y_min;
-        const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
-        const int C = min(2 * (w + h), w * h) + 1;
-        const int w2 = (w + 1) & ~1;
-        const size_t need = (size_t)(w2) + 2 * (size_t)h + 3 * (size_t)C + 72;
-        if (BIG != pack_big(x_min, w, h, big_points, pack_words)) continue;  // block-uniform: k_quad_edges_packed owns the rest
-        uint32_t* mem = s_mem;
-        if (BIG) {
-            const int slot = blockIdx.x;
-            if (slot >= kQuadScratchSlots || need > kScratchWords) {
-                if (tid == 0) {
-                    atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
-                    CandAux* ax = P.cand_aux + (size_t)frame * kCandCap + ci;
-                    ax->line0 = -1;
-                    ax->n_boundary = 0;
-                }
-                continue;
-            }
-            mem = P.scratch + (size_t)slot * kScratchWords;
-        }
-        uint16_t* top = reinterpret_cast<uint16_t*>(mem);
-        uint16_t* bot = top + w2;
-        uint32_t* lef = mem + w2;
-        uint32_t* rig = lef + h;
-        uint32_t* bufA = rig + h;      // E
-        uint32_t* bufB = bufA + C;     // DFS stack, later ping-pong partner
-        uint32_t* CL = bufB + C + 1;   // clusters (C + 64 words)
-
-        // ---- P1: silhouette first-hit arrays (corner_detector.cpp:184-232)
-        for (int x = tid; x < w; x += kQuadThreads) {
-            top[x] = 0xffff;
-            bot[x] = 0xffff;
-        }
-        for (int y = tid; y < h; y += kQuadThreads) {
-            lef[y] = 0xffffffffu;
-            rig[y] = 0u;
-        }
-        __syncthreads();
-        for (int y = 0; y < h; y++) {
-            const int gy = y_min + y;
-            const uint16_t* lrow = limg + (size_t)gy * g.lp;
-            const int trow = (gy / kTileH) * g.tiles_x;
-            for (int xb = 0; xb < w; xb += kQuadThreads) {
-                const int x = xb + tid;
-                bool fg = false;
-                if (x < w) {
-                    const int gx = x_min + x;
-                    const unsigned l = lrow[gx];
-                    if (l && l < 0x8000u) fg = rootof[tbase[trow + gx / kTileW] + (int)l - 1] == cd.root;  // bit 15: an unpublished speck (k_threshold_ccl_big)
-                    if (fg) {
-                        if (top[x] == 0xffff) top[x] = (uint16_t)y;
-                        bot[x] = (uint16_t)y;
-                    }
-                }
-                const uint64_t b = __ballot(fg);
-                if (b && lane == 0) {
-                    const int first = xb + wave * 64 + (__ffsll((unsigned long long)b) - 1);
-                    const int last = xb + wave * 64 + (63 - __clzll((long long)b));
-                    atomicMin(&lef[y], (unsigned)first);
-                    atomicMax(&rig[y], (unsigned)(last + 1));
-                }
-            }
-        }
-        __syncthreads();
-        stamp(0);
-        // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): explicit stack, wave 0; lanes 0..7 test
-        // the 8 neighbours (N,NE,E,SE,S,SW,W,NW) of the current frame at once, the first hit at or after the frame's
-        // resume index wins -- the same visiting order as the reference's recursion with its moving `starter` (B7).
-        if (wave == 0) {
-            // x_bias = {0,1,1,1,0,-1,-1,-1}, y_bias = {-1,-1,0,1,1,1,0,-1} packed as (bias+1) in 2 bits per direction
-            const int jd = lane & 7;
-            const int dxl = (int)((0x01A9u >> (2 * jd)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * jd)) & 3u) - 1;
-            int n = 0, sp = 0;
-            int fx = 0, fy = top[0], j0 = 0;  // top-of-stack frame lives in registers; bufB holds the frames below it
-            if (fy == 0xffff) {  // inconsistent labels (only after a flagged pool overflow): give up on this component
-                sp = -1;
-            } else {
-                if (lane == 0) {
-                    bufA[0] = pack_xy(x_min, fy + y_min);
-                    // the start pixel is the top of column 0; clear every list it heads
-                    top[0] = 0xffff;
-                    if (bot[0] == fy) bot[0] = 0xffff;
-                    if (lef[fy] == 0u) lef[fy] = 0xffffffffu;
-                    if (rig[fy] == 1u) rig[fy] = 0u;
-                }
-                n = 1;
-            }
-            while (sp >= 0) {
-                const int nx = fx + dxl, ny = fy + dyl;
-                unsigned why = 0;  // which silhouette lists hold (nx, ny): bit0 top, bit1 bottom, bit2 left, bit3 right
-                if (lane < 8 && jd >= j0 && ny >= 0 && ny < h && nx >= 0 && nx < w) {
-                    why = (top[nx] == ny ? 1u : 0u) | (bot[nx] == ny ? 2u : 0u) | (lef[ny] == (unsigned)nx ? 4u : 0u) |
-                          (rig[ny] == (unsigned)(nx + 1) ? 8u : 0u);
-                }
-                const unsigned m = (unsigned)(__ballot(why != 0) & 0xffull);
-                if (!m) {  // frame exhausted: pop
-                    sp--;
-                    if (sp >= 0) {
-                        const uint32_t f = bufB[sp];
-                        fx = (int)(f & 0x3fff);
-                        fy = (int)((f >> 14) & 0x3fff);
-                        j0 = (int)(f >> 28);
-                    }
-                    continue;
-                }
-                const int j = __ffs(m) - 1;
-                const unsigned hw = (unsigned)__shfl((int)why, j);
-                const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
-                if (lane == 0) {
-                    if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
-                    if (hw & 1u) top[hx] = 0xffff;  // visited.at(hy, hx) = 0
-                    if (hw & 2u) bot[hx] = 0xffff;
-                    if (hw & 4u) lef[hy] = 0xffffffffu;
-                    if (hw & 8u) rig[hy] = 0u;
-                    // the current frame moves to the hit pixel and resumes at j+1 (B7); it becomes the frame below the top
-                    if (sp <= C) bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
-                }
-                n++;
-                if (sp + 1 <= C) {
-                    sp++;
-                    fx = hx;
-                    fy = hy;
-                    j0 = 0;
-                } else {  // cannot happen (stack depth <= boundary points <= C); keep the frame we just stored
-                    fx = hx;
-                    fy = hy;
-                    j0 = j + 1;
-                }
-            }
-            if (lane == 0) {
-                s_i[1] = min(n, C);
-                s_sum[0] = 0ull;
-                s_sum[1] = 0ull;
-            }
-        }
-        __syncthreads();
-        int n = s_i[1];
-        const int n_boundary = n;
-        if (n == 0) {  // block-uniform
-            if (tid == 0) {
-                CandAux* ax = P.cand_aux + (size_t)frame * kCandCap + ci;
-                ax->line0 = -1;
-                ax->n_boundary = 0;
-            }
-            continue;
-        }
-        stamp(1);
-        // ---- P3: boundary centroid (:250-256), nearest point (:259-263), rotation (:264-275)
-        {
-            unsigned long long sx = 0, sy = 0;
-            for (int k = tid; k < n; k += kQuadThreads) {
-                sx += (unsigned)ux(bufA[k]);
-                sy += (unsigned)uy(bufA[k]);
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                sx += __shfl_down(sx, d);
-                sy += __shfl_down(sy, d);
-            }
-            if (lane == 0) {
-                atomicAdd(&s_sum[0], sx);
-                atomicAdd(&s_sum[1], sy);
-            }
-        }
-        __syncthreads();
-        const float acx = (float)(1.0 * (long long)s_sum[0] / (double)(unsigned long long)n);
-        const float acy = (float)(1.0 * (long long)s_sum[1] / (double)(unsigned long long)n);
-        {
-            float bd = 3.0e38f;
-            int bi = 0x7fffffff;
-            for (int k = tid; k < n; k += kQuadThreads) {
-                const float dx = (float)ux(bufA[k]) - acx, dy = (float)uy(bufA[k]) - acy;
-                const float d = ctm::sqrt32(dx * dx + dy * dy);
-                if (d < bd || (d == bd && k < bi)) {
-                    bd = d;
-                    bi = k;
-                }
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const float od = __shfl_down(bd, d);
-                const int oi = __shfl_down(bi, d);
-                if (od < bd || (od == bd && oi < bi)) {
-                    bd = od;
-                    bi = oi;
-                }
-            }
-            if (lane == 0) {
-                s_redf[wave] = bd;
-                s_redi[wave] = bi;
-            }
-        }
-        __syncthreads();
-        {
-            int b0 = s_redi[0];
-            float b0d = s_redf[0];
-            for (int q = 1; q < kQuadWaves; q++)
-                if (s_redf[q] < b0d || (s_redf[q] == b0d && s_redi[q] < b0)) {
-                    b0d = s_redf[q];
-                    b0 = s_redi[q];
-                }
-            for (int k = tid; k < n; k += kQuadThreads) {
-                int src = k + b0;
-                if (src >= n) src -= n;
-                bufB[k] = bufA[src];
-            }
-        }
-        __syncthreads();
-        uint32_t* W = bufB;   // working list
-        uint32_t* Wn = bufA;  // next list
-        stamp(2);
-        // ---- P4: extended RDP (:278-349).  Thread 0 drives; max-distance search and list surgery use all threads.
-        if (tid == 0) {
-            s_i[2] = 0;  // cnt_boundary
-            s_i[3] = 0;  // init
-            s_i[4] = 0;  // failed
-            s_cl_off[0] = 0;
-        }
-        __syncthreads();
-        while (true) {
-            int cnt = s_i[2], init = s_i[3];
-            if (n <= 0 || s_i[4] || cnt >= 4) break;  // uniform
-            auto tri2 = [&](int a) {
-                const uint32_t p0 = W[a], p2 = W[(a + 2) % n], p1 = W[(a + 1) % n];
-                const int vx = ux(p0) + ux(p2) - 2 * ux(p1), vy = uy(p0) + uy(p2) - 2 * uy(p1);
-                return vx * vx + vy * vy;
-            };
-            if (tid == 0) {
-                int end = 0;
-                if (n > 2) {
-                    int c2 = tri2(init);  // cost > 1.05  <=>  squared norm >= 2
-                    while (c2 >= 2 && init < n - 3) {
-                        init++;
-                        c2 = tri2(init);
-                    }
-                    end = init + n / 2;
-                    if (end > n - 1) end = n - 1;
-                } else {
-                    s_i[4] = 1;
-                }
-                s_i[3] = init;
-                s_i[5] = end;
-            }
-            __syncthreads();
-            if (s_i[4]) break;
-            init = s_i[3];
-            // inner split loop (:303-330)
-            while (true) {
-                const int end = s_i[5];
-                if (end <= init + 1) {
-                    if (tid == 0) s_i[4] = 1;
-                    break;
-                }
-                const uint32_t pi = W[init], pe = W[end];
-                float nl0;
-                if (ux(pi) == ux(pe)) {
-                    nl0 = 100;
-                } else {
-                    nl0 = (float)(1.0 * (uy(pe) - uy(pi)) / (ux(pe) - ux(pi)));
-                }
-                const float nl1 = -1;
-                const float d_line = -(nl0 * ux(pi) + nl1 * uy(pi));
-                const float den = ctm::sqrt32(nl0 * nl0 + 1);
-                float bd = -1.f;
-                int bi = -1;
-                for (int it = init + 1 + tid; it < end; it += kQuadThreads) {
-                    const uint32_t p = W[it];
-                    const float d = ctm::fabs32(nl0 * ux(p) + nl1 * uy(p) + d_line) / den;
-                    const int rel = it - init - 1;
-                    if (d > bd || (d == bd && rel > bi)) {
-                        bd = d;
-                        bi = rel;
-                    }
-                }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const float od = __shfl_down(bd, d);
-                    const int oi = __shfl_down(bi, d);
-                    if (od > bd || (od == bd && oi > bi)) {
-                        bd = od;
-                        bi = oi;
-                    }
-                }
-                __syncthreads();  // previous readers of s_redf / s_i[5] are done
-                if (lane == 0) {
-                    s_redf[wave] = bd;
-                    s_redi[wave] = bi;
-                }
-                __syncthreads();
-                float md = s_redf[0];
-                int mi = s_redi[0];
-                for (int q = 1; q < kQuadWaves; q++)
-                    if (s_redf[q] > md || (s_redf[q] == md && s_redi[q] > mi)) {
-                        md = s_redf[q];
-                        mi = s_redi[q];
-                    }
-                const int count = end - init - 1;
-                if (md > 1.8f && count > 1) {
-                    __syncthreads();
-                    if (tid == 0) s_i[5] = mi;  // literal index into dist2line
-                    __syncthreads();
-                    continue;
-                }
-                // ---- expand_line (:125-169) with exact integer moment sums, thread 0
-                if (tid == 0) {
-                    long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
-                    for (int k = init; k <= end; k++) {
-                        const long long x = ux(W[k]), y = uy(W[k]);
-                        Sx += x;
-                        Sy += y;
-                        Sxx += x * x;
-                        Syy += y * y;
-                        Sxy += x * y;
-                    }
-                    int m = end - init + 1;
-                    float line[4];
-                    moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
-                    bool fl = false, fr = false;
-                    int left = init - 1, right = end + 1, nl = 0, nr = 0;
-                    while ((!fl || !fr) && (left != right)) {
-                        if (!fl) {
-                            if (left == -1) left = n - 1;
-                            const uint32_t p = W[left];
-                            const float de = ctm::fabs32(ux(p) * line[1] - uy(p) * line[0] + line[0] * line[3] - line[1] * line[2]);
-                            if (de > 1.2f) {
-                                fl = true;
-                                continue;
-                            }
-                            const long long x = ux(p), y = uy(p);
-                            Sx += x;
-                            Sy += y;
-                            Sxx += x * x;
-                            Syy += y * y;
-                            Sxy += x * y;
-                            m++;
-                            nl++;
-                            left--;
-                            moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
-                            if (m == n) break;
-                        }
-                        if (!fr) {
-                            if (right == n) right = 0;
-                            const uint32_t p = W[right];
-                            const float de = ctm::fabs32(ux(p) * line[1] - uy(p) * line[0] + line[0] * line[3] - line[1] * line[2]);
-                            if (de > 1.2f) {
-                                fr = true;
-                                continue;
-                            }
-                            const long long x = ux(p), y = uy(p);
-                            Sx += x;
-                            Sy += y;
-                            Sxx += x * x;
-                            Syy += y * y;
-                            Sxy += x * y;
-                            m++;
-                            nr++;
-                            right++;
-                            moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
-                            if (m == n) break;
-                        }
-                    }
-                    // the span is a circular arc [a .. b] of m distinct indices
-                    const int a = ((init - nl) % n + n) % n;
-                    const int b = (end + nr) % n;
-                    const int span0 = (a > b) ? n - 1 : b;
-                    const int keep = tri2(span0) <= 1 ? 1 : 0;  // cost < 1.05 (:337-339)
-                    s_i[6] = a;
-                    s_i[7] = b;
-                    s_i[8] = m;
-                    s_i[9] = keep;
-                }
-                __syncthreads();
-                {
-                    const int a = s_i[6], b = s_i[7], m = s_i[8], keep = s_i[9];
-                    const bool wrap = a > b;
-                    const int off = s_cl_off[cnt];
-                    // cluster points in descending index order (:332-334)
-                    for (int k = tid; k < m; k += kQuadThreads) {
-                        int idx;
-                        if (!wrap) {
-                            idx = b - k;
-                        } else {
-                            idx = (k < n - a) ? (n - 1 - k) : (b - (k - (n - a)));
-                        }
-                        if (off + k < C + 64) CL[off + k] = W[idx];
-                    }
-                    // erase the span except (optionally) its largest index (:341-343)
-                    int new_n;
-                    if (!wrap) {
-                        new_n = n - m + keep;
-                        for (int k = tid; k < new_n; k += kQuadThreads) {
-                            int src;
-                            if (k < a) src = k;
-                            else if (keep && k == a) src = b;
-                            else src = k - keep + m;
-                            Wn[k] = W[src];
-                        }
-                    } else {
-                        new_n = n - m + keep;
-                        const int mid = a - b - 1;  // W[b+1 .. a-1]
-                        for (int k = tid; k < new_n; k += kQuadThreads) Wn[k] = (k < mid) ? W[b + 1 + k] : W[n - 1];
-                    }
-                    __syncthreads();
-                    if (tid == 0) {
-                        const int back = wrap ? 0 : a;
-                        s_cl_off[cnt + 1] = min(off + m, C + 64);
-                        s_i[2] = cnt + 1;
-                        s_i[3] = (back >= new_n) ? 0 : back;
-                        s_i[10] = new_n;
-                    }
-                    __syncthreads();
-                    n = s_i[10];
-                    uint32_t* t = W;
-                    W = Wn;
-                    Wn = t;
-                }
-                break;
-            }
-            __syncthreads();
-        }
-        __syncthreads();
-        stamp(3);
-        // ---- export: the four edge clusters go to the frame's cluster pool; k_welsch fits them, k_quad_final picks the quad
-        bool ok = true;
-        for (int j = 0; j < 4; j++) {
-            const int len = (j < s_i[2]) ? (s_cl_off[j + 1] - s_cl_off[j]) : 0;
-            if (len < 2) ok = false;  // flag_line_number (:353-357)
-        }
-        if (s_cl_off[min(s_i[2], 4)] >= C + 64) ok = false;
-        CandAux* aux = P.cand_aux + (size_t)frame * kCandCap + ci;
-        if (ok) {
-            const int total = s_cl_off[4];
-            if (tid == 0) {
-                const int l0 = atomicAdd(&P.line_count[frame], 4);
-                const int p0 = atomicAdd(&P.clp_used[frame], total);
-                s_i[11] = (l0 + 4 <= kLineCap && p0 + total <= kClPool) ? l0 : -1;
-                s_i[12] = p0;
-            }
-            __syncthreads();
-            const int l0 = s_i[11], p0 = s_i[12];
-            if (l0 < 0) {
-                ok = false;
-                if (tid == 0) atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
-            } else {
-                uint32_t* dst = P.cl_pool + (size_t)frame * kClPool + p0;
-                for (int k = tid; k < total; k += kQuadThreads) dst[k] = CL[k];
-                if (tid < 4) {
-                    LineDesc d;
-                    d.off = (uint32_t)(p0 + s_cl_off[tid]);
-                    d.n = s_cl_off[tid + 1] - s_cl_off[tid];
-                    P.line_desc[(size_t)frame * kLineCap + l0 + tid] = d;
-                }
-                if (tid == 0) {
-                    aux->line0 = l0;
-                    aux->acx = acx;
-                    aux->acy = acy;
-                    aux->n_boundary = n_boundary;
-                }
-            }
-        }
-        if (!ok && tid == 0) {
-            aux->line0 = -1;
-            aux->acx = 0.f;
-            aux->acy = 0.f;
-            aux->n_boundary = n_boundary;
-        }
-        stamp(4);
-    }
-    }
-}
-
-
 // =====================================================================================================
 // K6p: packs of a frame's candidates for k_quad_edges_packed: <= 8 components whose LDS needs sum to <= pack_words per wave.
 // Candidates are ranked by boundary capacity, LONGEST FIRST, and packed in that order: a pack's 8-lane sub-groups run in
 // lockstep, so its time is its longest component's -- components of similar length share a wave -- and the packs come out
 // longest first, which is the order the kernel dispatches them in across the whole batch (the long ones used to start
 // anywhere and were the kernel's tail: a 150-point boundary is ~0.3 ms of dependent LDS round trips).
-// One block per frame; rank sort in LDS like k_candidates.  Oversize components are skipped; k_quad_edges<true> takes them.
+// One block per frame; rank sort in LDS like k_candidates.  Oversize components are skipped; the whole-wave builds take them.
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words) {
     __shared__ int s_key[kCandCap];
@@ -813,7 +301,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
             words += need;
         }
         if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
-        int nbig = 0;  // the oversize components sort last: entries [nc - nbig, nc) of `order`, k_quad_edges<true> walks only those
+        int nbig = 0;  // the oversize components sort last: entries [nc - nbig, nc) of `order`, the whole-wave builds walk only those
         for (int r = nc - 1; r >= 0 && s_key[s_ord[r]] < 0; r--) nbig++;
         P.npacks[frame] = np | (nbig << 16);
     }
@@ -833,10 +321,12 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
 // does, and the prefix up to the first event (distance test fails, `left == right`, or every point used) is committed.
 // All quantities that decide anything are computed from exact sums, so the outcome equals the sequential loop's.
 // Returns nl / nr = points added on the left / right side.  All 8 lanes return the same values.
+template <int SG>
 __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, int& nl_out,
                                                int& nr_out) {
+    constexpr unsigned long long kSgMask = SG == 64 ? ~0ull : ((1ull << (SG & 63)) - 1ull);
     long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
-    for (int k = init + sl; k <= end; k += kSG) {
+    for (int k = init + sl; k <= end; k += SG) {
         const long long x = ux(W[k]), y = uy(W[k]);
         Sx += x;
         Sy += y;
@@ -845,7 +335,7 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
         Sxy += x * y;
     }
 #pragma unroll
-    for (int d = 4; d >= 1; d >>= 1) {
+    for (int d = SG / 2; d >= 1; d >>= 1) {
         Sx += __shfl_xor(Sx, d);
         Sy += __shfl_xor(Sy, d);
         Sxx += __shfl_xor(Sxx, d);
@@ -859,30 +349,72 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
     int left = init - 1, right = end + 1, nl = 0, nr = 0;
     while ((!fl || !fr) && (left != right)) {
         const int mode = (!fl && !fr) ? 0 : (!fl ? 1 : 2);  // 0: L,R alternate; 1: left only; 2: right only
-        // replay the index bookkeeping of steps 0..sl under the "all accepted" assumption
         int l = left, r = right, q_idx = 0, cfalse_at = 99;
         long long px = 0, py = 0, pxx = 0, pyy = 0, pxy = 0;
         uint32_t qpt = 0;
-        for (int u = 0; u <= sl; u++) {
-            const bool stepL = mode == 0 ? ((u & 1) == 0) : (mode == 1);
-            const bool checkC = mode == 0 ? ((u & 1) == 0) : true;  // `left != right` is tested at the top of an iteration
-            if (checkC && l == r && cfalse_at == 99) cfalse_at = u;
-            int idx;
-            if (stepL) {
-                idx = (l == -1) ? n - 1 : l;
-                l = idx - 1;
-            } else {
-                idx = (r == n) ? 0 : r;
-                r = idx + 1;
+        if constexpr (SG <= 8) {
+            // replay the index bookkeeping of steps 0..sl under the "all accepted" assumption
+            for (int u = 0; u <= sl; u++) {
+                const bool stepL = mode == 0 ? ((u & 1) == 0) : (mode == 1);
+                const bool checkC = mode == 0 ? ((u & 1) == 0) : true;  // `left != right` is tested at the top of an iteration
+                if (checkC && l == r && cfalse_at == 99) cfalse_at = u;
+                int idx;
+                if (stepL) {
+                    idx = (l == -1) ? n - 1 : l;
+                    l = idx - 1;
+                } else {
+                    idx = (r == n) ? 0 : r;
+                    r = idx + 1;
+                }
+                qpt = W[idx];
+                const long long x = ux(qpt), y = uy(qpt);
+                px += x;
+                py += y;
+                pxx += x * x;
+                pyy += y * y;
+                pxy += x * y;
+                q_idx = idx;
             }
-            qpt = W[idx];
-            const long long x = ux(qpt), y = uy(qpt);
-            px += x;
-            py += y;
-            pxx += x * x;
-            pyy += y * y;
-            pxy += x * y;
-            q_idx = idx;
+        } else {
+            // the same bookkeeping in closed form (a lane per step instead of a replay loop per lane): before step u the left
+            // cursor has moved kl times and the right one kr times; the k-th left step reads index (left - k) mod n and leaves
+            // the raw cursor at that index - 1, the k-th right step reads (right + k) mod n and leaves index + 1
+            // (`left` is in [-1, n-1], `right` in [0, n]: -1 and n are the not-yet-wrapped values the reference compares).
+            const bool stepL = mode == 0 ? ((sl & 1) == 0) : (mode == 1);
+            const bool checkC = mode == 0 ? ((sl & 1) == 0) : true;
+            const int kl = mode == 0 ? ((sl + 1) >> 1) : (mode == 1 ? sl : 0);  // left steps among steps 0..sl-1
+            const int kr = mode == 0 ? (sl >> 1) : (mode == 2 ? sl : 0);
+            auto idxL = [&](int k) { return ((left - k) % n + n) % n; };
+            auto idxR = [&](int k) { return (right + k) % n; };
+            const int l_before = kl == 0 ? left : idxL(kl - 1) - 1;
+            const int r_before = kr == 0 ? right : idxR(kr - 1) + 1;
+            const bool cstop = checkC && l_before == r_before;
+            const unsigned long long cm = (unsigned long long)__ballot(cstop) & kSgMask;
+            cfalse_at = cm ? (int)(__ffsll((unsigned long long)cm) - 1) : 99;  // every lane holds the sub-group's first stop
+            q_idx = stepL ? idxL(kl) : idxR(kr);
+            l = stepL ? q_idx - 1 : l_before;
+            r = stepL ? r_before : q_idx + 1;
+            qpt = W[q_idx];
+            // inclusive prefix sums of the five moments over the lanes; 32 bits hold them: coordinates < 2^13 (an 8K frame at
+            // half resolution), products < 2^26, 64 of them < 2^32
+            uint32_t a0 = (uint32_t)ux(qpt), a1 = (uint32_t)uy(qpt), a2 = a0 * a0, a3 = a1 * a1, a4 = a0 * a1;
+#pragma unroll
+            for (int d = 1; d < SG; d <<= 1) {
+                const uint32_t b0 = (uint32_t)__shfl_up((int)a0, d), b1 = (uint32_t)__shfl_up((int)a1, d), b2 = (uint32_t)__shfl_up((int)a2, d),
+                               b3 = (uint32_t)__shfl_up((int)a3, d), b4 = (uint32_t)__shfl_up((int)a4, d);
+                if (sl >= d) {
+                    a0 += b0;
+                    a1 += b1;
+                    a2 += b2;
+                    a3 += b3;
+                    a4 += b4;
+                }
+            }
+            px = a0;
+            py = a1;
+            pxx = a2;
+            pyy = a3;
+            pxy = a4;
         }
         float mine[4];
         moments_to_line((double)(Sx + px), (double)(Sy + py), (double)(Sxx + pxx), (double)(Syy + pyy), (double)(Sxy + pxy),
@@ -890,15 +422,15 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
         float lp[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float up = __shfl(mine[k], lane0 + ((sl + 7) & 7));
+            const float up = __shfl(mine[k], lane0 + ((sl + SG - 1) & (SG - 1)));
             lp[k] = sl == 0 ? line[k] : up;
         }
         const float de = ctm::fabs32(ux(qpt) * lp[1] - uy(qpt) * lp[0] + lp[0] * lp[3] - lp[1] * lp[2]);
-        const unsigned failm = (unsigned)((__ballot(de > 1.2f) >> sgshift) & 0xffull);
-        const int tf = failm ? (__ffs(failm) - 1) : 99;
-        const int tc = __shfl(cfalse_at, lane0 + 7);
+        const unsigned long long failm = ((unsigned long long)__ballot(de > 1.2f) >> sgshift) & kSgMask;
+        const int tf = failm ? (int)(__ffsll(failm) - 1) : 99;
+        const int tc = SG <= 8 ? __shfl(cfalse_at, lane0 + SG - 1) : cfalse_at;
         const int te_raw = n - m - 1;  // the add of step te makes Slide.size() == edge_point.size()
-        const int te = (te_raw >= 0 && te_raw < kSG) ? te_raw : 99;
+        const int te = (te_raw >= 0 && te_raw < SG) ? te_raw : 99;
         int accepted;
         bool done = false, failed_step = false;
         if (tc < 99 && tc <= tf && tc <= te) {
@@ -911,7 +443,7 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
             accepted = te + 1;
             done = true;
         } else {
-            accepted = kSG;
+            accepted = SG;
         }
         if (accepted > 0) {
             const int src = lane0 + accepted - 1;
@@ -956,13 +488,18 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
 // Every lane of a sub-group executes the serial control flow redundantly (uniform within the sub-group), so no
 // broadcasts are needed; loops over pixels / boundary points are strided over the 8 lanes.
 // =====================================================================================================
-template <int WORDS, int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes) {
-    __shared__ uint32_t s_mem[WORDS];
+template <int SG, int WORDS, int WAVES, bool DYN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes, int tier_lo) {
+    static_assert(SG == 8 || SG == 64, "8 lanes per component (packs) or the whole wave (oversize components)");
+    __shared__ uint32_t s_static[DYN ? 1 : WORDS];
+    extern __shared__ uint32_t s_dynamic[];
+    uint32_t* const s_mem = DYN ? s_dynamic : s_static;
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    const int lane = threadIdx.x, sub = lane >> 3, sl = lane & 7, lane0 = lane & ~7;
-    const int npk = P.npacks[frame] & 0xffff;
+    const int lane = threadIdx.x, sub = lane / SG, sl = lane % SG, lane0 = lane - sl;
+    // SG == 8: the frame's packs; SG == 64: the oversize tail of k_pack's order, one component per wave
+    const int nc = min(P.ncand[frame], kCandCap);
+    const int npk = SG == 8 ? (P.npacks[frame] & 0xffff) : (P.npacks[frame] >> 16);
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
@@ -979,8 +516,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     for (int pk = blockIdx.y; pk < npk; pk += gridDim.y) {
         __syncthreads();  // single-wave workgroup: the previous pack is done with s_mem
         stamp(-1);
-        const uint32_t pw = P.packs[(size_t)frame * kCandCap + pk];
-        const int first = (int)(pw & 0xffffu), cnt = (int)(pw >> 16);
+        int first, cnt;
+        if constexpr (SG == 8) {
+            const uint32_t pw = P.packs[(size_t)frame * kCandCap + pk];
+            first = (int)(pw & 0xffffu);
+            cnt = (int)(pw >> 16);
+        } else {
+            first = nc - npk + pk;
+            cnt = 1;
+        }
         const bool act = sub < cnt;
         const int ci = P.pack_order[(size_t)frame * kCandCap + first + (act ? sub : 0)];
         const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
@@ -990,12 +534,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         const int need = act ? pack_need(w, h) : 0;
         int off = 0;
 #pragma unroll
-        for (int k = 0; k < kSG; k++) {
-            const int v = __shfl(need, k * 8);
+        for (int k = 0; k < 64 / SG; k++) {
+            const int v = __shfl(need, k * SG);
             if (k < sub) off += v;
         }
         if (!act) continue;
         CandAux* aux = P.cand_aux + (size_t)frame * kCandCap + ci;
+        if constexpr (SG == 64) {
+            // two builds share the oversize components by working-set size: (tier_lo, WORDS] is this one's
+            if (need <= tier_lo) continue;
+            if (need > WORDS) {
+                if (tier_lo > 0 && sl == 0) {  // larger than the largest build: give up on this component, flagged
+                    atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+                    aux->line0 = -1;
+                    aux->acx = 0.f;
+                    aux->acy = 0.f;
+                    aux->n_boundary = 0;
+                }
+                continue;
+            }
+        }
         uint32_t* mem = s_mem + off;
         // silhouette as two sentinel-padded arrays: tb[x+1] = (top+2) | (bottom+2) << 16 per column, lr[y+1] = (left+2) |
         // (right+2) << 16 per row, 0 = none.  With the +2 bias a neighbour outside the box can never match, so the
@@ -1006,7 +564,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         uint32_t* bufB = bufA + C;        // C + 1 words
         uint32_t* lef = bufA;             // P1 only: row extents by atomics (h <= C words each)
         uint32_t* rig = bufB;
-        const int sgshift = sub * 8;
+        const int sgshift = sub * SG;
 
         stamp(6);
         // the component's pixels carry one tile-local label per CCL tile it touches: collect those (tile, label) keys
@@ -1035,23 +593,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // 16-byte load (64 columns per sub-group step, starting at a 16-byte aligned column), remembers the last
         // (tile-local label, tile) -> "is my component" decision so the two dependent gathers are rare, and has
         // the next row's load in flight while it digests the current one.
-        for (int x = sl; x < w + 2; x += kSG) tb[x] = 0u;
-        for (int y = sl; y < h; y += kSG) {
+        for (int x = sl; x < w + 2; x += SG) tb[x] = 0u;
+        for (int y = sl; y < h; y += SG) {
             lef[y] = 0xffffffffu;
             rig[y] = 0u;
         }
         SG_SYNC();
-        for (int xa = x_min & ~7; xa < x_min + w; xa += 128) {  // one pass per 128 columns of the box
+        constexpr int kChunk = 8 * SG;  // columns a sub-group covers with one 16-byte load per lane
+        for (int xa = x_min & ~7; xa < x_min + w; xa += 2 * kChunk) {  // one pass per two chunks of the box
             const int x_end = x_min + w;  // exclusive
-            const int gxf = xa + 8 * sl;  // this lane's 8 columns of chunk 0; chunk 1 is 64 columns further
+            const int gxf = xa + 8 * sl;  // this lane's 8 columns of chunk 0; chunk 1 is kChunk columns further
             // Eight 16-byte aligned columns never straddle a 320-column tile boundary, so one lane's pixels of a chunk
             // share a CCL tile; the component's label(s) in that tile are looked up once per tile row (every 30 rows).
-            const int tcol0 = gxf / kTileW, tcol1 = (gxf + 64) / kTileW;
+            const int tcol0 = gxf / kTileW, tcol1 = (gxf + kChunk) / kTileW;
             unsigned valid0 = 0, valid1 = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 if (gxf + q >= x_min && gxf + q < x_end) valid0 |= 1u << q;
-                if (gxf + 64 + q >= x_min && gxf + 64 + q < x_end) valid1 |= 1u << q;
+                if (gxf + kChunk + q >= x_min && gxf + kChunk + q < x_end) valid1 |= 1u << q;
             }
             const bool ld_ok = valid0 != 0, ld_ok1 = valid1 != 0;
             unsigned labA0 = 0xffffffffu, labB0 = 0xffffffffu, labA1 = 0xffffffffu, labB1 = 0xffffffffu;
@@ -1130,7 +689,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             };
             auto load_row1 = [&](int y) {
                 uint4 r = make_uint4(0, 0, 0, 0);
-                if (ld_ok1 && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf + 64);
+                if (ld_ok1 && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf + kChunk);
                 return r;
             };
             auto process_row = [&](const uint4& v, const uint4& v1, int y) {
@@ -1141,7 +700,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     labels_of_tile(trow + tcol1, labA1, labB1, over1);
                 }
                 note(fg_of(v, labA0, labB0, over0, trow + tcol0, valid0), y, top0, bot0, seen0, gxf - x_min);
-                if (ld_ok1) note(fg_of(v1, labA1, labB1, over1, trow + tcol1, valid1), y, top1, bot1, seen1, gxf + 64 - x_min);
+                if (ld_ok1) note(fg_of(v1, labA1, labB1, over1, trow + tcol1, valid1), y, top1, bot1, seen1, gxf + kChunk - x_min);
             };
             // label rows in flight per lane (the scan is bound by latency, not by bytes): 4 in the large configuration, 2 in the
             // small one, whose 128-register budget the eight row registers of the deeper pipeline would spill
@@ -1183,13 +742,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
                 if ((valid1 >> q) & 1u) {
                     const uint32_t t = (top1[q >> 1] >> (16 * (q & 1))) & 0xffffu, bb = (bot1[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                    tb[xl + 65] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
+                    tb[xl + kChunk + 1] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
                 }
             }
         }
         {
             SG_SYNC();  // row extents (LDS atomics) complete
-            for (int y = sl; y < h + 2; y += kSG) {
+            for (int y = sl; y < h + 2; y += SG) {
                 uint32_t v = 0u;
                 if (y >= 1 && y <= h) {
                     const uint32_t a = lef[y - 1], b = rig[y - 1];  // b = last + 1, 0 = empty row
@@ -1204,7 +763,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // 8 neighbours (N,NE,E,SE,S,SW,W,NW); the first hit at or after the frame's resume index wins (B7)
         int n = 0;
         {
-            const int dxl = (int)((0x01A9u >> (2 * sl)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * sl)) & 3u) - 1;
+            const int jd = sl & 7;  // only lanes 0..7 of the sub-group take part (sl < 8 below)
+            const int dxl = (int)((0x01A9u >> (2 * jd)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * jd)) & 3u) - 1;
             int sp = 0;
             int fx = 0, fy = 0, j0 = 0;  // top-of-stack frame in registers; bufB holds the frames below it
             {
@@ -1234,7 +794,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const int nx = fx + dxl, ny = fy + dyl;
                 const uint32_t c = tb[nx + 1], r = lr[ny + 1];
                 const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
-                const bool hit = sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
+                const bool hit = sl < 8 && sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
                 const unsigned m = (unsigned)((__ballot(hit) >> sgshift) & 0xffull);
                 if (!m) {  // frame exhausted: pop
                     sp--;
@@ -1289,12 +849,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         float acx, acy;
         {
             unsigned long long sx = 0, sy = 0;
-            for (int k = sl; k < n; k += kSG) {
+            for (int k = sl; k < n; k += SG) {
                 sx += (unsigned)ux(bufA[k]);
                 sy += (unsigned)uy(bufA[k]);
             }
 #pragma unroll
-            for (int d = 4; d >= 1; d >>= 1) {
+            for (int d = SG / 2; d >= 1; d >>= 1) {
                 sx += __shfl_xor(sx, d);
                 sy += __shfl_xor(sy, d);
             }
@@ -1302,7 +862,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             acy = (float)(1.0 * (long long)sy / (double)(unsigned long long)n);
             float bd = 3.0e38f;
             int bi = 0x7fffffff;
-            for (int k = sl; k < n; k += kSG) {
+            for (int k = sl; k < n; k += SG) {
                 const float dx = (float)ux(bufA[k]) - acx, dy = (float)uy(bufA[k]) - acy;
                 const float d = ctm::sqrt32(dx * dx + dy * dy);
                 if (d < bd || (d == bd && k < bi)) {
@@ -1311,7 +871,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
             }
 #pragma unroll
-            for (int d = 4; d >= 1; d >>= 1) {
+            for (int d = SG / 2; d >= 1; d >>= 1) {
                 const float od = __shfl_xor(bd, d);
                 const int oi = __shfl_xor(bi, d);
                 if (od < bd || (od == bd && oi < bi)) {
@@ -1319,7 +879,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     bi = oi;
                 }
             }
-            for (int k = sl; k < n; k += kSG) {
+            for (int k = sl; k < n; k += SG) {
                 int src = k + bi;
                 if (src >= n) src -= n;
                 bufB[k] = bufA[src];
@@ -1383,7 +943,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const float den = ctm::sqrt32(nl0 * nl0 + 1);
                 float bd = -1.f;
                 int bi = -1;
-                for (int it = init + 1 + sl; it < end; it += kSG) {
+                for (int it = init + 1 + sl; it < end; it += SG) {
                     const uint32_t q = W[it];
                     const float d = ctm::fabs32(nl0 * ux(q) + nl1 * uy(q) + d_line) / den;
                     const int rel = it - init - 1;
@@ -1393,7 +953,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
                 }
 #pragma unroll
-                for (int d = 4; d >= 1; d >>= 1) {
+                for (int d = SG / 2; d >= 1; d >>= 1) {
                     const float od = __shfl_xor(bd, d);
                     const int oi = __shfl_xor(bi, d);
                     if (od > bd || (od == bd && oi > bi)) {
@@ -1408,7 +968,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
                 // ---- expand_line (:125-169), speculative over the sub-group's 8 lanes
                 int nl, nr;
-                sg_expand_line(W, n, init, end, sl, lane0, sgshift, nl, nr);
+                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, nl, nr);
                 const int m = end - init + 1 + nl + nr;
                 // the span is a circular arc [a .. b] of m distinct indices
                 const int a = ((init - nl) % n + n) % n;
@@ -1417,7 +977,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const int span0 = wrap ? n - 1 : b;
                 const int keep = tri2(span0) <= 1 ? 1 : 0;  // cost < 1.05 (:337-339)
                 const int offc = cl_off[cnt_b];
-                for (int k = sl; k < m; k += kSG) {  // cluster points in descending index order (:332-334)
+                for (int k = sl; k < m; k += SG) {  // cluster points in descending index order (:332-334)
                     int idx;
                     if (!wrap) {
                         idx = b - k;
@@ -1428,7 +988,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
                 const int new_n = n - m + keep;  // erase the span except (optionally) its largest index (:341-343)
                 if (!wrap) {
-                    for (int k = sl; k < new_n; k += kSG) {
+                    for (int k = sl; k < new_n; k += SG) {
                         int src;
                         if (k < a) src = k;
                         else if (keep && k == a) src = b;
@@ -1437,7 +997,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
                 } else {
                     const int mid = a - b - 1;
-                    for (int k = sl; k < new_n; k += kSG) Wn[k] = (k < mid) ? W[b + 1 + k] : W[n - 1];
+                    for (int k = sl; k < new_n; k += SG) Wn[k] = (k < mid) ? W[b + 1 + k] : W[n - 1];
                 }
                 SG_SYNC();
                 const int back = wrap ? 0 : a;
@@ -1693,7 +1253,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     auto mark = [&]() {
         if (ev5) (void)hipEventRecord(ev5[evi++], s);
     };
-    QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.quad_scratch, ws.quad_scratch_used, ws.frame_flags,
+    QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.frame_flags,
                ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
@@ -1705,21 +1265,49 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     static const int pack_max_env = getenv("CTAG_PACK_MAX") ? atoi(getenv("CTAG_PACK_MAX")) : 0;
     const int pack_max = pack_max_env > 0 ? std::min(pack_max_env, kSG) : kSG;
     static const int big_env = getenv("CTAG_BIG_POINTS") ? atoi(getenv("CTAG_BIG_POINTS")) : 0;
-    const int big_points = big_env > 0 ? big_env : 0x7fffffff;
+    const bool latency = nframes <= kLatencyFrames;
+    const int big_points = ws.wave_points > 0 ? ws.wave_points : big_env > 0 ? big_env : (latency ? kLatencyBigPoints : 0x7fffffff);
     const bool small_cfg = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;  // up to 1920x1200 frames
     const int pack_words = small_cfg ? kPackWordsSmall : kPackWords;
     hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words);
     mark();
+    // A few frames per call (the reference's one detect() per camera frame): the call is as long as its slowest component,
+    // so the packs and the whole-wave components run side by side (second stream, fork/join by events)
+    const bool fork = latency && ws.aux_stream != nullptr;
+    hipStream_t sb = s;
+    if (fork) {
+        (void)hipEventRecord(ws.ev_fork, s);
+        (void)hipStreamWaitEvent(ws.aux_stream, ws.ev_fork, 0);
+        sb = ws.aux_stream;
+    }
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
     if (small_cfg)
-        hipLaunchKernelGGL((k_quad_edges_packed<kPackWordsSmall, kPackWavesSmall>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes);
+        hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0);
     else
-        hipLaunchKernelGGL((k_quad_edges_packed<kPackWords, CTAG_PACK_WAVES>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes);
+        hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0);
     mark();
+    // oversize components, a wave each: working sets up to kWaveWords in a 32 KB build (5 per CU), the rest (up to the 144 KB a
+    // 4K frame's longest possible boundary needs three times over) in a build that owns a CU's LDS
     static const int bcols_env = getenv("CTAG_BIG_COLS") ? atoi(getenv("CTAG_BIG_COLS")) : 0;
-    const int bcols = bcols_env > 0 ? bcols_env : 4;
-    hipLaunchKernelGGL(k_quad_edges<true>, dim3(std::min(bcols * nframes, kQuadScratchSlots)), dim3(kQuadThreads), 0, s, P, ws.g, nframes, big_points, bcols, pack_words);
+    const int bcols = bcols_env > 0 ? bcols_env : (latency ? 128 : 4);
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = dev < 0 || dev >= 64 ? 0 : dev;
+        static bool have[64] = {false};
+        if (!have[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_quad_edges_packed<64, kWaveWordsMax, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kWaveWordsMax * 4);
+            have[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWords, 2, false>), dim3(nframes, bcols), dim3(64), 0, sb, P, ws.g, nframes, 0);
+    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWordsMax, 2, true>), dim3(nframes, latency ? 8 : 2), dim3(64), kWaveWordsMax * 4, sb, P, ws.g, nframes, kWaveWords);
+    if (fork) {
+        (void)hipEventRecord(ws.ev_join, sb);
+        (void)hipStreamWaitEvent(s, ws.ev_join, 0);
+    }
     mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     mark();

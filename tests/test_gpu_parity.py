@@ -364,6 +364,43 @@ def test_graph_replay_option_gives_identical_records(detector, dictionary):
         detector.set_option(capi.OPT_GRAPH, 0)
 
 
+def test_whole_wave_components_give_identical_records(detector, oracle, dictionary, test_bmp):
+    """CTAG_OPT_WAVE_POINTS moves components from the packed boundary kernel (8 lanes each) to the whole-wave builds
+    (64 lanes, the 64-step speculative expand_line): any split returns the same bytes as the batch default, which equals the oracle;
+    calls of up to 4 frames (the automatic latency mode: fork / join on a second stream) do too."""
+    import torch
+    state, fs = dictionary
+    n, rows, cols = 24, 1080, 1920
+    frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+    detector.synth_frames_device(frames.data_ptr(), 700, n - 4, rows, cols, cols, rows * cols)
+    for k in range(4):  # camera content: the reference's frame, shifted
+        frames[n - 4 + k] = torch.from_numpy(np.ascontiguousarray(test_bmp[31 * k:31 * k + rows])).cuda()
+    torch.cuda.synchronize()
+    out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+
+    def run(first, m):
+        out.zero_()
+        torch.cuda.synchronize()
+        detector.detect_batch_device(frames[first:].data_ptr(), m, rows, cols, cols, rows * cols, out.data_ptr())
+        detector.sync()
+        return out[:m].cpu().numpy().view(ca.RESULT_DT).reshape(m)
+
+    want = run(0, n)
+    host = frames.cpu().numpy()
+    for k in (0, 11, n - 4, n - 1):
+        assert want[k].tobytes() == oracle.detect_fast(host[k], state, fs).tobytes(), k
+    assert (want["status"] == 0).all() and want["n_markers"].sum() >= 2 * n
+    try:
+        for wp in (1, 24, 60, 200, 1000):
+            detector.set_option(capi.OPT_WAVE_POINTS, wp)
+            assert run(0, n).tobytes() == want.tobytes(), wp
+        detector.set_option(capi.OPT_WAVE_POINTS, 0)
+        for first, m in ((0, 1), (5, 3), (n - 4, 4), (n - 1, 1), (n - 2, 2)):  # automatic latency mode
+            assert run(first, m).tobytes() == want[first:first + m].tobytes(), (first, m)
+    finally:
+        detector.set_option(capi.OPT_WAVE_POINTS, 0)
+
+
 def test_streamed_host_batch(detector, oracle, dictionary):
     """ctag_detect_batch_u8 streams sub-chunks through two device slabs (upload of k+1 overlapping detection of k): the
     records equal the ORACLE's for pinned and pageable frame memory, odd sub-chunk counts and strided rows."""
