@@ -55,6 +55,21 @@ struct FeatPtrs {
     FeatureDev* feat0;
     FeatureDev* feat1;
     FeatureDev* feat2;
+    unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1): clock ticks per phase of k_features, else null
+};
+
+// developer aid: phase clock of a block (thread 0), summed over blocks into `stamps[base + phase]`
+struct PhaseClock {
+    unsigned long long* stamps;
+    unsigned long long t_prev;
+    __device__ explicit PhaseClock(unsigned long long* s) : stamps(s), t_prev(s ? __builtin_amdgcn_s_memtime() : 0ull) {}
+    __device__ void mark(int slot) {
+        if (stamps && threadIdx.x == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            atomicAdd(&stamps[slot], t - t_prev);
+            t_prev = t;
+        }
+    }
 };
 
 __device__ __forceinline__ bool near_ang(float a, float b, float thr) {
@@ -141,6 +156,11 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
     __shared__ QuadDerived s_der[kPairCap];
     __shared__ uint32_t s_pred[kPairCap * (kPairCap / 32)];
     __shared__ uint32_t s_match[CTAG_MAX_FEATURES];
+    constexpr int kPairList = 2048;  // close pairs listed for the dense pass (a frame has a few hundred); more are evaluated in place
+    static_assert(kPairCap <= 256, "a listed pair is two bytes");
+    __shared__ uint16_t s_plist[kPairList];
+    __shared__ float s_reach[kPairCap];
+    __shared__ int s_npair;
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,6 +172,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
     FeatureDev* f1 = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES;
     FeatureDev* f2 = P.feat2 + (size_t)frame * CTAG_MAX_FEATURES;
 
+    PhaseClock clk(P.stamps);
     // compact accepted quads in candidate (= OpenCV label) order
     int Q = 0;
     for (int base = 0; base < nc; base += 128) {
@@ -190,6 +211,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         return;
     }
     __syncthreads();  // qidx visible to the block (global memory, same workgroup)
+    clk.mark(0);
     for (int q = tid; q < Q; q += 128) {
         const float* c = quads[qidx[q]].c;
         QuadDerived D;
@@ -209,18 +231,53 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         s_vis[q] = 0;
     }
     __syncthreads();
+    clk.mark(1);
     // ---- greedy pairing (:483-553): quad i takes the first unvisited j > i that passes the pair test.  The test does not
     // depend on the visited flags, so for Q <= kPairCap it is evaluated for all pairs at once (every lane busy, one atan2 per
     // pair) into a bit matrix, one lane replays the greedy order on the bits, and the matches are organised in parallel.
     if (Q <= kPairCap) {
-        for (int q = tid; q < Q; q += 128) s_der[q] = der[q];
+        for (int q = tid; q < Q; q += 128) {
+            const QuadDerived D = der[q];
+            s_der[q] = D;
+            s_reach[q] = fmaxf((D.d[0] + D.d[2]) / 2, (D.d[1] + D.d[3]) / 2);
+        }
         for (int w = tid; w < Q * (kPairCap / 32); w += 128) s_pred[w] = 0u;
+        if (tid == 0) s_npair = 0;
         __syncthreads();
-        for (int idx = tid; idx < Q * Q; idx += 128) {
-            const int i = idx / Q, j = idx - i * Q;
-            if (j > i && feature_pair(s_der[i], s_der[j])) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));
+        // The pair test costs an atan2 in double and most pairs are far apart, so a cheap necessary condition goes first: the
+        // test ends with  fl - L/2 < 0.3 (fl + L/2)  (fl = centre distance, L = d1l + d2l), and whichever branches are taken
+        // d1l <= reach_i = max((d0+d2)/2, (d1+d3)/2) -- the same float expressions -- hence L <= reach_i + reach_j =: S
+        // (rounding is monotonic).  With fl >= S the left side is >= fl/2 and the right side <= 0.45 fl: the test fails by a
+        // margin no rounding closes.  Pairs that survive are listed and evaluated densely, a pair per lane.
+        {
+            const int j0 = tid, j1 = tid + 128;
+            const bool h0 = j0 < Q, h1 = j1 < Q;
+            const float x0 = h0 ? s_der[j0].cx : 0.f, y0 = h0 ? s_der[j0].cy : 0.f, r0 = h0 ? s_reach[j0] : 0.f;
+            const float x1 = h1 ? s_der[j1].cx : 0.f, y1 = h1 ? s_der[j1].cy : 0.f, r1 = h1 ? s_reach[j1] : 0.f;
+            auto consider = [&](int i, int j) {
+                const int at = atomicAdd(&s_npair, 1);
+                if (at < kPairList) s_plist[at] = (uint16_t)(i | (j << 8));
+                else if (feature_pair(s_der[i], s_der[j])) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));  // list full: in place
+            };
+            for (int i = 0; i + 1 < Q; i++) {
+                const float xi = s_der[i].cx, yi = s_der[i].cy, ri = s_reach[i];
+                if (h0 && j0 > i) {
+                    const float S = ri + r0, dx = xi - x0, dy = yi - y0;
+                    if (!(dx * dx + dy * dy > S * S)) consider(i, j0);
+                }
+                if (h1 && j1 > i) {
+                    const float S = ri + r1, dx = xi - x1, dy = yi - y1;
+                    if (!(dx * dx + dy * dy > S * S)) consider(i, j1);
+                }
+            }
         }
         __syncthreads();
+        for (int t = tid; t < min(s_npair, kPairList); t += 128) {
+            const int i = (int)(s_plist[t] & 0xffu), j = (int)(s_plist[t] >> 8);
+            if (feature_pair(s_der[i], s_der[j])) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));
+        }
+        __syncthreads();
+        clk.mark(2);
         if (tid == 0) {
             uint32_t vis[kPairCap / 32];
             for (int w = 0; w < kPairCap / 32; w++) vis[w] = 0u;
@@ -241,6 +298,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
             s_nf = nm;
         }
         __syncthreads();
+        clk.mark(3);
         for (int k = tid; k < min(s_nf, CTAG_MAX_FEATURES); k += 128) {
             const int i = (int)(s_match[k] & 0xffffu), j = (int)(s_match[k] >> 16);
             const QuadDerived &Di = s_der[i], &Dj = s_der[j];
@@ -279,6 +337,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         }
     }
     __syncthreads();
+    clk.mark(4);
     const int nf = s_nf;
     int status = CTAG_OK;
     if (nf < feature_size) status = CTAG_NO_FEATURE;
@@ -300,6 +359,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         f1[k] = F;
         f2[k] = F;
     }
+    clk.mark(5);
 }
 
 // =====================================================================================================
@@ -542,6 +602,7 @@ struct MarkerPtrs {
     const int32_t* dict;
     ctag_frame_result* pre;  // optional (debug)
     ctag_frame_result* out;
+    unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1), slots 16..
 };
 
 // featureExtraction for one feature (:1056-1207); C = 8 corners (x,y), swapped in place when direction == 0
@@ -648,6 +709,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     if (frame >= nframes) return;
     const int tid = threadIdx.x;
     ctag_frame_result* out = P.out + frame;
+    PhaseClock clk(P.stamps);
     // every byte of a result record is defined (unused slots are zero): records are compared / gathered as raw bytes
     {
         uint32_t* w = reinterpret_cast<uint32_t*>(out);
@@ -679,118 +741,182 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     for (int i = tid; i < nf; i += 64) s_feat[i] = P.feat[(size_t)frame * CTAG_MAX_FEATURES + i];
     for (int i = tid; i < drows * dcols; i += 64) s_dict[i] = (uint8_t)P.dict[i];
     __syncthreads();
-    // ---- markerOrganization (:976-1052).  The O(F^2) pair predicate is evaluated on all lanes into a bit matrix;
-    // thread 0 then replays the unions of the true pairs in the reference's (i, j) order, which is all the
-    // union-find state depends on.
-    for (int i = 0; i < nf - 1; i++) {
-        const FeatureDev& A = s_feat[i];
-        const float threshold_angle = 5, threshold_vertical = 0.5f;
-        const float vlx = A.c[0] - A.c[10], vly = A.c[1] - A.c[11];
-        const double reach = 0.3 * dist2p(P2{A.c[0], A.c[1]}, P2{A.c[10], A.c[11]});
-        for (int j0 = 0; j0 < 128; j0 += 64) {  // both words written (CTAG_MAX_FEATURES <= 128)
-            const int j = j0 + tid;
-            bool hit = false;
-            if (j > i && j < nf) {
-                const FeatureDev& B = s_feat[j];
-                const float vcx = A.center[0] - B.center[0], vcy = A.center[1] - B.center[1];
-                const float center_angle = (vcx * vlx + vcy * vly) / ctm::sqrt32((vcx * vcx + vcy * vcy) * (vlx * vlx + vly * vly));
-                hit = (ctm::fabs32(A.angle - B.angle) < threshold_angle * 2 || ctm::fabs32(180 - ctm::fabs32(A.angle - B.angle)) < threshold_angle) &&
-                      (dist2p(P2{A.center[0], A.center[1]}, P2{B.center[0], B.center[1]}) < reach) &&
-                      (ctm::fabs32(center_angle) < threshold_vertical);
+    clk.mark(16);
+    // ---- markerOrganization (:976-1052).  The O(F^2) pair predicate is evaluated for all pairs i < j at once, a pair per lane
+    // (the triangle folded into a rectangle: rows r and nf-2-r together hold nf entries), into a bit matrix; the unions of
+    // the true pairs are then replayed in the reference's (i, j) order, which is all the union-find state depends on.
+    {
+        uint32_t* pair32 = reinterpret_cast<uint32_t*>(&s_pair[0][0]);
+        for (int w = tid; w < 4 * nf; w += 64) pair32[w] = 0u;
+        __syncthreads();
+        const int rows2 = nf / 2;  // ceil((nf - 1) / 2) folded rows
+        for (int idx = tid; idx < rows2 * nf; idx += 64) {
+            const int r = idx / nf, c = idx - r * nf;
+            int i, j;
+            if (c < nf - 1 - r) {
+                i = r;
+                j = r + 1 + c;
+            } else {
+                i = nf - 2 - r;
+                j = i + 1 + (c - (nf - 1 - r));
+                if (i == r) continue;  // the middle row pairs with itself: its entries are the first part
             }
-            const unsigned long long m = __ballot(hit);
-            if (tid == 0) s_pair[i][j0 >> 6] = m;
+            const FeatureDev &A = s_feat[i], &B = s_feat[j];
+            const float threshold_angle = 5, threshold_vertical = 0.5f;
+            const float vlx = A.c[0] - A.c[10], vly = A.c[1] - A.c[11];
+            const double reach = 0.3 * dist2p(P2{A.c[0], A.c[1]}, P2{A.c[10], A.c[11]});
+            const float vcx = A.center[0] - B.center[0], vcy = A.center[1] - B.center[1];
+            const float center_angle = (vcx * vlx + vcy * vly) / ctm::sqrt32((vcx * vcx + vcy * vcy) * (vlx * vlx + vly * vly));
+            const bool hit = (ctm::fabs32(A.angle - B.angle) < threshold_angle * 2 || ctm::fabs32(180 - ctm::fabs32(A.angle - B.angle)) < threshold_angle) &&
+                             (dist2p(P2{A.center[0], A.center[1]}, P2{B.center[0], B.center[1]}) < reach) && (ctm::fabs32(center_angle) < threshold_vertical);
+            if (hit) atomicOr(&pair32[i * 4 + (j >> 5)], 1u << (j & 31));
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    clk.mark(17);
+    // The union-find runs on the whole wave in lockstep with its state in registers: father[k] lives in lane k & 63 (fa for k < 64,
+    // fb above), read with v_readlane (the index is wave-uniform) instead of a chain of dependent LDS round trips.
+    int cnt;
+    {
+        int fa = tid, fb = 64 + tid;
+        auto fget = [&](int x) { return x < 64 ? __builtin_amdgcn_readlane(fa, x) : __builtin_amdgcn_readlane(fb, x - 64); };
+        auto fset = [&](int x, int v) {
+            if (tid == (x & 63)) {
+                if (x < 64) fa = v;
+                else fb = v;
+            }
+        };
         auto uf = [&](int x) {
             int r = x;
-            while (s_father[r] != r) r = s_father[r];
-            while (s_father[x] != r) {  // path compression as the recursive union_find does
-                const int nx = s_father[x];
-                s_father[x] = r;
+            for (int f = fget(r); f != r; f = fget(r)) r = f;
+            for (int nx = fget(x); nx != r; nx = fget(x)) {  // path compression as the recursive union_find does
+                fset(x, r);
                 x = nx;
             }
             return r;
         };
-        for (int i = 0; i < nf; i++) s_father[i] = i;
+        // row i of the bit matrix: lane i & 63 holds it (rows 64.. in the second pair of registers)
+        const unsigned long long p0a = tid < nf ? s_pair[tid][0] : 0ull, p0b = tid < nf ? s_pair[tid][1] : 0ull;
+        const unsigned long long p1a = tid + 64 < nf ? s_pair[tid + 64][0] : 0ull, p1b = tid + 64 < nf ? s_pair[tid + 64][1] : 0ull;
+        auto rl64 = [&](unsigned long long v, int l) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+            return (unsigned long long)lo | ((unsigned long long)hi << 32);
+        };
         for (int i = 0; i < nf - 1; i++) {
             for (int w = 0; w < 2; w++) {
-                unsigned long long m = s_pair[i][w];
+                unsigned long long m = i < 64 ? rl64(w ? p0b : p0a, i) : rl64(w ? p1b : p1a, i - 64);
                 while (m) {
                     const int j = w * 64 + __builtin_ctzll(m);
                     m &= m - 1;
                     const int fi = uf(i), fj = uf(j);
-                    if (fi != fj) s_father[fj] = fi;
+                    if (fi != fj) fset(fj, fi);
                 }
             }
         }
         // groups in first-seen order (:993-1019).  father[0] is captured BEFORE the flattening loop, exactly as
         // the reference pushes it (it may be a stale non-root: literal quirk).
-        int* db = s_mfirst;  // temporarily: father_database
-        int cnt = 0;
-        db[cnt] = s_father[0];
-        s_group[0] = cnt++;
-        for (int i = 1; i < nf; i++) s_father[i] = uf(s_father[i]);
+        int dba = -1, dbb = -1;  // father_database[k] in lane k & 63
+        int ga = 0, gb = 0;      // marker index of feature tid / tid + 64
+        cnt = 1;
+        {
+            const int f0 = fget(0);
+            if (tid == 0) dba = f0;
+        }
+        for (int i = 1; i < nf; i++) fset(i, uf(fget(i)));
         for (int i = 1; i < nf; i++) {
-            int found = -1;
-            for (int j = 0; j < cnt; j++)
-                if (s_father[i] == db[j]) {
-                    found = j;
-                    break;
-                }
+            const int f = fget(i);
+            const unsigned long long ma = __ballot(tid < cnt && dba == f), mb = __ballot(tid + 64 < cnt && dbb == f);
+            int found = ma ? __builtin_ctzll(ma) : (mb ? 64 + __builtin_ctzll(mb) : -1);
             if (found < 0) {
-                db[cnt] = s_father[i];
+                if (tid == (cnt & 63)) {
+                    if (cnt < 64) dba = f;
+                    else dbb = f;
+                }
                 found = cnt++;
             }
-            s_group[i] = found;
+            if (tid == (i & 63)) {
+                if (i < 64) ga = found;
+                else gb = found;
+            }
         }
-        s_misc[0] = cnt;
         // features of each marker in ascending feature index (the order marker_ID[j] is filled)
+        const unsigned long long lt = tid ? (~0ull >> (64 - tid)) : 0ull;
         int pos = 0;
         for (int m = 0; m < cnt; m++) {
-            s_father[m] = pos;  // s_father is free now: first slot of marker m in s_order
-            for (int i = 0; i < nf; i++)
-                if (s_group[i] == m) s_order[pos++] = i;
+            const unsigned long long ba = __ballot(tid < nf && ga == m), bb = __ballot(tid + 64 < nf && gb == m);
+            if (tid == 0) s_mfirst[m] = pos;
+            if (tid < nf && ga == m) {
+                const int slot = pos + __popcll(ba & lt);
+                s_order[slot] = tid;
+                s_father[slot] = m;  // s_father: marker owning slot k
+            }
+            if (tid + 64 < nf && gb == m) {
+                const int slot = pos + __popcll(ba) + __popcll(bb & lt);
+                s_order[slot] = tid + 64;
+                s_father[slot] = m;
+            }
+            pos += __popcll(ba) + __popcll(bb);
         }
-        s_father[cnt] = pos;
+        if (tid == 0) s_mfirst[cnt] = pos;
     }
     __syncthreads();
-    const int cnt = s_misc[0];
-    if (tid == 0) {
-        for (int m = 0; m <= cnt; m++) s_mfirst[m] = s_father[m];
+    clk.mark(18);
+    // ---- per marker: orientation (the angles of its features are summed in order, :1021-1031) and the stable sort of its
+    // features: angles and ranks are computed a feature slot per lane, only the sum is a lane per marker
+    double* s_ang = reinterpret_cast<double*>(&s_pair[0][0]);  // the bit matrix is dead: folded direction of the feature in slot k
+    for (int k = tid; k < nf; k += 64) {
+        const FeatureDev& F = s_feat[s_order[k]];
+        double angle_now = ctm::fast_atan2_deg(F.c[1] - F.c[11], F.c[0] - F.c[10]);
+        if (angle_now > 180) angle_now -= 180;
+        s_ang[k] = angle_now;
     }
     __syncthreads();
-    // ---- per marker (lane per marker): orientation and the sort of its features
     for (int m = tid; m < cnt; m += 64) {
         const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
         float marker_angle = 0;
-        for (int k = a; k < b; k++) {
-            const FeatureDev& F = s_feat[s_order[k]];
-            double angle_now = ctm::fast_atan2_deg(F.c[1] - F.c[11], F.c[0] - F.c[10]);
-            if (angle_now > 180) angle_now -= 180;
-            marker_angle = (float)(marker_angle + angle_now);
-        }
+        for (int k = a; k < b; k++) marker_angle = (float)(marker_angle + s_ang[k]);
         marker_angle /= (float)n;
-        const int direc = (ctm::fabs32(marker_angle) < 45 || ctm::fabs32(marker_angle) > 135) ? 0 : 1;
-        // insertion sort of the marker's features (std::sort on <= 16 elements; stable)
-        for (int x = a + 1; x < b; x++) {
-            const int v = s_order[x];
-            const float kv = direc == 0 ? s_feat[v].center[1] : s_feat[v].center[0];
-            int y = x - 1;
-            while (y >= a) {
-                const float ky = direc == 0 ? s_feat[s_order[y]].center[1] : s_feat[s_order[y]].center[0];
-                const bool before = direc == 0 ? (kv > ky) : (kv < ky);
-                if (!before) break;
-                s_order[y + 1] = s_order[y];
-                y--;
-            }
-            s_order[y + 1] = v;
-        }
-        for (int k = a; k < b; k++) s_group[k] = direc;  // s_group is free now: direction of the marker owning slot k
+        s_group[m] = (ctm::fabs32(marker_angle) < 45 || ctm::fabs32(marker_angle) > 135) ? 0 : 1;
     }
     __syncthreads();
+    {
+        // rank of slot k among its marker's slots: std::sort on <= 16 elements is an insertion sort, i.e. stable
+        int newv[2] = {0, 0}, newk[2] = {-1, -1}, dirk[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int k = tid + 64 * q;
+            if (k >= nf) continue;
+            const int m = s_father[k], a = s_mfirst[m], b = s_mfirst[m + 1], direc = s_group[m];
+            const int v = s_order[k];
+            const float kv = direc == 0 ? s_feat[v].center[1] : s_feat[v].center[0];
+            int rank = 0;
+            for (int x = a; x < b; x++) {
+                const int vx = s_order[x];
+                const float kx = direc == 0 ? s_feat[vx].center[1] : s_feat[vx].center[0];
+                const bool x_before = direc == 0 ? (kx > kv) : (kx < kv);
+                const bool k_before = direc == 0 ? (kv > kx) : (kv < kx);
+                rank += (x_before || (!k_before && x < k)) ? 1 : 0;
+            }
+            newv[q] = v;
+            newk[q] = a + rank;
+            dirk[q] = direc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (newk[q] < 0) continue;
+            s_order[newk[q]] = newv[q];
+        }
+        __syncthreads();
+        // s_group becomes: direction of the marker owning slot k (s_father keeps the marker of slot k; a marker's slots do not move)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int k = tid + 64 * q;
+            if (k < nf) s_group[k] = dirk[q];
+        }
+    }
+    __syncthreads();
+    clk.mark(19);
     // ---- featureExtraction (lane per feature slot).  ID_left / ID_right persist from one feature to the next when no
     // cross-ratio band matches, so each lane reports "matched value or carry" and thread 0 replays the carry.
     constexpr int kCarry = -99;
@@ -820,6 +946,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         R.id_right = nr;
     }
     __syncthreads();
+    clk.mark(20);
     if (tid == 0) {
         int ID_left = 0, ID_right = 0;  // reset per detect()
         for (int k = 0; k < nf; k++) {
@@ -853,6 +980,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         }
         for (int k = tid; k < nf; k += 64) pre->features[k] = s_rec[k];
     }
+    clk.mark(21);
     // ---- markerDecoder (:1211-1250) + match_dictionary (:1269-1324)
     int out_markers = 0, out_features = 0;
     uint32_t oflags = flags;
@@ -860,7 +988,44 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
         if (n < feature_size) continue;  // uniform
         __syncthreads();
-        if (tid == 0) {
+        if (n <= 64) {
+            // code positions (:1218-1227) a feature per lane: gap_j from features j-1 and j, position = running sum of the gaps;
+            // the sequential loop stops at the first bad gap or position, which any lane reports; of several features on one
+            // position the last one stays
+            const int j = tid;
+            int gap = 0, bad = 0, idj = -1;
+            if (j < n) {
+                const ctag_feature_rec& Rj = s_rec[a + j];
+                idj = Rj.id;
+                if (j >= 1) {
+                    const ctag_feature_rec& Rp = s_rec[a + j - 1];
+                    const float dist_fea = dist2p(P2{Rj.center[0], Rj.center[1]}, P2{Rp.center[0], Rp.center[1]});
+                    const float gap_f = ctm::round32(dist_fea / ((Rj.edge_length + Rp.edge_length) * 3 / 4));
+                    if (!(gap_f >= 0.f && gap_f < (float)CTAG_MAX_CODE_POS)) bad = 1;
+                    else gap = (int)gap_f;
+                }
+            }
+            int pos = gap;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(pos, d);
+                if (tid >= d) pos += o;
+            }
+            if (j < n && pos >= CTAG_MAX_CODE_POS) bad = 1;
+            const int overflow = __ballot(bad != 0) != 0ull;
+            if (tid < CTAG_MAX_CODE_POS) s_code[tid] = -1;
+            __syncthreads();
+            const int pos_next = __shfl_down(pos, 1);
+            if (!overflow && j < n && (j == n - 1 || pos_next != pos)) s_code[pos] = idj;
+            __syncthreads();
+            const unsigned long long lg = __ballot(tid < CTAG_MAX_CODE_POS && s_code[tid < CTAG_MAX_CODE_POS ? tid : 0] > -1);
+            const int pos_last = __shfl(pos, n - 1);
+            if (tid == 0) {
+                s_misc[2] = pos_last;
+                s_misc[3] = overflow;
+                s_misc[4] = __popcll(lg);
+            }
+        } else if (tid == 0) {
             for (int k = 0; k < CTAG_MAX_CODE_POS; k++) s_code[k] = -1;
             int pos_now = 0, overflow = 0;
             s_code[0] = s_rec[a].id;
@@ -887,36 +1052,43 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             s_misc[4] = legal;
         }
         __syncthreads();
+        clk.mark(22);
         if (s_misc[3]) {
             oflags |= CTAG_FLAG_CODE_OVERFLOW;
             continue;
         }
         const int length = s_misc[2], legal = s_misc[4];
-        // coverage of every hypothesis: each lane owns a contiguous run of (dir, row, col) in the reference's scan order
+        // coverage of every hypothesis: each lane owns a contiguous run of (dir, row, col) in the reference's scan order.
+        // The code and its reversed+inverted form sit in registers; the CTAG_MAX_CODE_POS dictionary bytes of a hypothesis are
+        // requested together (positions beyond `length` are masked), not one dependent LDS round trip per position.
         const int hyp = drows * dcols;
         const int per = (2 * hyp + 63) / 64;
         const int h_lo = min(tid * per, 2 * hyp), h_hi = min(h_lo + per, 2 * hyp);
         int lane_max = -1;
         {
+            int codef[CTAG_MAX_CODE_POS], codeb[CTAG_MAX_CODE_POS];
+#pragma unroll
+            for (int k = 0; k < CTAG_MAX_CODE_POS; k++) {
+                const int cd = s_code[k];
+                codef[k] = k <= length ? cd : -2;                                  // -2 / -3: never equal to a dictionary byte
+                codeb[k] = k <= length ? ((7 - cd / 8) + (7 - cd % 8) * 8) : -3;  // a -1 gives 71: no match either
+            }
             int dir = h_lo >= hyp ? 1 : 0;
             const int rc0 = h_lo - dir * hyp;
             int i = rc0 / dcols, j = rc0 - i * dcols;  // one division per lane; (dir, i, j) advance incrementally
             for (int h = h_lo; h < h_hi; h++) {
                 const uint8_t* row = s_dict + i * dcols;
                 int cov = 0;
-                if (dir == 0) {
-                    int c = j;
-                    for (int k = 0; k <= length; k++) {
-                        if ((int)row[c] == s_code[k]) cov++;
-                        if (++c == dcols) c = 0;
-                    }
-                } else {
-                    for (int k = 0; k <= length; k++) {
-                        const int cd = s_code[k];
-                        int c = j - k + dcols;  // (j - k + dcols) % dcols with C semantics; a negative column never matches
-                        if (c >= dcols) c -= dcols;
-                        if (c >= 0 && (int)row[c] == ((7 - cd / 8) + (7 - cd % 8) * 8)) cov++;
-                    }
+                int cf = j;  // forward: column (j + k) % dcols
+#pragma unroll
+                for (int k = 0; k < CTAG_MAX_CODE_POS; k++) {
+                    int cb = j - k + dcols;  // reversed: (j - k + dcols) % dcols with C semantics; a negative column never matches
+                    if (cb >= dcols) cb -= dcols;
+                    const int c = dir ? cb : cf;
+                    const int want = dir ? codeb[k] : codef[k];
+                    const int got = (int)row[max(c, 0)];  // unconditional load: the 20 bytes of a hypothesis are requested together
+                    cov += (int)(c >= 0) & (int)(got == want);
+                    if (++cf == dcols) cf = 0;
                 }
                 s_cov[h] = (uint8_t)cov;
                 lane_max = max(lane_max, cov);
@@ -929,6 +1101,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
                 }
             }
         }
+        clk.mark(23);
         // order-dependent max / second bookkeeping (:1280-1311): an element updates `second` iff it does not raise the
         // running maximum, so every lane replays its run from the exclusive prefix maximum of the lanes before it
         int run = lane_max;
@@ -998,6 +1171,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             out_markers++;
             out_features += n;
         }
+        clk.mark(24);
     }
     if (tid == 0) {
         out->status = CTAG_OK;
@@ -1010,8 +1184,29 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
 // =====================================================================================================
 // launchers
 // =====================================================================================================
+// developer aid (CTAG_FEAT_STAMPS=1): phase clocks of k_features (slots 0-5) and k_markers (16-24); `report` waits and prints
+static unsigned long long* feat_stamps(hipStream_t s, bool report) {
+    static const bool want = getenv("CTAG_FEAT_STAMPS") != nullptr;
+    static unsigned long long* d = nullptr;
+    if (!want) return nullptr;
+    if (!d) {
+        (void)hipMalloc(reinterpret_cast<void**>(&d), 32 * 8);
+        (void)hipMemset(d, 0, 32 * 8);
+    }
+    if (report) {
+        unsigned long long h[32];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipMemset(d, 0, 32 * 8);
+        fprintf(stderr, "[k_features ticks] compact %llu derive %llu pairs %llu greedy %llu organise %llu obtain %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+        fprintf(stderr, "[k_markers ticks] load %llu pairs %llu union %llu sort %llu ids %llu carry+pre %llu | code %llu coverage %llu pick+store %llu\n", h[16], h[17], h[18],
+                h[19], h[20], h[21], h[22], h[23], h[24]);
+    }
+    return d;
+}
+
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
-    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2};
+    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false)};
     hipLaunchKernelGGL(k_features, dim3(nframes), dim3(128), 0, s, P, nframes, p.feature_size);
     return hipGetLastError();
 }
@@ -1022,8 +1217,9 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     return hipGetLastError();
 }
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s) {
-    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out};
+    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false)};
     hipLaunchKernelGGL(k_markers, dim3(nframes), dim3(64), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
+    (void)feat_stamps(s, true);
     return hipGetLastError();
 }
 

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     auto stamp = [&](int phase) {  // developer aid: wave-level cycles per phase (the sub-groups reconverge between phases)
         if (P.stamps) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (phase >= 0 && lane == 0) atomicAdd(&P.stamps[phase], t - t_prev);
+            if (phase >= 0 && lane == 0) atomicAdd(&P.stamps[phase + (SG == 64 ? 8 : 0)], t - t_prev);
             t_prev = t;
         }
     };
@@ -1319,11 +1319,14 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
-        unsigned long long tot = 0;
-        for (int i = 0; i < 5; i++) tot += h[i];
-        fprintf(stderr, "[packed P1 detail] header %.1f%% keys+init %.1f%% of total\n", 100.0 * h[6] / (tot + h[5] + h[6]), 100.0 * h[5] / (tot + h[5] + h[6]));
-        fprintf(stderr, "[k_quad_edges cycles] silhouette %.1f%% traversal %.1f%% centroid/rotate %.1f%% rdp %.1f%% export %.1f%% (total %llu)\n",
-                100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, tot);
+        for (int b = 0; b < 16; b += 8) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 5; i++) tot += h[b + i];
+            if (!tot) continue;
+            fprintf(stderr, "[%s cycles] header %.1f%% keys+init %.1f%% | silhouette %.1f%% traversal %.1f%% centroid/rotate %.1f%% rdp %.1f%% export %.1f%% (total %llu)\n",
+                    b ? "whole-wave" : "packed", 100.0 * h[b + 6] / (tot + h[b + 5] + h[b + 6]), 100.0 * h[b + 5] / (tot + h[b + 5] + h[b + 6]), 100.0 * h[b + 0] / tot,
+                    100.0 * h[b + 1] / tot, 100.0 * h[b + 2] / tot, 100.0 * h[b + 3] / tot, 100.0 * h[b + 4] / tot, tot);
+        }
     }
     return hipGetLastError();
 }
