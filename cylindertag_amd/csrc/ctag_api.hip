@@ -36,6 +36,7 @@ struct ctag_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<int32_t> dict;
     int32_t* d_dict = nullptr;
+    uint32_t* d_dict_pos = nullptr;  // [dict_rows][64]: columns holding each symbol (k_markers' bit-parallel coverage); null for > 32 columns
     uint8_t* d_pick_table = nullptr;
     int dict_rows = 0, dict_cols = 0, feature_size = 0;
     Workspace ws;
@@ -434,7 +435,7 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
     const int chunk = std::min(n, h->max_chunk);
     const int wr = ensure_workspace(h, rows, cols, adaptive_thresh, std::max(chunk, h->ws_rows == rows && h->ws_cols == cols ? h->ws_cap : 0));
     if (wr != CTAG_OK) return wr;
-    DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict};
+    DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int m = std::min(chunk, n - f0);
         const int r = run_chunk(h, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0);
@@ -540,6 +541,13 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_dict), h->dict.size() * 4) == hipSuccess;
     ok = ok && hipMemcpy(h->d_dict, h->dict.data(), h->dict.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && dict_cols <= 32) {
+        std::vector<uint32_t> pos((size_t)dict_rows * 64, 0u);
+        for (int i = 0; i < dict_rows; i++)
+            for (int c = 0; c < dict_cols; c++) pos[(size_t)i * 64 + (state[(size_t)i * dict_cols + c] & 63)] |= 1u << c;
+        ok = hipMalloc(reinterpret_cast<void**>(&h->d_dict_pos), pos.size() * 4) == hipSuccess &&
+             hipMemcpy(h->d_dict_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok) {
         std::vector<uint8_t> tab((size_t)kPickN * 200);
         build_pick_table(tab.data());
@@ -566,6 +574,7 @@ void ctag_destroy(ctag_handle* h) {
     drop_graphs(h);
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->d_dict) (void)hipFree(h->d_dict);
+    if (h->d_dict_pos) (void)hipFree(h->d_dict_pos);
     if (h->d_pick_table) (void)hipFree(h->d_pick_table);
     if (h->d_frames) (void)hipFree(h->d_frames);
     if (h->d_results) (void)hipFree(h->d_results);

@@ -148,6 +148,7 @@ struct DetectParams {
     int feature_size;
     int dict_rows, dict_cols;
     const int32_t* dict;  // device pointer
+    const uint32_t* dict_pos;  // device pointer: [dict_rows][64] column sets per symbol (k_markers), null for > 32 columns
 };
 
 // kernel launchers (each enqueues on `s`, returns hipGetLastError())

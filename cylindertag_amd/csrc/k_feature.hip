@@ -278,24 +278,65 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         }
         __syncthreads();
         clk.mark(2);
-        if (tid == 0) {
-            uint32_t vis[kPairCap / 32];
-            for (int w = 0; w < kPairCap / 32; w++) vis[w] = 0u;
-            int nm = 0;
-            for (int i = 0; i + 1 < Q; i++) {
-                if ((vis[i >> 5] >> (i & 31)) & 1u) continue;
-                int j = -1;
-                for (int w = (i + 1) >> 5; w < (Q + 31) >> 5 && j < 0; w++) {
-                    const uint32_t m = s_pred[i * (kPairCap / 32) + w] & ~vis[w];
-                    if (m) j = w * 32 + __ffs(m) - 1;
+        if (wave == 0) {
+            // the greedy replay (first unvisited j of every unvisited i, ascending i) on wave 0 in lockstep: the visited bits live
+            // in lanes 0..5 (a 32-bit word each), a row of the bit matrix is read by those lanes at once, rows without a
+            // candidate are skipped from a bitmap built in parallel, and the next row is in flight while this one is decided
+            constexpr int kW = kPairCap / 32;
+            static_assert(kPairCap <= 192, "three 64-row bitmap words");
+            unsigned long long rows0, rows1, rows2;
+            {
+                bool any[3];
+#pragma unroll
+                for (int b3 = 0; b3 < 3; b3++) {
+                    const int q = b3 * 64 + lane;
+                    any[b3] = false;
+                    if (q < Q)
+                        for (int w = 0; w < kW; w++) any[b3] = any[b3] || s_pred[q * kW + w] != 0u;
                 }
-                if (j < 0) continue;
-                vis[i >> 5] |= 1u << (i & 31);
-                vis[j >> 5] |= 1u << (j & 31);
-                if (nm < CTAG_MAX_FEATURES) s_match[nm] = (uint32_t)i | ((uint32_t)j << 16);
-                nm++;
+                rows0 = __ballot(any[0]);
+                rows1 = __ballot(any[1]);
+                rows2 = __ballot(any[2]);
             }
-            s_nf = nm;
+            auto next_row = [&]() {
+                int r = -1;
+                if (rows0) {
+                    r = __builtin_ctzll(rows0);
+                    rows0 &= rows0 - 1;
+                } else if (rows1) {
+                    r = 64 + __builtin_ctzll(rows1);
+                    rows1 &= rows1 - 1;
+                } else if (rows2) {
+                    r = 128 + __builtin_ctzll(rows2);
+                    rows2 &= rows2 - 1;
+                }
+                return r;
+            };
+            uint32_t visw = 0u;  // lane w < kW: visited bits of quads 32 w .. 32 w + 31
+            int nm = 0;
+            int i = next_row();
+            uint32_t cur = (i >= 0 && lane < kW) ? s_pred[i * kW + lane] : 0u;
+            while (i >= 0) {
+                const int inext = next_row();
+                const uint32_t nxt = (inext >= 0 && lane < kW) ? s_pred[inext * kW + lane] : 0u;
+                const uint32_t vi = (uint32_t)__builtin_amdgcn_readlane((int)visw, i >> 5);
+                if (!((vi >> (i & 31)) & 1u)) {
+                    const uint32_t m = cur & ~visw;  // a row holds bits j > i only
+                    const unsigned long long bal = __ballot(m != 0u);
+                    if (bal) {
+                        const int w0 = __builtin_ctzll(bal);
+                        const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)m, w0);
+                        const int j = w0 * 32 + __ffs(mw) - 1;
+                        if (lane == (i >> 5)) visw |= 1u << (i & 31);
+                        if (lane == (j >> 5)) visw |= 1u << (j & 31);
+                        if (lane == 0 && nm < CTAG_MAX_FEATURES) s_match[nm] = (uint32_t)i | ((uint32_t)j << 16);
+                        nm++;
+                    }
+                }
+                i = inext;
+                cur = nxt;
+            }
+            if (lane == 0) s_nf = nm;
         }
         __syncthreads();
         clk.mark(3);
@@ -603,6 +644,7 @@ struct MarkerPtrs {
     ctag_frame_result* pre;  // optional (debug)
     ctag_frame_result* out;
     unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1), slots 16..
+    const uint32_t* dict_pos;    // [dict_rows][64] columns holding symbol v, bit c = column c; null when the dictionary has > 32 columns
 };
 
 // featureExtraction for one feature (:1056-1207); C = 8 corners (x,y), swapped in place when direction == 0
@@ -769,7 +811,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             const float center_angle = (vcx * vlx + vcy * vly) / ctm::sqrt32((vcx * vcx + vcy * vcy) * (vlx * vlx + vly * vly));
             const bool hit = (ctm::fabs32(A.angle - B.angle) < threshold_angle * 2 || ctm::fabs32(180 - ctm::fabs32(A.angle - B.angle)) < threshold_angle) &&
                              (dist2p(P2{A.center[0], A.center[1]}, P2{B.center[0], B.center[1]}) < reach) && (ctm::fabs32(center_angle) < threshold_vertical);
-            if (hit) atomicOr(&pair32[i * 4 + (j >> 5)], 1u << (j & 31));
+            if (hit) atomicOr(&pair32[j * 4 + (i >> 5)], 1u << (i & 31));  // column j of the matrix: the i < j paired with it
         }
     }
     __syncthreads();
@@ -795,16 +837,33 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             }
             return r;
         };
-        // row i of the bit matrix: lane i & 63 holds it (rows 64.. in the second pair of registers)
-        const unsigned long long p0a = tid < nf ? s_pair[tid][0] : 0ull, p0b = tid < nf ? s_pair[tid][1] : 0ull;
-        const unsigned long long p1a = tid + 64 < nf ? s_pair[tid + 64][0] : 0ull, p1b = tid + 64 < nf ? s_pair[tid + 64][1] : 0ull;
-        auto rl64 = [&](unsigned long long v, int l) {
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-            return (unsigned long long)lo | ((unsigned long long)hi << 32);
-        };
+        // column j of the bit matrix sits in lane j & 63 (columns 64.. in the second pair of registers), so row i -- the j paired
+        // with i -- is a ballot over "my column has bit i", with no cross-lane read at all
+        const unsigned long long c0a = tid < nf ? s_pair[tid][0] : 0ull, c0b = tid < nf ? s_pair[tid][1] : 0ull;
+        const unsigned long long c1a = tid + 64 < nf ? s_pair[tid + 64][0] : 0ull, c1b = tid + 64 < nf ? s_pair[tid + 64][1] : 0ull;
         for (int i = 0; i < nf - 1; i++) {
+            unsigned long long m0, m1;
+            if (i < 64) {
+                m0 = __ballot((c0a >> i) & 1ull);
+                m1 = __ballot((c1a >> i) & 1ull);
+            } else {
+                m0 = __ballot((c0b >> (i - 64)) & 1ull);
+                m1 = __ballot((c1b >> (i - 64)) & 1ull);
+            }
+            if (!(m0 | m1)) continue;
+            // Most true pairs join features that already hang directly under the same root: for those the reference's two
+            // union_find calls write nothing.  With r = father[i] a root, every j whose father is r is such a pair, now and for the
+            // rest of row i (a union only hangs another root under r), so one ballot removes them from the row.
+            {
+                const int ri = fget(i);
+                const unsigned long long roots = ri < 64 ? __ballot(fa == tid) >> ri : __ballot(fb == tid + 64) >> (ri - 64);
+                if (roots & 1ull) {
+                    m0 &= ~__ballot(fa == ri);
+                    m1 &= ~__ballot(fb == ri);
+                }
+            }
             for (int w = 0; w < 2; w++) {
-                unsigned long long m = i < 64 ? rl64(w ? p0b : p0a, i) : rl64(w ? p1b : p1a, i - 64);
+                unsigned long long m = w ? m1 : m0;
                 while (m) {
                     const int j = w * 64 + __builtin_ctzll(m);
                     m &= m - 1;
@@ -813,30 +872,32 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
                 }
             }
         }
-        // groups in first-seen order (:993-1019).  father[0] is captured BEFORE the flattening loop, exactly as
-        // the reference pushes it (it may be a stale non-root: literal quirk).
-        int dba = -1, dbb = -1;  // father_database[k] in lane k & 63
-        int ga = 0, gb = 0;      // marker index of feature tid / tid + 64
+        // groups in first-seen order (:993-1019).  father[0] is captured BEFORE the flattening loop, exactly as the reference
+        // pushes it (it may be a stale non-root: literal quirk).  The flattening father[i] = union_find(father[i]), i >= 1, leaves
+        // every such entry at the root of its set whatever the order, so it is done by pointer jumping on all lanes; the groups
+        // are then numbered a set at a time, in the order of their first member i >= 1 (father_database[0] = the captured value).
+        const int db0 = fget(0);
+        for (;;) {
+            const int ga2 = __shfl(fa, fa & 63), gb2 = __shfl(fb, fa & 63), ha2 = __shfl(fa, fb & 63), hb2 = __shfl(fb, fb & 63);
+            const int na = fa < 64 ? ga2 : gb2, nb = fb < 64 ? ha2 : hb2;  // father[father[k]]
+            const bool moved = (tid >= 1 && na != fa) || nb != fb;
+            if (tid >= 1) fa = na;  // entry 0 is not flattened by the reference (and not read below)
+            fb = nb;
+            if (!__ballot(moved)) break;
+        }
+        int ga = 0, gb = 0;  // marker index of feature tid / tid + 64
         cnt = 1;
         {
-            const int f0 = fget(0);
-            if (tid == 0) dba = f0;
-        }
-        for (int i = 1; i < nf; i++) fset(i, uf(fget(i)));
-        for (int i = 1; i < nf; i++) {
-            const int f = fget(i);
-            const unsigned long long ma = __ballot(tid < cnt && dba == f), mb = __ballot(tid + 64 < cnt && dbb == f);
-            int found = ma ? __builtin_ctzll(ma) : (mb ? 64 + __builtin_ctzll(mb) : -1);
-            if (found < 0) {
-                if (tid == (cnt & 63)) {
-                    if (cnt < 64) dba = f;
-                    else dbb = f;
-                }
-                found = cnt++;
-            }
-            if (tid == (i & 63)) {
-                if (i < 64) ga = found;
-                else gb = found;
+            unsigned long long ra = __ballot(tid >= 1 && tid < nf), rb = __ballot(tid + 64 < nf);  // features not numbered yet
+            while (ra | rb) {
+                const int lead = ra ? __builtin_ctzll(ra) : 64 + __builtin_ctzll(rb);
+                const int r = fget(lead);
+                const int g = r == db0 ? 0 : cnt++;
+                const unsigned long long ma = __ballot(fa == r) & ra, mb = __ballot(fb == r) & rb;
+                if ((ma >> tid) & 1ull) ga = g;
+                if ((mb >> tid) & 1ull) gb = g;
+                ra &= ~ma;
+                rb &= ~mb;
             }
         }
         // features of each marker in ascending feature index (the order marker_ID[j] is filled)
@@ -1058,45 +1119,90 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             continue;
         }
         const int length = s_misc[2], legal = s_misc[4];
-        // coverage of every hypothesis: each lane owns a contiguous run of (dir, row, col) in the reference's scan order.
-        // The code and its reversed+inverted form sit in registers; the CTAG_MAX_CODE_POS dictionary bytes of a hypothesis are
-        // requested together (positions beyond `length` are masked), not one dependent LDS round trip per position.
+        // coverage of every hypothesis (dir, row, col), stored in the reference's scan order
         const int hyp = drows * dcols;
         const int per = (2 * hyp + 63) / 64;
         const int h_lo = min(tid * per, 2 * hyp), h_hi = min(h_lo + per, 2 * hyp);
         int lane_max = -1;
-        {
-            int codef[CTAG_MAX_CODE_POS], codeb[CTAG_MAX_CODE_POS];
-#pragma unroll
-            for (int k = 0; k < CTAG_MAX_CODE_POS; k++) {
-                const int cd = s_code[k];
-                codef[k] = k <= length ? cd : -2;                                  // -2 / -3: never equal to a dictionary byte
-                codeb[k] = k <= length ? ((7 - cd / 8) + (7 - cd % 8) * 8) : -3;  // a -1 gives 71: no match either
-            }
-            int dir = h_lo >= hyp ? 1 : 0;
-            const int rc0 = h_lo - dir * hyp;
-            int i = rc0 / dcols, j = rc0 - i * dcols;  // one division per lane; (dir, i, j) advance incrementally
-            for (int h = h_lo; h < h_hi; h++) {
-                const uint8_t* row = s_dict + i * dcols;
-                int cov = 0;
-                int cf = j;  // forward: column (j + k) % dcols
+        if (P.dict_pos) {
+            // Bit-parallel form, a dictionary row per lane: dict_pos[row][v] is the set of columns holding symbol v (built once per
+            // handle), so position k of the code contributes the column set of its symbol rotated by k -- bit j of the rotated
+            // set says "hypothesis (row, j) matches at k" -- and the matches of all columns are counted at once in five
+            // bit planes.  Reversed direction: the inverted symbol, rotation the other way, and a column that the reference's
+            // (j - k + dcols) leaves negative (k > j + dcols) never matches.
+            const uint32_t dmask = dcols >= 32 ? 0xffffffffu : ((1u << dcols) - 1u);
+            for (int i = tid; i < drows; i += 64) {
+                const uint32_t* Ti = P.dict_pos + (size_t)i * 64;
+                uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+                int sh = 0;  // k % dcols
 #pragma unroll
                 for (int k = 0; k < CTAG_MAX_CODE_POS; k++) {
-                    int cb = j - k + dcols;  // reversed: (j - k + dcols) % dcols with C semantics; a negative column never matches
-                    if (cb >= dcols) cb -= dcols;
-                    const int c = dir ? cb : cf;
-                    const int want = dir ? codeb[k] : codef[k];
-                    const int got = (int)row[max(c, 0)];  // unconditional load: the 20 bytes of a hypothesis are requested together
-                    cov += (int)(c >= 0) & (int)(got == want);
-                    if (++cf == dcols) cf = 0;
+                    if (k <= length) {  // uniform
+                        const int cd = s_code[k];
+                        const bool have = cd >= 0;  // -1: no feature at this position; matches nothing in either direction
+                        const uint32_t mf = have ? Ti[cd & 63] : 0u;
+                        const uint32_t mb = have ? Ti[((7 - cd / 8) + (7 - cd % 8) * 8) & 63] : 0u;
+                        uint32_t x = sh ? (((mf >> sh) | (mf << (dcols - sh))) & dmask) : mf;
+                        uint32_t y = sh ? (((mb << sh) | (mb >> (dcols - sh))) & dmask) : mb;
+                        if (k > dcols) y &= ~((1u << (k - dcols)) - 1u);
+                        uint32_t c;
+                        c = f0 & x, f0 ^= x, x = c;
+                        c = f1 & x, f1 ^= x, x = c;
+                        c = f2 & x, f2 ^= x, x = c;
+                        c = f3 & x, f3 ^= x, x = c;
+                        f4 ^= x;
+                        c = b0 & y, b0 ^= y, y = c;
+                        c = b1 & y, b1 ^= y, y = c;
+                        c = b2 & y, b2 ^= y, y = c;
+                        c = b3 & y, b3 ^= y, y = c;
+                        b4 ^= y;
+                    }
+                    if (++sh == dcols) sh = 0;
                 }
-                s_cov[h] = (uint8_t)cov;
-                lane_max = max(lane_max, cov);
-                if (++j == dcols) {
-                    j = 0;
-                    if (++i == drows) {
-                        i = 0;
-                        dir = 1;
+                for (int j = 0; j < dcols; j++) {
+                    s_cov[i * dcols + j] = (uint8_t)(((f0 >> j) & 1u) | (((f1 >> j) & 1u) << 1) | (((f2 >> j) & 1u) << 2) | (((f3 >> j) & 1u) << 3) | (((f4 >> j) & 1u) << 4));
+                    s_cov[hyp + i * dcols + j] =
+                        (uint8_t)(((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1) | (((b2 >> j) & 1u) << 2) | (((b3 >> j) & 1u) << 3) | (((b4 >> j) & 1u) << 4));
+                }
+            }
+            __syncthreads();
+            for (int h = h_lo; h < h_hi; h++) lane_max = max(lane_max, (int)s_cov[h]);
+        } else {
+            // more than 32 dictionary columns: a contiguous run of hypotheses per lane, the code and its reversed+inverted form in
+            // registers, the CTAG_MAX_CODE_POS dictionary bytes of a hypothesis requested together
+            {
+                int codef[CTAG_MAX_CODE_POS], codeb[CTAG_MAX_CODE_POS];
+    #pragma unroll
+                for (int k = 0; k < CTAG_MAX_CODE_POS; k++) {
+                    const int cd = s_code[k];
+                    codef[k] = k <= length ? cd : -2;                                  // -2 / -3: never equal to a dictionary byte
+                    codeb[k] = k <= length ? ((7 - cd / 8) + (7 - cd % 8) * 8) : -3;  // a -1 gives 71: no match either
+                }
+                int dir = h_lo >= hyp ? 1 : 0;
+                const int rc0 = h_lo - dir * hyp;
+                int i = rc0 / dcols, j = rc0 - i * dcols;  // one division per lane; (dir, i, j) advance incrementally
+                for (int h = h_lo; h < h_hi; h++) {
+                    const uint8_t* row = s_dict + i * dcols;
+                    int cov = 0;
+                    int cf = j;  // forward: column (j + k) % dcols
+    #pragma unroll
+                    for (int k = 0; k < CTAG_MAX_CODE_POS; k++) {
+                        int cb = j - k + dcols;  // reversed: (j - k + dcols) % dcols with C semantics; a negative column never matches
+                        if (cb >= dcols) cb -= dcols;
+                        const int c = dir ? cb : cf;
+                        const int want = dir ? codeb[k] : codef[k];
+                        const int got = (int)row[max(c, 0)];  // unconditional load: the 20 bytes of a hypothesis are requested together
+                        cov += (int)(c >= 0) & (int)(got == want);
+                        if (++cf == dcols) cf = 0;
+                    }
+                    s_cov[h] = (uint8_t)cov;
+                    lane_max = max(lane_max, cov);
+                    if (++j == dcols) {
+                        j = 0;
+                        if (++i == drows) {
+                            i = 0;
+                            dir = 1;
+                        }
                     }
                 }
             }
@@ -1217,7 +1323,7 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     return hipGetLastError();
 }
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s) {
-    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false)};
+    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false), p.dict_pos};
     hipLaunchKernelGGL(k_markers, dim3(nframes), dim3(64), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
     (void)feat_stamps(s, true);
     return hipGetLastError();

@@ -401,6 +401,26 @@ def test_whole_wave_components_give_identical_records(detector, oracle, dictiona
         detector.set_option(capi.OPT_WAVE_POINTS, 0)
 
 
+def test_decoder_paths_on_other_dictionary_shapes(oracle, dictionary, test_bmp):
+    """k_markers counts code matches bit-parallel over the dictionary's columns (<= 32 columns: a row per lane, symbol -> column-set
+    table built per handle) and hypothesis by hypothesis otherwise.  Dictionaries of 12, 24 and 36 columns (the reference's rows
+    repeated, so the best match is ambiguous and every marker is rejected or kept exactly as the oracle decides), 7 columns
+    (shorter than a code: the reversed walk leaves columns negative) and a 41 x 33 random one."""
+    state, fs = dictionary
+    frames = [test_bmp, ca.synth_frame_host(state, 3)[0], ca.synth_frame_host(state, 11)[0]]
+    rng = np.random.RandomState(5)
+    for name, st in (("12", state), ("24", np.tile(state, (1, 2))), ("36", np.tile(state, (1, 3))), ("7", np.ascontiguousarray(state[:, :7])),
+                     ("33 random", rng.randint(0, 64, (41, 33)).astype(np.int32)), ("5 rows", np.ascontiguousarray(state[:5]))):
+        st = np.ascontiguousarray(st, dtype=np.int32)
+        det = ca.Detector(st, fs)
+        try:
+            for k, img in enumerate(frames):
+                got, want = det.detect(img), oracle.detect_fast(img, st, fs)
+                assert_same_record(got, want, "dictionary %s, frame %d" % (name, k))
+        finally:
+            det.close()
+
+
 def test_streamed_host_batch(detector, oracle, dictionary):
     """ctag_detect_batch_u8 streams sub-chunks through two device slabs (upload of k+1 overlapping detection of k): the
     records equal the ORACLE's for pinned and pageable frame memory, odd sub-chunk counts and strided rows."""
