@@ -758,6 +758,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             }
         }
         SG_SYNC();
+        // distinct silhouette pixels: two per column (one where top == bottom) plus the row ends that head no column list.  The
+        // traversal below visits every listed pixel at most once, so once it has appended this many points nothing is left to
+        // find and the rest of its work -- unwinding a stack as deep as the boundary is long, a full neighbour test per frame --
+        // changes nothing: it stops there.
+        int ntotal = 0;
+        for (int x = sl; x < w; x += SG) {
+            const uint32_t t = tb[x + 1];
+            if (t) ntotal += 1 + ((t & 0xffffu) != (t >> 16) ? 1 : 0);
+        }
+        for (int y = sl; y < h; y += SG) {
+            const uint32_t v = lr[y + 1];
+            if (v) {
+                const uint32_t ky = (uint32_t)(y + 2), xl = (v & 0xffffu) - 2u, xr = (v >> 16) - 2u;
+                const uint32_t tl = tb[xl + 1], tr = tb[xr + 1];
+                if ((tl & 0xffffu) != ky && (tl >> 16) != ky) ntotal++;
+                if (xr != xl && (tr & 0xffffu) != ky && (tr >> 16) != ky) ntotal++;
+            }
+        }
+#pragma unroll
+        for (int d = SG / 2; d >= 1; d >>= 1) ntotal += __shfl_xor(ntotal, d);
         stamp(0);
         // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): lanes 0..7 of the sub-group test the
         // 8 neighbours (N,NE,E,SE,S,SW,W,NW); the first hit at or after the frame's resume index wins (B7)
@@ -790,7 +810,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 lr[fy + 1] = r;
             }
             SG_SYNC();
-            while (sp >= 0) {
+            while (sp >= 0 && n < ntotal) {
                 const int nx = fx + dxl, ny = fy + dyl;
                 const uint32_t c = tb[nx + 1], r = lr[ny + 1];
                 const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
