@@ -227,6 +227,7 @@ constexpr int kPackWords = CTAG_PACK_WORDS;  // LDS words shared by the up to 8 
 // components four times the size and keep the large one (same-box A/B: 8.4 vs 7.9 ms per 1024 frames with the small one).
 constexpr int kPackWordsSmall = 2560, kPackWavesSmall = 4;
 constexpr int kSG = 8;
+constexpr int kUnwind = 8;  // stack frames the whole-wave build tests at once when it unwinds (<= 8: 8 lanes each)
 constexpr int kWaveWords = 8192;      // LDS words of the common whole-wave build (32 KB: five components per CU)
 constexpr int kWaveWordsMax = 36864;  // ... of the build for the longest boundaries (144 KB: one per CU)
 constexpr int kLatencyFrames = 4;     // calls with at most this many frames are tuned for the latency of the call
@@ -668,6 +669,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 return bits & valid;
             };
             auto note = [&](unsigned bits, int y, uint32_t* tp, uint32_t* bt, uint32_t* sn, int xl0) {
+                if constexpr (SG == 64) {
+                    // row extents of a whole-wave component: the lanes are in column order, so the row's first and last foreground
+                    // lanes come from one ballot and lane 0 updates the row's words
+                    const unsigned long long bm = __ballot(bits != 0u);
+                    if (bm) {
+                        const int lo = xl0 + __ffs(bits) - 1, hi = xl0 + 32 - __clz(bits);
+                        const int first = __shfl(lo, __builtin_ctzll(bm)), last1 = __shfl(hi, 63 - __builtin_clzll(bm));
+                        if (sl == 0) {
+                            lef[y] = min(lef[y], (uint32_t)first);
+                            rig[y] = max(rig[y], (uint32_t)last1);
+                        }
+                    }
+                }
                 if (!bits) return;
                 const uint32_t ypk = (uint32_t)y * 0x10001u;
 #pragma unroll
@@ -678,9 +692,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     tp[d] = (tp[d] & ~nm) | (ypk & nm);
                     sn[d] |= m;
                 }
-                // row extents by LDS atomics (no result needed, so no latency is exposed)
-                atomicMin(&lef[y], (unsigned)(xl0 + __ffs(bits) - 1));
-                atomicMax(&rig[y], (unsigned)(xl0 + 32 - __clz(bits)));
+                if constexpr (SG != 64) {
+                    // row extents by LDS atomics (no result needed, so no latency is exposed)
+                    atomicMin(&lef[y], (unsigned)(xl0 + __ffs(bits) - 1));
+                    atomicMax(&rig[y], (unsigned)(xl0 + 32 - __clz(bits)));
+                }
             };
             auto load_row = [&](int y) {
                 uint4 r = make_uint4(0, 0, 0, 0);
@@ -700,7 +716,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     labels_of_tile(trow + tcol1, labA1, labB1, over1);
                 }
                 note(fg_of(v, labA0, labB0, over0, trow + tcol0, valid0), y, top0, bot0, seen0, gxf - x_min);
-                if (ld_ok1) note(fg_of(v1, labA1, labB1, over1, trow + tcol1, valid1), y, top1, bot1, seen1, gxf + kChunk - x_min);
+                if (SG == 64 || ld_ok1) note(fg_of(v1, labA1, labB1, over1, trow + tcol1, valid1), y, top1, bot1, seen1, gxf + kChunk - x_min);  // whole wave: note() holds a ballot
             };
             // label rows in flight per lane (the scan is bound by latency, not by bytes): 4 in the large configuration, 2 in the
             // small one, whose 128-register budget the eight row registers of the deeper pipeline would spill
@@ -810,25 +826,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 lr[fy + 1] = r;
             }
             SG_SYNC();
-            while (sp >= 0 && n < ntotal) {
-                const int nx = fx + dxl, ny = fy + dyl;
-                const uint32_t c = tb[nx + 1], r = lr[ny + 1];
+            // a hit: lane `hl` of the sub-group holds the list words (c, r) of the hit pixel (nx, ny), neighbour hl & 7 of frame (fx, fy)
+            auto take_hit = [&](int hl, int nx, int ny, uint32_t c, uint32_t r) {
                 const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
-                const bool hit = sl < 8 && sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
-                const unsigned m = (unsigned)((__ballot(hit) >> sgshift) & 0xffull);
-                if (!m) {  // frame exhausted: pop
-                    sp--;
-                    if (sp >= 0) {
-                        const uint32_t f = bufB[sp];
-                        fx = (int)(f & 0x3fff);
-                        fy = (int)((f >> 14) & 0x3fff);
-                        j0 = (int)(f >> 28);
-                    }
-                    continue;
-                }
-                const int j = __ffs(m) - 1;
+                const int j = hl & 7;
                 const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
-                if (sl == j) {  // the hit lane holds the list words of (hx, hy): it appends the point and clears them
+                if (sl == hl) {  // the hit lane appends the point and clears it from the lists it heads
                     if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
                     uint32_t c2 = c, r2 = r;
                     if ((c2 & 0xffffu) == ky) c2 &= 0xffff0000u;
@@ -847,8 +850,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 if (sp + 1 <= C) {
                     sp++;
                     j0 = 0;
-                } else {
+                } else {  // cannot happen (stack depth <= boundary points <= C); keep the frame just stored
                     j0 = j + 1;
+                }
+            };
+            while (sp >= 0 && n < ntotal) {
+                const int nx = fx + dxl, ny = fy + dyl;
+                const uint32_t c = tb[nx + 1], r = lr[ny + 1];
+                const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
+                const bool hit = sl < 8 && sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
+                const unsigned m = (unsigned)((__ballot(hit) >> sgshift) & 0xffull);
+                if (m) {
+                    take_hit(__ffs(m) - 1, nx, ny, c, r);
+                    continue;
+                }
+                // frame exhausted
+                if constexpr (SG == 64) {
+                    // The whole wave unwinds kUnwind frames at a time: lane 8 q + d tests neighbour d of the q-th frame below the top;
+                    // the first hit in lane order is the frame nearest to the top with its first direction, exactly what single
+                    // pops would find.  (Kept as two separate calls of take_hit: with the hit lane merged into one variable across
+                    // the branches hipcc 7.2 produced a wrong lane index for this path.)
+                    const int q = sl >> 3, fidx = sp - 1 - q;
+                    const bool fv = fidx >= 0 && q < kUnwind;
+                    const uint32_t f = fv ? bufB[fidx] : 0u;
+                    const int qx = (int)(f & 0x3fff), qy = (int)((f >> 14) & 0x3fff), qj0 = (int)(f >> 28);
+                    const int ux2 = qx + dxl, uy2 = qy + dyl;
+                    const uint32_t c2 = fv ? tb[ux2 + 1] : 0u, r2 = fv ? lr[uy2 + 1] : 0u;
+                    const uint32_t ky2 = (uint32_t)(uy2 + 2), kx2 = (uint32_t)(ux2 + 2);
+                    const bool hit2 = fv && jd >= qj0 && ((c2 & 0xffffu) == ky2 || (c2 >> 16) == ky2 || (r2 & 0xffffu) == kx2 || (r2 >> 16) == kx2);
+                    const unsigned long long bal = __ballot(hit2);
+                    if (!bal) {  // all of them exhausted
+                        sp -= kUnwind;
+                        j0 = 8;  // the frame now on top is one of them: nothing to test
+                        continue;
+                    }
+                    const int hl = __builtin_ctzll(bal);
+                    sp -= 1 + (hl >> 3);
+                    fx = __shfl(qx, hl);
+                    fy = __shfl(qy, hl);
+                    take_hit(hl, ux2, uy2, c2, r2);
+                } else {  // pop
+                    sp--;
+                    if (sp >= 0) {
+                        const uint32_t f = bufB[sp];
+                        fx = (int)(f & 0x3fff);
+                        fy = (int)((f >> 14) & 0x3fff);
+                        j0 = (int)(f >> 28);
+                    }
                 }
             }
             n = min(n, C);

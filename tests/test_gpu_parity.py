@@ -372,7 +372,7 @@ def test_whole_wave_components_give_identical_records(detector, oracle, dictiona
     state, fs = dictionary
     n, rows, cols = 24, 1080, 1920
     frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
-    detector.synth_frames_device(frames.data_ptr(), 700, n - 4, rows, cols, cols, rows * cols)
+    detector.synth_frames_device(frames.data_ptr(), 0, n - 4, rows, cols, cols, rows * cols)
     for k in range(4):  # camera content: the reference's frame, shifted
         frames[n - 4 + k] = torch.from_numpy(np.ascontiguousarray(test_bmp[31 * k:31 * k + rows])).cuda()
     torch.cuda.synchronize()
