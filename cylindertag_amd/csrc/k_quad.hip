@@ -590,6 +590,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             }
             many = e >= 0;  // more members than keys: fall back to the gather test
         }
+        // Whole-wave components cross many CCL tiles and carry many labels (a long boundary: more members than keys, several labels
+        // per tile), which would put every lane on the gather test.  They get a membership bitmap instead: for every CCL tile the box
+        // touches, 128 bits "label l of this tile belongs to my component", filled by the whole wave at once (lane l asks root_of
+        // of pool entry tile_base + l - 1; a bit for a label the tile does not have is harmless, no pixel carries it).  Labels above
+        // 128 exist only in tiles that took the second CCL pass; those keep the gather test.
+        constexpr int kMemberTiles = 96;
+        __shared__ unsigned long long s_member[SG == 64 ? kMemberTiles : 1][2];
+        const int mt_x0 = x_min / kTileW, mt_y0 = y_min / kTileH;
+        const int mt_nx = (x_min + w - 1) / kTileW - mt_x0 + 1, mt_ny = (y_min + h - 1) / kTileH - mt_y0 + 1;
+        const bool bitmap = SG == 64 && mt_nx * mt_ny <= kMemberTiles;
+        if constexpr (SG == 64) {
+            if (bitmap) {
+                const int nt = mt_nx * mt_ny;
+                for (int t0 = 0; t0 < nt; t0 += 4) {  // four tiles per step: their loads are in flight together
+                    int base[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int t = min(t0 + u, nt - 1);
+                        base[u] = tbase[(mt_y0 + t / mt_nx) * g.tiles_x + mt_x0 + t % mt_nx];
+                    }
+                    int ra[4], rb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int ea = min(base[u] + lane, g.pool_cap - 1), eb = min(base[u] + 64 + lane, g.pool_cap - 1);
+                        ra[u] = rootof[ea];
+                        rb[u] = rootof[eb];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const unsigned long long ma = __ballot(ra[u] == cd.root), mb = __ballot(rb[u] == cd.root);
+                        if (lane == 0 && t0 + u < nt) {
+                            s_member[t0 + u][0] = ma;
+                            s_member[t0 + u][1] = mb;
+                        }
+                    }
+                }
+            }
+        }
         // ---- P1: silhouette first-hit arrays (corner_detector.cpp:184-232).  Each lane reads 8 labels with one
         // 16-byte load (64 columns per sub-group step, starting at a 16-byte aligned column), remembers the last
         // (tile-local label, tile) -> "is my component" decision so the two dependent gathers are rare, and has
@@ -601,6 +639,86 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
         SG_SYNC();
         constexpr int kChunk = 8 * SG;  // columns a sub-group covers with one 16-byte load per lane
+        if constexpr (SG == 64) {
+            // Whole-wave scan: 512 columns per pass, eight label rows requested together (unconditional loads from clamped
+            // addresses: bits of lanes and rows outside the box are masked), membership from the bitmap, and the row extents from
+            // one ballot per row -- the row's first and last foreground lanes each send ONE no-return LDS atomic (64 lanes'
+            // atomics on one address are served one after the other).  Nothing in the loop waits for memory but the row batch.
+            const int x_end = x_min + w;
+            stamp(5);
+            for (int xa = x_min & ~7; xa < x_end; xa += kChunk) {
+                const int gxf = xa + 8 * lane;
+                unsigned valid = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (gxf + q >= x_min && gxf + q < x_end) valid |= 1u << q;
+                const int col = valid ? gxf : (x_min & ~7);
+                const int tcol = col / kTileW;  // eight 16-byte aligned columns share a CCL tile
+                const int xl0 = gxf - x_min;
+                uint32_t top[4], bot[4], seen[4], bm[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    top[d] = bot[d] = 0xffffffffu;
+                    seen[d] = 0u;
+                }
+                int cur_ty = -1;
+                for (int y0 = 0; y0 < h; y0 += 8) {
+                    uint4 rr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) rr[u] = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y0 + u, h - 1)) * g.lp + col);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int y = y0 + u;
+                        if (y >= h) break;  // uniform
+                        const int ty = (y_min + y) / kTileH;
+                        if (ty != cur_ty) {
+                            cur_ty = ty;
+                            if (bitmap) {
+                                const int t = (ty - mt_y0) * mt_nx + (tcol - mt_x0);
+                                const unsigned long long a0 = s_member[t][0], a1 = s_member[t][1];
+                                bm[0] = (uint32_t)a0, bm[1] = (uint32_t)(a0 >> 32), bm[2] = (uint32_t)a1, bm[3] = (uint32_t)(a1 >> 32);
+                            }
+                        }
+                        const uint32_t wv[4] = {rr[u].x, rr[u].y, rr[u].z, rr[u].w};
+                        unsigned bits = 0;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const unsigned l = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                            const unsigned k = l - 1u;  // label 0 (background) wraps to a huge index
+                            const uint32_t word = (k & 64u) ? ((k & 32u) ? bm[3] : bm[2]) : ((k & 32u) ? bm[1] : bm[0]);
+                            bool in = bitmap && k < 128u && ((word >> (k & 31u)) & 1u);
+                            if ((!bitmap || k >= 128u) && l != 0u && l < 0x8000u && ((valid >> q) & 1u))  // rare: a second-pass tile's label, or a box over > 96 tiles
+                                in = rootof[tbase[ty * g.tiles_x + tcol] + (int)l - 1] == cd.root;
+                            bits |= (in ? 1u : 0u) << q;
+                        }
+                        bits &= valid;
+                        const unsigned long long rowm = __ballot(bits != 0u);
+                        if (rowm) {
+                            if (lane == __builtin_ctzll(rowm)) atomicMin(&lef[y], (unsigned)(xl0 + __ffs(bits) - 1));
+                            if (lane == 63 - __builtin_clzll(rowm)) atomicMax(&rig[y], (unsigned)(xl0 + 32 - __clz(bits)));
+                        }
+                        if (bits) {
+                            const uint32_t ypk = (uint32_t)y * 0x10001u;
+#pragma unroll
+                            for (int d = 0; d < 4; d++) {
+                                const uint32_t m = ((bits >> (2 * d)) & 1u) * 0xffffu + ((bits >> (2 * d + 1)) & 1u) * 0xffff0000u;
+                                bot[d] = (bot[d] & ~m) | (ypk & m);
+                                const uint32_t nm = m & ~seen[d];
+                                top[d] = (top[d] & ~nm) | (ypk & nm);
+                                seen[d] |= m;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    if ((valid >> q) & 1u) {  // every column of a component's bounding box holds a pixel
+                        const uint32_t t = (top[q >> 1] >> (16 * (q & 1))) & 0xffffu, bb = (bot[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        tb[xl0 + q + 1] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
+                    }
+                }
+            }
+        } else
         for (int xa = x_min & ~7; xa < x_min + w; xa += 2 * kChunk) {  // one pass per two chunks of the box
             const int x_end = x_min + w;  // exclusive
             const int gxf = xa + 8 * sl;  // this lane's 8 columns of chunk 0; chunk 1 is kChunk columns further
@@ -762,6 +880,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
             }
         }
+        stamp(7);
         {
             SG_SYNC();  // row extents (LDS atomics) complete
             for (int y = sl; y < h + 2; y += SG) {
@@ -826,76 +945,120 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 lr[fy + 1] = r;
             }
             SG_SYNC();
-            // a hit: lane `hl` of the sub-group holds the list words (c, r) of the hit pixel (nx, ny), neighbour hl & 7 of frame (fx, fy)
-            auto take_hit = [&](int hl, int nx, int ny, uint32_t c, uint32_t r) {
-                const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
-                const int j = hl & 7;
-                const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
-                if (sl == hl) {  // the hit lane appends the point and clears it from the lists it heads
-                    if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
-                    uint32_t c2 = c, r2 = r;
-                    if ((c2 & 0xffffu) == ky) c2 &= 0xffff0000u;
-                    if ((c2 >> 16) == ky) c2 &= 0xffffu;
-                    if ((r2 & 0xffffu) == kx) r2 &= 0xffff0000u;
-                    if ((r2 >> 16) == kx) r2 &= 0xffffu;
-                    tb[nx + 1] = c2;
-                    lr[ny + 1] = r2;
-                    // the current frame moves to the hit pixel and resumes at j+1 (B7); it becomes the frame below the top
-                    if (sp <= C) bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
-                }
-                SG_SYNC();
-                n++;
-                fx = hx;
-                fy = hy;
-                if (sp + 1 <= C) {
-                    sp++;
-                    j0 = 0;
-                } else {  // cannot happen (stack depth <= boundary points <= C); keep the frame just stored
-                    j0 = j + 1;
-                }
-            };
-            while (sp >= 0 && n < ntotal) {
-                const int nx = fx + dxl, ny = fy + dyl;
-                const uint32_t c = tb[nx + 1], r = lr[ny + 1];
-                const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
-                const bool hit = sl < 8 && sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
-                const unsigned m = (unsigned)((__ballot(hit) >> sgshift) & 0xffull);
-                if (m) {
-                    take_hit(__ffs(m) - 1, nx, ny, c, r);
-                    continue;
-                }
-                // frame exhausted
-                if constexpr (SG == 64) {
-                    // The whole wave unwinds kUnwind frames at a time: lane 8 q + d tests neighbour d of the q-th frame below the top;
-                    // the first hit in lane order is the frame nearest to the top with its first direction, exactly what single
-                    // pops would find.  (Kept as two separate calls of take_hit: with the hit lane merged into one variable across
-                    // the branches hipcc 7.2 produced a wrong lane index for this path.)
-                    const int q = sl >> 3, fidx = sp - 1 - q;
-                    const bool fv = fidx >= 0 && q < kUnwind;
-                    const uint32_t f = fv ? bufB[fidx] : 0u;
-                    const int qx = (int)(f & 0x3fff), qy = (int)((f >> 14) & 0x3fff), qj0 = (int)(f >> 28);
-                    const int ux2 = qx + dxl, uy2 = qy + dyl;
-                    const uint32_t c2 = fv ? tb[ux2 + 1] : 0u, r2 = fv ? lr[uy2 + 1] : 0u;
-                    const uint32_t ky2 = (uint32_t)(uy2 + 2), kx2 = (uint32_t)(ux2 + 2);
-                    const bool hit2 = fv && jd >= qj0 && ((c2 & 0xffffu) == ky2 || (c2 >> 16) == ky2 || (r2 & 0xffffu) == kx2 || (r2 >> 16) == kx2);
-                    const unsigned long long bal = __ballot(hit2);
-                    if (!bal) {  // all of them exhausted
-                        sp -= kUnwind;
-                        j0 = 8;  // the frame now on top is one of them: nothing to test
+            if constexpr (SG == 64) {
+                // a hit: lane `hl` of the sub-group holds the list words (c, r) of the hit pixel (nx, ny), neighbour hl & 7 of frame (fx, fy)
+                auto take_hit = [&](int hl, int nx, int ny, uint32_t c, uint32_t r) {
+                    const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
+                    const int j = hl & 7;
+                    const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
+                    if (sl == hl) {  // the hit lane appends the point and clears it from the lists it heads
+                        if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
+                        uint32_t c2 = c, r2 = r;
+                        if ((c2 & 0xffffu) == ky) c2 &= 0xffff0000u;
+                        if ((c2 >> 16) == ky) c2 &= 0xffffu;
+                        if ((r2 & 0xffffu) == kx) r2 &= 0xffff0000u;
+                        if ((r2 >> 16) == kx) r2 &= 0xffffu;
+                        tb[nx + 1] = c2;
+                        lr[ny + 1] = r2;
+                        // the current frame moves to the hit pixel and resumes at j+1 (B7); it becomes the frame below the top
+                        if (sp <= C) bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
+                    }
+                    SG_SYNC();
+                    n++;
+                    fx = hx;
+                    fy = hy;
+                    if (sp + 1 <= C) {
+                        sp++;
+                        j0 = 0;
+                    } else {  // cannot happen (stack depth <= boundary points <= C); keep the frame just stored
+                        j0 = j + 1;
+                    }
+                };
+                while (sp >= 0 && n < ntotal) {
+                    const int nx = fx + dxl, ny = fy + dyl;
+                    const uint32_t c = tb[nx + 1], r = lr[ny + 1];
+                    const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
+                    const bool hit = sl < 8 && sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
+                    const unsigned m = (unsigned)((__ballot(hit) >> sgshift) & 0xffull);
+                    if (m) {
+                        take_hit(__ffs(m) - 1, nx, ny, c, r);
                         continue;
                     }
-                    const int hl = __builtin_ctzll(bal);
-                    sp -= 1 + (hl >> 3);
-                    fx = __shfl(qx, hl);
-                    fy = __shfl(qy, hl);
-                    take_hit(hl, ux2, uy2, c2, r2);
-                } else {  // pop
-                    sp--;
-                    if (sp >= 0) {
-                        const uint32_t f = bufB[sp];
-                        fx = (int)(f & 0x3fff);
-                        fy = (int)((f >> 14) & 0x3fff);
-                        j0 = (int)(f >> 28);
+                    // frame exhausted
+                    if constexpr (SG == 64) {
+                        // The whole wave unwinds kUnwind frames at a time: lane 8 q + d tests neighbour d of the q-th frame below the top;
+                        // the first hit in lane order is the frame nearest to the top with its first direction, exactly what single
+                        // pops would find.  (Kept as two separate calls of take_hit: with the hit lane merged into one variable across
+                        // the branches hipcc 7.2 produced a wrong lane index for this path.)
+                        const int q = sl >> 3, fidx = sp - 1 - q;
+                        const bool fv = fidx >= 0 && q < kUnwind;
+                        const uint32_t f = fv ? bufB[fidx] : 0u;
+                        const int qx = (int)(f & 0x3fff), qy = (int)((f >> 14) & 0x3fff), qj0 = (int)(f >> 28);
+                        const int ux2 = qx + dxl, uy2 = qy + dyl;
+                        const uint32_t c2 = fv ? tb[ux2 + 1] : 0u, r2 = fv ? lr[uy2 + 1] : 0u;
+                        const uint32_t ky2 = (uint32_t)(uy2 + 2), kx2 = (uint32_t)(ux2 + 2);
+                        const bool hit2 = fv && jd >= qj0 && ((c2 & 0xffffu) == ky2 || (c2 >> 16) == ky2 || (r2 & 0xffffu) == kx2 || (r2 >> 16) == kx2);
+                        const unsigned long long bal = __ballot(hit2);
+                        if (!bal) {  // all of them exhausted
+                            sp -= kUnwind;
+                            j0 = 8;  // the frame now on top is one of them: nothing to test
+                            continue;
+                        }
+                        const int hl = __builtin_ctzll(bal);
+                        sp -= 1 + (hl >> 3);
+                        fx = __shfl(qx, hl);
+                        fy = __shfl(qy, hl);
+                        take_hit(hl, ux2, uy2, c2, r2);
+                    } else {  // pop
+                        sp--;
+                        if (sp >= 0) {
+                            const uint32_t f = bufB[sp];
+                            fx = (int)(f & 0x3fff);
+                            fy = (int)((f >> 14) & 0x3fff);
+                            j0 = (int)(f >> 28);
+                        }
+                    }
+                }
+            } else {
+                while (sp >= 0 && n < ntotal) {
+                    const int nx = fx + dxl, ny = fy + dyl;
+                    const uint32_t c = tb[nx + 1], r = lr[ny + 1];
+                    const uint32_t ky = (uint32_t)(ny + 2), kx = (uint32_t)(nx + 2);
+                    const bool hit = sl < 8 && sl >= j0 && ((c & 0xffffu) == ky || (c >> 16) == ky || (r & 0xffffu) == kx || (r >> 16) == kx);
+                    const unsigned m = (unsigned)((__ballot(hit) >> sgshift) & 0xffull);
+                    if (!m) {  // frame exhausted: pop
+                        sp--;
+                        if (sp >= 0) {
+                            const uint32_t f = bufB[sp];
+                            fx = (int)(f & 0x3fff);
+                            fy = (int)((f >> 14) & 0x3fff);
+                            j0 = (int)(f >> 28);
+                        }
+                        continue;
+                    }
+                    const int j = __ffs(m) - 1;
+                    const int hx = fx + ((int)((0x01A9u >> (2 * j)) & 3u) - 1), hy = fy + ((int)((0x1A90u >> (2 * j)) & 3u) - 1);
+                    if (sl == j) {  // the hit lane holds the list words of (hx, hy): it appends the point and clears them
+                        if (n < C) bufA[n] = pack_xy(hx + x_min, hy + y_min);
+                        uint32_t c2 = c, r2 = r;
+                        if ((c2 & 0xffffu) == ky) c2 &= 0xffff0000u;
+                        if ((c2 >> 16) == ky) c2 &= 0xffffu;
+                        if ((r2 & 0xffffu) == kx) r2 &= 0xffff0000u;
+                        if ((r2 >> 16) == kx) r2 &= 0xffffu;
+                        tb[nx + 1] = c2;
+                        lr[ny + 1] = r2;
+                        // the current frame moves to the hit pixel and resumes at j+1 (B7); it becomes the frame below the top
+                        if (sp <= C) bufB[sp] = (uint32_t)hx | ((uint32_t)hy << 14) | ((uint32_t)(j + 1) << 28);
+                    }
+                    SG_SYNC();
+                    n++;
+                    fx = hx;
+                    fy = hy;
+                    if (sp + 1 <= C) {
+                        sp++;
+                        j0 = 0;
+                    } else {
+                        j0 = j + 1;
                     }
                 }
             }
@@ -1389,8 +1552,10 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
         for (int b = 0; b < 16; b += 8) {
             unsigned long long tot = 0;
+            h[b + 0] += h[b + 7];  // the row scan is stamped separately; it belongs to the silhouette phase
             for (int i = 0; i < 5; i++) tot += h[b + i];
             if (!tot) continue;
+            fprintf(stderr, "[%s] row scan %llu of the silhouette phase's %llu ticks\n", b ? "whole-wave" : "packed", h[b + 7], h[b + 0]);
             fprintf(stderr, "[%s cycles] header %.1f%% keys+init %.1f%% | silhouette %.1f%% traversal %.1f%% centroid/rotate %.1f%% rdp %.1f%% export %.1f%% (total %llu)\n",
                     b ? "whole-wave" : "packed", 100.0 * h[b + 6] / (tot + h[b + 5] + h[b + 6]), 100.0 * h[b + 5] / (tot + h[b + 5] + h[b + 6]), 100.0 * h[b + 0] / tot,
                     100.0 * h[b + 1] / tot, 100.0 * h[b + 2] / tot, 100.0 * h[b + 3] / tot, 100.0 * h[b + 4] / tot, tot);
