@@ -1528,13 +1528,13 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         dev = dev < 0 || dev >= 64 ? 0 : dev;
         static bool have[64] = {false};
         if (!have[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_quad_edges_packed<64, kWaveWordsMax, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_quad_edges_packed<64, kWaveWordsMax, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kWaveWordsMax * 4);
             have[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWords, 2, false>), dim3(nframes, bcols), dim3(64), 0, sb, P, ws.g, nframes, 0);
-    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWordsMax, 2, true>), dim3(nframes, latency ? 8 : 2), dim3(64), kWaveWordsMax * 4, sb, P, ws.g, nframes, kWaveWords);
+    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWords, 1, false>), dim3(nframes, bcols), dim3(64), 0, sb, P, ws.g, nframes, 0);
+    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWordsMax, 1, true>), dim3(nframes, latency ? 8 : 2), dim3(64), kWaveWordsMax * 4, sb, P, ws.g, nframes, kWaveWords);
     if (fork) {
         (void)hipEventRecord(ws.ev_join, sb);
         (void)hipStreamWaitEvent(s, ws.ev_join, 0);
