@@ -228,7 +228,8 @@ def issue_rooflines(stage_ms, n_frames):
     out = {"source": "instruction counts replayed from %s (rocprofv3 --pmc, 1024-frame pass); times from this run's HIP events" % os.path.relpath(cands[-1], ROOT),
            "model": "issue_bound_ms = (2 * (VALU - FP64) + 4 * FP64 wave-instructions) / (1024 SIMDs * 2.4 GHz): the SIMDs' peak issue rate", "kernels": {}}
     for stage, kname in ISSUE_KERNELS.items():
-        e = next((v for k, v in prof["kernels"].items() if k == kname or k.startswith(kname + "<")), None)  # template arguments vary
+        hits = [v for k, v in prof["kernels"].items() if k == kname or k.startswith(kname + "<")]  # template arguments vary; several builds of a kernel:
+        e = max(hits, key=lambda v: v["wave_instructions"]["valu"]) if hits else None                    # the one that does the work
         if not e or stage_ms.get(stage, 0) <= 0:
             continue
         per_frame = e["issue_model"]["issue_cycles"] / 1024.0
