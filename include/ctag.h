@@ -81,7 +81,9 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value);
 /* Per-stage device time of the LAST ctag_detect_batch_* call, milliseconds measured with HIP events on
  * the handle's stream (needs CTAG_OPT_TIMING).  Order: decimate, threshold_ccl, seam_merge, resolve,
  * candidates, quad_pack, quad_edges, quad_edges_big, line_sort, welsch, quad_final, features, edge_refine,
- * markers (one entry per kernel; names from ctag_stage_name).  Returns the number of stages written. */
+ * markers (one entry per kernel; names from ctag_stage_name; quad_edges_big = the whole-wave builds of the boundary kernel: in calls of
+ * up to 4 frames they run beside quad_edges on a second stream and the entry is the time the chain waited for them after quad_edges).
+ * Returns the number of stages written. */
 #define CTAG_NUM_STAGES 14
 int ctag_get_timings(ctag_handle* h, float* ms, int capacity);
 const char* ctag_stage_name(int stage);
