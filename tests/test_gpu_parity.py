@@ -321,6 +321,53 @@ def test_dense_speckle_and_texture_take_the_second_ccl_pass(detector, oracle, di
         detector.set_option(capi.OPT_KEEP_PREMARKERS, 0)
 
 
+def _draw_polyline(img, pts, width, value=12):
+    """dark polyline of the given full-resolution width"""
+    for (x0, y0), (x1, y1) in zip(pts[:-1], pts[1:]):
+        n = int(max(abs(x1 - x0), abs(y1 - y0))) + 1
+        xs = np.linspace(x0, x1, n).round().astype(int)
+        ys = np.linspace(y0, y1, n).round().astype(int)
+        for dy in range(width):
+            for dx in range(width):
+                img[np.clip(ys + dy, 0, img.shape[0] - 1), np.clip(xs + dx, 0, img.shape[1] - 1)] = value
+
+
+def test_long_thin_components_take_the_whole_wave_builds(detector, oracle, dictionary):
+    """Components whose boundary does not fit a pack's LDS budget get a wave of their own: the 32 KB build (membership bitmap
+    over the CCL tiles the box touches) and, beyond 8192 working-set words, the 144 KB build; a box over more than 96 tiles
+    falls back to the gather test.  A 3840x2160 frame with a corner-to-corner band (both), a zig-zag with several labels per
+    tile, a comb whose teeth join below a tile border, and a spiral; and the same shapes at 1080p around real markers."""
+    state, fs = dictionary
+    detector.set_option(capi.OPT_KEEP_PREMARKERS, 1)
+    try:
+        big = np.full((2160, 3840), 205, np.uint8)
+        big[::7, ::5] = 190  # a little texture
+        _draw_polyline(big, [(120, 90), (3700, 2050)], 6)                                        # ~2000 half-res points long
+        _draw_polyline(big, [(150 + 90 * k, 1700 + (260 if k % 2 else 0)) for k in range(30)], 6)   # zig-zag
+        for k in range(14):                                                                        # comb: teeth ...
+            _draw_polyline(big, [(2300 + 60 * k, 200), (2300 + 60 * k, 560)], 8)
+        _draw_polyline(big, [(2300, 560), (2300 + 60 * 13 + 8, 560)], 8)                           # ... joined at the bottom
+        sp = [(3000 + int(r * np.cos(a)), 1400 + int(r * np.sin(a))) for a, r in ((0.35 * k, 30 + 9 * k) for k in range(60))]
+        _draw_polyline(big, sp, 6)
+        o, r, lab = _stage_check(detector, oracle, state, fs, big, "4K long thin components")
+        cand = o["candidates"]
+        w, h = cand[:, 4] - cand[:, 2] + 1, cand[:, 5] - cand[:, 3] + 1
+        need = ((w + 1) & ~1) + 2 * h + 2 * (np.minimum(2 * (w + h), w * h) + 1) + 4
+        assert (need > 8192).any() and ((need > 5120) & (need <= 8192)).any()  # both whole-wave builds had work
+        frame, truth = ca.synth_frame_host(state, 21)
+        hd = frame.copy()
+        _draw_polyline(hd, [(40, 6), (1880, 40)], 5)  # a long shallow band along the top: a wave of its own, bitmap over 6 tiles
+        for k in range(10):
+            _draw_polyline(hd, [(60 + 44 * k, 60), (60 + 44 * k, 300)], 6)
+        _draw_polyline(hd, [(60, 300), (60 + 44 * 9 + 6, 300)], 6)
+        o, r, lab = _stage_check(detector, oracle, state, fs, hd, "1080p shapes beside markers")
+        cand = o["candidates"]
+        w, h = cand[:, 4] - cand[:, 2] + 1, cand[:, 5] - cand[:, 3] + 1
+        assert r["status"] == 0 and (((w + 1) & ~1) + 2 * h + 2 * (np.minimum(2 * (w + h), w * h) + 1) + 4 > 2560).any()
+    finally:
+        detector.set_option(capi.OPT_KEEP_PREMARKERS, 0)
+
+
 def test_batch_equals_single_and_is_repeatable(detector, dictionary):
     state, fs = dictionary
     frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
