@@ -420,6 +420,30 @@ def main():
             gather_impl = "torch.distributed.all_gather_into_tensor of fixed records (another rank's ctag_comm_init failed)"
         if comm is None and n * world != n_total:
             raise SystemExit("the torch.distributed fallback gather needs equal shards")
+    # N > 1: consecutive steps alternate between two handles (two streams, two workspaces): a rank's shard is small (512 frames
+    # of the 4096 at N = 8) and the tails of its kernels -- a few long boundary / Welsch blocks -- would otherwise idle most of
+    # the GPU at the end of every kernel; the next step's kernels fill them (112 -> 149 K frames/s per GPU at 512
+    # frames per step).  Every handle gathers through a communicator of its own.  CTAG_BENCH_PINGPONG=0 turns it off.
+    dets, comms = [det], [comm]
+    if world > 1 and os.environ.get("CTAG_BENCH_PINGPONG", "1") != "0":
+        det2, comm2 = None, None
+        try:
+            det2 = ca.Detector(state, fs, device=dev_index)
+            det2.set_option(capi.OPT_MAX_CHUNK, chunk)
+            if comm is not None:
+                comm2 = CommGather(det2, dist)
+        except Exception:  # noqa: BLE001
+            det2 = None
+        ok2 = torch.tensor([1 if det2 is not None else 0], dtype=torch.int32, device="cpu" if dist.get_backend() != "nccl" else dev)
+        dist.all_reduce(ok2, op=dist.ReduceOp.MIN)  # all ranks take the same path
+        if int(ok2.item()) == 1:
+            dets.append(det2)
+            comms.append(comm2)
+        else:
+            if comm2 is not None:
+                comm2.close()
+            if det2 is not None:
+                det2.close()
     step_no = [0]
     pending = []  # gathers begun and not yet ended: (index of the gathered buffer)
 
@@ -427,20 +451,21 @@ def main():
         while pending:
             k = pending.pop(0)
             if comm is not None:
-                comm.end(gathered[k % 2])
+                comms[k % len(comms)].end(gathered[k % 2])
 
     def step():
         k = step_no[0]
         step_no[0] += 1
         buf = local_bufs[k % len(local_bufs)]
-        det.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, buf.data_ptr(), 5, subpix, 5)
+        d = dets[k % len(dets)]
+        d.detect_batch_device(frames.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, buf.data_ptr(), 5, subpix, 5)
         if world > 1:
             if comm is not None:
                 finish_pending()            # sizes of step k-1 are in (its detection ended while step k was being enqueued)
-                comm.begin(buf[:n], n_total)  # pack + size exchange of step k behind its detection, on the gather stream
+                comms[k % len(comms)].begin(buf[:n], n_total)  # pack + size exchange of step k behind its detection, on its handle's gather stream
                 pending.append(k)
             else:
-                det.sync()
+                d.sync()
                 if host_gather:  # developer aid (gloo): through host memory
                     out_h = torch.empty((n_total, rec_bytes), dtype=torch.uint8)
                     dist.all_gather_into_tensor(out_h.view(-1), buf[:n].cpu().reshape(-1))
@@ -450,9 +475,11 @@ def main():
 
     def fence():
         finish_pending()
-        if comm is not None:
-            comm.wait()
-        det.sync()
+        for c in comms:
+            if c is not None:
+                c.wait()
+        for d in dets:
+            d.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -530,7 +557,8 @@ def main():
                                       "CTag_2f12c markers each, detect(img,5,%s,5), inputs resident in HBM"
                                       % (n_total, world, args.markers, "true" if subpix else "false"),
                           "frames_per_step": n_total, "frames_per_gpu": n, "chunk": chunk, "parallelism": "frames sharded, dp%d" % world,
-                          "gather": gather_impl},
+                          "gather": gather_impl,
+                          "pipelining": ("steps alternate between %d handles (streams)" % len(dets)) if len(dets) > 1 else "one handle, one stream"},
                "roofline": roofline,
                "issue_roofline": issue_rooflines(stage_ms, n),
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -583,10 +611,12 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        if comm is not None:
-            comm.close()
+        for c in comms:
+            if c is not None:
+                c.close()
         dist.destroy_process_group()
-    det.close()
+    for d in dets:
+        d.close()
     return rc
 
 

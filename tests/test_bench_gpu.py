@@ -46,3 +46,4 @@ def test_one_gpu_line_and_two_rank_hash():
     two = _line(p.stdout)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["frames_per_gpu"] == 96 and two["frames_ok"] == 192
     assert two["results_sha256"] == one["results_sha256"]  # the gathered list equals the one-GPU list
+    assert two["config"]["pipelining"].startswith("steps alternate between 2 handles")

@@ -657,6 +657,28 @@ def test_packed_shards_and_rccl_gather_single_rank(detector, dictionary):
         detector.gather_wait()
         detector.sync()
         assert (out.cpu().numpy() == host).all() and (rec2.cpu().numpy() == host).all()
+        # bench.py's N > 1 pattern: steps alternate between two handles, each with a communicator of its own; the gather of a
+        # step ends while the next step's detection (other handle, other stream) runs
+        det2 = ca.Detector(state, fs)
+        det2.comm_init(capi.comm_unique_id(), 0, 1)
+        try:
+            dets, recs, outs = [detector, det2], [torch.zeros_like(rec) for _ in range(2)], [torch.zeros_like(rec) for _ in range(2)]
+            pending = None
+            for k in range(5):
+                d = dets[k % 2]
+                d.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, recs[k % 2].data_ptr())
+                if pending is not None:
+                    dets[pending % 2].gather_end(outs[pending % 2].data_ptr())
+                d.gather_begin(recs[k % 2].data_ptr(), n, n)
+                pending = k
+            dets[pending % 2].gather_end(outs[pending % 2].data_ptr())
+            for d in dets:
+                d.gather_wait()
+                d.sync()
+            assert (outs[0].cpu().numpy() == host).all() and (outs[1].cpu().numpy() == host).all()
+        finally:
+            det2.comm_destroy()
+            det2.close()
     finally:
         detector.comm_destroy()
 
