@@ -399,10 +399,12 @@ def test_graph_replay_option_gives_identical_records(detector, dictionary):
         detector.sync()
         return out[:m].cpu().numpy().tobytes()
 
-    want24, want7 = run(24), run(7)
+    want24, want7, want1, want3 = run(24), run(7), run(1), run(3)
     detector.set_option(capi.OPT_GRAPH, 1)
     try:
         assert run(24) == want24 and run(24) == want24 and run(7) == want7 and run(24) == want24
+        # few-frame calls fork the boundary kernels onto a second stream: the fork / join is captured with the chain
+        assert run(1) == want1 and run(3) == want3 and run(1) == want1 and run(3) == want3
         detector.synth_frames_device(frames.data_ptr(), 950, n, rows, cols, cols, rows * cols)  # new content, same pointers
         got = run(24)
         detector.set_option(capi.OPT_GRAPH, 0)
