@@ -77,7 +77,9 @@ struct ctag_handle {
     };
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
-    int use_graph = 0;   // CTAG_OPT_GRAPH; back to 0 after a capture failed once (the direct path takes over for good)
+    int use_graph = 2;   // CTAG_OPT_GRAPH: 0 off, 1 every chunk, 2 (default) few-frame calls whose pointers / sizes / parameters repeat;
+                         // back to 0 after a capture failed once (the direct path takes over for good)
+    GraphEntry last_key;  // automatic mode: the previous few-frame chunk (a graph is only worth capturing for a repeat)
     // state of the pose back end (k_pose.hip), created on first use
     void* pose_state = nullptr;
     void (*pose_state_free)(void*) = nullptr;
@@ -397,7 +399,16 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
         h->ev_sets_used++;
     }
     static const bool stamps = getenv("CTAG_CCL_STAMPS") != nullptr || getenv("CTAG_QUAD_STAMPS") != nullptr;  // developer aids that synchronise inside the chain
-    if (!evs && h->use_graph && !stamps) {
+    bool graph = h->use_graph == 1;
+    if (h->use_graph == 2 && n <= kLatencyFrames) {  // one frame per call in a loop (main.cpp:52-59): same staging buffers, same sizes every time
+        ctag_handle::GraphEntry& k = h->last_key;
+        graph = k.frames == frames_dev && k.out == out_dev && k.ws_base == h->ws.base && k.n == n && k.rows == h->ws.g.rows && k.cols == h->ws.g.cols &&
+                k.tw == p.adaptive_thresh && k.subpix == p.corner_subpix && k.dist == p.subpix_dist && k.keep_pre == (h->keep_pre ? 1 : 0) &&
+                k.row_stride == row_stride && k.frame_stride == frame_stride;
+        k.frames = frames_dev, k.out = out_dev, k.ws_base = h->ws.base, k.n = n, k.rows = h->ws.g.rows, k.cols = h->ws.g.cols, k.tw = p.adaptive_thresh,
+        k.subpix = p.corner_subpix, k.dist = p.subpix_dist, k.keep_pre = h->keep_pre ? 1 : 0, k.row_stride = row_stride, k.frame_stride = frame_stride;
+    }
+    if (!evs && graph && !stamps) {
         if (run_chunk_graph(h, frames_dev, n, row_stride, frame_stride, p, out_dev)) return CTAG_OK;
         h->use_graph = 0;  // capture / instantiate / launch failed: direct launches from now on
         drop_graphs(h);
@@ -631,7 +642,8 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
         case CTAG_OPT_TIMING: h->timing = value != 0; return CTAG_OK;
         case CTAG_OPT_KEEP_PREMARKERS: h->keep_pre = value != 0; return CTAG_OK;
         case CTAG_OPT_GRAPH:
-            h->use_graph = value != 0;
+            if (value < 0 || value > 2) return CTAG_ERR_ARG;
+            h->use_graph = (int)value;
             if (!h->use_graph) drop_graphs(h);
             return CTAG_OK;
         case CTAG_OPT_WAVE_POINTS:

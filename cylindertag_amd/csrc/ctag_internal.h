@@ -35,6 +35,7 @@ constexpr int kCandCap = 2048;          // max area-filtered candidates per fram
 constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range [1, 32]
 
 // ---- K6 limits ----------------------------------------------------------------------------------------------
+constexpr int kLatencyFrames = 4;           // calls with at most this many frames are tuned for the latency of the call (launch_quads, hipGraph replay)
 constexpr int kLineCap = 4 * kCandCap;     // fitted edges per frame (4 per candidate that survives the RDP split)
 constexpr int kClPool = 262144;           // edge-cluster points per frame (a candidate reserves its boundary capacity + 64)
 constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table

@@ -230,7 +230,6 @@ constexpr int kSG = 8;
 constexpr int kUnwind = 8;  // stack frames the whole-wave build tests at once when it unwinds (<= 8: 8 lanes each)
 constexpr int kWaveWords = 8192;      // LDS words of the common whole-wave build (32 KB: five components per CU)
 constexpr int kWaveWordsMax = 36864;  // ... of the build for the longest boundaries (144 KB: one per CU)
-constexpr int kLatencyFrames = 4;     // calls with at most this many frames are tuned for the latency of the call
 constexpr int kLatencyBigPoints = 96; // ... there, components with a boundary capacity above this get a wave of their own
 __host__ __device__ __forceinline__ int pack_points(int w, int h) { return min(2 * (w + h), w * h) + 1; }
 // LDS words one component needs in the packed kernel: silhouette arrays + boundary list + stack / ping-pong list

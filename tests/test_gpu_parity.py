@@ -399,6 +399,7 @@ def test_graph_replay_option_gives_identical_records(detector, dictionary):
         detector.sync()
         return out[:m].cpu().numpy().tobytes()
 
+    detector.set_option(capi.OPT_GRAPH, 0)
     want24, want7, want1, want3 = run(24), run(7), run(1), run(3)
     detector.set_option(capi.OPT_GRAPH, 1)
     try:
@@ -409,8 +410,11 @@ def test_graph_replay_option_gives_identical_records(detector, dictionary):
         got = run(24)
         detector.set_option(capi.OPT_GRAPH, 0)
         assert got == run(24) and got != want24
+        got1, got3 = run(1), run(3)
+        detector.set_option(capi.OPT_GRAPH, 2)  # the default: few-frame calls only, from the second identical call on
+        assert run(1) == got1 and run(1) == got1 and run(1) == got1 and run(3) == got3 and run(3) == got3 and run(24) == got
     finally:
-        detector.set_option(capi.OPT_GRAPH, 0)
+        detector.set_option(capi.OPT_GRAPH, 2)
 
 
 def test_whole_wave_components_give_identical_records(detector, oracle, dictionary, test_bmp):
