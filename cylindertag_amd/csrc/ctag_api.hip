@@ -201,6 +201,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_lfit = take(F * kLineCap * 16);
     const size_t o_aux = take(F * kCandCap * sizeof(CandAux));
     const size_t o_npk = take(F * 4), o_pk = take(F * kCandCap * 4), o_pord = take(F * kCandCap * 2);
+    const size_t o_wrs = take(std::min<size_t>(F, kLatencyFrames) * kLatLines * 20 * 6 * 4);
     const size_t o_der = take(F * kCandCap * 48);
     const size_t o_qidx = take(F * kCandCap * 4);
     const size_t o_nq = take(F * 4), o_nf = take(F * 4), o_st = take(F * 4);
@@ -246,6 +247,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.npacks = reinterpret_cast<int32_t*>(b + o_npk);
     W.packs = reinterpret_cast<uint32_t*>(b + o_pk);
     W.pack_order = reinterpret_cast<uint16_t*>(b + o_pord);
+    W.welsch_rs = reinterpret_cast<float*>(b + o_wrs);
     W.pick_table = h->d_pick_table;
     W.aux_stream = h->aux_stream;
     W.wave_points = h->wave_points;

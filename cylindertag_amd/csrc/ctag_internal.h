@@ -36,6 +36,8 @@ constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range
 
 // ---- K6 limits ----------------------------------------------------------------------------------------------
 constexpr int kLatencyFrames = 4;           // calls with at most this many frames are tuned for the latency of the call (launch_quads, hipGraph replay)
+constexpr int kLatLines = 2048;             // edges per frame / points per edge the one-wave-per-restart Welsch kernel of such calls holds;
+constexpr int kLatPoints = 1024;            // a frame beyond either takes the batch kernel
 constexpr int kLineCap = 4 * kCandCap;     // fitted edges per frame (4 per candidate that survives the RDP split)
 constexpr int kClPool = 262144;           // edge-cluster points per frame (a candidate reserves its boundary capacity + 64)
 constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table
@@ -119,6 +121,7 @@ struct Workspace {
     int32_t* npacks = nullptr;      // [F]
     uint32_t* packs = nullptr;      // [F][kCandCap]
     uint16_t* pack_order = nullptr; // [F][kCandCap]
+    float* welsch_rs = nullptr;     // [min(F, kLatencyFrames)][kLatLines][20][6]: line + err (as a double) of every restart, few-frame calls only
     const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
     hipStream_t aux_stream = nullptr;     // owned by the handle: side branch for few-frame calls (launch_quads)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -1366,13 +1366,207 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int f
     }
 }
 
+// ---- few-frame calls: one wave per (edge, restart) ------------------------------------------------------------------
+// A restart is one lane's sequential walk in k_welsch -- two passes over the edge's points per IRLS iteration, ~180 cycles per point:
+// 0.15 ms for the 450-point edges of the reference's test frame, whatever else the GPU is doing.  Only the SUMS of an iteration are
+// order-dependent; the per-point work (distance, weight, the five weighted products) is not.  Here the wave's lanes compute
+// the terms of 64 points at a time into LDS and then one lane per sum adds its column in point order -- the same additions in the
+// same order, so the same bits -- a load and an add per term instead of the whole point.  All 20 restarts of all edges run at once;
+// k_welsch_pick then applies fitLine2D's selection (first restart below EPS, else the first minimum) per edge.
+__device__ __forceinline__ bool welsch_lat_takes(const QuadPtrs& P, int frame, int L) {
+    if (L > kLatLines) return false;
+    if (L == 0) return true;
+    const int longest = P.line_sorted[(size_t)frame * kLineCap];  // sorted by descending point count
+    return P.line_desc[(size_t)frame * kLineCap + longest].n <= kLatPoints;
+}
+
+// a += src[j] for j = 0 .. n-1 in that order; eight terms are loaded ahead of the additions that wait for one another
+__device__ __forceinline__ double ordered_sum(const float* src, int n) {
+    double a = 0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a += v[u];
+    }
+    for (; j < n; j++) a += src[j];
+    return a;
+}
+
+// NP: points per edge this build holds in LDS (9 bytes each: 256 points = 9 KB, sixteen waves per CU; the 1024-point build takes the
+// few longer edges -- the first ranks of the frame's list, which is sorted by descending point count)
+template <int NP, int LO>
+__global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, float* rs) {
+    __shared__ uint32_t s_p[NP];
+    __shared__ float s_r[NP], s_w[NP];
+    __shared__ float s_t[6][NP];
+    __shared__ double s_sum[8];
+    __shared__ uint16_t s_pk[10];
+    const int frame = blockIdx.z, k = blockIdx.y, lane = threadIdx.x;
+    if (frame >= nframes) return;
+    const int L = min(P.line_count[frame], kLineCap);
+    if (!welsch_lat_takes(P, frame, L)) return;
+    const float c = 1 / 2.9846f;
+    for (int rank = blockIdx.x; rank < L; rank += gridDim.x) {
+        __syncthreads();  // single wave: the previous edge is done with the arrays
+        const int lid = P.line_sorted[(size_t)frame * kLineCap + rank];
+        const LineDesc d = P.line_desc[(size_t)frame * kLineCap + lid];
+        const int n = d.n;
+        if (n <= LO) break;     // block-uniform; the rest of the list is shorter still: the other build's
+        if (n > NP) continue;
+        const uint32_t* pts = P.cl_pool + (size_t)frame * kClPool + d.off;
+        for (int j = lane; j < n; j += 64) s_p[j] = pts[j];
+        const int npick = min(n, 10);
+        if (lane == 0) {  // the restart's initial sample (ascending), as welsch_three builds it
+            if (n < kPickN) {
+                const uint8_t* t = P.pick_table + ((size_t)n * 20 + k) * 10;
+                for (int q = 0; q < npick; q++) s_pk[q] = t[q];
+            } else {
+                CvRng rng;
+                rng.state = 0xffffffffffffffffULL;
+                for (int kk = 0; kk <= k; kk++) {
+                    int got = 0;
+                    while (got < npick) {
+                        const int j = (int)(rng.next() % (unsigned)n);
+                        bool dup = false;
+                        for (int q = 0; q < got; q++) dup |= (s_pk[q] == j);
+                        if (!dup) s_pk[got++] = (uint16_t)j;
+                    }
+                }
+                for (int a = 1; a < npick; a++) {
+                    const uint16_t v = s_pk[a];
+                    int b = a - 1;
+                    while (b >= 0 && s_pk[b] > v) {
+                        s_pk[b + 1] = s_pk[b];
+                        b--;
+                    }
+                    s_pk[b + 1] = v;
+                }
+            }
+        }
+        __syncthreads();
+        float line[4], prev[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
+            for (int i = 0; i < npick; i++) {
+                const uint32_t p = s_p[s_pk[i]];
+                const float px = (float)ux(p), py = (float)uy(p);
+                x += px;
+                y += py;
+                x2 += px * px;
+                y2 += py * py;
+                xy += px * py;
+                w += 1.f;
+            }
+            moments_to_line(x, y, x2, y2, xy, w, line);
+        }
+        const double EPS = n * 1.1920928955078125e-07;
+        double err = 0;
+        for (int it = 0; it < 30; it++) {
+            if (it > 0) {
+                const float t = line[0] * prev[0] + line[1] * prev[1];
+                if (t >= ctm::kAcosBelowTenMilli) {
+                    const float dx = ctm::fabs32(line[2] - prev[2]);
+                    const float dy = ctm::fabs32(line[3] - prev[3]);
+                    const float dd = dx > dy ? dx : dy;
+                    if (dd < 0.01f) break;
+                }
+            }
+            const float lx = line[2], ly = line[3], nx = line[1], ny = -line[0];
+            for (int j = lane; j < n; j += 64) {
+                const uint32_t p = s_p[j];
+                const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
+                const float r = ctm::fabs32(nx * x + ny * y);
+                s_r[j] = r;
+                s_w[j] = ctm::exp32(-r * r * c * c);
+            }
+            __syncthreads();
+            if (lane < 2) {  // err += r and sum_w += w, in point order
+                s_sum[lane] = ordered_sum(lane == 0 ? s_r : s_w, n);
+            }
+            __syncthreads();
+            err = s_sum[0];
+            const double sum_w = s_sum[1];
+            if (err < EPS) break;
+            if (ctm::fabs64(sum_w) > 1.1920928955078125e-07) {
+                const double inv = 1. / sum_w;
+                for (int j = lane; j < n; j += 64) {
+                    const uint32_t p = s_p[j];
+                    const float px = (float)ux(p), py = (float)uy(p);
+                    const float wj = (float)(s_w[j] * inv);
+                    s_t[0][j] = wj * px;
+                    s_t[1][j] = wj * py;
+                    s_t[2][j] = wj * px * px;
+                    s_t[3][j] = wj * py * py;
+                    s_t[4][j] = wj * px * py;
+                    s_t[5][j] = wj;
+                }
+            } else {
+                for (int j = lane; j < n; j += 64) {
+                    const uint32_t p = s_p[j];
+                    const float px = (float)ux(p), py = (float)uy(p);
+                    s_t[0][j] = px;
+                    s_t[1][j] = py;
+                    s_t[2][j] = px * px;
+                    s_t[3][j] = py * py;
+                    s_t[4][j] = px * py;
+                    s_t[5][j] = 1.f;
+                }
+            }
+            __syncthreads();
+            if (lane < 6) {  // x, y, x2, y2, xy, w: each a column added in point order
+                s_sum[2 + lane] = ordered_sum(s_t[lane], n);
+            }
+            __syncthreads();
+            prev[0] = line[0];
+            prev[1] = line[1];
+            prev[2] = line[2];
+            prev[3] = line[3];
+            moments_to_line(s_sum[2], s_sum[3], s_sum[4], s_sum[5], s_sum[6], s_sum[7], line);
+        }
+        if (lane == 0) {
+            float* o = rs + (((size_t)frame * kLatLines + rank) * 20 + k) * 6;
+            o[0] = line[0];
+            o[1] = line[1];
+            o[2] = line[2];
+            o[3] = line[3];
+            *reinterpret_cast<double*>(o + 4) = err;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_welsch_pick(QuadPtrs P, int nframes, const float* rs) {
+    const int frame = blockIdx.y, rank = blockIdx.x * 256 + threadIdx.x;
+    if (frame >= nframes) return;
+    const int L = min(P.line_count[frame], kLineCap);
+    if (rank >= L || !welsch_lat_takes(P, frame, L)) return;
+    const int lid = P.line_sorted[(size_t)frame * kLineCap + rank];
+    const int n = P.line_desc[(size_t)frame * kLineCap + lid].n;
+    const double EPS = n * 1.1920928955078125e-07;
+    double min_err = 1.7976931348623157e308;
+    float best[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* r = rs + ((size_t)frame * kLatLines + rank) * 20 * 6;
+    for (int kk = 0; kk < 20; kk++) {  // fitLine2D: the first restart below EPS ends the search, else the first minimum wins
+        const double e = *reinterpret_cast<const double*>(r + kk * 6 + 4);
+        if (e < min_err) {
+            min_err = e;
+            for (int q = 0; q < 4; q++) best[q] = r[kk * 6 + q];
+            if (e < EPS) break;
+        }
+    }
+    float* o = P.line_fit + ((size_t)frame * kLineCap + lid) * 4;
+    for (int q = 0; q < 4; q++) o[q] = best[q];
+}
+
 #ifndef CTAG_WELSCH_PRIO_RANKS
 #define CTAG_WELSCH_PRIO_RANKS 16
 #endif
 #ifndef CTAG_WELSCH_WAVES
 #define CTAG_WELSCH_WAVES 5
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes, int skip_lat) {
     // Longest first across the WHOLE batch: blockIdx.x (the fast dispatch index) is the frame, blockIdx.y the rank of the
     // edge triple in the frame's list sorted by descending point count.  The longest triples of all frames are dispatched
     // first and the kernel drains on the short ones: a long triple runs ~0.3 ms as a lone wave, and with the triple rank on
@@ -1381,6 +1575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
+    if (skip_lat && welsch_lat_takes(P, frame, L)) return;  // few-frame call: k_welsch_lat has done this frame
     // the first ranks are the long edges: their waves are the kernel's critical path, so they get issue priority over the short
     // ones they share a SIMD with (s_setprio; the bulk fills the slots they leave)
     if (blockIdx.y < (unsigned)CTAG_WELSCH_PRIO_RANKS) __builtin_amdgcn_s_setprio(3);
@@ -1542,7 +1737,20 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
     mark();
     static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 144;  // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144: fewer empty blocks, 6.74 -> 6.59 ms)
-    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx), dim3(64), 0, s, P, nframes);
+    if (latency && ws.welsch_rs) {  // one wave per (edge, restart); frames it declines (more edges / longer edges than it holds) fall through to k_welsch
+        if (fork) {  // the long edges beside the short ones
+            (void)hipEventRecord(ws.ev_fork, s);
+            (void)hipStreamWaitEvent(ws.aux_stream, ws.ev_fork, 0);
+        }
+        hipLaunchKernelGGL((k_welsch_lat<kLatPoints, 256>), dim3(64, 20, nframes), dim3(64), 0, fork ? ws.aux_stream : s, P, nframes, ws.welsch_rs);
+        hipLaunchKernelGGL((k_welsch_lat<256, 0>), dim3(512, 20, nframes), dim3(64), 0, s, P, nframes, ws.welsch_rs);
+        if (fork) {
+            (void)hipEventRecord(ws.ev_join, ws.aux_stream);
+            (void)hipStreamWaitEvent(s, ws.ev_join, 0);
+        }
+        hipLaunchKernelGGL(k_welsch_pick, dim3(kLatLines / 256, nframes), dim3(256), 0, s, P, nframes, ws.welsch_rs);
+    }
+    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? 1 : 0);
     mark();
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {

@@ -72,7 +72,7 @@ void* ctag_stream(ctag_handle* h);
 #define CTAG_OPT_KEEP_PREMARKERS 3 /* 1: keep the markers before decoding for ctag_debug_fetch */
 #define CTAG_OPT_HOST_SUBCHUNK 4   /* frames per upload/detect pipeline step of ctag_detect_batch_u8; default 128 */
 #define CTAG_OPT_GRAPH 5           /* replay a chunk whose pointers / sizes / parameters repeat as one hipGraph launch: 0 never, 1 every chunk, 2 (default)
-                                      calls of up to 4 frames only -- one frame per call in a loop gains 0.03-0.04 ms of 0.73; batches gain
+                                      calls of up to 4 frames only -- one frame per call in a loop gains 0.03-0.04 ms of 0.7; batches gain
                                       nothing, their chain is not launch-bound */
 #define CTAG_OPT_WAVE_POINTS 6     /* components whose boundary can hold more than this many points get a wave of their own instead of 8 lanes of a
                                       shared one (the longest boundary decides how long a one-frame call takes); 0 = automatic: 96 for calls of
