@@ -1,5 +1,6 @@
-// k_quad.hip -- K6: one workgroup per candidate component: silhouette boundary, ordered traversal,
-// extended Ramer-Douglas-Peucker split into <= 4 edges, robust (Welsch) line fits, quad selection.
+// k_quad.hip -- K6: per candidate component: silhouette boundary, ordered traversal, extended Ramer-Douglas-Peucker
+// split into <= 4 edges (k_pack + k_quad_edges_packed: 8 components per wave, or a wave each for long boundaries), robust
+// (Welsch) line fits (k_line_sort + k_welsch; k_welsch_lat + k_welsch_pick in few-frame calls), quad selection (k_quad_final).
 // GPU counterpart of corner_detector::edgeExtraction and helpers
 //   /root/reference/corner_detector.cpp:125-169 (expand_line), :171-405 (edgeExtraction),
 //   :407-418 (get_orientedEdgePoints), :420-452 (get_permutation), :454-463 (quadJudgment)
@@ -7,10 +8,10 @@
 //
 // Design (not a translation): the reference builds a bbox mask + visited image and recurses; here the
 // silhouette is kept as four sparse first-hit arrays (top/bottom per column, left/right per row), the
-// recursion is an explicit stack, expand_line's per-point refits use exact integer moment sums, the 20
-// Welsch restarts of each of the 4 edges run on 80 lanes at once (the cv::RNG pick sequence depends only
-// on the point count, so it is replayed up front), and every floating-point sum that the reference
-// accumulates sequentially is accumulated in the same order so results are bit-identical to the oracle.
+// recursion is an explicit stack that is never unwound past the last silhouette pixel, expand_line's per-point refits use
+// exact integer moment sums and are speculated 8 (or 64) steps at a time, the 20 Welsch restarts of an edge run on lanes at
+// once (the cv::RNG pick sequence depends only on the point count, so it is replayed up front), and every floating-point sum
+// that the reference accumulates sequentially is accumulated in the same order so results are bit-identical to the oracle.
 #include "ctag_internal.h"
 #include "ctag_math.h"
 #include <cstdio>
@@ -230,7 +231,7 @@ constexpr int kSG = 8;
 constexpr int kUnwind = 8;  // stack frames the whole-wave build tests at once when it unwinds (<= 8: 8 lanes each)
 constexpr int kWaveWords = 8192;      // LDS words of the common whole-wave build (32 KB: five components per CU)
 constexpr int kWaveWordsMax = 36864;  // ... of the build for the longest boundaries (144 KB: one per CU)
-constexpr int kLatencyBigPoints = 96; // ... there, components with a boundary capacity above this get a wave of their own
+constexpr int kLatencyBigPoints = 96; // calls of <= kLatencyFrames frames: components with a boundary capacity above this get a wave of their own
 __host__ __device__ __forceinline__ int pack_points(int w, int h) { return min(2 * (w + h), w * h) + 1; }
 // LDS words one component needs in the packed kernel: silhouette arrays + boundary list + stack / ping-pong list
 __host__ __device__ __forceinline__ int pack_need(int w, int h) {
