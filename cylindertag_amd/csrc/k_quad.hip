@@ -261,6 +261,7 @@ struct CornerPre {
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words) {
     __shared__ int s_key[kCandCap];
+    __shared__ int s_need[kCandCap];
     __shared__ uint16_t s_ord[kCandCap];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
         const Candidate c = cand[i];
         const int w = c.x_max - c.x_min + 1, h = c.y_max - c.y_min + 1;
         s_key[i] = pack_big(c.x_min, w, h, big_points, pack_words) ? -1 : pack_points(w, h);  // -1: not packed, sorts last
+        s_need[i] = pack_need(w, h);  // for the pack builder below: one lane walks the sorted list, it should not wait for global memory
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nc; i += 64) {
@@ -290,8 +292,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
         for (int r = 0; r < nc; r++) {
             const int i = s_ord[r];
             if (s_key[i] < 0) break;  // the rest is oversize
-            const Candidate c = cand[i];
-            const int need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
+            const int need = s_need[i];
             if (cnt > 0 && (cnt == max_per_pack || words + need > pack_words)) {  // a pack = consecutive entries of `order`
                 packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
                 cnt = 0;

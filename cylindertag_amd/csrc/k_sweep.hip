@@ -253,8 +253,9 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
     const int xblocks = (lanes + 63) / 64;
     int bands = 4 * ((g.hrows + 4 * kDecBandMax - 1) / (4 * kDecBandMax));
     // small batches (a single frame through ctag_detect_u8): a band is a sequential walk of a wave, so shorter bands -- more
-    // waves -- cut the latency (one 1080p frame: 135-row bands 0.19 ms, 15-row bands 0.06 ms); a full batch keeps the tall ones
-    while ((long)nframes * xblocks * bands < 2048 && (g.hrows + 2 * bands - 1) / (2 * bands) >= 15) bands *= 2;
+    // waves -- cut the latency (one 1080p frame: 135-row bands 0.19 ms, 15-row bands 0.034 ms, 4-row bands < 0.02 ms); a full batch keeps the tall ones
+    static const int min_band = getenv("CTAG_DEC_MIN_BAND") ? atoi(getenv("CTAG_DEC_MIN_BAND")) : 4;  // one frame: 15-row bands 34 us, 8 rows 21, 4 rows < 20
+    while ((long)nframes * xblocks * bands < 2048 && (g.hrows + 2 * bands - 1) / (2 * bands) >= min_band) bands *= 2;
     const int band_rows = (g.hrows + bands - 1) / bands;
     const int yblocks = bands / 4;
     const int grid = grid_for(nframes, xblocks * yblocks);
