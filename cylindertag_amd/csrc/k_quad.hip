@@ -592,12 +592,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             many = e >= 0;  // more members than keys: fall back to the gather test
         }
         // Whole-wave components cross many CCL tiles and carry many labels (a long boundary: more members than keys, several labels
-        // per tile), which would put every lane on the gather test.  They get a membership bitmap instead: for every CCL tile the box
-        // touches, 128 bits "label l of this tile belongs to my component", filled by the whole wave at once (lane l asks root_of
-        // of pool entry tile_base + l - 1; a bit for a label the tile does not have is harmless, no pixel carries it).  Labels above
-        // 128 exist only in tiles that took the second CCL pass; those keep the gather test.
-        constexpr int kMemberTiles = 96;
-        __shared__ unsigned long long s_member[SG == 64 ? kMemberTiles : 1][2];
+        // per tile), which would put every lane on the gather test.  They get a membership table instead: for every CCL tile the box
+        // touches, a byte per label 1..128 "label l of this tile belongs to my component", filled by the whole wave at once (lane l
+        // asks root_of of pool entry tile_base + l - 1; a 1 for a label the tile does not have is harmless, no pixel carries
+        // it).  Entry 0 (background) is 0, entry 129 -- where larger labels are clamped to -- says "ask root_of": labels above 128
+        // exist only in tiles that took the second CCL pass.  One more table, all "ask", serves boxes over more than 96 tiles.
+        constexpr int kMemberTiles = 96, kLutPitch = 132;
+        __shared__ uint8_t s_lut[SG == 64 ? (kMemberTiles + 1) * kLutPitch : 4];
         const int mt_x0 = x_min / kTileW, mt_y0 = y_min / kTileH;
         const int mt_nx = (x_min + w - 1) / kTileW - mt_x0 + 1, mt_ny = (y_min + h - 1) / kTileH - mt_y0 + 1;
         const bool bitmap = SG == 64 && mt_nx * mt_ny <= kMemberTiles;
@@ -620,13 +621,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const unsigned long long ma = __ballot(ra[u] == cd.root), mb = __ballot(rb[u] == cd.root);
-                        if (lane == 0 && t0 + u < nt) {
-                            s_member[t0 + u][0] = ma;
-                            s_member[t0 + u][1] = mb;
+                        if (t0 + u < nt) {
+                            uint8_t* T = s_lut + (t0 + u) * kLutPitch;
+                            T[1 + lane] = ra[u] == cd.root ? 1 : 0;
+                            T[65 + lane] = rb[u] == cd.root ? 1 : 0;
+                            if (lane == 0) {
+                                T[0] = 0;
+                                T[129] = 2;
+                            }
                         }
                     }
                 }
+            } else {
+                uint8_t* T = s_lut + kMemberTiles * kLutPitch;
+                for (int i = lane; i < 130; i += 64) T[i] = i ? 2 : 0;
             }
         }
         // ---- P1: silhouette first-hit arrays (corner_detector.cpp:184-232).  Each lane reads 8 labels with one
@@ -656,7 +664,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const int col = valid ? gxf : (x_min & ~7);
                 const int tcol = col / kTileW;  // eight 16-byte aligned columns share a CCL tile
                 const int xl0 = gxf - x_min;
-                uint32_t top[4], bot[4], seen[4], bm[4] = {0u, 0u, 0u, 0u};
+                uint32_t top[4], bot[4], seen[4];
+                const uint8_t* lut = s_lut + kMemberTiles * kLutPitch;  // membership table of this lane's tile
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     top[d] = bot[d] = 0xffffffffu;
@@ -674,22 +683,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         const int ty = (y_min + y) / kTileH;
                         if (ty != cur_ty) {
                             cur_ty = ty;
-                            if (bitmap) {
-                                const int t = (ty - mt_y0) * mt_nx + (tcol - mt_x0);
-                                const unsigned long long a0 = s_member[t][0], a1 = s_member[t][1];
-                                bm[0] = (uint32_t)a0, bm[1] = (uint32_t)(a0 >> 32), bm[2] = (uint32_t)a1, bm[3] = (uint32_t)(a1 >> 32);
-                            }
+                            if (bitmap) lut = s_lut + ((ty - mt_y0) * mt_nx + (tcol - mt_x0)) * kLutPitch;
                         }
                         const uint32_t wv[4] = {rr[u].x, rr[u].y, rr[u].z, rr[u].w};
                         unsigned bits = 0;
+                        unsigned lab[8], mv[8];
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
-                            const unsigned l = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                            const unsigned k = l - 1u;  // label 0 (background) wraps to a huge index
-                            const uint32_t word = (k & 64u) ? ((k & 32u) ? bm[3] : bm[2]) : ((k & 32u) ? bm[1] : bm[0]);
-                            bool in = bitmap && k < 128u && ((word >> (k & 31u)) & 1u);
-                            if ((!bitmap || k >= 128u) && l != 0u && l < 0x8000u && ((valid >> q) & 1u))  // rare: a second-pass tile's label, or a box over > 96 tiles
-                                in = rootof[tbase[ty * g.tiles_x + tcol] + (int)l - 1] == cd.root;
+                            lab[q] = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                            mv[q] = lut[min(lab[q], 129u)];  // the eight table bytes are requested together
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            bool in = mv[q] == 1u;
+                            if (mv[q] == 2u && lab[q] < 0x8000u && ((valid >> q) & 1u))  // rare: a second-pass tile's label, or a box over > 96 tiles
+                                in = rootof[tbase[ty * g.tiles_x + tcol] + (int)lab[q] - 1] == cd.root;
                             bits |= (in ? 1u : 0u) << q;
                         }
                         bits &= valid;
