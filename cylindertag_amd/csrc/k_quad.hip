@@ -1,6 +1,6 @@
 // k_quad.hip -- K6: per candidate component: silhouette boundary, ordered traversal, extended Ramer-Douglas-Peucker
 // split into <= 4 edges (k_pack + k_quad_edges_packed: 8 components per wave, or a wave each for long boundaries), robust
-// (Welsch) line fits (k_line_sort + k_welsch; k_welsch_lat + k_welsch_pick in few-frame calls), quad selection (k_quad_final).
+// (Welsch) line fits (k_line_sort + k_welsch; k_welsch_lat in few-frame calls), quad selection (k_quad_final).
 // GPU counterpart of corner_detector::edgeExtraction and helpers
 //   /root/reference/corner_detector.cpp:125-169 (expand_line), :171-405 (edgeExtraction),
 //   :407-418 (get_orientedEdgePoints), :420-452 (get_permutation), :454-463 (quadJudgment)
@@ -1382,7 +1382,7 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int f
 // order-dependent; the per-point work (distance, weight, the five weighted products) is not.  Here the wave's lanes compute
 // the terms of 64 points at a time into LDS and then one lane per sum adds its column in point order -- the same additions in the
 // same order, so the same bits -- a load and an add per term instead of the whole point.  All 20 restarts of all edges run at once;
-// k_welsch_pick then applies fitLine2D's selection (first restart below EPS, else the first minimum) per edge.
+// k_welsch, launched behind, then applies fitLine2D's selection (first restart below EPS, else the first minimum) per edge.
 __device__ __forceinline__ bool welsch_lat_takes(const QuadPtrs& P, int frame, int L) {
     if (L > kLatLines) return false;
     if (L == 0) return true;
@@ -1547,18 +1547,15 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
     }
 }
 
-__global__ __launch_bounds__(256) void k_welsch_pick(QuadPtrs P, int nframes, const float* rs) {
-    const int frame = blockIdx.y, rank = blockIdx.x * 256 + threadIdx.x;
-    if (frame >= nframes) return;
-    const int L = min(P.line_count[frame], kLineCap);
-    if (rank >= L || !welsch_lat_takes(P, frame, L)) return;
+// fitLine2D's choice among the restarts of the edge of sorted rank `rank`: the first restart below EPS ends the search, else the first minimum wins
+__device__ __forceinline__ void welsch_pick(const QuadPtrs& P, int frame, int rank, const float* rs) {
     const int lid = P.line_sorted[(size_t)frame * kLineCap + rank];
     const int n = P.line_desc[(size_t)frame * kLineCap + lid].n;
     const double EPS = n * 1.1920928955078125e-07;
     double min_err = 1.7976931348623157e308;
     float best[4] = {0.f, 0.f, 0.f, 0.f};
     const float* r = rs + ((size_t)frame * kLatLines + rank) * 20 * 6;
-    for (int kk = 0; kk < 20; kk++) {  // fitLine2D: the first restart below EPS ends the search, else the first minimum wins
+    for (int kk = 0; kk < 20; kk++) {
         const double e = *reinterpret_cast<const double*>(r + kk * 6 + 4);
         if (e < min_err) {
             min_err = e;
@@ -1576,7 +1573,7 @@ __global__ __launch_bounds__(256) void k_welsch_pick(QuadPtrs P, int nframes, co
 #ifndef CTAG_WELSCH_WAVES
 #define CTAG_WELSCH_WAVES 5
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes, int skip_lat) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes, const float* lat_rs) {
     // Longest first across the WHOLE batch: blockIdx.x (the fast dispatch index) is the frame, blockIdx.y the rank of the
     // edge triple in the frame's list sorted by descending point count.  The longest triples of all frames are dispatched
     // first and the kernel drains on the short ones: a long triple runs ~0.3 ms as a lone wave, and with the triple rank on
@@ -1585,7 +1582,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
-    if (skip_lat && welsch_lat_takes(P, frame, L)) return;  // few-frame call: k_welsch_lat has done this frame
+    if (lat_rs && welsch_lat_takes(P, frame, L)) {  // few-frame call: k_welsch_lat has run the restarts of this frame's edges; pick per edge
+        for (int rank = (int)blockIdx.y * 64 + (int)threadIdx.x; rank < L; rank += (int)gridDim.y * 64) welsch_pick(P, frame, rank, lat_rs);
+        return;
+    }
     // the first ranks are the long edges: their waves are the kernel's critical path, so they get issue priority over the short
     // ones they share a SIMD with (s_setprio; the bulk fills the slots they leave)
     if (blockIdx.y < (unsigned)CTAG_WELSCH_PRIO_RANKS) __builtin_amdgcn_s_setprio(3);
@@ -1619,67 +1619,119 @@ __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int 
         for (int j = 0; j < 4; j++)
             for (int q = 0; q < 4; q++) lf[j][q] = src[j * 4 + q];
     }
-    CornerPre cp[6];
-    int ncp = 0;
-    for (int j = 0; j < 3; j++)
-        for (int k = j + 1; k < 4; k++) {
-            const float a00 = lf[j][1], a01 = -lf[j][0], a10 = lf[k][1], a11 = -lf[k][0];
-            const float b0 = lf[j][1] * lf[j][2] - lf[j][0] * lf[j][3];
-            const float b1 = lf[k][1] * lf[k][2] - lf[k][0] * lf[k][3];
-            CornerPre c;
-            if (solve2x2(a00, a01, a10, a11, b0, b1, c.x, c.y)) {
-                c.dis = ctm::sqrt32((c.x - acx) * (c.x - acx) + (c.y - acy) * (c.y - acy));
-                c.ang = (float)(ctm::atan2_32(c.y - acy, c.x - acx) * 180 / 3.1415926535897932384626433832795);
-                if (c.dis < g.hcols && c.dis < g.hrows) cp[ncp++] = c;
+    // The reference collects the valid pairwise intersections in (j, k) order, sorts them by angle (std::sort on <= 6 elements: an
+    // insertion sort, i.e. stable) and tries the 4-subsets in lexicographic order of the sorted list.  Same thing with every index
+    // a compile-time constant (arrays indexed at run time live in scratch memory: a thread spent most of its 25 us there): the
+    // six slots carry a valid flag, the stable sort is a rank computation, the sorted list is built by selects.
+    CornerPre raw[6];
+    bool ok6[6];
+    {
+        int q = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int k = j + 1; k < 4; k++) {
+                const float a00 = lf[j][1], a01 = -lf[j][0], a10 = lf[k][1], a11 = -lf[k][0];
+                const float b0 = lf[j][1] * lf[j][2] - lf[j][0] * lf[j][3];
+                const float b1 = lf[k][1] * lf[k][2] - lf[k][0] * lf[k][3];
+                CornerPre c{0.f, 0.f, 0.f, 0.f};
+                bool ok = solve2x2(a00, a01, a10, a11, b0, b1, c.x, c.y);
+                if (ok) {
+                    c.dis = ctm::sqrt32((c.x - acx) * (c.x - acx) + (c.y - acy) * (c.y - acy));
+                    c.ang = (float)(ctm::atan2_32(c.y - acy, c.x - acx) * 180 / 3.1415926535897932384626433832795);
+                    ok = c.dis < g.hcols && c.dis < g.hrows;
+                }
+                raw[q] = c;
+                ok6[q] = ok;
+                q++;
             }
-        }
-    for (int a = 1; a < ncp; a++) {  // std::sort on <= 6 elements: insertion sort
-        const CornerPre v = cp[a];
-        int b = a - 1;
-        while (b >= 0 && v.ang < cp[b].ang) {
-            cp[b + 1] = cp[b];
-            b--;
-        }
-        cp[b + 1] = v;
+    }
+    int ncp = 0;
+    int rank6[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        ncp += ok6[i] ? 1 : 0;
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            if (j != i) r += (ok6[j] && (raw[j].ang < raw[i].ang || (!(raw[i].ang < raw[j].ang) && j < i))) ? 1 : 0;  // stable: ties keep collection order
+        rank6[i] = ok6[i] ? r : 6;
+    }
+    CornerPre cp[6];
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        CornerPre c{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            if (rank6[i] == p) c = raw[i];
+        cp[p] = c;
     }
     float rac_min = 0.3f;
-    int best[4] = {-1, -1, -1, -1};
-        for (int i0 = 0; i0 < ncp; i0++)
-        for (int i1 = i0 + 1; i1 < ncp; i1++)
-            for (int i2 = i1 + 1; i2 < ncp; i2++)
-                for (int i3 = i2 + 1; i3 < ncp; i3++) {
-                    const CornerPre &p0 = cp[i0], &p1 = cp[i1], &p2 = cp[i2], &p3 = cp[i3];
-                    const float s1 = p0.x * p1.y + p1.x * p2.y + p2.x * p0.y - p0.x * p2.y - p1.x * p0.y - p2.x * p1.y;
-                    const float s2 = p1.x * p2.y + p2.x * p3.y + p3.x * p1.y - p1.x * p3.y - p2.x * p1.y - p3.x * p2.y;
-                    const float s3 = p2.x * p3.y + p3.x * p0.y + p0.x * p2.y - p2.x * p0.y - p3.x * p2.y - p0.x * p3.y;
-                    const float s4 = p0.x * p1.y + p1.x * p3.y + p3.x * p0.y - p0.x * p3.y - p1.x * p0.y - p3.x * p1.y;
-                    if (ctm::fabs32(s1) < 1 || ctm::fabs32(s2) < 1 || ctm::fabs32(s3) < 1 || ctm::fabs32(s4) < 1) continue;
-                    float qa = 0;
-                    qa += p0.x * p1.y - p0.y * p1.x;
-                    qa += p1.x * p2.y - p1.y * p2.x;
-                    qa += p2.x * p3.y - p2.y * p3.x;
-                    qa += p3.x * p0.y - p3.y * p0.x;
-                    qa /= 2;
-                    const float rac = ctm::fabs32(ctm::fabs32(qa) - areaPx) / areaPx;
-                    if (rac < rac_min) {
-                        rac_min = rac;
-                        best[0] = i0;
-                        best[1] = i1;
-                        best[2] = i2;
-                        best[3] = i3;
+    int best_id = -1;
+    {
+        int id = 0;
+#pragma unroll
+        for (int i0 = 0; i0 < 6; i0++)
+#pragma unroll
+            for (int i1 = i0 + 1; i1 < 6; i1++)
+#pragma unroll
+                for (int i2 = i1 + 1; i2 < 6; i2++)
+#pragma unroll
+                    for (int i3 = i2 + 1; i3 < 6; i3++) {
+                        const int my = id++;
+                        if (i3 >= ncp) continue;
+                        const CornerPre &p0 = cp[i0], &p1 = cp[i1], &p2 = cp[i2], &p3 = cp[i3];
+                        const float s1 = p0.x * p1.y + p1.x * p2.y + p2.x * p0.y - p0.x * p2.y - p1.x * p0.y - p2.x * p1.y;
+                        const float s2 = p1.x * p2.y + p2.x * p3.y + p3.x * p1.y - p1.x * p3.y - p2.x * p1.y - p3.x * p2.y;
+                        const float s3 = p2.x * p3.y + p3.x * p0.y + p0.x * p2.y - p2.x * p0.y - p3.x * p2.y - p0.x * p3.y;
+                        const float s4 = p0.x * p1.y + p1.x * p3.y + p3.x * p0.y - p0.x * p3.y - p1.x * p0.y - p3.x * p1.y;
+                        if (ctm::fabs32(s1) < 1 || ctm::fabs32(s2) < 1 || ctm::fabs32(s3) < 1 || ctm::fabs32(s4) < 1) continue;
+                        float qa = 0;
+                        qa += p0.x * p1.y - p0.y * p1.x;
+                        qa += p1.x * p2.y - p1.y * p2.x;
+                        qa += p2.x * p3.y - p2.y * p3.x;
+                        qa += p3.x * p0.y - p3.y * p0.x;
+                        qa /= 2;
+                        const float rac = ctm::fabs32(ctm::fabs32(qa) - areaPx) / areaPx;
+                        if (rac < rac_min) {
+                            rac_min = rac;
+                            best_id = my;
+                        }
                     }
-                }
-    int valid = best[0] >= 0 ? 1 : 0;
+    }
+    // the winning subset's corners, again by selects over the 15 subsets
+    CornerPre bc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    {
+        int id = 0;
+#pragma unroll
+        for (int i0 = 0; i0 < 6; i0++)
+#pragma unroll
+            for (int i1 = i0 + 1; i1 < 6; i1++)
+#pragma unroll
+                for (int i2 = i1 + 1; i2 < 6; i2++)
+#pragma unroll
+                    for (int i3 = i2 + 1; i3 < 6; i3++) {
+                        if (id++ == best_id) {
+                            bc[0] = cp[i0];
+                            bc[1] = cp[i1];
+                            bc[2] = cp[i2];
+                            bc[3] = cp[i3];
+                        }
+                    }
+    }
+    int valid = best_id >= 0 ? 1 : 0;
     if (valid) {
+#pragma unroll
         for (int j = 0; j < 4; j++) {
-            const CornerPre& c = cp[best[j]];
+            const CornerPre& c = bc[j];
             if (c.x < 0 || c.y < 0 || c.x > g.hcols || c.y > g.hrows) valid = 0;
         }
     }
     out->valid = valid;
+#pragma unroll
     for (int j = 0; j < 4; j++) {
-        out->c[2 * j] = valid ? cp[best[j]].x : 0.f;
-        out->c[2 * j + 1] = valid ? cp[best[j]].y : 0.f;
+        out->c[2 * j] = valid ? bc[j].x : 0.f;
+        out->c[2 * j + 1] = valid ? bc[j].y : 0.f;
     }
 }
 
@@ -1758,9 +1810,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
             (void)hipEventRecord(ws.ev_join, ws.aux_stream);
             (void)hipStreamWaitEvent(s, ws.ev_join, 0);
         }
-        hipLaunchKernelGGL(k_welsch_pick, dim3(kLatLines / 256, nframes), dim3(256), 0, s, P, nframes, ws.welsch_rs);
     }
-    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? 1 : 0);
+    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr);
     mark();
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {
