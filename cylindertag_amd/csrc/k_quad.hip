@@ -1288,16 +1288,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 // K6s: per frame, order the edge clusters by descending point count so that the three edges a Welsch wave
 // fits together cost about the same (scheduling only: results do not depend on this order).
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_line_sort(QuadPtrs P, int nframes) {
+constexpr int kLineSortThreads = 1024;  // a rank sort: L / threads passes of L comparisons each; one frame has ~400 edges
+__global__ __launch_bounds__(kLineSortThreads) void k_line_sort(QuadPtrs P, int nframes) {
     __shared__ int s_n[kLineCap];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
     const LineDesc* d = P.line_desc + (size_t)frame * kLineCap;
-    for (int i = threadIdx.x; i < L; i += 256) s_n[i] = d[i].n;
+    for (int i = threadIdx.x; i < L; i += kLineSortThreads) s_n[i] = d[i].n;
     __syncthreads();
     int32_t* out = P.line_sorted + (size_t)frame * kLineCap;
-    for (int i = threadIdx.x; i < L; i += 256) {
+    for (int i = threadIdx.x; i < L; i += kLineSortThreads) {
         const int ni = s_n[i];
         int rank = 0;
         for (int j = 0; j < L; j++) {
@@ -1796,7 +1797,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         (void)hipStreamWaitEvent(s, ws.ev_join, 0);
     }
     mark();
-    hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(256), 0, s, P, nframes);
+    hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(kLineSortThreads), 0, s, P, nframes);
     mark();
     static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 144;  // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144: fewer empty blocks, 6.74 -> 6.59 ms)
     if (latency && ws.welsch_rs) {  // one wave per (edge, restart); frames it declines (more edges / longer edges than it holds) fall through to k_welsch
