@@ -15,6 +15,7 @@
 #include "ctag_internal.h"
 #include "ctag_math.h"
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 namespace ctag {
@@ -655,77 +656,110 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             // atomics on one address are served one after the other).  Nothing in the loop waits for memory but the row batch.
             const int x_end = x_min + w;
             stamp(5);
-            for (int xa = x_min & ~7; xa < x_end; xa += kChunk) {
-                const int gxf = xa + 8 * lane;
-                unsigned valid = 0;
+            // kGather = false: membership from the table alone, so nothing but the row batches touches global memory, the compiler can
+            // count the loads in flight and the next batch streams in under the current one; a pixel the table does not cover
+            // flags the component, which is then rescanned by the kGather = true build (root_of asked per such pixel).
+            bool redo = false;
+            auto wave_scan = [&](auto gather_tag) {
+                constexpr bool kGather = decltype(gather_tag)::value;
+                for (int xa = x_min & ~7; xa < x_end; xa += kChunk) {
+                    const int gxf = xa + 8 * lane;
+                    unsigned valid = 0;
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (gxf + q >= x_min && gxf + q < x_end) valid |= 1u << q;
-                const int col = valid ? gxf : (x_min & ~7);
-                const int tcol = col / kTileW;  // eight 16-byte aligned columns share a CCL tile
-                const int xl0 = gxf - x_min;
-                uint32_t top[4], bot[4], seen[4];
-                const uint8_t* lut = s_lut + kMemberTiles * kLutPitch;  // membership table of this lane's tile
+                    for (int q = 0; q < 8; q++)
+                        if (gxf + q >= x_min && gxf + q < x_end) valid |= 1u << q;
+                    const int col = valid ? gxf : (x_min & ~7);
+                    const int tcol = col / kTileW;  // eight 16-byte aligned columns share a CCL tile
+                    const int xl0 = gxf - x_min;
+                    uint32_t top[4], bot[4], seen[4];
+                    const uint8_t* lut = s_lut + kMemberTiles * kLutPitch;  // membership table of this lane's tile
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    top[d] = bot[d] = 0xffffffffu;
-                    seen[d] = 0u;
-                }
-                int cur_ty = -1;
-                for (int y0 = 0; y0 < h; y0 += 8) {
-                    uint4 rr[8];
+                    for (int d = 0; d < 4; d++) {
+                        top[d] = bot[d] = 0xffffffffu;
+                        seen[d] = 0u;
+                    }
+                    int cur_ty = -1;
+                    auto load_batch = [&](int y0, uint4 (&rr)[8]) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) rr[u] = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y0 + u, h - 1)) * g.lp + col);
+                        for (int u = 0; u < 8; u++) rr[u] = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y0 + u, h - 1)) * g.lp + col);
+                    };
+                    auto digest_batch = [&](int y0, const uint4 (&rr)[8]) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int y = y0 + u;
-                        if (y >= h) break;  // uniform
-                        const int ty = (y_min + y) / kTileH;
-                        if (ty != cur_ty) {
-                            cur_ty = ty;
-                            if (bitmap) lut = s_lut + ((ty - mt_y0) * mt_nx + (tcol - mt_x0)) * kLutPitch;
-                        }
-                        const uint32_t wv[4] = {rr[u].x, rr[u].y, rr[u].z, rr[u].w};
-                        unsigned bits = 0;
-                        unsigned lab[8], mv[8];
+                        for (int u = 0; u < 8; u++) {
+                            const int y = y0 + u;
+                            if (y >= h) break;  // uniform
+                            const int ty = (y_min + y) / kTileH;
+                            if (ty != cur_ty) {
+                                cur_ty = ty;
+                                if (bitmap) lut = s_lut + ((ty - mt_y0) * mt_nx + (tcol - mt_x0)) * kLutPitch;
+                            }
+                            const uint32_t wv[4] = {rr[u].x, rr[u].y, rr[u].z, rr[u].w};
+                            unsigned bits = 0;
+                            unsigned lab[8], mv[8];
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            lab[q] = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                            mv[q] = lut[min(lab[q], 129u)];  // the eight table bytes are requested together
-                        }
+                            for (int q = 0; q < 8; q++) {
+                                lab[q] = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                                mv[q] = lut[min(lab[q], 129u)];  // the eight table bytes are requested together
+                            }
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            bool in = mv[q] == 1u;
-                            if (mv[q] == 2u && lab[q] < 0x8000u && ((valid >> q) & 1u))  // rare: a second-pass tile's label, or a box over > 96 tiles
-                                in = rootof[tbase[ty * g.tiles_x + tcol] + (int)lab[q] - 1] == cd.root;
-                            bits |= (in ? 1u : 0u) << q;
-                        }
-                        bits &= valid;
-                        const unsigned long long rowm = __ballot(bits != 0u);
-                        if (rowm) {
-                            if (lane == __builtin_ctzll(rowm)) atomicMin(&lef[y], (unsigned)(xl0 + __ffs(bits) - 1));
-                            if (lane == 63 - __builtin_clzll(rowm)) atomicMax(&rig[y], (unsigned)(xl0 + 32 - __clz(bits)));
-                        }
-                        if (bits) {
-                            const uint32_t ypk = (uint32_t)y * 0x10001u;
+                            for (int q = 0; q < 8; q++) {
+                                bool in = mv[q] == 1u;
+                                const bool ask = mv[q] == 2u && lab[q] < 0x8000u && ((valid >> q) & 1u);  // rare: a second-pass tile's label, or a box over > 96 tiles
+                                if constexpr (kGather) {
+                                    if (ask) in = rootof[tbase[ty * g.tiles_x + tcol] + (int)lab[q] - 1] == cd.root;
+                                } else {
+                                    redo = redo || ask;
+                                }
+                                bits |= (in ? 1u : 0u) << q;
+                            }
+                            bits &= valid;
+                            const unsigned long long rowm = __ballot(bits != 0u);
+                            if (rowm) {
+                                if (lane == __builtin_ctzll(rowm)) atomicMin(&lef[y], (unsigned)(xl0 + __ffs(bits) - 1));
+                                if (lane == 63 - __builtin_clzll(rowm)) atomicMax(&rig[y], (unsigned)(xl0 + 32 - __clz(bits)));
+                            }
+                            if (bits) {
+                                const uint32_t ypk = (uint32_t)y * 0x10001u;
 #pragma unroll
-                            for (int d = 0; d < 4; d++) {
-                                const uint32_t m = ((bits >> (2 * d)) & 1u) * 0xffffu + ((bits >> (2 * d + 1)) & 1u) * 0xffff0000u;
-                                bot[d] = (bot[d] & ~m) | (ypk & m);
-                                const uint32_t nm = m & ~seen[d];
-                                top[d] = (top[d] & ~nm) | (ypk & nm);
-                                seen[d] |= m;
+                                for (int d = 0; d < 4; d++) {
+                                    const uint32_t m = ((bits >> (2 * d)) & 1u) * 0xffffu + ((bits >> (2 * d + 1)) & 1u) * 0xffff0000u;
+                                    bot[d] = (bot[d] & ~m) | (ypk & m);
+                                    const uint32_t nm = m & ~seen[d];
+                                    top[d] = (top[d] & ~nm) | (ypk & nm);
+                                    seen[d] |= m;
+                                }
                             }
                         }
+                    };
+                    uint4 ra[8], rb[8];
+                    load_batch(0, ra);
+                    for (int y0 = 0; y0 < h; y0 += 16) {
+                        load_batch(y0 + 8, rb);
+                        digest_batch(y0, ra);
+                        load_batch(y0 + 16, ra);
+                        digest_batch(y0 + 8, rb);
                     }
-                }
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    if ((valid >> q) & 1u) {  // every column of a component's bounding box holds a pixel
-                        const uint32_t t = (top[q >> 1] >> (16 * (q & 1))) & 0xffffu, bb = (bot[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                        tb[xl0 + q + 1] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
+                    for (int q = 0; q < 8; q++) {
+                        if ((valid >> q) & 1u) {  // every column of a component's bounding box holds a pixel
+                            const uint32_t t = (top[q >> 1] >> (16 * (q & 1))) & 0xffffu, bb = (bot[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                            tb[xl0 + q + 1] = t == 0xffffu ? 0u : ((t + 2) | ((bb + 2) << 16));
+                        }
                     }
                 }
+            };
+            if (bitmap) wave_scan(std::false_type{});
+            if (!bitmap || __ballot(redo)) {
+                if (bitmap) {  // start over
+                    SG_SYNC();
+                    for (int x = sl; x < w + 2; x += SG) tb[x] = 0u;
+                    for (int y = sl; y < h; y += SG) {
+                        lef[y] = 0xffffffffu;
+                        rig[y] = 0u;
+                    }
+                    SG_SYNC();
+                }
+                wave_scan(std::true_type{});
             }
         } else
         for (int xa = x_min & ~7; xa < x_min + w; xa += 2 * kChunk) {  // one pass per two chunks of the box
