@@ -106,8 +106,16 @@ def test_edge_cases(detector, oracle, dictionary, test_bmp):
             h, w = 22 + (gx + gy) % 7, 26 + (3 * gx + gy) % 9
             if grid[y0 - 6:y0 + h + 6, x0 - 6:x0 + w + 6].min() > 120:
                 grid[y0:y0 + h, x0:x0 + w] = 20
+    # 840 dark rectangles on a bright frame: > 2048 fitted edges, more than the one-wave-per-restart Welsch kernel of few-frame calls
+    # holds -> the frame takes the batch kernel (k_welsch) although it arrives alone
+    many = np.full((1080, 1920), 200, np.uint8)
+    for gy in range(28):
+        for gx in range(30):
+            y0, x0 = 10 + gy * 38, 12 + gx * 63
+            many[y0:y0 + 20 + (gx + gy) % 5, x0:x0 + 30 + (3 * gx + gy) % 7] = 25
     for name, img, want_status in (("blank", blank, 1), ("one quad", one, 2), ("all dark", dark, None),
-                                   ("noise", noise, None), ("ragged", ragged, None), ("grid of squares", grid, None)):
+                                   ("noise", noise, None), ("ragged", ragged, None), ("grid of squares", grid, None),
+                                   ("840 rectangles", many, None)):
         got, want = detector.detect(img), oracle.detect_fast(img, state, fs)
         if want_status is not None:
             assert want["status"] == want_status
