@@ -120,6 +120,7 @@ def test_edge_cases(detector, oracle, dictionary, test_bmp):
         if want_status is not None:
             assert want["status"] == want_status
         assert_same_record(got, want, name)
+    _stage_check(detector, oracle, state, fs, many, "840 rectangles, stage by stage")  # every fitted quad, not only the (empty) record
     # non-contiguous rows (row_stride > cols) through the raw ABI
     import ctypes as C
     res = np.zeros(1, ca.RESULT_DT)
