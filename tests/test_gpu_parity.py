@@ -377,6 +377,21 @@ def test_long_thin_components_take_the_whole_wave_builds(detector, oracle, dicti
         detector.set_option(capi.OPT_KEEP_PREMARKERS, 0)
 
 
+def test_many_markers_per_frame(detector, oracle, dictionary):
+    """6 and 8 planted markers: 71-96 features per frame, i.e. both register halves of k_markers' wave-resident union-find / group
+    numbering / rank sort (feature k lives in lane k & 63 of one of two registers) and its feature cap (100) within reach; one frame
+    per call and as a batch."""
+    state, fs = dictionary
+    frames = [ca.synth_frame_host(state, idx, markers=mk)[0] for mk in (6, 8) for idx in (5, 6, 7, 8)]
+    want = np.array([oracle.detect_fast(f, state, fs) for f in frames])
+    assert (want["n_features"] > 64).all() and want["n_features"].max() >= 95 and (want["status"] == 0).all()
+    for k, f in enumerate(frames):
+        assert_same_record(detector.detect(f), want[k], "many markers, frame %d alone" % k)
+    got = detector.detect_batch(np.stack(frames))
+    for k in range(len(frames)):
+        assert_same_record(got[k], want[k], "many markers, frame %d in the batch" % k)
+
+
 def test_batch_equals_single_and_is_repeatable(detector, dictionary):
     state, fs = dictionary
     frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
