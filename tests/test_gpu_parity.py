@@ -369,6 +369,15 @@ def test_long_thin_components_take_the_whole_wave_builds(detector, oracle, dicti
         for k in range(10):
             _draw_polyline(hd, [(60 + 44 * k, 60), (60 + 44 * k, 300)], 6)
         _draw_polyline(hd, [(60, 300), (60 + 44 * 9 + 6, 300)], 6)
+        # a long band through CCL tiles that took the second labelling pass (400 specks on each tile's top row: more than the 128
+        # labels the membership table covers) -> its label there is "ask root_of": the table-only scan flags it and the rescan build runs
+        sp2 = np.full((1080, 1920), 205, np.uint8)
+        for row in (300, 360, 420):
+            for x in range(100, 1800, 4):
+                sp2[row:row + 2, x:x + 2] = 0
+        _draw_polyline(sp2, [(100, 310), (1800, 470)], 7)
+        o, r, lab = _stage_check(detector, oracle, state, fs, sp2, "band through second-pass tiles")
+        assert len(o["candidates"]) == 1 and (o["binary"][150] > 0).sum() > 128
         o, r, lab = _stage_check(detector, oracle, state, fs, hd, "1080p shapes beside markers")
         cand = o["candidates"]
         w, h = cand[:, 4] - cand[:, 2] + 1, cand[:, 5] - cand[:, 3] + 1
