@@ -201,6 +201,109 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     }
 }
 
+// Wide variant for frames whose half width is a multiple of 16 and needs no row tail (1080p, 4K): a lane owns SIXTEEN output pixels
+// (two 16-byte source loads per source row, one 16-byte store per output row), so one wave covers 2048 source columns -- a whole
+// 1080p row, read contiguously and with no halo loads at all (the neighbours' pixels come from the lanes next door, the image border
+// is clamped) -- and keeps 128 instead of 64 bytes in flight per lane: the kernel is bound by memory latency x bytes in flight.
+struct Raw34 {  // source pixels x0-1 .. x0+33 of one row
+    uint32_t w[8];
+    uint32_t left, right2;
+};
+__device__ __forceinline__ Raw34 load_row_wide(const uint8_t* __restrict__ rowp, int x0, int cols, bool active, int lane) {
+    Raw34 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.w[i] = 0;
+    if (active) {  // aligned, x0 + 32 <= cols by construction
+        const uint4 a = *reinterpret_cast<const uint4*>(rowp + x0), b = *reinterpret_cast<const uint4*>(rowp + x0 + 16);
+        r.w[0] = a.x, r.w[1] = a.y, r.w[2] = a.z, r.w[3] = a.w;
+        r.w[4] = b.x, r.w[5] = b.y, r.w[6] = b.z, r.w[7] = b.w;
+    }
+    uint32_t left = __shfl_up(r.w[7] >> 24, 1);
+    uint32_t right2 = __shfl_down(r.w[0] & 0xffffu, 1);
+    if (active) {
+        if (lane == 0) left = x0 > 0 ? (uint32_t)rowp[x0 - 1] : (r.w[0] & 0xffu);  // index clamp at the image border
+        if (lane == 63 || x0 + 32 >= cols)
+            right2 = x0 + 32 >= cols ? ((r.w[7] >> 24) * 0x0101u) : ((uint32_t)rowp[x0 + 32] | ((uint32_t)rowp[min(x0 + 33, cols - 1)] << 8));
+    }
+    r.left = left;
+    r.right2 = right2;
+    return r;
+}
+__device__ __forceinline__ int pxw(const Raw34& r, int k) {  // k in [-1, 33]
+    if (k < 0) return (int)r.left;
+    if (k >= 32) return (int)((r.right2 >> (8 * (k - 32))) & 0xff);
+    return (int)((r.w[k >> 2] >> (8 * (k & 3))) & 0xff);
+}
+__device__ __forceinline__ void hpass_wide(const Raw34& r, uint32_t q[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int q0 = 19 * (pxw(r, 4 * i) + pxw(r, 4 * i + 1)) - 3 * (pxw(r, 4 * i - 1) + pxw(r, 4 * i + 2));
+        const int q1 = 19 * (pxw(r, 4 * i + 2) + pxw(r, 4 * i + 3)) - 3 * (pxw(r, 4 * i + 1) + pxw(r, 4 * i + 4));
+        q[i] = pack_s16(q0, q1);
+    }
+}
+#ifndef CTAG_DEC_WIDE_WAVES
+#define CTAG_DEC_WIDE_WAVES 4
+#endif
+template <int BAND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CTAG_DEC_WIDE_WAVES))) void k_decimate_wide(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride,
+                                                                                                           ptrdiff_t row_stride, uint8_t* __restrict__ half, FrameGeom g,
+                                                                                                           int nframes, int xblocks, int yblocks, int band_rows_rt) {
+    const int band_rows = BAND ? BAND : band_rows_rt;
+    int frame, idx;
+    if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
+    const int bx = idx % xblocks, by = idx / xblocks;
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const int band = by * 4 + wy;
+    const int y_begin = band * band_rows;
+    if (y_begin >= g.hrows) return;  // wave-uniform
+    const int y_end = min(y_begin + band_rows, g.hrows);
+    const int hx0 = (bx * 64 + lane) * 16;
+    const int x0 = hx0 * 2;
+    const bool active = hx0 < g.hcols;
+    const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
+    uint8_t* __restrict__ dst = half + ((size_t)frame * g.hrows) * g.hp;
+    const int rmax = g.rows - 1;
+    auto rowp = [&](int r) { return src + (ptrdiff_t)min(max(r, 0), rmax) * row_stride; };
+    uint32_t qa[8], qb[8], qc[8], qd[8];
+    {
+        const Raw34 ra = load_row_wide(rowp(2 * y_begin - 1), x0, g.cols, active, lane);
+        const Raw34 rb = load_row_wide(rowp(2 * y_begin), x0, g.cols, active, lane);
+        const Raw34 rc = load_row_wide(rowp(2 * y_begin + 1), x0, g.cols, active, lane);
+        const Raw34 rd = load_row_wide(rowp(2 * y_begin + 2), x0, g.cols, active, lane);
+        hpass_wide(ra, qa);
+        hpass_wide(rb, qb);
+        hpass_wide(rc, qc);
+        hpass_wide(rd, qd);
+    }
+    auto emit = [&](int y, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = vpack4(vpass2(a[2 * k], b[2 * k], c[2 * k], d[2 * k], 0), vpass2(a[2 * k + 1], b[2 * k + 1], c[2 * k + 1], d[2 * k + 1], 0));
+        if (active) *reinterpret_cast<uint4*>(dst + (size_t)y * g.hp + hx0) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    Raw34 n0 = load_row_wide(rowp(2 * y_begin + 3), x0, g.cols, active, lane);
+    Raw34 n1 = load_row_wide(rowp(2 * y_begin + 4), x0, g.cols, active, lane);
+    for (int y = y_begin; y < y_end; y += 2) {
+        const Raw34 m0 = load_row_wide(rowp(2 * y + 5), x0, g.cols, active, lane);
+        const Raw34 m1 = load_row_wide(rowp(2 * y + 6), x0, g.cols, active, lane);
+        emit(y, qa, qb, qc, qd);
+        uint32_t qe[8], qf[8];
+        hpass_wide(n0, qe);
+        hpass_wide(n1, qf);
+        if (y + 1 < y_end) emit(y + 1, qc, qd, qe, qf);  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            qa[i] = qe[i];
+            qb[i] = qf[i];
+        }
+        hpass_wide(m0, qc);
+        hpass_wide(m1, qd);
+        n0 = load_row_wide(rowp(2 * y + 7), x0, g.cols, active, lane);
+        n1 = load_row_wide(rowp(2 * y + 8), x0, g.cols, active, lane);
+    }
+}
+
 // General sizes (odd rows or cols: the scale is not exactly 2, every output column / row has its own cubic taps).
 // One thread per output pixel; the tap tables come from the host (build_resize_tables in ctag_api.hip).  Same
 // arithmetic as OpenCV's resizeGeneric_ for 8UC1 INTER_CUBIC: integer horizontal pass with per-tap index clamping,
@@ -264,7 +367,12 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
     hipLaunchKernelGGL((k_decimate<AL, B, TL>), dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, \
                        yblocks, band_rows)
     const bool has_tail = (g.hcols & 7) != 0;
-    if (aligned && band_rows == 135 && !has_tail)  // 1080p and 4K frames
+    static const int wide_env = getenv("CTAG_DEC_WIDE") ? atoi(getenv("CTAG_DEC_WIDE")) : 1;  // same-box A/B on 4096 1080p frames: 2.276 -> 2.209 ms (5 waves per SIMD: 2.28)
+    if (wide_env && aligned && !has_tail && (g.hcols & 15) == 0 && band_rows == 135) {  // a lane owns 16 output pixels: a wave spans 1024 half-res columns
+        const int xb = (g.hcols / 16 + 63) / 64;
+        hipLaunchKernelGGL((k_decimate_wide<135>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xb, yblocks,
+                           band_rows);
+    } else if (aligned && band_rows == 135 && !has_tail)  // 1080p and 4K frames
         CTAG_DEC_LAUNCH(true, 135, false);
     else if (aligned)
         CTAG_DEC_LAUNCH(true, 0, true);
