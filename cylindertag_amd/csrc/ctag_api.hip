@@ -583,6 +583,7 @@ void ctag_destroy(ctag_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
     if (h->ws.base) (void)hipFree(h->ws.base);
@@ -692,6 +693,7 @@ int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, i
 // every reallocation of the staging slabs (an upload still running on copy_stream must not lose its destination)
 static int quiesce(ctag_handle* h) {
     if (h->copy_stream) HIP_TRY(hipStreamSynchronize(h->copy_stream));
+    if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));  // side branch of few-frame calls
     HIP_TRY(hipStreamSynchronize(h->stream));
     return CTAG_OK;
 }
