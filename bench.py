@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--size", default="1920x1080", help="frame size WxH; the headline metric is 1920x1080 (other sizes are side measurements)")
     ap.add_argument("--no-subpix", action="store_true")
     ap.add_argument("--latency-calls", type=int, default=200, help="single-frame ctag_detect_u8 calls of the latency side measurement, 0 = skip")
+    ap.add_argument("--allow-torch-gather", action="store_true",
+                    help="N > 1: if the library's RCCL gather (ctag_gather, the C ABI) cannot come up, fall back to torch.distributed's all_gather "
+                         "of the fixed records instead of failing.  Without this flag such a run exits non-zero: the line must not hide a gather failure")
     return ap.parse_args()
 
 
@@ -63,6 +66,7 @@ def host_stream_rate(det, frames_dev, m, subpix):
     """Side measurement (never `value`): the same frames handed over as HOST buffers through ctag_detect_batch_u8 --
     pinned memory, uploads double-buffered against detection, results downloaded.  Bounded by PCIe."""
     import cylindertag_amd as ca
+    import testkit as tk
     host = ca.pinned_empty((m, ROWS, COLS), np.uint8)
     host[...] = frames_dev[:m].cpu().numpy()
     res = ca.pinned_empty((m,), ca.RESULT_DT)
@@ -84,6 +88,7 @@ def pose_side(det, m, dev):
     reference's CTag_2f12c.model / cameraParams.yml), everything device-resident.  The CPU pose oracle is timed beside it."""
     import torch
     import cylindertag_amd as ca
+    import testkit as tk
     from cylindertag_amd import capi
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from ctag_testlib import GOLDEN, read_bmp_gray
@@ -142,13 +147,14 @@ def pose_side_3d(det, state, m, dev, frames_cap):
     with the objects' 3-D corner lists, everything device-resident; the recovered poses are compared with the planted ones."""
     import torch
     import cylindertag_amd as ca
+    import testkit as tk
     from cylindertag_amd import capi
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from pose_testlib import PoseOracle, make_camera, make_model_view, rodrigues
     m = max(1, min(m, frames_cap))
     f = 5200.0 * COLS / 3840.0
     K = np.array([[f, 0, COLS / 2.0], [0, f, ROWS / 2.0], [0, 0, 1]])
-    model, corners = ca.synth3d_model(state)
+    model, corners = tk.synth3d_model(state)
     cam = ca.make_camera(K, np.zeros(5))
     frames = torch.empty((m, ROWS, COLS), dtype=torch.uint8, device=dev)
     det.synth3d_frames_device(frames.data_ptr(), 0, m, ROWS, COLS, COLS, ROWS * COLS, K)
@@ -179,7 +185,7 @@ def pose_side_3d(det, state, m, dev, frames_cap):
     # planted poses of the first frames (the host layout: no rendering needed beyond a 1-row image)
     ang, rel = [], []
     for fr in range(min(m, 64)):
-        truth = ca.synth3d_frame_host(state, fr, K, rows=ROWS, cols=COLS)[1] if fr < 2 else None
+        truth = tk.synth3d_frame_host(state, fr, K, rows=ROWS, cols=COLS)[1] if fr < 2 else None
         if truth is None:
             break
         for p in P[offs[fr]:offs[fr + 1]]:
@@ -308,23 +314,34 @@ def cpu_baseline(frames_dev, n_one, per_thread, state, fs, subpix):
 
 
 def opencv_stage_probe(frames_host):
-    """BASELINE.md's optional stage-level sanity baseline: if an OpenCV build is importable on this host, time its own
+    """BASELINE.md's optional stage-level sanity baseline: if an OpenCV build is importable on this host, (1) COMPARE its
+    primitives with the oracle's replicas (tests/cv2_pins.py: resize INTER_CUBIC, connectedComponentsWithStats BBDT label order,
+    fitLine L2 / Welsch, fastAtan2 -- the [OCV-recall] items of SURVEY App. A) and print the mismatches, (2) time its own
     resize(INTER_CUBIC, 1/2) + connectedComponentsWithStats(8, CCL_BBDT) -- the two OpenCV primitives of the sweep
     (CylinderTag.cpp:79, corner_detector.cpp:82) -- on a few frames of the batch and say which version; otherwise say so.
-    (This image and the GPU box have no OpenCV: the probe reports its absence.)"""
+    (This image and the GPU boxes of this pool have no OpenCV: the probe reports its absence.)"""
     try:
         import cv2
     except Exception as e:  # noqa: BLE001
-        return {"available": False, "note": "no OpenCV importable on this host (%s): stage-level OpenCV baseline not measured" % type(e).__name__}
+        return {"available": False, "note": "no OpenCV importable on this host (%s): stage-level OpenCV baseline not measured, oracle primitives "
+                                            "not compared (tests/cv2_pins.py)" % type(e).__name__}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ctag_testlib import GOLDEN, Oracle, read_bmp_gray
+    import cv2_pins
+    try:
+        pins = cv2_pins.run_all(Oracle(), read_bmp_gray(os.path.join(GOLDEN, "test.bmp")))
+    except Exception as e:  # noqa: BLE001
+        pins = {"error": "%s: %s" % (type(e).__name__, e)}
     n = min(16, len(frames_host))
     t0 = time.perf_counter()
     for f in frames_host[:n]:
-        half = cv2.resize(f, (f.shape[1] // 2, f.shape[0] // 2), 0.5, 0.5, cv2.INTER_CUBIC)
+        half = cv2.resize(f, (f.shape[1] // 2, f.shape[0] // 2), None, 0.5, 0.5, cv2.INTER_CUBIC)
         binary = ((half.astype(np.float32) * np.float32(1.0 / 255)) < 0.3).astype(np.uint8) * 255  # stand-in mask: the threshold is the reference's own code
-        cv2.connectedComponentsWithStats(binary, 8, cv2.CV_32S, cv2.CCL_BBDT)
+        cv2.connectedComponentsWithStatsWithAlgorithm(binary, 8, cv2.CV_32S, cv2.CCL_BBDT)
     dt = time.perf_counter() - t0
     return {"available": True, "version": cv2.__version__, "threads": cv2.getNumThreads(), "frames": n,
-            "resize_plus_ccl_frames_per_s": round(n / dt, 1), "note": "OpenCV resize INTER_CUBIC + connectedComponentsWithStats(8, CCL_BBDT) only"}
+            "resize_plus_ccl_frames_per_s": round(n / dt, 1), "note": "OpenCV resize INTER_CUBIC + connectedComponentsWithStats(8, CCL_BBDT) only",
+            "oracle_vs_opencv_primitives": pins}
 
 
 def latency_side(det, state, fs, calls=200):
@@ -354,6 +371,7 @@ def main():
     import hashlib
     import torch
     import cylindertag_amd as ca
+    import testkit as tk
     from cylindertag_amd import capi
     from cylindertag_amd.dist import CommGather, shard_range
 
@@ -383,7 +401,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
-    det = ca.Detector(state, fs, device=dev_index)
+    det = tk.Detector(state, fs, device=dev_index)
     subpix = not args.no_subpix
 
     # ---- the job: n_total frames per step; this rank owns frames [lo, hi) of it
@@ -399,9 +417,9 @@ def main():
     local_bufs = [torch.zeros((max(n, 1), rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
     gather_impl, comm, gathered = "none (1 GPU)", None, None
     if world > 1:
-        # the path's only exchange: final marker lists.  The library's own RCCL gather (packed shards); should its
-        # communicator fail to come up, torch.distributed's all_gather of the fixed records (also RCCL) takes over and the
-        # line says so.
+        # the path's only exchange: final marker lists, through the library's own RCCL gather (packed shards, C ABI).  Should its
+        # communicator fail to come up the run FAILS -- unless --allow-torch-gather (or the gloo developer backend, which has no
+        # RCCL at all) asks for torch.distributed's all_gather of the fixed records, and then the line says so.
         gathered = [torch.zeros((n_total, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         host_gather = dist.get_backend() != "nccl"
         try:
@@ -418,20 +436,29 @@ def main():
             comm.close()
             comm = None
             gather_impl = "torch.distributed.all_gather_into_tensor of fixed records (another rank's ctag_comm_init failed)"
+        if comm is None and not host_gather and not args.allow_torch_gather:
+            if rank == 0:
+                print("bench.py: the C-ABI gather is not the path in use: %s (pass --allow-torch-gather to measure the fallback)" % gather_impl,
+                      file=sys.stderr, flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            return 3
         if comm is None and n * world != n_total:
             raise SystemExit("the torch.distributed fallback gather needs equal shards")
     # N > 1: consecutive steps alternate between two handles (two streams, two workspaces): a rank's shard is small (512 frames
     # of the 4096 at N = 8) and the tails of its kernels -- a few long boundary / Welsch blocks -- would otherwise idle most of
     # the GPU at the end of every kernel; the next step's kernels fill them (112 -> 149 K frames/s per GPU at 512
-    # frames per step).  Every handle gathers through a communicator of its own.  CTAG_BENCH_PINGPONG=0 turns it off.
+    # frames per step).  Both handles gather through ONE communicator (the second attaches to the first's: collectives of a
+    # communicator run in issue order, so no rank can start two communicators' kernels in a different order than its peers).
+    # CTAG_BENCH_PINGPONG=0 turns it off.
     dets, comms = [det], [comm]
     if world > 1 and os.environ.get("CTAG_BENCH_PINGPONG", "1") != "0":
         det2, comm2 = None, None
         try:
-            det2 = ca.Detector(state, fs, device=dev_index)
+            det2 = tk.Detector(state, fs, device=dev_index)
             det2.set_option(capi.OPT_MAX_CHUNK, chunk)
             if comm is not None:
-                comm2 = CommGather(det2, dist)
+                comm2 = CommGather(det2, dist, share=comm)
         except Exception:  # noqa: BLE001
             det2 = None
         ok2 = torch.tensor([1 if det2 is not None else 0], dtype=torch.int32, device="cpu" if dist.get_backend() != "nccl" else dev)
@@ -611,7 +638,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        for c in comms:
+        for c in reversed(comms):  # the attached handle lets go before the owner destroys the communicator
             if c is not None:
                 c.close()
         dist.destroy_process_group()

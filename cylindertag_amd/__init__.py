@@ -7,7 +7,7 @@ interface (``csrc/CylinderTag.h``).  This Python module is only the thin ctypes 
 missing or no GPU is usable, construction raises.
 """
 from .capi import (CameraC, CtagError, Detector, Model, POSE_DT, load_camera, make_camera, FEATURE_DT, MARKER_DT, RESULT_DT, STAGE_NAMES, build, lib_path, load_library,
-                   load_marker_file, pinned_empty, synth_frame_host, synth_truth, synth3d_frame_host, synth3d_model)
+                   load_marker_file, pinned_empty)
 
 __all__ = ["CameraC", "Model", "POSE_DT", "load_camera", "make_camera", "CtagError", "Detector", "FEATURE_DT", "MARKER_DT", "RESULT_DT", "STAGE_NAMES", "build", "lib_path",
-           "load_library", "load_marker_file", "pinned_empty", "synth_frame_host", "synth_truth", "synth3d_frame_host", "synth3d_model"]
+           "load_library", "load_marker_file", "pinned_empty"]

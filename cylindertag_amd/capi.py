@@ -15,29 +15,22 @@ FEATURE_DT = np.dtype([("pos", "<i4"), ("id", "<i4"), ("id_left", "<i4"), ("id_r
 MARKER_DT = np.dtype([("marker_id", "<i4"), ("first_feature", "<i4"), ("n_features", "<i4"), ("n_pos", "<i4")])
 RESULT_DT = np.dtype([("status", "<i4"), ("n_markers", "<i4"), ("n_features", "<i4"), ("flags", "<u4"),
                       ("markers", MARKER_DT, (MAX_MARKERS,)), ("features", FEATURE_DT, (MAX_FEATURES,))])
-TRUTH3D_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("_pad", "<i4", (1,)), ("R", "<f8", (8, 9)), ("t", "<f8", (8, 3)),
-                       ("radius", "<f8", (8,))])
-TRUTH_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("strip_len", "<f4", (8,)),
-                     ("corners", "<f4", (8, 8))])
 STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates", "quad_pack", "quad_edges", "quad_edges_big",
                "line_sort", "welsch", "quad_final", "features", "edge_refine", "markers"]
 QUAD_STAGES = ["quad_pack", "quad_edges", "quad_edges_big", "line_sort", "welsch", "quad_final"]  # a4: edgeExtraction
 
 OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OPT_WAVE_POINTS = 1, 2, 3, 4, 5, 6
-DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS = range(1, 9)
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)
 EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
            "ctag_detect_batch_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
-           "ctag_stage_name", "ctag_strerror", "ctag_version", "ctag_debug_fetch", "ctag_math_probe",
-           "ctag_synth_frames_device", "ctag_synth_frame_host", "ctag_synth_layout_truth", "ctag_synth3d_frames_device",
-           "ctag_synth3d_frame_host", "ctag_synth3d_model"]
+           "ctag_stage_name", "ctag_strerror", "ctag_version"]
 # ... and include/ctag_pose.h
 POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag_model_get_view", "ctag_camera_load",
                 "ctag_pose_batch_device", "ctag_estimate_pose", "ctag_pose_last_ms"]
 # ... and include/ctag_gather.h
 GATHER_EXPORTS = ["ctag_shard_range", "ctag_packed_capacity", "ctag_pack_results", "ctag_unpack_results", "ctag_comm_unique_id",
-                  "ctag_comm_init", "ctag_comm_attach", "ctag_comm_destroy", "ctag_comm_last_error", "ctag_gather_begin",
+                  "ctag_comm_init", "ctag_comm_attach", "ctag_comm_destroy", "ctag_comm_native", "ctag_comm_last_error", "ctag_gather_begin",
                   "ctag_gather_end", "ctag_gather_wait", "ctag_gather", "ctag_gather_last_bytes"]
 EXPORTS = EXPORTS + POSE_EXPORTS + GATHER_EXPORTS
 COMM_ID_BYTES = 128
@@ -122,26 +115,6 @@ def load_library():
     L.ctag_strerror.restype = C.c_char_p
     L.ctag_strerror.argtypes = [C.c_int]
     L.ctag_version.restype = C.c_int
-    L.ctag_debug_fetch.restype = C.c_long
-    L.ctag_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
-    L.ctag_math_probe.restype = C.c_int
-    L.ctag_math_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
-    L.ctag_synth_frames_device.restype = C.c_int
-    L.ctag_synth_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t,
-                                           C.c_uint64, C.c_int]
-    L.ctag_synth_frame_host.restype = C.c_int
-    L.ctag_synth_frame_host.argtypes = [i32p, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_uint64,
-                                        C.c_int, vp]
-    L.ctag_synth_layout_truth.restype = C.c_int
-    L.ctag_synth_layout_truth.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp]
-    L.ctag_synth3d_frames_device.restype = C.c_int
-    L.ctag_synth3d_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_uint64, C.c_int,
-                                             C.c_double, C.c_double, C.c_double, C.c_double]
-    L.ctag_synth3d_frame_host.restype = C.c_int
-    L.ctag_synth3d_frame_host.argtypes = [i32p, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_uint64, C.c_int, C.c_double,
-                                          C.c_double, C.c_double, C.c_double, vp]
-    L.ctag_synth3d_model.restype = C.c_int
-    L.ctag_synth3d_model.argtypes = [i32p, C.c_int, C.c_int, vp]
     L.ctag_model_load.restype = C.c_int
     L.ctag_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.ctag_model_create.restype = C.c_int
@@ -175,6 +148,8 @@ def load_library():
     L.ctag_comm_attach.argtypes = [vp, vp, C.c_int, C.c_int]
     L.ctag_comm_destroy.restype = C.c_int
     L.ctag_comm_destroy.argtypes = [vp]
+    L.ctag_comm_native.restype = vp
+    L.ctag_comm_native.argtypes = [vp]
     L.ctag_comm_last_error.restype = C.c_char_p
     L.ctag_comm_last_error.argtypes = [vp]
     L.ctag_gather_begin.restype = C.c_int
@@ -295,60 +270,6 @@ def make_camera(K, dist):
     return cam
 
 
-SYNTH_SEED = 0x4354616753594E00  # "CTagSYN\0", SURVEY.md 8(d)
-
-
-def synth_frame_host(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, markers=4):
-    """Host rendering of synthetic frame `frame_index` (same code path as the device generator)."""
-    L = load_library()
-    state = np.ascontiguousarray(state, dtype=np.int32)
-    img = np.zeros((rows, cols), np.uint8)
-    truth = np.zeros(1, TRUTH_DT)
-    st = L.ctag_synth_frame_host(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1],
-                                 img.ctypes.data, frame_index, rows, cols, img.strides[0], seed, markers,
-                                 truth.ctypes.data)
-    if st != 0:
-        raise CtagError(st)
-    return img, truth[0]
-
-
-def synth3d_frame_host(state, frame_index, K, rows=2160, cols=3840, seed=SYNTH_SEED, markers=4):
-    """Host rendering of frame `frame_index` of the 3-D scene (cylinders with planted poses, camera matrix K) -> (image, truth)."""
-    L = load_library()
-    state = np.ascontiguousarray(state, dtype=np.int32)
-    img = np.zeros((rows, cols), np.uint8)
-    truth = np.zeros(1, TRUTH3D_DT)
-    K = np.asarray(K, np.float64)
-    st = L.ctag_synth3d_frame_host(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1], img.ctypes.data, frame_index,
-                                   rows, cols, img.strides[0], seed, markers, K[0, 0], K[1, 1], K[0, 2], K[1, 2], truth.ctypes.data)
-    if st != 0:
-        raise CtagError(st, "ctag_synth3d_frame_host")
-    return img, truth[0]
-
-
-def synth3d_model(state):
-    """3-D corner lists of the synthetic cylinders, one model per dictionary row (marker id = row) -> Model."""
-    L = load_library()
-    state = np.ascontiguousarray(state, dtype=np.int32)
-    corners = np.zeros((state.shape[0], state.shape[1] * 8, 3), np.float32)
-    st = L.ctag_synth3d_model(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1], corners.ctypes.data)
-    if st != 0:
-        raise CtagError(st, "ctag_synth3d_model")
-    return Model(ids=np.arange(state.shape[0], dtype=np.int32), corners=corners, model_size=state.shape[1]), corners
-
-
-def synth_truth(state, frame_index, rows=1080, cols=1920, seed=SYNTH_SEED, markers=4):
-    """Planted markers (dictionary rows, strip corners) of synthetic frame `frame_index`, without rendering."""
-    L = load_library()
-    state = np.ascontiguousarray(state, dtype=np.int32)
-    truth = np.zeros(1, TRUTH_DT)
-    st = L.ctag_synth_layout_truth(state.ctypes.data_as(C.POINTER(C.c_int32)), state.shape[0], state.shape[1], frame_index, rows,
-                            cols, seed, markers, truth.ctypes.data)
-    if st != 0:
-        raise CtagError(st)
-    return truth[0]
-
-
 class _Pinned:
     """Owner of one ctag_host_alloc() block (page-locked host memory)."""
 
@@ -449,19 +370,6 @@ class Detector:
         n = self.L.ctag_get_timings(self.h, buf, len(STAGE_NAMES))
         return {STAGE_NAMES[i]: float(buf[i]) for i in range(n)}
 
-    def synth_frames_device(self, frames_ptr, first, n, rows, cols, row_stride, frame_stride, seed=SYNTH_SEED, markers=4):
-        st = self.L.ctag_synth_frames_device(self.h, frames_ptr, first, n, rows, cols, row_stride, frame_stride, seed,
-                                             markers)
-        if st != 0:
-            raise CtagError(st, "ctag_synth_frames_device")
-
-    def synth3d_frames_device(self, frames_ptr, first, n, rows, cols, row_stride, frame_stride, K, seed=SYNTH_SEED, markers=4):
-        K = np.asarray(K, np.float64)
-        st = self.L.ctag_synth3d_frames_device(self.h, frames_ptr, first, n, rows, cols, row_stride, frame_stride, seed, markers,
-                                               K[0, 0], K[1, 1], K[0, 2], K[1, 2])
-        if st != 0:
-            raise CtagError(st, "ctag_synth3d_frames_device")
-
     # ---- multi-GPU gather (include/ctag_gather.h); pointers are plain integers
     def _gcheck(self, st, what):
         if st != 0:
@@ -481,6 +389,12 @@ class Detector:
 
     def comm_destroy(self):
         self.L.ctag_comm_destroy(self.h)
+
+    def comm_native(self):
+        return self.L.ctag_comm_native(self.h)
+
+    def comm_attach(self, nccl_comm, rank, world):
+        self._gcheck(self.L.ctag_comm_attach(self.h, nccl_comm, rank, world), "ctag_comm_attach")
 
     def gather_begin(self, local_ptr, n_local, n_total):
         self._gcheck(self.L.ctag_gather_begin(self.h, local_ptr, n_local, n_total), "ctag_gather_begin")
@@ -520,37 +434,3 @@ class Detector:
 
     def pose_last_ms(self):
         return float(self.L.ctag_pose_last_ms(self.h))
-
-    # ---- parity probes
-    def debug(self, frame, what):
-        n = self.L.ctag_debug_fetch(self.h, frame, what, None, 0)
-        if n < 0:
-            raise CtagError(-1, "ctag_debug_fetch(%d)" % what)
-        if what == DBG_HALF:
-            a = np.zeros(n, np.uint8)
-        elif what in (DBG_LABELS, DBG_CANDIDATES):
-            a = np.zeros(n, np.int32)
-        elif what == DBG_PREMARKERS:
-            a = np.zeros(1, RESULT_DT)
-        else:
-            a = np.zeros(n, np.float32)
-        if n:
-            got = self.L.ctag_debug_fetch(self.h, frame, what, a.ctypes.data, max(n, 1))
-            if got < 0:
-                raise CtagError(-2, "ctag_debug_fetch(%d)" % what)
-        if what in (DBG_CANDIDATES, DBG_CAND_QUADS):
-            return a.reshape(-1, 8)
-        if what in (DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2):
-            return a.reshape(-1, 19)
-        if what == DBG_PREMARKERS:
-            return a[0]
-        return a
-
-    def math(self, op, a, b=None):
-        a = np.ascontiguousarray(a, dtype=np.float64)
-        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float64)
-        out = np.zeros_like(a)
-        st = self.L.ctag_math_probe(self.h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
-        if st != 0:
-            raise CtagError(st, "ctag_math_probe")
-        return out

@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int kMaxWorld = 64;
+constexpr int kSoloSlot = kMaxWorld;                 // size slot of the stand-alone ctag_pack_results (the gather owns slots 0..world-1)
 constexpr int kHeadBytes = 16;                      // shard header, and the per-frame head {status, n_markers, n_features, flags}
 constexpr int kRecWords = sizeof(ctag_frame_result) / 4;
 constexpr int kMarkerWords = sizeof(ctag_marker_rec) / 4;
@@ -117,8 +118,8 @@ GatherState* gather_state(ctag_handle* h) {
         ok = ok && hipStreamCreateWithFlags(&g->gstream, hipStreamNonBlocking) == hipSuccess;
         for (hipEvent_t* e : {&g->ev_main, &g->ev_packed, &g->ev_sizes, &g->ev_done})
             ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipMalloc(reinterpret_cast<void**>(&g->d_sizes), kMaxWorld * sizeof(uint64_t)) == hipSuccess;
-        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g->h_sizes), kMaxWorld * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&g->d_sizes), (kMaxWorld + 1) * sizeof(uint64_t)) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&g->h_sizes), (kMaxWorld + 1) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
         if (!ok) {
             gather_state_free(g);
             return nullptr;
@@ -267,6 +268,23 @@ __global__ __launch_bounds__(256) void k_unpack(const unsigned char* gathered, S
     }
 }
 
+// segment table of a `world`-rank job: shard r = ctag_shard_range(n_total, r, world), placed at r * width in the gathered buffer
+Segments build_segments(int n_total, int world, uint64_t width) {
+    Segments S{};
+    S.world = world;
+    uint64_t off0 = 0;
+    for (int r = 0; r < world; r++) {
+        int lo = 0, hi = 0;
+        (void)ctag_shard_range(n_total, r, world, &lo, &hi);
+        S.lo[r] = lo;
+        S.n[r] = hi - lo;
+        S.base[r] = (uint64_t)r * width;
+        S.off0[r] = off0;
+        off0 += (uint64_t)(hi - lo) + 1;
+    }
+    return S;
+}
+
 int enqueue_pack(GatherState* g, bool main_stream, const ctag_frame_result* results_dev, int n, unsigned char* packed, uint64_t* size_dev, hipStream_t s) {
     uint64_t** off = main_stream ? &g->d_off_main : &g->d_off;
     const int r = grow_off(g, off, main_stream ? &g->off_main_cap : &g->off_cap, (size_t)n + 1 + kMaxWorld);
@@ -292,6 +310,22 @@ int enqueue_unpack(GatherState* g, bool main_stream, const unsigned char* gather
 
 }  // namespace
 
+namespace ctag {
+int gather_unpack_gathered(ctag_handle* h, const void* gathered_dev, int n_total, int world, uint64_t width, ctag_frame_result* out_dev) {
+    if (!h || !gathered_dev || n_total < 0 || world < 1 || world > kMaxWorld || (n_total > 0 && !out_dev) || (width & 255)) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
+    if (g->in_flight) return CTAG_ERR_ARG;
+    G_HIP(hipSetDevice(g->device));
+    const Segments S = build_segments(n_total, world, width);
+    const int rc = enqueue_unpack(g, false, static_cast<const unsigned char*>(gathered_dev), S, n_total, out_dev, g->gstream);
+    if (rc != CTAG_OK) return rc;
+    G_HIP(hipStreamSynchronize(g->gstream));
+    return CTAG_OK;
+}
+}  // namespace ctag
+
 extern "C" {
 
 int ctag_shard_range(int n_total, int rank, int world, int* lo, int* hi) {
@@ -311,14 +345,15 @@ int ctag_pack_results(ctag_handle* h, const ctag_frame_result* results_dev, int 
     if (!h || n < 0 || (n > 0 && !results_dev) || !packed_dev || capacity < ctag_packed_capacity(n)) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     G_HIP(hipSetDevice(g->device));
     hipStream_t s = static_cast<hipStream_t>(ctag_stream(h));
-    const int r = enqueue_pack(g, true, results_dev, n, static_cast<unsigned char*>(packed_dev), packed_bytes_host ? g->d_sizes : nullptr, s);
+    const int r = enqueue_pack(g, true, results_dev, n, static_cast<unsigned char*>(packed_dev), packed_bytes_host ? g->d_sizes + kSoloSlot : nullptr, s);
     if (r != CTAG_OK) return r;
-    if (packed_bytes_host) {
-        G_HIP(hipMemcpyAsync(g->h_sizes, g->d_sizes, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    if (packed_bytes_host) {  // a slot of its own: a gather in flight on the gather stream owns slots 0..world-1
+        G_HIP(hipMemcpyAsync(g->h_sizes + kSoloSlot, g->d_sizes + kSoloSlot, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         G_HIP(hipStreamSynchronize(s));
-        *packed_bytes_host = g->h_sizes[0];
+        *packed_bytes_host = g->h_sizes[kSoloSlot];
     }
     return CTAG_OK;
 }
@@ -327,6 +362,7 @@ int ctag_unpack_results(ctag_handle* h, const void* packed_dev, int n, ctag_fram
     if (!h || n < 0 || !packed_dev || (n > 0 && !out_dev)) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     G_HIP(hipSetDevice(g->device));
     Segments S{};
     S.world = 1;
@@ -349,6 +385,7 @@ int ctag_comm_destroy(ctag_handle* h) {
     if (!h) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     if (g->comm) {
         (void)hipSetDevice(g->device);
         (void)hipStreamSynchronize(g->gstream);
@@ -366,6 +403,7 @@ int ctag_comm_init(ctag_handle* h, const void* id_bytes, int rank, int world) {
     if (!h || !id_bytes || world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     Rccl* R = rccl();
     if (!R->lib) {
         std::snprintf(g->err, sizeof(g->err), "%s", R->err);
@@ -386,6 +424,7 @@ int ctag_comm_attach(ctag_handle* h, void* nccl_comm, int rank, int world) {
     if (!h || !nccl_comm || world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     Rccl* R = rccl();
     if (!R->lib) {
         std::snprintf(g->err, sizeof(g->err), "%s", R->err);
@@ -399,6 +438,12 @@ int ctag_comm_attach(ctag_handle* h, void* nccl_comm, int rank, int world) {
     return CTAG_OK;
 }
 
+void* ctag_comm_native(ctag_handle* h) {
+    if (!h) return nullptr;
+    GatherState* g = gather_state(h);
+    return g ? static_cast<void*>(g->comm) : nullptr;
+}
+
 const char* ctag_comm_last_error(ctag_handle* h) {
     if (!h) return "";
     GatherState* g = gather_state(h);
@@ -409,6 +454,7 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
     if (!h || n_local < 0 || n_total < n_local || (n_local > 0 && !local_dev)) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     if (g->in_flight) return CTAG_ERR_ARG;
     int lo = 0, hi = 0;
     (void)ctag_shard_range(n_total, g->rank, g->world, &lo, &hi);
@@ -424,8 +470,12 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
     G_HIP(hipSetDevice(g->device));
     hipStream_t main_s = static_cast<hipStream_t>(ctag_stream(h));
     const int n_max = (n_total + g->world - 1) / g->world;
-    int r = grow(g, &g->d_packed, &g->packed_cap, ctag_packed_capacity(n_max));
+    // the payload all-gather sends the largest packed size ROUNDED UP to 256 bytes from this buffer
+    const size_t packed_need = (ctag_packed_capacity(n_max) + 255) & ~(size_t)255;
+    const bool fresh = g->packed_cap < packed_need;
+    int r = grow(g, &g->d_packed, &g->packed_cap, packed_need);
     if (r != CTAG_OK) return r;
+    if (fresh) G_HIP(hipMemsetAsync(g->d_packed, 0, g->packed_cap, g->gstream));  // padding bytes that travel are defined
     // the gather stream picks up behind the detection already enqueued on the main stream
     G_HIP(hipEventRecord(g->ev_main, main_s));
     G_HIP(hipStreamWaitEvent(g->gstream, g->ev_main, 0));
@@ -447,6 +497,7 @@ int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
     if (!h || !out_dev) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     if (!g->in_flight) return CTAG_ERR_ARG;
     g->in_flight = false;
     Rccl* R = rccl();
@@ -463,18 +514,7 @@ int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
     width = (width + 255) & ~(uint64_t)255;
     g->last_local = g->h_sizes[g->rank];
     g->last_padded = width;
-    Segments S{};
-    S.world = g->world;
-    uint64_t off0 = 0;
-    for (int r = 0; r < g->world; r++) {
-        int lo = 0, hi = 0;
-        (void)ctag_shard_range(g->n_total, r, g->world, &lo, &hi);
-        S.lo[r] = lo;
-        S.n[r] = hi - lo;
-        S.base[r] = (uint64_t)r * width;
-        S.off0[r] = off0;
-        off0 += (uint64_t)(hi - lo) + 1;
-    }
+    const Segments S = build_segments(g->n_total, g->world, width);
     const unsigned char* gathered = g->d_packed;
     if (g->comm) {
         const int rc = grow(g, &g->d_gathered, &g->gathered_cap, (size_t)width * g->world);
@@ -492,6 +532,7 @@ int ctag_gather_wait(ctag_handle* h) {
     if (!h) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     G_HIP(hipSetDevice(g->device));
     G_HIP(hipStreamSynchronize(g->gstream));
     return CTAG_OK;
@@ -509,6 +550,7 @@ int ctag_gather_last_bytes(ctag_handle* h, uint64_t* local_bytes, uint64_t* padd
     if (!h) return CTAG_ERR_ARG;
     GatherState* g = gather_state(h);
     if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
     if (local_bytes) *local_bytes = g->last_local;
     if (padded_bytes) *padded_bytes = g->last_padded;
     return CTAG_OK;

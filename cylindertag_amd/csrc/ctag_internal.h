@@ -166,7 +166,6 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s);
-hipError_t launch_math_probe(int op, int n, const double* a, const double* b, double* out, hipStream_t s);
 size_t threshold_ccl_lds_bytes(int tw);
 hipError_t upload_threshold_table();  // once per device before the first K2 launch
 void build_pick_table(uint8_t* table);  // kPickN*20*10 bytes
@@ -178,5 +177,22 @@ void** handle_pose_slot(struct ::ctag_handle* h, void (*free_fn)(void*));
 void** handle_gather_slot(struct ::ctag_handle* h, void (*free_fn)(void*));
 bool handle_timing(const struct ::ctag_handle* h);
 int handle_device(const struct ::ctag_handle* h);
+
+// Private window for libctag_testkit.so (include/ctag_testkit.h: parity probes, synthetic frames).  Not declared in any
+// public header; the product itself never calls these two.
+struct HandleView {
+    int device;
+    const Workspace* ws;            // workspace of the last chunk (null before the first call)
+    int last_chunk_frames;
+    bool keep_pre;
+    const int32_t* dict;            // host copy of the dictionary
+    int dict_rows, dict_cols;
+    const uint8_t* gray;            // device gray frames of the last BGR call (null otherwise)
+    ptrdiff_t gray_row_stride, gray_frame_stride;
+};
+void handle_view(const struct ::ctag_handle* h, HandleView* out);
+// the part of ctag_gather_end behind the payload all-gather: segment table of a `world`-rank job + unpack kernels on the
+// handle's gather stream, on a caller-supplied gathered buffer (world shards of `width` bytes); waits for completion
+int gather_unpack_gathered(struct ::ctag_handle* h, const void* gathered_dev, int n_total, int world, uint64_t width, ctag_frame_result* out_dev);
 
 }  // namespace ctag

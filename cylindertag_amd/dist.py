@@ -97,12 +97,20 @@ def gather_records(local, n_total, dist=None, stats=None):
 class CommGather:
     """The library's RCCL gather (include/ctag_gather.h) for one Detector: __init__ bootstraps the communicator (rank 0's
     ncclUniqueId travels through the already-initialised torch.distributed group, the only thing torch does here);
-    begin/end/wait map 1:1 onto ctag_gather_begin/_end/_wait."""
+    begin/end/wait map 1:1 onto ctag_gather_begin/_end/_wait.  `share` = another CommGather of this process: the detector
+    then gathers through THAT communicator (ctag_comm_native -> ctag_comm_attach) instead of creating a second one -- a process
+    holds one library communicator however many handles it pipelines."""
 
-    def __init__(self, det, dist):
+    def __init__(self, det, dist, share=None):
         import torch
         from . import capi
         self.det, self.rank, self.world = det, dist.get_rank(), dist.get_world_size()
+        if share is not None:
+            native = share.det.comm_native()
+            if not native:
+                raise RuntimeError("the shared CommGather holds no communicator")
+            det.comm_attach(native, self.rank, self.world)
+            return
         ident = [capi.comm_unique_id() if self.rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         det.comm_init(ident[0], self.rank, self.world)

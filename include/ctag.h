@@ -69,7 +69,7 @@ void* ctag_stream(ctag_handle* h);
 /* ---- options / introspection --------------------------------------------------------------------- */
 #define CTAG_OPT_MAX_CHUNK 1      /* frames processed per pass (workspace is sized for it); default 1024 */
 #define CTAG_OPT_TIMING 2         /* 1: bracket every kernel with HIP events (ctag_get_timings) */
-#define CTAG_OPT_KEEP_PREMARKERS 3 /* 1: keep the markers before decoding for ctag_debug_fetch */
+#define CTAG_OPT_KEEP_PREMARKERS 3 /* 1: also keep every frame's markers before decoding (read by the test kit, include/ctag_testkit.h) */
 #define CTAG_OPT_HOST_SUBCHUNK 4   /* frames per upload/detect pipeline step of ctag_detect_batch_u8; default 128 */
 #define CTAG_OPT_GRAPH 5           /* replay a chunk whose pointers / sizes / parameters repeat as one hipGraph launch: 0 never, 1 every chunk, 2 (default)
                                       calls of up to 4 frames only -- one frame per call in a loop gains 0.03-0.04 ms of 0.7; batches gain
@@ -90,60 +90,6 @@ int ctag_get_timings(ctag_handle* h, float* ms, int capacity);
 const char* ctag_stage_name(int stage);
 const char* ctag_strerror(int status);
 int ctag_version(void);
-
-/* ---- parity probes (tests only): intermediates of frame `frame` of the last chunk -------------------- */
-#define CTAG_DBG_HALF 1       /* uint8  [hrows*hcols]   half-resolution image (a1) */
-#define CTAG_DBG_LABELS 2     /* int32  [hrows*hcols]   0 = background, else 1 + frame-local root id (a2,a3) */
-#define CTAG_DBG_CANDIDATES 3 /* int32  [ncand*8]       area, x_min, y_min, x_max, y_max, has_quad, n_boundary, root */
-#define CTAG_DBG_CAND_QUADS 4 /* float  [ncand*8] */
-#define CTAG_DBG_FEATURES0 5  /* float  [nfeat*19]      after featureRecovery (half-res) */
-#define CTAG_DBG_FEATURES1 6  /* float  [nfeat*19]      after cornerObtain */
-#define CTAG_DBG_FEATURES2 7  /* float  [nfeat*19]      after edgeRefine */
-#define CTAG_DBG_PREMARKERS 8 /* ctag_frame_result      markers before decoding */
-/* returns the number of ELEMENTS available (copies min(available, capacity) elements), < 0 on error */
-long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t capacity_elems);
-
-/* evaluates the shared deterministic math (cylindertag_amd/csrc/ctag_math.h) on the device; op codes as
- * oracle/ctag_oracle.h:ctago_math_probe.  Host arrays in/out. */
-int ctag_math_probe(ctag_handle* h, int op, int n, const double* a, const double* b, double* out);
-
-/* ---- synthetic frames (bench / tests) ---------------------------------------
- * Frame f is a pure function of (seed + f): gray background with a ramp and noise plus `markers` planted
- * CylinderTag strips of the given dictionary.  The same code renders on the device and on the host. */
-typedef struct ctag_synth_truth {
-    int32_t n_markers;
-    int32_t dict_row[8];
-    float strip_len[8];      /* L, full-res pixels */
-    float corners[8][8];     /* image positions of the strip's 4 outer corners */
-} ctag_synth_truth;
-int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols,
-                             ptrdiff_t row_stride, ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame);
-int ctag_synth_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows,
-                          int cols, ptrdiff_t row_stride, uint64_t seed, int markers_per_frame, ctag_synth_truth* truth);
-
-/* planted markers of synthetic frame `frame_index` without rendering it */
-int ctag_synth_layout_truth(const int32_t* state, int dict_rows, int dict_cols, int frame_index, int rows, int cols, uint64_t seed,
-                     int markers_per_frame, ctag_synth_truth* truth);
-
-/* ---- synthetic 3-D scenes (BASELINE config 5: detect() + estimatePose with known answers) ---------------------
- * The same strips printed on cylinders (strip height 60 mm, a radius fixed per dictionary row) in front of a pinhole
- * camera (fx, fy, cx, cy; no distortion), every marker with a planted rigid pose; the image is ray-cast.
- * ctag_synth3d_model gives the objects' 3-D corner lists -- the `.model` of CylinderTag.cpp:168-188 for them:
- * corners[row][feature*8 + k][3] in mm, corner order as detect() emits it -- ready for ctag_model_create with
- * marker ids 0..dict_rows-1. */
-typedef struct ctag_synth3d_truth {
-    int32_t n_markers;
-    int32_t dict_row[8];
-    double R[8][9];    /* object -> camera rotation, row-major */
-    double t[8][3];    /* mm */
-    double radius[8];  /* mm */
-} ctag_synth3d_truth;
-int ctag_synth3d_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride,
-                               ptrdiff_t frame_stride, uint64_t seed, int markers_per_frame, double fx, double fy, double cx, double cy);
-int ctag_synth3d_frame_host(const int32_t* state, int dict_rows, int dict_cols, uint8_t* frame, int frame_index, int rows, int cols,
-                            ptrdiff_t row_stride, uint64_t seed, int markers_per_frame, double fx, double fy, double cx, double cy,
-                            ctag_synth3d_truth* truth);
-int ctag_synth3d_model(const int32_t* state, int dict_rows, int dict_cols, float* corners);
 
 #ifdef __cplusplus
 }

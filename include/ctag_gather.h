@@ -55,6 +55,11 @@ int ctag_comm_unique_id(void* id_bytes);
 int ctag_comm_init(ctag_handle* h, const void* id_bytes, int rank, int world);
 int ctag_comm_attach(ctag_handle* h, void* nccl_comm, int rank, int world);
 int ctag_comm_destroy(ctag_handle* h);
+/* the handle's communicator as an ncclComm_t (NULL if none).  A second handle of the same process (its own stream and
+ * workspace, e.g. to overlap consecutive batches) gathers through the SAME communicator when it is given to
+ * ctag_comm_attach: collectives of one communicator execute in issue order whatever stream they are enqueued on, so a
+ * process never holds two communicators whose kernels could start in different orders on different ranks. */
+void* ctag_comm_native(ctag_handle* h);
 /* text of the last failure of the gather layer on this handle (RCCL / dlopen message), "" if none */
 const char* ctag_comm_last_error(ctag_handle* h);
 

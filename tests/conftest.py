@@ -36,7 +36,8 @@ def test_bmp():
 def detector(dictionary):
     """The HIP detector.  Fails loudly when the library or the GPU is missing: there is no fallback."""
     import cylindertag_amd as ca
+    import testkit as tk
     state, fs = dictionary
-    det = ca.Detector(state, fs, device=0)
+    det = tk.Detector(state, fs, device=0)
     yield det
     det.close()

@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from ctag_testlib import GOLDEN, Oracle, read_bmp_gray, read_marker_file  # noqa: E402
 from sequences import avi_substitute  # noqa: E402
 import cylindertag_amd as ca  # noqa: E402
+import testkit as tk  # noqa: E402
 
 
 def sha(a):
@@ -38,7 +39,7 @@ def main():
     out["seq_results"] = np.array([orc.detect_fast(f, state, fs) for f in seq])
     syn = []
     for f in range(8):
-        frame, truth = ca.synth_frame_host(state, f)
+        frame, truth = tk.synth_frame_host(state, f)
         syn.append(orc.detect_fast(frame, state, fs))
     out["synth_results"] = np.array(syn)
     np.savez_compressed(os.path.join(HERE, "golden_v1.npz"), **out)

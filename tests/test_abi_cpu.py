@@ -10,14 +10,19 @@ import numpy as np
 import pytest
 
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 from ctag_testlib import GOLDEN, ROOT, read_marker_file
 
 
+def _declared(*headers):
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in headers)
+    return set(re.findall(r"\b(ctag_[a-z0-9_]+)\s*\(", hdr))
+
+
 def test_library_exports_every_declared_symbol():
-    ca.build()
-    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("ctag.h", "ctag_pose.h", "ctag_gather.h"))
-    declared = set(re.findall(r"\b(ctag_[a-z0-9_]+)\s*\(", hdr))
+    tk.build()
+    declared = _declared("ctag.h", "ctag_pose.h", "ctag_gather.h")
     assert declared == set(capi.EXPORTS)
     L = capi.load_library()
     for s in declared:
@@ -26,6 +31,21 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert re.search(r"\bT %s\b" % s, nm), s
     assert L.ctag_version() >= 100
+    # the product library exports the C ABI of its three headers and nothing else with C linkage: the test / bench scaffolding
+    # (include/ctag_testkit.h) lives in libctag_testkit.so
+    c_syms = set(re.findall(r"\bT (ctag_[a-z0-9_]+)\b", nm))
+    assert c_syms == declared, c_syms ^ declared
+
+
+def test_testkit_library_exports_every_declared_symbol():
+    tk.build()
+    declared = _declared("ctag_testkit.h")
+    assert declared == set(tk.EXPORTS)
+    T = tk.load_library()
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", tk.lib_path()]).decode()
+    for s in declared:
+        assert hasattr(T, s) and re.search(r"\bT %s\b" % s, nm), s
+    assert not (declared & _declared("ctag.h", "ctag_pose.h", "ctag_gather.h"))
 
 
 def test_result_record_layout_matches_header():
@@ -65,9 +85,9 @@ def test_no_cpu_fallback_without_gpu(dictionary):
 
 def test_synthetic_generator_is_deterministic_and_planted(dictionary):
     state, fs = dictionary
-    a, ta = ca.synth_frame_host(state, 7, rows=540, cols=960)
-    b, tb = ca.synth_frame_host(state, 7, rows=540, cols=960)
-    c, tc = ca.synth_frame_host(state, 8, rows=540, cols=960)
+    a, ta = tk.synth_frame_host(state, 7, rows=540, cols=960)
+    b, tb = tk.synth_frame_host(state, 7, rows=540, cols=960)
+    c, tc = tk.synth_frame_host(state, 8, rows=540, cols=960)
     assert (a == b).all() and ta.tobytes() == tb.tobytes() and not (a == c).all()
     assert ta["n_markers"] == 4 and (ta["strip_len"][:4] > 100).all()
     assert a.min() < 60 and a.max() > 200  # black quads and white paper are present

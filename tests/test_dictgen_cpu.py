@@ -41,6 +41,7 @@ def test_inverse_is_an_involution_and_matches_the_decoder_rule():
 
 def test_generated_dictionaries_are_legal_unique_and_loadable(tmp_path):
     import cylindertag_amd as ca
+    import testkit as tk
     for col, fs, num, seed in ((12, 2, 24, 3), (15, 2, 12, 4), (9, 3, 4, 5)):
         code = dg.Generator(col, fs, seed=seed, node_budget=40000).generate(num)
         assert code.shape == (num, col), (col, fs, code.shape)
@@ -87,12 +88,13 @@ def test_other_dictionary_shapes_15c3f_18c4f(oracle):
     tools/dict_gen.py (seed 3; `python tools/dict_gen.py 15 3 24 ... 3`) satisfy the generator predicates, and synthetic frames planted
     with them decode only to planted rows (feature_size 3 and 4 paths of markerDecoder, corner_detector.cpp:1215)."""
     import cylindertag_amd as ca
+    import testkit as tk
     for name, shape, fs in (("CTag_3f15c_gen.marker", (24, 15), 3), ("CTag_4f18c_gen.marker", (24, 18), 4)):
         state, got_fs = read_marker_file(os.path.join(GOLDEN, name))
         assert state.shape == shape and got_fs == fs and all(dg.legal_code(int(c)) for c in state.ravel()) and dg.test_conflict(state, fs)
         exact = 0
         for f in range(4):
-            img, truth = ca.synth_frame_host(state, 100 + f)
+            img, truth = tk.synth_frame_host(state, 100 + f)
             res = oracle.detect_fast(img, state, fs)
             planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
             found = sorted(int(m["marker_id"]) for m in res["markers"][:res["n_markers"]])

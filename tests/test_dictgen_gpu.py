@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import ROOT, Oracle
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -19,11 +20,11 @@ pytestmark = pytest.mark.gpu
 def test_generated_dictionary_round_trip():
     code = dg.Generator(12, 2, seed=11).generate(30)
     assert code.shape == (30, 12) and dg.test_conflict(code, 2)
-    det, orc = ca.Detector(code, 2, device=0), Oracle()
+    det, orc = tk.Detector(code, 2, device=0), Oracle()
     exact = 0
     n = 24
     for f in range(n):
-        frame, truth = ca.synth_frame_host(code, 700 + f)
+        frame, truth = tk.synth_frame_host(code, 700 + f)
         got = det.detect(frame, 5, True, 5)
         want = orc.detect_fast(frame, code, 2, 5, True, 5)
         assert got.tobytes() == want.tobytes(), f
@@ -61,8 +62,8 @@ def test_other_dictionary_shapes_match_the_oracle(name, fs):
     from ctag_testlib import GOLDEN, read_marker_file
     state, got_fs = read_marker_file(os.path.join(GOLDEN, name))
     assert got_fs == fs
-    det, orc = ca.Detector(state, fs, device=0), Oracle()
-    frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
+    det, orc = tk.Detector(state, fs, device=0), Oracle()
+    frames = np.stack([tk.synth_frame_host(state, 100 + f)[0] for f in range(6)])
     got = det.detect_batch(frames)
     for f in range(6):
         want = orc.detect_fast(frames[f], state, fs)
@@ -71,11 +72,11 @@ def test_other_dictionary_shapes_match_the_oracle(name, fs):
     # the same dictionary on cylinders with planted poses: the pose kernel's large point set (18 columns x 8 corners = 144 > 96)
     from pose_testlib import PoseOracle, make_camera, make_model_view, rodrigues
     K = np.array([[2600.0, 0, 960.0], [0, 2600.0, 540.0], [0, 0, 1]])
-    M, corners = ca.synth3d_model(state)
+    M, corners = tk.synth3d_model(state)
     ids = np.arange(state.shape[0], dtype=np.int32)
     mv = make_model_view({"ids": ids, "size": state.shape[1], "base": np.zeros((len(ids), 3), np.float32),
                           "axis": np.zeros((len(ids), 3), np.float32), "corners": corners})
-    img, truth = ca.synth3d_frame_host(state, 1, K, rows=1080, cols=1920)
+    img, truth = tk.synth3d_frame_host(state, 1, K, rows=1080, cols=1920)
     rec = det.detect(img)
     assert rec.tobytes() == orc.detect_fast(img, state, fs).tobytes()
     poses = det.estimate_pose(rec, M, ca.make_camera(K, np.zeros(5)))

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 from ctag_testlib import GOLDEN, result_markers
 from sequences import avi_substitute
@@ -49,18 +50,18 @@ def test_test_bmp_every_stage(detector, oracle, dictionary, test_bmp):
     detector.set_option(capi.OPT_KEEP_PREMARKERS, 1)
     o = oracle.detect(test_bmp, state, fs)
     r = detector.detect(test_bmp)
-    assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all()
-    lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+    assert (detector.debug(0, tk.DBG_HALF).reshape(o["half"].shape) == o["half"]).all()
+    lab = detector.debug(0, tk.DBG_LABELS).reshape(o["labels"].shape)
     assert ((lab > 0) == (o["binary"] > 0)).all()
     pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
     assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))  # same partition
-    cand = detector.debug(0, capi.DBG_CANDIDATES)
+    cand = detector.debug(0, tk.DBG_CANDIDATES)
     assert (cand[:, 0:5] == o["candidates"][:, 1:6]).all()  # area, bbox, in OpenCV label order
     assert (cand[:, 5] == o["candidates"][:, 6]).all() and (cand[:, 6] == o["candidates"][:, 7]).all()
-    assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
-    for st, what in enumerate((capi.DBG_FEATURES0, capi.DBG_FEATURES1, capi.DBG_FEATURES2)):
+    assert detector.debug(0, tk.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
+    for st, what in enumerate((tk.DBG_FEATURES0, tk.DBG_FEATURES1, tk.DBG_FEATURES2)):
         assert detector.debug(0, what).tobytes() == o["features"][st].tobytes()
-    assert detector.debug(0, capi.DBG_PREMARKERS).tobytes() == o["premarkers"].tobytes()
+    assert detector.debug(0, tk.DBG_PREMARKERS).tobytes() == o["premarkers"].tobytes()
     assert_same_record(r, o["result"], "test.bmp")
     assert [m["marker_id"] for m in result_markers(r)] == [23, 0, 1, 17, 5]
 
@@ -73,7 +74,7 @@ def test_golden_fixtures(detector, test_bmp, dictionary):
     res = detector.detect_batch(seq)
     for k in range(64):
         assert_same_record(res[k], g["seq_results"][k], "sequence frame %d" % k)
-    syn = np.stack([ca.synth_frame_host(state, f)[0] for f in range(8)])
+    syn = np.stack([tk.synth_frame_host(state, f)[0] for f in range(8)])
     res = detector.detect_batch(syn)
     for k in range(8):
         assert_same_record(res[k], g["synth_results"][k], "synthetic frame %d" % k)
@@ -99,7 +100,7 @@ def test_edge_cases(detector, oracle, dictionary, test_bmp):
     strided = np.ascontiguousarray(test_bmp[:, :1900])[:, :1888]
     # more accepted quads than k_features' all-pairs path holds (192): a marker frame plus a lattice of dark squares on
     # its bright areas -> the row-by-row path, with real features among the quads
-    grid = ca.synth_frame_host(state, 7)[0].copy()
+    grid = tk.synth_frame_host(state, 7)[0].copy()
     for gy in range(20):
         for gx in range(24):
             y0, x0 = 20 + gy * 52 + (gx % 3), 20 + gx * 78 + (gy % 5)
@@ -140,7 +141,7 @@ def test_odd_sizes_and_resize_row_tail(detector, oracle, dictionary, test_bmp):
         img = np.ascontiguousarray(img)
         o = oracle.detect(img, state, fs)
         r = detector.detect(img)
-        assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all(), name
+        assert (detector.debug(0, tk.DBG_HALF).reshape(o["half"].shape) == o["half"]).all(), name
         assert_same_record(r, oracle.detect_fast(img, state, fs), name)
     # columns alternating 16 / 17 put every output pixel exactly on a rounding tie (V / 1024 = 16.5)
     tie = np.zeros((64, 2 * 853), np.uint8)
@@ -148,15 +149,15 @@ def test_odd_sizes_and_resize_row_tail(detector, oracle, dictionary, test_bmp):
     want = oracle.resize_half(tie)
     assert (want[8:-8, 16:848] == 16).all() and (want[8:-8, 848:852] == 17).all()  # body: half-even, tail: half-up
     detector.detect(tie)
-    assert (detector.debug(0, capi.DBG_HALF).reshape(want.shape) == want).all()
+    assert (detector.debug(0, tk.DBG_HALF).reshape(want.shape) == want).all()
     # the general kernel on an even size equals the exact-2x kernel
     os.environ["CTAG_GENERAL_RESIZE"] = "1"
     try:
         detector.detect(tie)
-        assert (detector.debug(0, capi.DBG_HALF).reshape(want.shape) == want).all()
+        assert (detector.debug(0, tk.DBG_HALF).reshape(want.shape) == want).all()
         o = oracle.detect(test_bmp, state, fs)
         detector.detect(test_bmp)
-        assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all()
+        assert (detector.debug(0, tk.DBG_HALF).reshape(o["half"].shape) == o["half"]).all()
     finally:
         del os.environ["CTAG_GENERAL_RESIZE"]
 
@@ -166,7 +167,7 @@ def _random_shapes_frame(state, seed, rows=720, cols=1152):
     rectangles and quads of many sizes (incl. long bars wider than 128 half-res px and blobs near the 1 % area limit),
     rings, L-shapes, stacked quad pairs (feature candidates), tiny specks, some touching the frame border or a marker."""
     rng = np.random.RandomState(1000 + seed)
-    base = ca.synth_frame_host(state, 500 + seed)[0]
+    base = tk.synth_frame_host(state, 500 + seed)[0]
     y0, x0 = rng.randint(0, base.shape[0] - rows + 1), rng.randint(0, base.shape[1] - cols + 1)
     img = base[y0:y0 + rows, x0:x0 + cols].astype(np.float32)
     yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
@@ -234,15 +235,15 @@ def test_random_shapes_fuzz(detector, oracle, dictionary):
             o = oracle.detect(img, state, fs)
             r = detector.detect(img)
             what = "fuzz seed %d" % seed
-            assert (detector.debug(0, capi.DBG_HALF).reshape(o["half"].shape) == o["half"]).all(), what
-            lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+            assert (detector.debug(0, tk.DBG_HALF).reshape(o["half"].shape) == o["half"]).all(), what
+            lab = detector.debug(0, tk.DBG_LABELS).reshape(o["labels"].shape)
             assert ((lab > 0) == (o["binary"] > 0)).all(), what
             pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
             assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1])), what
-            cand = detector.debug(0, capi.DBG_CANDIDATES)
+            cand = detector.debug(0, tk.DBG_CANDIDATES)
             assert cand.shape[0] == o["candidates"].shape[0] and (cand[:, 0:7] == o["candidates"][:, 1:8]).all(), what
-            assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes(), what
-            for st, which in enumerate((capi.DBG_FEATURES0, capi.DBG_FEATURES1, capi.DBG_FEATURES2)):
+            assert detector.debug(0, tk.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes(), what
+            for st, which in enumerate((tk.DBG_FEATURES0, tk.DBG_FEATURES1, tk.DBG_FEATURES2)):
                 assert detector.debug(0, which).tobytes() == o["features"][st].tobytes(), (what, st)
             assert_same_record(r, oracle.detect_fast(img, state, fs), what)
     finally:
@@ -268,11 +269,11 @@ def test_components_across_tile_seams(detector, oracle, dictionary):
     img[10:1070:7, 636:646] = 20  # thin bars crossing the vertical seam every few rows
     o = oracle.detect(img, state, fs)
     r = detector.detect(img)
-    lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+    lab = detector.debug(0, tk.DBG_LABELS).reshape(o["labels"].shape)
     assert ((lab > 0) == (o["binary"] > 0)).all()
     pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
     assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
-    cand = detector.debug(0, capi.DBG_CANDIDATES)
+    cand = detector.debug(0, tk.DBG_CANDIDATES)
     assert len(cand) == len(o["candidates"]) and (cand[:, 0:5] == o["candidates"][:, 1:6]).all()
     assert_same_record(r, o["result"], "seam stress")
 
@@ -280,13 +281,13 @@ def test_components_across_tile_seams(detector, oracle, dictionary):
 def _stage_check(detector, oracle, state, fs, img, what):
     o = oracle.detect(img, state, fs)
     r = detector.detect(img)
-    lab = detector.debug(0, capi.DBG_LABELS).reshape(o["labels"].shape)
+    lab = detector.debug(0, tk.DBG_LABELS).reshape(o["labels"].shape)
     assert ((lab != 0) == (o["binary"] > 0)).all(), what
     pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
     assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1])), what  # same partition
-    cand = detector.debug(0, capi.DBG_CANDIDATES)
+    cand = detector.debug(0, tk.DBG_CANDIDATES)
     assert cand.shape[0] == o["candidates"].shape[0] and (cand[:, 0:7] == o["candidates"][:, 1:8]).all(), what
-    assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes(), what
+    assert detector.debug(0, tk.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes(), what
     assert_same_record(r, o["result"], what)
     return o, r, lab
 
@@ -307,7 +308,7 @@ def test_dense_speckle_and_texture_take_the_second_ccl_pass(detector, oracle, di
         runs = (np.diff((o["binary"] > 0).astype(np.int8), axis=1, prepend=0) == 1)[:30, :320].sum()
         assert runs > 2048  # the first tile really exceeds the first pass
         # 2. a marker frame with a band of dark noise (640 x 60 and more): the markers elsewhere are still decoded
-        frame, truth = ca.synth_frame_host(state, 11)
+        frame, truth = tk.synth_frame_host(state, 11)
         band = frame.copy()
         band[300:420, 200:1500] = np.clip(rng.normal(25, 8, (120, 1300)), 0, 255).astype(np.uint8)
         o, r, lab = _stage_check(detector, oracle, state, fs, band, "noise band beside markers")
@@ -315,7 +316,7 @@ def test_dense_speckle_and_texture_take_the_second_ccl_pass(detector, oracle, di
         # 3. a lattice of 2x2 half-res dots around the markers of a 1080p frame: ~600 specks per tile fit the first pass, but
         # 54 tiles of them do not fit the frame's component pool -> the tiles that find it full are handed over and the
         # second pass publishes only what can matter
-        dots, truth = ca.synth_frame_host(state, 12)
+        dots, truth = tk.synth_frame_host(state, 12)
         dots = dots.copy()
         yy, xx = np.mgrid[0:1080, 0:1920]
         lattice = ((yy % 8) < 4) & ((xx % 8) < 4)
@@ -363,7 +364,7 @@ def test_long_thin_components_take_the_whole_wave_builds(detector, oracle, dicti
         w, h = cand[:, 4] - cand[:, 2] + 1, cand[:, 5] - cand[:, 3] + 1
         need = ((w + 1) & ~1) + 2 * h + 2 * (np.minimum(2 * (w + h), w * h) + 1) + 4
         assert (need > 8192).any() and ((need > 5120) & (need <= 8192)).any()  # both whole-wave builds had work
-        frame, truth = ca.synth_frame_host(state, 21)
+        frame, truth = tk.synth_frame_host(state, 21)
         hd = frame.copy()
         _draw_polyline(hd, [(40, 6), (1880, 40)], 5)  # a long shallow band along the top: a wave of its own, bitmap over 6 tiles
         for k in range(10):
@@ -391,7 +392,7 @@ def test_many_markers_per_frame(detector, oracle, dictionary):
     numbering / rank sort (feature k lives in lane k & 63 of one of two registers) and its feature cap (100) within reach; one frame
     per call and as a batch."""
     state, fs = dictionary
-    frames = [ca.synth_frame_host(state, idx, markers=mk)[0] for mk in (6, 8) for idx in (5, 6, 7, 8)]
+    frames = [tk.synth_frame_host(state, idx, markers=mk)[0] for mk in (6, 8) for idx in (5, 6, 7, 8)]
     want = np.array([oracle.detect_fast(f, state, fs) for f in frames])
     assert (want["n_features"] > 64).all() and want["n_features"].max() >= 95 and (want["status"] == 0).all()
     for k, f in enumerate(frames):
@@ -403,7 +404,7 @@ def test_many_markers_per_frame(detector, oracle, dictionary):
 
 def test_batch_equals_single_and_is_repeatable(detector, dictionary):
     state, fs = dictionary
-    frames = np.stack([ca.synth_frame_host(state, 100 + f)[0] for f in range(6)])
+    frames = np.stack([tk.synth_frame_host(state, 100 + f)[0] for f in range(6)])
     a = detector.detect_batch(frames)
     b = detector.detect_batch(frames[::-1].copy())[::-1]
     assert a.tobytes() == b.tobytes()  # results do not depend on batch order / neighbours
@@ -493,12 +494,12 @@ def test_decoder_paths_on_other_dictionary_shapes(oracle, dictionary, test_bmp):
     repeated, so the best match is ambiguous and every marker is rejected or kept exactly as the oracle decides), 7 columns
     (shorter than a code: the reversed walk leaves columns negative) and a 41 x 33 random one."""
     state, fs = dictionary
-    frames = [test_bmp, ca.synth_frame_host(state, 3)[0], ca.synth_frame_host(state, 11)[0]]
+    frames = [test_bmp, tk.synth_frame_host(state, 3)[0], tk.synth_frame_host(state, 11)[0]]
     rng = np.random.RandomState(5)
     for name, st in (("12", state), ("24", np.tile(state, (1, 2))), ("36", np.tile(state, (1, 3))), ("7", np.ascontiguousarray(state[:, :7])),
                      ("33 random", rng.randint(0, 64, (41, 33)).astype(np.int32)), ("5 rows", np.ascontiguousarray(state[:5]))):
         st = np.ascontiguousarray(st, dtype=np.int32)
-        det = ca.Detector(st, fs)
+        det = tk.Detector(st, fs)
         try:
             for k, img in enumerate(frames):
                 got, want = det.detect(img), oracle.detect_fast(img, st, fs)
@@ -512,7 +513,7 @@ def test_streamed_host_batch(detector, oracle, dictionary):
     records equal the ORACLE's for pinned and pageable frame memory, odd sub-chunk counts and strided rows."""
     state, fs = dictionary
     n = 7
-    frames = np.stack([ca.synth_frame_host(state, 300 + f)[0] for f in range(n)])
+    frames = np.stack([tk.synth_frame_host(state, 300 + f)[0] for f in range(n)])
     want = np.array([oracle.detect_fast(f, state, fs) for f in frames])
     assert (want["status"] == 0).all() and want["n_markers"].sum() >= 2 * n
     pinned = ca.pinned_empty(frames.shape, np.uint8)
@@ -577,7 +578,7 @@ def test_batch_with_many_oversize_components(detector, oracle, dictionary):
         assert_same_record(got[f], want, "bars frame %d" % f)
         detector.detect(frames[f])
         o = oracle.detect(frames[f], state, fs)
-        assert detector.debug(0, capi.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
+        assert detector.debug(0, tk.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
         assert o["candidates"].shape[0] >= 10
 
 
@@ -590,7 +591,7 @@ def test_full_size_batch_properties(detector, oracle, dictionary):
     n, rows, cols = 512, 1080, 1920
     frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
     detector.synth_frames_device(frames.data_ptr(), 0, n, rows, cols, cols, rows * cols)
-    host0, truth0 = ca.synth_frame_host(state, 0)
+    host0, truth0 = tk.synth_frame_host(state, 0)
     assert (frames[0].cpu().numpy() == host0).all()
     out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
     detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr())
@@ -605,7 +606,7 @@ def test_full_size_batch_properties(detector, oracle, dictionary):
     assert (a["status"] == 0).all() and ((a["flags"] & ~np.uint32(4)) == 0).all()
     exact = 0
     for f in range(n):
-        truth = ca.synth_truth(state, f)
+        truth = tk.synth_truth(state, f)
         planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
         found = sorted(int(x) for x in a[f]["markers"]["marker_id"][:a[f]["n_markers"]])
         exact += planted == found
@@ -696,10 +697,11 @@ def test_packed_shards_and_rccl_gather_single_rank(detector, dictionary):
         detector.gather_wait()
         detector.sync()
         assert (out.cpu().numpy() == host).all() and (rec2.cpu().numpy() == host).all()
-        # bench.py's N > 1 pattern: steps alternate between two handles, each with a communicator of its own; the gather of a
-        # step ends while the next step's detection (other handle, other stream) runs
-        det2 = ca.Detector(state, fs)
-        det2.comm_init(capi.comm_unique_id(), 0, 1)
+        # bench.py's N > 1 pattern: steps alternate between two handles that gather through ONE communicator (the second attaches
+        # to the first's); the gather of a step ends while the next step's detection (other handle, other stream) runs
+        det2 = tk.Detector(state, fs)
+        assert detector.comm_native() and not det2.comm_native()
+        det2.comm_attach(detector.comm_native(), 0, 1)
         try:
             dets, recs, outs = [detector, det2], [torch.zeros_like(rec) for _ in range(2)], [torch.zeros_like(rec) for _ in range(2)]
             pending = None
@@ -720,6 +722,90 @@ def test_packed_shards_and_rccl_gather_single_rank(detector, dictionary):
             det2.close()
     finally:
         detector.comm_destroy()
+
+
+def _gathered_buffer(records, world, width=None):
+    """What the payload all-gather of a `world`-rank job delivers for `records` (uint8 [n_total, 11616]): every rank's packed shard
+    (cylindertag_amd/dist.pack_records, the host restatement of the format) at r * width, padding filled with 0xA5."""
+    from cylindertag_amd.dist import pack_records, shard_range
+    n_total = records.shape[0]
+    shards = [pack_records(records[slice(*shard_range(n_total, r, world))]) for r in range(world)]
+    w = (max(s.size for s in shards) + 255) & ~255
+    width = w if width is None else width
+    assert width >= w and width % 256 == 0
+    buf = np.full(world * width, 0xA5, np.uint8)
+    for r, sh in enumerate(shards):
+        buf[r * width:r * width + sh.size] = sh
+    return buf, width
+
+
+def test_multi_rank_unpack_on_one_gpu(detector, dictionary):
+    """The device path of ctag_gather_end that only a communicator of more than one rank reaches -- the segment table (shard bases
+    r * width, per-shard offset tables, uneven and EMPTY shards) and k_unpack_scan / k_unpack over several segments -- executed on
+    one GPU: the gathered buffer is built on the host from real detector records exactly as the payload all-gather would deliver
+    it, and the unpacked list must equal the one-GPU list byte for byte (include/ctag_testkit.h: ctag_testkit_unpack_gathered)."""
+    import torch
+    n, rows, cols = 160, 1080, 1920
+    frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+    detector.synth_frames_device(frames.data_ptr(), 700, n, rows, cols, cols, rows * cols)
+    frames[3] = 180      # "No corner detected!"
+    frames[4] = 0
+    frames[9, 500:560, 900:930] = 10   # one component, no feature
+    frames[n - 1] = 200  # the last frame of the last shard is an early return
+    torch.cuda.synchronize()
+    rec = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, rec.data_ptr())
+    detector.sync()
+    del frames
+    base = rec.cpu().numpy()
+    assert len(set(base.view(ca.RESULT_DT).ravel()["status"])) >= 2
+    rng = np.random.RandomState(5)
+
+    def check(records, world, width=None):
+        buf, width = _gathered_buffer(records, world, width)
+        n_total = records.shape[0]
+        g = torch.from_numpy(buf).cuda()
+        out = torch.full((max(n_total, 1), ca.RESULT_DT.itemsize), 0xEE, dtype=torch.uint8, device="cuda")
+        detector.unpack_gathered(g.data_ptr(), n_total, world, width, out.data_ptr())
+        got = out.cpu().numpy()[:n_total]
+        assert got.shape == records.shape and (got == records).all(), "world %d, %d frames" % (world, n_total)
+
+    big = base[rng.randint(0, n, 4099)]  # 4099 = 8 * 512 + 3: the first three ranks own one frame more
+    big[-1] = base[n - 1]
+    for world in (2, 4, 8):
+        check(big, world)
+    check(big[:1031], 8, width=((capi.packed_capacity(129) + 255) & ~255))  # a width far above the packed sizes
+    check(base[:3], 8)     # ranks 3..7 own no frame at all
+    check(base[:1], 2)
+    check(base[3:6], 4)    # early returns only: shards without any payload
+    check(base[:0], 4)     # an empty job
+    check(base, 64)        # the largest world the segment table holds
+    check(base, 1)
+    with pytest.raises(ca.CtagError):
+        detector.unpack_gathered(rec.data_ptr(), n, 65, 256, rec.data_ptr())
+    with pytest.raises(ca.CtagError):
+        detector.unpack_gathered(rec.data_ptr(), n, 2, 100, rec.data_ptr())  # width not a multiple of 256
+
+
+def test_two_rank_rccl_gather_when_two_gpus_are_present(dictionary):
+    """A TRUE two-rank ctag_gather (uneven shards, a zero-frame job, two handles sharing one communicator) whenever the box has two
+    GPUs; the one-GPU boxes of this pool skip it (RCCL refuses two ranks on one device)."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    from ctag_testlib import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "gather_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "GATHER_WORKER_OK" in p.stdout
 
 
 def test_cpp_cylindertag_class_demo(oracle, dictionary, test_bmp):
@@ -757,7 +843,7 @@ def test_cpp_cylindertag_class_demo(oracle, dictionary, test_bmp):
 def test_4k_frame(detector, oracle, dictionary):
     """BASELINE config 5 (detect only): a 3840x2160 synthetic frame (strips of 440..840 px) equals the oracle."""
     state, fs = dictionary
-    frame, truth = ca.synth_frame_host(state, 2, rows=2160, cols=3840)
+    frame, truth = tk.synth_frame_host(state, 2, rows=2160, cols=3840)
     got, want = detector.detect(frame), oracle.detect_fast(frame, state, fs)
     assert_same_record(got, want, "4K synthetic frame")
     assert sorted(int(m["marker_id"]) for m in want["markers"][:want["n_markers"]]) == sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])

@@ -21,6 +21,7 @@ def _libasan():
 
 def test_oracles_are_clean_under_asan_ubsan(tmp_path, dictionary):
     import cylindertag_amd as ca
+    import testkit as tk
     lib = _libasan()
     if lib is None:
         pytest.skip("libasan.so not found next to g++")
@@ -32,7 +33,7 @@ def test_oracles_are_clean_under_asan_ubsan(tmp_path, dictionary):
     for k, f in enumerate(avi_substitute(bmp, 4)):
         inputs["seq%d" % k] = f
     for f in range(8):  # the 8 synthetic goldens' inputs
-        inputs["synth%d" % f] = ca.synth_frame_host(state, f)[0]
+        inputs["synth%d" % f] = tk.synth_frame_host(state, f)[0]
     inputs["noise"] = rng.randint(0, 256, (360, 500)).astype(np.uint8)
     inputs["dark_noise"] = rng.randint(0, 40, (300, 420)).astype(np.uint8)       # dense low-level speckle
     inputs["blank"] = np.full((200, 320), 180, np.uint8)

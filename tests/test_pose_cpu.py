@@ -8,6 +8,7 @@ import pytest
 from scipy.optimize import least_squares
 
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import GOLDEN, Oracle, read_bmp_gray, read_marker_file
 from pose_testlib import (PoseOracle, make_camera, make_model_view, project, read_camera_yml, read_model_file, rodrigues,
                           synth_pose_results)
@@ -288,7 +289,7 @@ def test_planted_3d_poses_are_recovered_end_to_end():
     orc, po = Oracle(), PoseOracle()
     rows, cols = 1080, 1920
     K = np.array([[2600.0, 0, 960.0], [0, 2600.0, 540.0], [0, 0, 1]])
-    M, corners = ca.synth3d_model(state)
+    M, corners = tk.synth3d_model(state)
     ids = np.arange(state.shape[0], dtype=np.int32)
     mv = make_model_view({"ids": ids, "size": state.shape[1], "base": np.zeros((len(ids), 3), np.float32),
                           "axis": np.zeros((len(ids), 3), np.float32), "corners": corners})
@@ -296,7 +297,7 @@ def test_planted_3d_poses_are_recovered_end_to_end():
     cam = make_camera(K, np.zeros(5))
     npose = 0
     for f in (0, 1, 2):
-        img, truth = ca.synth3d_frame_host(state, f, K, rows=rows, cols=cols)
+        img, truth = tk.synth3d_frame_host(state, f, K, rows=rows, cols=cols)
         res = orc.detect_fast(img, state, fs)
         assert res["status"] == 0
         planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import GOLDEN, read_bmp_gray
 from pose_testlib import PoseOracle, make_camera, make_model_view, read_camera_yml, read_model_file, synth_pose_results
 
@@ -24,7 +25,7 @@ def env():
     K, dist = read_camera_yml(CAM_PATH)
     model = read_model_file(MODEL_PATH)
     state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
-    det = ca.Detector(state, fs, device=0)
+    det = tk.Detector(state, fs, device=0)
     e = {"K": K, "dist": dist, "model": model, "cam_o": make_camera(K, dist), "mv": make_model_view(model),
          "po": PoseOracle(), "det": det, "M": ca.Model(MODEL_PATH), "cam": ca.load_camera(CAM_PATH)}
     yield e
@@ -131,14 +132,14 @@ def test_config5_4k_detect_plus_pose_known_answers(env):
     state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
     rows, cols, n = 2160, 3840, 6
     K = np.array([[5200.0, 0, 1920.0], [0, 5200.0, 1080.0], [0, 0, 1]])
-    M, corners = ca.synth3d_model(state)
+    M, corners = tk.synth3d_model(state)
     ids = np.arange(state.shape[0], dtype=np.int32)
     mv = make_model_view({"ids": ids, "size": state.shape[1], "base": np.zeros((len(ids), 3), np.float32),
                           "axis": np.zeros((len(ids), 3), np.float32), "corners": corners})
     cam_c, cam_o = ca.make_camera(K, np.zeros(5)), make_camera(K, np.zeros(5))
     frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
     det.synth3d_frames_device(frames.data_ptr(), 0, n, rows, cols, cols, rows * cols, K)
-    host0, truth0 = ca.synth3d_frame_host(state, 0, K)
+    host0, truth0 = tk.synth3d_frame_host(state, 0, K)
     assert (frames[0].cpu().numpy() == host0).all()
     res = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
     det.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, res.data_ptr(), 5, True, 5)
@@ -158,7 +159,7 @@ def test_config5_4k_detect_plus_pose_known_answers(env):
     assert P.tobytes() == want_p.tobytes()
     nposes = 0
     for f in range(n):
-        img_f, truth = (host0, truth0) if f == 0 else ca.synth3d_frame_host(state, f, K)  # the planted poses (and the host rendering)
+        img_f, truth = (host0, truth0) if f == 0 else tk.synth3d_frame_host(state, f, K)  # the planted poses (and the host rendering)
         assert (frames[f].cpu().numpy() == img_f).all()
         planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
         found = sorted(int(m["marker_id"]) for m in recs[f]["markers"][:recs[f]["n_markers"]])

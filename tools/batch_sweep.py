@@ -5,6 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 from ctag_testlib import Oracle, read_marker_file, GOLDEN
 state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
@@ -14,7 +15,7 @@ exec(src[src.index("def _random_shapes_frame"):src.index("def test_random_shapes
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 rows, cols = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (720, 1152)
 frames = np.stack([ns["_random_shapes_frame"](state, 5000 + i, rows, cols) for i in range(n)])
-orc, det = Oracle(), ca.Detector(state, fs)
+orc, det = Oracle(), tk.Detector(state, fs)
 for chunk in (1024, 37):
     det.set_option(capi.OPT_MAX_CHUNK, chunk)
     got = det.detect_batch(frames)

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cylindertag_amd as ca  # noqa: E402
+import testkit as tk  # noqa: E402
 from ctag_testlib import GOLDEN, Oracle, read_marker_file  # noqa: E402
 
 state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
@@ -21,7 +22,7 @@ for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys
     if os.path.exists(p):
         print(p, open(p).read().strip())
 print("loadavg", open("/proc/loadavg").read().strip())
-frames = np.stack([ca.synth_frame_host(state, f)[0] for f in range(64)])
+frames = np.stack([tk.synth_frame_host(state, f)[0] for f in range(64)])
 t = 1
 while t <= hw:
     n = max(16, min(4 * t, 1024))

@@ -8,9 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import read_bmp_gray, GOLDEN
 state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
-det = ca.Detector(state, fs)
+det = tk.Detector(state, fs)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 frames = torch.empty((n, 1080, 1920), dtype=torch.uint8, device="cuda")

@@ -3,14 +3,15 @@ import os, sys
 import numpy as np
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 from ctag_testlib import *
 state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
 img = read_bmp_gray(os.path.join(GOLDEN, "test.bmp"))
-det = ca.Detector(state, fs); orc = Oracle()
+det = tk.Detector(state, fs); orc = Oracle()
 o = orc.resize_half(img)
 det.detect(img)
-h = det.debug(0, capi.DBG_HALF).reshape(o.shape)
+h = det.debug(0, tk.DBG_HALF).reshape(o.shape)
 d = np.argwhere(h != o)
 print("mismatches", len(d), "of", o.size)
 for y, x in d[:12]:

@@ -6,13 +6,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 from ctag_testlib import read_bmp_gray, GOLDEN
 state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
-det = ca.Detector(state, fs)
+det = tk.Detector(state, fs)
 if os.environ.get("LAT_GRAPH"):  # replay the chain as a hipGraph (CTAG_OPT_GRAPH)
     det.set_option(capi.OPT_GRAPH, 1)
-imgs = {"bmp": read_bmp_gray(os.path.join(GOLDEN, "test.bmp")), "syn": ca.synth_frame_host(state, 0)[0]}
+imgs = {"bmp": read_bmp_gray(os.path.join(GOLDEN, "test.bmp")), "syn": tk.synth_frame_host(state, 0)[0]}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for name, img in imgs.items():
     for _ in range(5): det.detect(img)

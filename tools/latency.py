@@ -5,12 +5,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 from ctag_testlib import read_bmp_gray, GOLDEN
 state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
-det = ca.Detector(state, fs)
+det = tk.Detector(state, fs)
 bmp = read_bmp_gray(os.path.join(GOLDEN, "test.bmp"))
-syn = ca.synth_frame_host(state, 0)[0]
+syn = tk.synth_frame_host(state, 0)[0]
 model = ca.Model(os.path.join(GOLDEN, "CTag_2f12c.model")); cam = ca.load_camera(os.path.join(GOLDEN, "cameraParams.yml"))
 for name, img in (("test.bmp 1920x1200", bmp), ("synthetic 1920x1080", syn)):
     for _ in range(5): r = det.detect(img)

@@ -6,22 +6,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import Oracle, read_bmp_gray, read_marker_file, GOLDEN
 state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
 bmp = read_bmp_gray(os.path.join(GOLDEN, "test.bmp"))
-orc, det = Oracle(), ca.Detector(state, fs)
+orc, det = Oracle(), tk.Detector(state, fs)
 rng = np.random.RandomState(2024)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
 for case in range(n):
     kind = rng.randint(0, 3)
     if kind == 0:
-        img = ca.synth_frame_host(state, 2000 + case)[0]
+        img = tk.synth_frame_host(state, 2000 + case)[0]
     elif kind == 1:
         y0, x0 = rng.randint(0, 100), rng.randint(0, 200)
         img = np.ascontiguousarray(bmp[y0:y0 + rng.randint(500, 1100), x0:x0 + rng.randint(700, 1700)])
     else:
-        img = ca.synth_frame_host(state, 3000 + case)[0]
+        img = tk.synth_frame_host(state, 3000 + case)[0]
         h, w = rng.randint(300, 1081), rng.randint(400, 1921)  # any size, odd ones included
         img = np.ascontiguousarray(img[:h, :w])
     tw = int(rng.choice([3, 4, 5, 5, 5, 6, 7, 9, 12]))

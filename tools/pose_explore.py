@@ -1,13 +1,14 @@
 import os, sys, numpy as np, torch, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import *
 from pose_testlib import *
 K, dist = read_camera_yml(os.path.join(GOLDEN, "cameraParams.yml"))
 model = read_model_file(os.path.join(GOLDEN, "CTag_2f12c.model"))
 cam_o = make_camera(K, dist); mv = make_model_view(model); po = PoseOracle()
 state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
-det = ca.Detector(state, fs)
+det = tk.Detector(state, fs)
 M = ca.Model(os.path.join(GOLDEN, "CTag_2f12c.model")); cam = ca.load_camera(os.path.join(GOLDEN, "cameraParams.yml"))
 res = det.detect(read_bmp_gray(os.path.join(GOLDEN, "test.bmp")), 5, True, 5)
 got = det.estimate_pose(res, M, cam)

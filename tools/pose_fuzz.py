@@ -6,12 +6,13 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import GOLDEN
 from pose_testlib import PoseOracle, make_camera, make_model_view, read_camera_yml, read_model_file, synth_pose_results
 K, dist = read_camera_yml(os.path.join(GOLDEN, "cameraParams.yml"))
 model = read_model_file(os.path.join(GOLDEN, "CTag_2f12c.model"))
 state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
-det = ca.Detector(state, fs)
+det = tk.Detector(state, fs)
 M, cam = ca.Model(os.path.join(GOLDEN, "CTag_2f12c.model")), ca.load_camera(os.path.join(GOLDEN, "cameraParams.yml"))
 po, cam_o, mv = PoseOracle(), make_camera(K, dist), make_model_view(model)
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 16

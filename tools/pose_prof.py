@@ -10,6 +10,7 @@ import torch
 sys.path.insert(0, "tests")
 sys.path.insert(0, ".")
 import cylindertag_amd as ca
+import testkit as tk
 from ctag_testlib import GOLDEN
 from pose_testlib import read_camera_yml, read_model_file, synth_pose_results
 
@@ -17,7 +18,7 @@ n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K, dist = read_camera_yml(os.path.join(GOLDEN, "cameraParams.yml"))
 model = read_model_file(os.path.join(GOLDEN, "CTag_2f12c.model"))
 state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
-det = ca.Detector(state, fs)
+det = tk.Detector(state, fs)
 M = ca.Model(os.path.join(GOLDEN, "CTag_2f12c.model"))
 cam = ca.load_camera(os.path.join(GOLDEN, "cameraParams.yml"))
 recs, truth = synth_pose_results(model, K, dist, 512, 1)

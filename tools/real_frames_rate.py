@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 from ctag_testlib import read_bmp_gray, read_marker_file, GOLDEN
 from sequences import avi_substitute
@@ -16,7 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rows, cols = seq.shape[1:]
 frames = torch.from_numpy(np.concatenate([seq] * (n // len(seq)))).cuda()
 n = frames.shape[0]
-det = ca.Detector(state, fs); det.set_option(capi.OPT_MAX_CHUNK, n)
+det = tk.Detector(state, fs); det.set_option(capi.OPT_MAX_CHUNK, n)
 out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
 run = lambda: det.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr(), 5, True, 5)
 run(); det.sync()

@@ -7,12 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
 rows, cols = 1080, 1920
-dets = [ca.Detector(state, fs) for _ in range(3)]
+dets = [tk.Detector(state, fs) for _ in range(3)]
 frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
 dets[0].synth_frames_device(frames.data_ptr(), 0, n, rows, cols, cols, rows * cols)
 outs = [torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda") for _ in range(3)]

@@ -8,18 +8,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import cylindertag_amd as ca
+import testkit as tk
 from cylindertag_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ways_list = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4]
 state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
 rows, cols = 1080, 1920
 frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
-d0 = ca.Detector(state, fs)
+d0 = tk.Detector(state, fs)
 d0.synth_frames_device(frames.data_ptr(), 0, n, rows, cols, cols, rows * cols)
 out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
 ref = None
 for ways in ways_list:
-    dets = [ca.Detector(state, fs) for _ in range(ways)]
+    dets = [tk.Detector(state, fs) for _ in range(ways)]
     m = n // ways
     for d in dets:
         d.set_option(capi.OPT_MAX_CHUNK, m)
