@@ -176,7 +176,7 @@ void CylinderTag::loadCamera(const std::string& path, CamInfo& camera) {
 // markers[first...] -> one flat record; returns the index of the first marker that did not fit (records hold at most
 // CTAG_MAX_MARKERS markers / CTAG_MAX_FEATURES features: estimatePose walks a longer list in several records, nothing
 // is dropped).  A single marker with more features than a record holds cannot come from detect() (the reference's
-// father[100], corner_detector.h:143) and is reported.
+// father[100], corner_detector.h:143); estimatePose rejects such a list before it calls this.
 static size_t flatten(const std::vector<MarkerInfo>& markers, size_t first, ctag_frame_result& r) {
     std::memset(&r, 0, sizeof(r));
     r.status = CTAG_OK;
@@ -185,8 +185,7 @@ static size_t flatten(const std::vector<MarkerInfo>& markers, size_t first, ctag
     for (; m < markers.size() && r.n_markers < CTAG_MAX_MARKERS; m++) {
         const MarkerInfo& mi = markers[m];
         const int n = (int)mi.cornerLists.size();
-        if (n > CTAG_MAX_FEATURES) throw std::string("estimatePose, a marker with more than 100 features\n");
-        if (nf + n > CTAG_MAX_FEATURES) break;
+        if (nf + n > CTAG_MAX_FEATURES) break;  // n <= CTAG_MAX_FEATURES: estimatePose validated the list
         ctag_marker_rec& M = r.markers[r.n_markers++];
         M.marker_id = mi.markerID;
         M.first_feature = nf;
@@ -216,6 +215,8 @@ void CylinderTag::estimatePose(const Mat& img, std::vector<MarkerInfo> markers, 
     (void)useDensePoseRefine;
     pose.clear();
     if (markers.empty()) return;
+    for (const MarkerInfo& mi : markers)  // checked before anything is allocated: flatten() cannot fail afterwards
+        if (mi.cornerLists.size() > (size_t)CTAG_MAX_FEATURES) throw std::string("estimatePose, a marker with more than 100 features\n");
     // vector<ModelInfo> -> ctag_model (every model must hold the same number of corners, as loadModel produces)
     const size_t nm = reconstruct_model.size();
     const size_t per = nm ? reconstruct_model[0].corners.size() : 8;

@@ -201,7 +201,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_ncand = take(F * 4);
     const size_t o_cand = take(F * kCandCap * sizeof(Candidate));
     const size_t o_quads = take(F * kCandCap * sizeof(QuadOut));
-    const size_t o_lcount = take(F * 4), o_clused = take(F * 4);
+    const size_t o_lcount = take(F * 4), o_clused = take(F * 4), o_llong = take(F * 4);
     const size_t o_clpool = take(F * kClPool * 4);
     const size_t o_ldesc = take(F * kLineCap * sizeof(LineDesc));
     const size_t o_lsort = take(F * kLineCap * 4);
@@ -249,6 +249,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.cl_pool = reinterpret_cast<uint32_t*>(b + o_clpool);
     W.line_desc = reinterpret_cast<LineDesc*>(b + o_ldesc);
     W.line_sorted = reinterpret_cast<int32_t*>(b + o_lsort);
+    W.line_long = reinterpret_cast<int32_t*>(b + o_llong);
     W.line_fit = reinterpret_cast<float*>(b + o_lfit);
     W.cand_aux = reinterpret_cast<CandAux*>(b + o_aux);
     W.npacks = reinterpret_cast<int32_t*>(b + o_npk);

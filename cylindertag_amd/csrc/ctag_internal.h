@@ -116,6 +116,7 @@ struct Workspace {
     uint32_t* cl_pool = nullptr;    // [F][kClPool]
     LineDesc* line_desc = nullptr;  // [F][kLineCap]
     int32_t* line_sorted = nullptr; // [F][kLineCap]
+    int32_t* line_long = nullptr;   // [F] edges of more than 10 points (the first ranks of line_sorted)
     float* line_fit = nullptr;      // [F][kLineCap][4]
     CandAux* cand_aux = nullptr;    // [F][kCandCap]
     int32_t* npacks = nullptr;      // [F]

@@ -34,6 +34,7 @@ struct QuadPtrs {
     uint32_t* cl_pool;     // [F][kClPool] packed (x | y << 16) points, in the order the reference pushes them
     LineDesc* line_desc;   // [F][kLineCap]
     int32_t* line_sorted;  // [F][kLineCap] line ids by descending point count
+    int32_t* line_long;    // [F] edges of more than kWShort points = the first ranks of line_sorted
     float* line_fit;       // [F][kLineCap][4]
     CandAux* cand_aux;     // [F][kCandCap]
     const uint8_t* pick_table;  // [kPickN][20][10] cv::RNG initial samples of fitLine2D for every point count < kPickN
@@ -97,15 +98,56 @@ struct CvRng {
 #define CTAG_PRAGMA_(x) _Pragma(#x)
 #define CTAG_PRAGMA(x) CTAG_PRAGMA_(x)
 constexpr int kWCap = CTAG_WCAP;  // Welsch weights of the first kWCap points are kept in LDS between the two passes
-// wc: this lane's column of a [kWCap][64] float array in LDS (element j at wc[j * 64]); nullptr = always recompute
-__device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks, int npick, double EPS, float* out_line, double* out_err, float* wc = nullptr) {
+// Point sources of a restart: the cluster in global memory as packed (x | y << 16) words, or -- for a wave's three edges of at most
+// kWPts points -- the same points converted to float pairs once per block in LDS (the 20 restarts of an edge read the same
+// address: a broadcast, and the two integer unpacks, two converts and the scattered global load per point and pass are gone).
+struct GlobalPts {
+    const uint32_t* p;
+    __device__ __forceinline__ float2 operator()(int j) const {
+        const uint32_t v = p[j];
+        return make_float2((float)ux(v), (float)uy(v));
+    }
+};
+struct LdsPts {
+    const float2* p;
+    __device__ __forceinline__ float2 operator()(int j) const { return p[j]; }
+};
+// Initial samples: the precomputed cv::RNG table (bytes, point counts below kPickN), a replayed list (16-bit), or -- short edges --
+// every point of the edge.
+struct TablePicks {
+    const uint8_t* t;
+    __device__ __forceinline__ int operator()(int i) const { return t[i]; }
+};
+struct ListPicks {
+    const uint16_t* t;
+    __device__ __forceinline__ int operator()(int i) const { return t[i]; }
+};
+struct AllPicks {
+    __device__ __forceinline__ int operator()(int i) const { return i; }
+};
+// wc: this lane's column of a [kWCap][64] float array in LDS (element j at wc[j * 64]); nullptr = always recompute.
+// The restart's results go to res[q * rstride]: the line in q = 0..3, the two halves of the error (a double) in q = 4, 5 -- with
+// res = wc and rstride = 64 they land in the lane's own weight column, which is dead by then (needs kWCap >= 6).
+struct RestartResult {
+    float line[4];
+    double err;
+};
+__device__ __forceinline__ RestartResult restart_result(const float* res, int rstride) {
+    RestartResult r;
+    for (int q = 0; q < 4; q++) r.line[q] = res[q * rstride];
+    const uint64_t lo = ctm::f32_to_bits(res[4 * rstride]), hi = ctm::f32_to_bits(res[5 * rstride]);
+    r.err = ctm::bits_to_f64(lo | (hi << 32));
+    return r;
+}
+template <class Pts, class Picks>
+__device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npick, double EPS, float* res, int rstride, float* wc = nullptr) {
     const int ncache = wc ? min(n, kWCap) : 0;
     float line[4], prev[4] = {0.f, 0.f, 0.f, 0.f};
     {
         double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
         for (int i = 0; i < npick; i++) {  // zero-weight points add +0.0: skipping them is exact
-            const uint32_t p = pts[picks[i]];
-            const float px = (float)ux(p), py = (float)uy(p);
+            const float2 p = pts(picks(i));
+            const float px = p.x, py = p.y;
             x += px;
             y += py;
             x2 += px * px;
@@ -133,24 +175,24 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
         const float lx = line[2], ly = line[3], nx = line[1], ny = -line[0];
         double sum_w = 0;
         err = 0;
-        uint32_t pn0 = pts[min(0, n - 1)];  // next point, loaded one trip ahead
+        float2 pn0 = pts(min(0, n - 1));  // next point, loaded one trip ahead
         CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = 0; j < ncache; j++) {
-            const uint32_t p = pn0;
-            pn0 = pts[min(j + 1, n - 1)];
-            const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
+            const float2 p = pn0;
+            pn0 = pts(min(j + 1, n - 1));
+            const float x = p.x - lx, y = p.y - ly;
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
             const float wj = ctm::exp32(-r * r * c * c);
             wc[j * 64] = wj;
             sum_w += wj;
         }
-        uint32_t pn1 = pts[min(ncache, n - 1)];  // next point, loaded one trip ahead
+        float2 pn1 = pts(min(ncache, n - 1));  // next point, loaded one trip ahead
         CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = ncache; j < n; j++) {
-            const uint32_t p = pn1;
-            pn1 = pts[min(j + 1, n - 1)];
-            const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
+            const float2 p = pn1;
+            pn1 = pts(min(j + 1, n - 1));
+            const float x = p.x - lx, y = p.y - ly;
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
             sum_w += ctm::exp32(-r * r * c * c);
@@ -159,12 +201,12 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
         double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
         if (ctm::fabs64(sum_w) > 1.1920928955078125e-07) {
             const double inv = 1. / sum_w;
-        uint32_t pn2 = pts[min(0, n - 1)];  // next point, loaded one trip ahead
+        float2 pn2 = pts(min(0, n - 1));  // next point, loaded one trip ahead
             CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = 0; j < ncache; j++) {
-                const uint32_t p = pn2;
-                pn2 = pts[min(j + 1, n - 1)];
-                const float px = (float)ux(p), py = (float)uy(p);
+                const float2 p = pn2;
+                pn2 = pts(min(j + 1, n - 1));
+                const float px = p.x, py = p.y;
                 const float wj = (float)(wc[j * 64] * inv);
                 x += wj * px;
                 y += wj * py;
@@ -173,12 +215,12 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
                 xy += wj * px * py;
                 w += wj;
             }
-        uint32_t pn3 = pts[min(ncache, n - 1)];  // next point, loaded one trip ahead
+        float2 pn3 = pts(min(ncache, n - 1));  // next point, loaded one trip ahead
             CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = ncache; j < n; j++) {
-                const uint32_t p = pn3;
-                pn3 = pts[min(j + 1, n - 1)];
-                const float px = (float)ux(p), py = (float)uy(p);
+                const float2 p = pn3;
+                pn3 = pts(min(j + 1, n - 1));
+                const float px = p.x, py = p.y;
                 const float r = ctm::fabs32(nx * (px - lx) + ny * (py - ly));
                 const float wj = (float)(ctm::exp32(-r * r * c * c) * inv);
                 x += wj * px;
@@ -189,11 +231,11 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
                 w += wj;
             }
         } else {
-            uint32_t pn4 = pts[min(0, n - 1)];  // next point, loaded one trip ahead
+            float2 pn4 = pts(min(0, n - 1));  // next point, loaded one trip ahead
             for (int j = 0; j < n; j++) {
-                const uint32_t p = pn4;
-                pn4 = pts[min(j + 1, n - 1)];
-                const float px = (float)ux(p), py = (float)uy(p);
+                const float2 p = pn4;
+                pn4 = pts(min(j + 1, n - 1));
+                const float px = p.x, py = p.y;
                 x += px;
                 y += py;
                 x2 += px * px;
@@ -208,11 +250,10 @@ __device__ void welsch_restart(const uint32_t* pts, int n, const uint16_t* picks
         prev[3] = line[3];
         moments_to_line(x, y, x2, y2, xy, w, line);
     }
-    out_line[0] = line[0];
-    out_line[1] = line[1];
-    out_line[2] = line[2];
-    out_line[3] = line[3];
-    *out_err = err;
+    for (int q = 0; q < 4; q++) res[q * rstride] = line[q];
+    const uint64_t eb = ctm::f64_to_bits(err);
+    res[4 * rstride] = ctm::bits_to_f32((uint32_t)eb);
+    res[5 * rstride] = ctm::bits_to_f32((uint32_t)(eb >> 32));
 }
 
 // ---- sub-wave packing: 8 components per wave, 8 lanes each (k_quad_edges_packed) -------------------------
@@ -1318,15 +1359,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 // K6s: per frame, order the edge clusters by descending point count so that the three edges a Welsch wave
 // fits together cost about the same (scheduling only: results do not depend on this order).
 // =====================================================================================================
+// An edge of at most 10 points: fitLine2D's initial sample of min(n, 10) distinct indices is ALL of its points whatever cv::RNG
+// draws, so its 20 restarts are the same computation twenty times and the selection keeps restart 0 (a later equal error
+// is not smaller).  Such edges -- 46 % of the edges of the synthetic batch -- are fitted once, a lane each (welsch_short).
+constexpr int kWShort = 10;
 constexpr int kLineSortThreads = 1024;  // a rank sort: L / threads passes of L comparisons each; one frame has ~400 edges
 __global__ __launch_bounds__(kLineSortThreads) void k_line_sort(QuadPtrs P, int nframes) {
     __shared__ int s_n[kLineCap];
+    __shared__ int s_long;
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], kLineCap);
     const LineDesc* d = P.line_desc + (size_t)frame * kLineCap;
-    for (int i = threadIdx.x; i < L; i += kLineSortThreads) s_n[i] = d[i].n;
+    if (threadIdx.x == 0) s_long = 0;
     __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < L; i += kLineSortThreads) {
+        const int n = d[i].n;
+        s_n[i] = n;
+        mine += n > kWShort ? 1 : 0;
+    }
+    if (mine) atomicAdd(&s_long, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) P.line_long[frame] = s_long;  // ranks [0, s_long) of the sorted list hold the edges of more than kWShort points
     int32_t* out = P.line_sorted + (size_t)frame * kLineCap;
     for (int i = threadIdx.x; i < L; i += kLineSortThreads) {
         const int ni = s_n[i];
@@ -1345,11 +1400,34 @@ __global__ __launch_bounds__(kLineSortThreads) void k_line_sort(QuadPtrs P, int 
 // sequence depends only on the point count, so it comes from a table (or is replayed for very long edges).
 // The best-restart selection replays the reference's sequential `err < min_err` / `err < EPS` logic.
 // =====================================================================================================
-__device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int first, int L) {
-    __shared__ double s_err[60];
-    __shared__ float s_line[60][4];
-    __shared__ uint16_t s_pk[60][10];
-    __shared__ float s_wc[kWCap > 0 ? kWCap * 64 : 1];
+// fitLine2D's choice among `count` restarts whose results sit at res + kk * kstride (element q at [q * rstride]): the first restart
+// below EPS ends the search, else the first minimum wins
+__device__ __forceinline__ void welsch_select(const QuadPtrs& P, int frame, int lid, int n, const float* res, int kstride, int rstride, int count) {
+    const double EPS = n * 1.1920928955078125e-07;
+    double min_err = 1.7976931348623157e308;
+    float best[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < count; kk++) {
+        const RestartResult r = restart_result(res + kk * kstride, rstride);
+        if (r.err < min_err) {
+            min_err = r.err;
+            for (int q = 0; q < 4; q++) best[q] = r.line[q];
+            if (r.err < EPS) break;
+        }
+    }
+    float* o = P.line_fit + ((size_t)frame * kLineCap + lid) * 4;
+    for (int q = 0; q < 4; q++) o[q] = best[q];
+}
+
+// LDS of a k_welsch wave: the weight columns (which also receive the restarts' results) and the staged points of its three edges;
+// the replayed pick lists of edges of kPickN points and more (never staged: kPickN > kWPts) live in the point area
+constexpr int kWPts = 128;  // points of an edge staged in LDS as float pairs; a triple with a longer edge reads global memory
+static_assert(kWCap >= 10 && kWPts < kPickN && 3 * kWPts * 8 >= 64 * 10 * 2, "k_welsch LDS layout");
+struct WelschLds {
+    float wc[kWCap * 64];
+    float2 pt[3][kWPts];
+};
+
+__device__ __forceinline__ void welsch_three(const QuadPtrs& P, WelschLds& S, int frame, int first, int L) {
     const int lane = threadIdx.x;
     const int grp = lane / 20, k = lane - grp * 20;
     const bool active = lane < 60 && first + grp < L;
@@ -1360,24 +1438,37 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int f
         const LineDesc d = P.line_desc[(size_t)frame * kLineCap + lid];
         n = d.n;
         pts = P.cl_pool + (size_t)frame * kClPool + d.off;
-        const int npick = min(n, 10);
-        uint16_t* pk = s_pk[lane];
+    }
+    // the triple's edges are sorted by descending length: the first one decides whether all three fit the staged form
+    const int n_first = __shfl(n, 0, 64);
+    const double EPS = n * 1.1920928955078125e-07;
+    if (n_first <= kWPts) {
+        if (active) {
+            for (int j = k; j < n; j += 20) {
+                const uint32_t v = pts[j];
+                S.pt[grp][j] = make_float2((float)ux(v), (float)uy(v));
+            }
+        }
+        __syncthreads();
+        if (active)
+            welsch_restart(LdsPts{S.pt[grp]}, n, TablePicks{P.pick_table + ((size_t)n * 20 + k) * 10}, min(n, 10), EPS, S.wc + lane, 64, S.wc + lane);
+    } else if (active) {
         if (n < kPickN) {
-            const uint8_t* t = P.pick_table + ((size_t)n * 20 + k) * 10;
-            for (int q = 0; q < npick; q++) pk[q] = t[q];
+            welsch_restart(GlobalPts{pts}, n, TablePicks{P.pick_table + ((size_t)n * 20 + k) * 10}, 10, EPS, S.wc + lane, 64, S.wc + lane);
         } else {  // replay cv::RNG up to this restart
+            uint16_t* pk = reinterpret_cast<uint16_t*>(&S.pt[0][0]) + lane * 10;
             CvRng rng;
             rng.state = 0xffffffffffffffffULL;
             for (int kk = 0; kk <= k; kk++) {
                 int got = 0;
-                while (got < npick) {
+                while (got < 10) {
                     const int j = (int)(rng.next() % (unsigned)n);
                     bool dup = false;
                     for (int q = 0; q < got; q++) dup |= (pk[q] == j);
                     if (!dup) pk[got++] = (uint16_t)j;
                 }
             }
-            for (int a = 1; a < npick; a++) {
+            for (int a = 1; a < 10; a++) {
                 const uint16_t v = pk[a];
                 int b = a - 1;
                 while (b >= 0 && pk[b] > v) {
@@ -1386,25 +1477,22 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, int frame, int f
                 }
                 pk[b + 1] = v;
             }
+            welsch_restart(GlobalPts{pts}, n, ListPicks{pk}, 10, EPS, S.wc + lane, 64, S.wc + lane);
         }
-        welsch_restart(pts, n, pk, npick, n * 1.1920928955078125e-07, s_line[lane], &s_err[lane], kWCap > 0 ? s_wc + lane : nullptr);
     }
     __syncthreads();
-    if (active && k == 0) {
-        const double EPS = n * 1.1920928955078125e-07;
-        double min_err = 1.7976931348623157e308;
-        float best[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int kk = 0; kk < 20; kk++) {
-            const double e = s_err[grp * 20 + kk];
-            if (e < min_err) {
-                min_err = e;
-                for (int q = 0; q < 4; q++) best[q] = s_line[grp * 20 + kk][q];
-                if (e < EPS) break;
-            }
-        }
-        float* o = P.line_fit + ((size_t)frame * kLineCap + lid) * 4;
-        for (int q = 0; q < 4; q++) o[q] = best[q];
-    }
+    if (active && k == 0) welsch_select(P, frame, lid, n, S.wc + lane, 1, 64, 20);
+}
+
+// Edges of at most kWShort points, a lane each: ONE restart on all of the edge's points (see kWShort)
+__device__ __forceinline__ void welsch_short(const QuadPtrs& P, WelschLds& S, int frame, int first, int L) {
+    const int lane = threadIdx.x;
+    if (first + lane >= L) return;
+    const int lid = P.line_sorted[(size_t)frame * kLineCap + first + lane];
+    const LineDesc d = P.line_desc[(size_t)frame * kLineCap + lid];
+    const int n = d.n;  // 2 <= n <= kWShort <= kWCap: every weight stays in LDS
+    welsch_restart(GlobalPts{P.cl_pool + (size_t)frame * kClPool + d.off}, n, AllPicks{}, n, n * 1.1920928955078125e-07, S.wc + lane, 64, S.wc + lane);
+    welsch_select(P, frame, lid, n, S.wc + lane, 0, 64, 1);
 }
 
 // ---- few-frame calls: one wave per (edge, restart) ------------------------------------------------------------------
@@ -1604,7 +1692,7 @@ __device__ __forceinline__ void welsch_pick(const QuadPtrs& P, int frame, int ra
 #ifndef CTAG_WELSCH_WAVES
 #define CTAG_WELSCH_WAVES 5
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes, const float* lat_rs) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes, const float* lat_rs, int gy_long) {
     // Longest first across the WHOLE batch: blockIdx.x (the fast dispatch index) is the frame, blockIdx.y the rank of the
     // edge triple in the frame's list sorted by descending point count.  The longest triples of all frames are dispatched
     // first and the kernel drains on the short ones: a long triple runs ~0.3 ms as a lone wave, and with the triple rank on
@@ -1620,9 +1708,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_
     // the first ranks are the long edges: their waves are the kernel's critical path, so they get issue priority over the short
     // ones they share a SIMD with (s_setprio; the bulk fills the slots they leave)
     if (blockIdx.y < (unsigned)CTAG_WELSCH_PRIO_RANKS) __builtin_amdgcn_s_setprio(3);
-    for (int first = (int)blockIdx.y * 3; first < L; first += gridDim.y * 3) {
-        welsch_three(P, frame, first, L);
-        __syncthreads();
+    __shared__ WelschLds S;
+    const int nlong = min(P.line_long[frame], L);  // ranks [0, nlong): edges of more than kWShort points, three per wave x 20 restarts
+    if ((int)blockIdx.y < gy_long) {
+        for (int first = (int)blockIdx.y * 3; first < nlong; first += gy_long * 3) {
+            welsch_three(P, S, frame, first, nlong);
+            __syncthreads();
+        }
+    } else {  // ranks [nlong, L): 64 short edges per wave, one restart each
+        for (int first = nlong + ((int)blockIdx.y - gy_long) * 64; first < L; first += ((int)gridDim.y - gy_long) * 64) welsch_short(P, S, frame, first, L);
     }
 }
 
@@ -1772,7 +1866,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         if (ev5) (void)hipEventRecord(ev5[evi++], s);
     };
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
@@ -1829,7 +1923,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(kLineSortThreads), 0, s, P, nframes);
     mark();
-    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 144;  // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144: fewer empty blocks, 6.74 -> 6.59 ms)
+    static const int welsch_gs = getenv("CTAG_WELSCH_GS") ? atoi(getenv("CTAG_WELSCH_GS")) : 4;   // blocks per frame for the edges of <= 10 points, 64 per wave
+    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 72;   // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144 -> 72 once the short edges left: fewer empty blocks)
     if (latency && ws.welsch_rs) {  // one wave per (edge, restart); frames it declines (more edges / longer edges than it holds) fall through to k_welsch
         if (fork) {  // the long edges beside the short ones
             (void)hipEventRecord(ws.ev_fork, s);
@@ -1842,7 +1937,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
             (void)hipStreamWaitEvent(s, ws.ev_join, 0);
         }
     }
-    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr);
+    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx + welsch_gs), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr, welsch_gx);
     mark();
     hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {

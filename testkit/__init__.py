@@ -18,7 +18,7 @@ TRUTH3D_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("_pad",
                        ("radius", "<f8", (8,))])
 TRUTH_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("strip_len", "<f4", (8,)),
                      ("corners", "<f4", (8, 8))])
-DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS, DBG_GRAY = range(1, 10)
+DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS, DBG_GRAY, DBG_LINES = range(1, 11)
 SYNTH_SEED = 0x4354616753594E00  # "CTagSYN\0", SURVEY.md 8(d)
 
 # every symbol include/ctag_testkit.h declares (tests check the library exports all of them)
@@ -154,7 +154,7 @@ class Detector(ca.Detector):
             raise CtagError(-1, "ctag_debug_fetch(%d)" % what)
         if what in (DBG_HALF, DBG_GRAY):
             a = np.zeros(n, np.uint8)
-        elif what in (DBG_LABELS, DBG_CANDIDATES):
+        elif what in (DBG_LABELS, DBG_CANDIDATES, DBG_LINES):
             a = np.zeros(n, np.int32)
         elif what == DBG_PREMARKERS:
             a = np.zeros(1, ca.RESULT_DT)

@@ -214,6 +214,18 @@ long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t cap
             }
             return (long)nf * 19;
         }
+        case CTAG_DBG_LINES: {
+            int nl = 0;
+            if (!d2h(&nl, W.line_count + frame, 4)) return -2;
+            nl = std::min(nl, kLineCap);
+            if (dst && cap >= (size_t)nl && nl > 0) {
+                std::vector<LineDesc> d(nl);
+                if (!d2h(d.data(), W.line_desc + (size_t)frame * kLineCap, sizeof(LineDesc) * nl)) return -2;
+                int32_t* o = static_cast<int32_t*>(dst);
+                for (int i = 0; i < nl; i++) o[i] = d[i].n;
+            }
+            return (long)nl;
+        }
         case CTAG_DBG_PREMARKERS: {
             if (!v.keep_pre) return -1;
             if (dst && cap >= 1) {
