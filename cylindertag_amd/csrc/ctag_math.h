@@ -49,37 +49,21 @@ CTM_HD double atan64(double x) {
         double z = hi3 + lo3;
         return neg ? -z : z;
     }
-    int id;
-    double t;
-    if (ax < 0.4375) {
-        if (ax < 3.725290298461914e-09) return x;  // 2^-28
-        id = -1;
-        t = ax;
-    } else if (ax < 0.6875) {
-        id = 0;
-        t = (2.0 * ax - 1.0) / (2.0 + ax);
-    } else if (ax < 1.1875) {
-        id = 1;
-        t = (ax - 1.0) / (ax + 1.0);
-    } else if (ax < 2.4375) {
-        id = 2;
-        t = (ax - 1.5) / (1.0 + 1.5 * ax);
-    } else {
-        id = 3;
-        t = -1.0 / ax;
-    }
+    // One division whatever the range (selected numerator / denominator: a wave whose lanes fall into different ranges runs
+    // one division, not five paths one after the other); below 0.4375 t = ax / 1.0, which is ax exactly.
+    if (ax < 3.725290298461914e-09) return x;  // 2^-28
+    const int id = ax < 0.4375 ? -1 : ax < 0.6875 ? 0 : ax < 1.1875 ? 1 : ax < 2.4375 ? 2 : 3;
+    const double num = id < 0 ? ax : id == 0 ? 2.0 * ax - 1.0 : id == 1 ? ax - 1.0 : id == 2 ? ax - 1.5 : -1.0;
+    const double den = id < 0 ? 1.0 : id == 0 ? 2.0 + ax : id == 1 ? ax + 1.0 : id == 2 ? 1.0 + 1.5 * ax : ax;
+    const double t = num / den;
     const double z = t * t;
     const double w = z * z;
     const double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
     const double s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
-    double r;
-    if (id < 0) {
-        r = t - t * (s1 + s2);
-    } else {
-        const double h = id == 0 ? hi0 : id == 1 ? hi1 : id == 2 ? hi2 : hi3;
-        const double l = id == 0 ? lo0 : id == 1 ? lo1 : id == 2 ? lo2 : lo3;
-        r = h - ((t * (s1 + s2) - l) - t);
-    }
+    const double h = id == 0 ? hi0 : id == 1 ? hi1 : id == 2 ? hi2 : hi3;
+    const double l = id == 0 ? lo0 : id == 1 ? lo1 : id == 2 ? lo2 : lo3;
+    const double ts = t * (s1 + s2);
+    const double r = id < 0 ? t - ts : h - ((ts - l) - t);
     return neg ? -r : r;
 }
 
@@ -179,6 +163,18 @@ CTM_HD double cos64(double x) {
     }
 }
 
+// sin64(x) and cos64(x) at once, bit for bit what the two calls return: one argument reduction, both kernels evaluated once and
+// assigned by quadrant with selects (lanes in different quadrants do not run the four cases one after the other)
+CTM_HD void sincos64(double x, double* s, double* c) {
+    double r = x;
+    int q = 0;
+    if (!(fabs64(x) <= 7.85398163397448278999e-01)) q = rem_pio2_64(x, &r);
+    const double ks = ksin64(r), kc = kcos64(r);
+    const double sv = (q & 1) ? kc : ks, cv = (q & 1) ? ks : kc;
+    *s = (q & 2) ? -sv : sv;
+    *c = ((q + 1) & 2) ? -cv : cv;
+}
+
 // ---------------------------------------------------------------- exp (double), acos (double)
 // exp(x) = 2^k * 2^(j/32) * exp(r),  x = (32k + j) * ln2/32 + r,  |r| <= ln2/64: a 32-entry table of correctly rounded
 // 2^(j/32) and the Taylor series of exp(r) to r^6 (truncation < 4e-17 on the reduced range); no division.
@@ -227,6 +223,12 @@ constexpr float kAcosBelowTenMilli = 0.99995005130767822266f;
 CTM_HD float atan2_32(float y, float x) { return (float)atan2_64((double)y, (double)x); }
 CTM_HD float sin32(float x) { return (float)sin64((double)x); }
 CTM_HD float cos32(float x) { return (float)cos64((double)x); }
+CTM_HD void sincos32(float x, float* s, float* c) {  // sin32(x), cos32(x)
+    double sd, cd;
+    sincos64((double)x, &sd, &cd);
+    *s = (float)sd;
+    *c = (float)cd;
+}
 // expf as the Welsch weight uses it (fitLine's weightWelsch calls std::exp on a float).  Evaluated in FLOAT arithmetic
 // only -- the Welsch loop calls it twice per point and iteration, and FP64 runs at half rate on the vector unit:
 //   x = k ln2 + r (Cody-Waite, k ln2_hi exact for |k| < 2^8),  exp(r) = 1 + r + r^2 P(r),  P of degree 4 (near-minimax

@@ -605,8 +605,10 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         const double normal_theta = .5 * ctm::atan2_32((float)(-2 * Cxy), (float)(Cyy - Cxx));
         s_lines[pass][edge][0] = Ex;
         s_lines[pass][edge][1] = Ey;
-        s_lines[pass][edge][2] = ctm::cos32((float)normal_theta);
-        s_lines[pass][edge][3] = ctm::sin32((float)normal_theta);
+        float sn, cs;
+        ctm::sincos32((float)normal_theta, &sn, &cs);  // == sin32, cos32 of the same angle: one reduction, no quadrant divergence
+        s_lines[pass][edge][2] = cs;
+        s_lines[pass][edge][3] = sn;
     }
     __syncthreads();
     if (tid < 4) {  // :757-776 one refined corner per lane

@@ -60,8 +60,10 @@ __device__ __forceinline__ void moments_to_line(double x, double y, double x2, d
     xy /= w;
     const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
     const float t = (float)ctm::atan2_64(2 * dxy, dx2 - dy2) / 2;
-    line[0] = (float)ctm::cos64(t);
-    line[1] = (float)ctm::sin64(t);
+    double sn, cs;
+    ctm::sincos64(t, &sn, &cs);  // == sin64(t), cos64(t): one reduction, no quadrant divergence
+    line[0] = (float)cs;
+    line[1] = (float)sn;
     line[2] = (float)x;
     line[3] = (float)y;
 }

@@ -1,1 +1,3 @@
-python -m pytest tests/test_gpu_parity.py tests/test_dictgen_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error|^FAILED|assert" | head -20
+python -m pytest tests/test_gpu_parity.py tests/test_dictgen_gpu.py tests/test_pose_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error|^FAILED|assert" | head -20
+B="python bench.py --cpu-frames 0 --host-frames 0 --pose-frames 0 --latency-calls 0"
+$B 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('default', d['value'], d['stage_ms_per_step'])"
