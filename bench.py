@@ -81,6 +81,27 @@ def host_stream_rate(det, frames_dev, m, subpix):
                     "with detection of sub-chunk k"}
 
 
+def host_stream_rate_bgr(det, frames_dev, m, subpix):
+    """Side measurement (never `value`): BGR camera frames (main.cpp:52-54 hands cvtColor(BGR2GRAY) a colour frame) as pinned HOST
+    buffers through ctag_detect_batch_bgr8 -- 3 bytes per pixel over PCIe, converted on the device."""
+    import cylindertag_amd as ca
+    host = ca.pinned_empty((m, ROWS, COLS, 3), np.uint8)
+    g = frames_dev[:m].cpu().numpy()
+    for c in range(3):
+        host[..., c] = g  # gray-valued BGR: the converted image is the gray batch itself (1868 + 9617 + 4899 = 16384)
+    del g
+    res = ca.pinned_empty((m,), ca.RESULT_DT)
+    det.detect_batch_bgr(host, 5, subpix, 5, out=res)  # warm
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        det.detect_batch_bgr(host, 5, subpix, 5, out=res)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(m / dt, 1), "unit": "frames/s", "frames": m, "host_gb_per_s": round(m * ROWS * COLS * 3 / dt / 1e9, 2),
+            "frames_ok": int((res["status"] == 0).sum()),
+            "note": "ctag_detect_batch_bgr8: pinned host BGR frames in (3 B/px), BGR2GRAY on the device, host results out"}
+
+
 def pose_side(det, m, dev):
     """Side measurement (never `value`; SURVEY.md 8(f) rank 2 / BASELINE config 5's estimatePose leg): camera content --
     the 64-frame sequence derived from the reference's test.bmp (config 2's test.avi substitute, 5 physical markers in
@@ -626,6 +647,7 @@ def main():
             side("opencv_stage_probe", lambda: opencv_stage_probe(frames[:16].cpu().numpy()))
         if world == 1 and args.host_frames > 0:
             side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
+            side("pcie_inclusive_bgr", lambda: host_stream_rate_bgr(det, frames, min(args.host_frames // 2, n), subpix))
         if world == 1 and args.latency_calls > 0:
             side("single_frame_latency", lambda: latency_side(det, state, fs, args.latency_calls))
         if world == 1 and args.pose_frames > 0:

@@ -23,7 +23,7 @@ OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OP
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)
 EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
-           "ctag_detect_batch_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
+           "ctag_detect_batch_device", "ctag_detect_bgr8", "ctag_detect_batch_bgr8", "ctag_detect_batch_bgr8_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
            "ctag_stage_name", "ctag_strerror", "ctag_version"]
 # ... and include/ctag_pose.h
 POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag_model_get_view", "ctag_camera_load",
@@ -98,6 +98,12 @@ def load_library():
                                        C.c_int, vp]
     L.ctag_detect_batch_device.restype = C.c_int
     L.ctag_detect_batch_device.argtypes = L.ctag_detect_batch_u8.argtypes
+    L.ctag_detect_bgr8.restype = C.c_int
+    L.ctag_detect_bgr8.argtypes = L.ctag_detect_u8.argtypes
+    L.ctag_detect_batch_bgr8.restype = C.c_int
+    L.ctag_detect_batch_bgr8.argtypes = L.ctag_detect_batch_u8.argtypes
+    L.ctag_detect_batch_bgr8_device.restype = C.c_int
+    L.ctag_detect_batch_bgr8_device.argtypes = L.ctag_detect_batch_u8.argtypes
     L.ctag_host_alloc.restype = vp
     L.ctag_host_alloc.argtypes = [C.c_size_t]
     L.ctag_host_free.restype = None
@@ -348,6 +354,36 @@ class Detector:
         if st != 0:
             raise CtagError(st, "ctag_detect_batch_u8")
         return res
+
+    # ---- BGR frames (rows, cols, 3) uint8: cvtColor(BGR2GRAY) of main.cpp:36,52-54 happens on the device
+    def detect_bgr(self, bgr, adaptive_thresh=5, subpix=True, subpix_dist=5):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert bgr.ndim == 3 and bgr.shape[2] == 3
+        res = np.zeros(1, RESULT_DT)
+        st = self.L.ctag_detect_bgr8(self.h, bgr.ctypes.data, bgr.shape[0], bgr.shape[1], bgr.strides[0], adaptive_thresh, int(subpix), subpix_dist,
+                                     res.ctypes.data)
+        if st < 0:
+            raise CtagError(st, "ctag_detect_bgr8")
+        return res[0]
+
+    def detect_batch_bgr(self, frames, adaptive_thresh=5, subpix=True, subpix_dist=5, out=None):
+        """frames: (n, rows, cols, 3) uint8 in host memory (pinned_empty() arrays overlap upload and detection)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, rows, cols, ch = frames.shape
+        assert ch == 3
+        res = np.zeros(n, RESULT_DT) if out is None else out
+        assert res.dtype == RESULT_DT and res.shape == (n,) and res.flags.c_contiguous
+        st = self.L.ctag_detect_batch_bgr8(self.h, frames.ctypes.data, n, rows, cols, frames.strides[1], frames.strides[0], adaptive_thresh, int(subpix),
+                                           subpix_dist, res.ctypes.data)
+        if st != 0:
+            raise CtagError(st, "ctag_detect_batch_bgr8")
+        return res
+
+    def detect_batch_bgr_device(self, frames_ptr, n, rows, cols, row_stride, frame_stride, out_ptr, adaptive_thresh=5, subpix=True, subpix_dist=5):
+        st = self.L.ctag_detect_batch_bgr8_device(self.h, frames_ptr, n, rows, cols, row_stride, frame_stride, adaptive_thresh, int(subpix), subpix_dist,
+                                                  out_ptr)
+        if st != 0:
+            raise CtagError(st, "ctag_detect_batch_bgr8_device")
 
     # ---- device-memory entry point (pointers are plain integers, e.g. torch.Tensor.data_ptr())
     def detect_batch_device(self, frames_ptr, n, rows, cols, row_stride, frame_stride, out_ptr, adaptive_thresh=5,

@@ -105,11 +105,13 @@ void CylinderTag::detect(const Mat& img, std::vector<MarkerInfo>& markers_info, 
                          int cornerSubPixDist) {
     ctag_frame_result res;
 #ifdef CTAG_WITH_OPENCV
-    const int st = ctag_detect_u8(h_, img.ptr<unsigned char>(0), img.rows, img.cols, (ptrdiff_t)img.step, adaptiveThresh, cornerSubPix ? 1 : 0,
-                                  cornerSubPixDist, &res);
+    const unsigned char* px = img.ptr<unsigned char>(0);
 #else
-    const int st = ctag_detect_u8(h_, img.data, img.rows, img.cols, (ptrdiff_t)img.step, adaptiveThresh, cornerSubPix ? 1 : 0, cornerSubPixDist, &res);
+    const unsigned char* px = img.data;
 #endif
+    const int st = img.channels() == 3
+                       ? ctag_detect_bgr8(h_, px, img.rows, img.cols, (ptrdiff_t)img.step, adaptiveThresh, cornerSubPix ? 1 : 0, cornerSubPixDist, &res)
+                       : ctag_detect_u8(h_, px, img.rows, img.cols, (ptrdiff_t)img.step, adaptiveThresh, cornerSubPix ? 1 : 0, cornerSubPixDist, &res);
     if (st == CTAG_NO_CORNER) {
         std::cout << "No corner detected!" << std::endl;  // CylinderTag.cpp:88; output left untouched
         return;

@@ -38,14 +38,16 @@ struct Point3f {
     Point3f() = default;
     Point3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
 };
-// borrowed 8-bit single-channel image view (what detect() needs from cv::Mat)
+// borrowed 8-bit image view (what detect() needs from cv::Mat): one channel (gray) or three (BGR, as a camera delivers it)
 struct Mat {
     int rows = 0, cols = 0;
     size_t step = 0;  // bytes per row
     const unsigned char* data = nullptr;
+    int nch = 1;
     Mat() = default;
-    Mat(int r, int c, const unsigned char* d, size_t s = 0) : rows(r), cols(c), step(s ? s : (size_t)c), data(d) {}
+    Mat(int r, int c, const unsigned char* d, size_t s = 0, int ch = 1) : rows(r), cols(c), step(s ? s : (size_t)c * ch), data(d), nch(ch) {}
     bool empty() const { return !data || rows <= 0 || cols <= 0; }
+    int channels() const { return nch; }
 };
 // dictionary matrix (what the reference takes as cv::Mat1i)
 struct Mat1i {
@@ -108,7 +110,8 @@ class CylinderTag {
     CylinderTag(const CylinderTag&) = delete;
     CylinderTag& operator=(const CylinderTag&) = delete;
 
-    // Marker Detector (reference: header/CylinderTag.h:21, CylinderTag.cpp:67-159)
+    // Marker Detector (reference: header/CylinderTag.h:21, CylinderTag.cpp:67-159).  A three-channel image is taken as the BGR frame the
+    // reference's caller would have passed through cvtColor(BGR2GRAY) first (main.cpp:36,54): that conversion then runs on the device.
     void detect(const ctag_host::Mat& img, std::vector<MarkerInfo>& cornerList, int adaptiveThresh = 5,
                 const bool cornerSubPix = false, int cornerSubPixDist = 3);
 

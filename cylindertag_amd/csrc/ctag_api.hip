@@ -56,6 +56,11 @@ struct ctag_handle {
     size_t d_results_count = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {}, ev_done[2] = {};
+    // BGR ingest (ctag_detect_*bgr8*): the gray frames of the chunk in flight, written by k_bgr2gray and read by K1 / K8
+    uint8_t* d_gray = nullptr;
+    size_t d_gray_bytes = 0;
+    ptrdiff_t gray_row_stride = 0, gray_frame_stride = 0;
+    bool last_was_bgr = false;
     int host_sub = 128;
     int last_chunk_frames = 0;
     char last_error[256] = {0};
@@ -103,8 +108,9 @@ void handle_view(const ctag_handle* h, HandleView* out) {
     out->dict = h->dict.data();
     out->dict_rows = h->dict_rows;
     out->dict_cols = h->dict_cols;
-    out->gray = nullptr;
-    out->gray_row_stride = out->gray_frame_stride = 0;
+    out->gray = h->last_was_bgr ? h->d_gray : nullptr;
+    out->gray_row_stride = h->gray_row_stride;
+    out->gray_frame_stride = h->gray_frame_stride;
 }
 }  // namespace ctag
 
@@ -474,6 +480,84 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// BGR ingest: cvtColor(BGR2GRAY) of the reference's stream loop (main.cpp:36,52-54) on the device
+// ---------------------------------------------------------------------------------------------------
+// OpenCV's 8-bit BGR2GRAY is fixed point: (B*1868 + G*9617 + R*4899 + 8192) >> 14 (RGB2Gray<uchar>: B2Y, G2Y, R2Y at yuv_shift 14,
+// [OCV-recall of color_rgb.simd.hpp]; the same formula as the host BMP reader, csrc/ctag_io.h).  A lane converts four pixels:
+// three aligned words in, one word out -- consecutive lanes read consecutive 12-byte groups, so a wave's loads are contiguous.
+__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) { return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14; }
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bgr, ptrdiff_t frame_stride, ptrdiff_t row_stride, uint8_t* __restrict__ gray,
+                                                  ptrdiff_t gframe_stride, ptrdiff_t grow_stride, int rows, int cols, int aligned) {
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
+    if (x4 >= cols) return;
+    const uint8_t* src = bgr + (ptrdiff_t)f * frame_stride + (ptrdiff_t)y * row_stride + (ptrdiff_t)x4 * 3;
+    uint8_t* dst = gray + (ptrdiff_t)f * gframe_stride + (ptrdiff_t)y * grow_stride + x4;
+    if (aligned && x4 + 3 < cols) {
+        const uint32_t w0 = reinterpret_cast<const uint32_t*>(src)[0], w1 = reinterpret_cast<const uint32_t*>(src)[1], w2 = reinterpret_cast<const uint32_t*>(src)[2];
+        // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint32_t g0 = gray_of(w0 & 0xffu, (w0 >> 8) & 0xffu, (w0 >> 16) & 0xffu);
+        const uint32_t g1 = gray_of(w0 >> 24, w1 & 0xffu, (w1 >> 8) & 0xffu);
+        const uint32_t g2 = gray_of((w1 >> 16) & 0xffu, w1 >> 24, w2 & 0xffu);
+        const uint32_t g3 = gray_of((w2 >> 8) & 0xffu, (w2 >> 16) & 0xffu, w2 >> 24);
+        *reinterpret_cast<uint32_t*>(dst) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    } else {
+        for (int k = 0; k < 4 && x4 + k < cols; k++) dst[k] = (uint8_t)gray_of(src[3 * k], src[3 * k + 1], src[3 * k + 2]);
+    }
+}
+
+// gray slab for `frames` frames of rows x cols (rows padded to 16 bytes); grows only
+static int ensure_gray(ctag_handle* h, int frames, int rows, int cols) {
+    const ptrdiff_t pitch = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;
+    const size_t need = (size_t)pitch * rows * (size_t)frames;
+    if (h->d_gray_bytes < need || h->gray_row_stride != pitch || h->gray_frame_stride != pitch * rows) {
+        if (h->d_gray_bytes < need) {
+            if (h->copy_stream) HIP_TRY(hipStreamSynchronize(h->copy_stream));
+            if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            drop_graphs(h);  // they hold the old slab's address
+            if (h->d_gray) HIP_TRY(hipFree(h->d_gray));
+            h->d_gray = nullptr;
+            h->d_gray_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_gray), need));
+            h->d_gray_bytes = need;
+        }
+        h->gray_row_stride = pitch;
+        h->gray_frame_stride = pitch * rows;
+    }
+    return CTAG_OK;
+}
+
+static int enqueue_bgr2gray(ctag_handle* h, const uint8_t* bgr_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride) {
+    const int aligned = ((reinterpret_cast<uintptr_t>(bgr_dev) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 3u) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_bgr2gray, dim3((cols + 1023) / 1024, rows, n), dim3(256), 0, h->stream, bgr_dev, frame_stride, row_stride, h->d_gray, h->gray_frame_stride,
+                       h->gray_row_stride, rows, cols, aligned);
+    HIP_TRY(hipGetLastError());
+    return CTAG_OK;
+}
+
+// n BGR frames in device memory -> gray (chunk by chunk, on the handle's stream) -> the detection chain
+static int detect_bgr_device_impl(ctag_handle* h, const uint8_t* bgr_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                                  int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev) {
+    if (row_stride < (ptrdiff_t)cols * 3) return CTAG_ERR_ARG;
+    const int rc = check_args(h, bgr_dev, n, rows, cols, ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15, adaptive_thresh, subpix_dist);
+    if (rc != CTAG_OK) return rc;
+    if (n == 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int chunk = std::min(n, h->max_chunk);
+    const int gr = ensure_gray(h, chunk, rows, cols);
+    if (gr != CTAG_OK) return gr;
+    for (int f0 = 0; f0 < n; f0 += chunk) {
+        const int m = std::min(chunk, n - f0);
+        int r = enqueue_bgr2gray(h, bgr_dev + (ptrdiff_t)f0 * frame_stride, m, rows, cols, row_stride, frame_stride);
+        if (r != CTAG_OK) return r;
+        r = detect_device_impl(h, h->d_gray, m, rows, cols, h->gray_row_stride, h->gray_frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev + f0);
+        if (r != CTAG_OK) return r;
+    }
+    h->last_was_bgr = true;
+    return CTAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
@@ -554,6 +638,7 @@ void ctag_destroy(ctag_handle* h) {
     if (h->d_pick_table) (void)hipFree(h->d_pick_table);
     if (h->d_frames) (void)hipFree(h->d_frames);
     if (h->d_results) (void)hipFree(h->d_results);
+    if (h->d_gray) (void)hipFree(h->d_gray);
     if (h->pose_state && h->pose_state_free) h->pose_state_free(h->pose_state);
     if (h->gather_state && h->gather_state_free) h->gather_state_free(h->gather_state);
     for (auto& e : h->ev)
@@ -642,6 +727,7 @@ int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, i
                              int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev) {
     if (!h || !out_dev) return CTAG_ERR_ARG;
     begin_timings(h);
+    h->last_was_bgr = false;
     const int r = detect_device_impl(h, frames_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev);
     if (r != CTAG_OK) {
         h->ev_sets_used = 0;
@@ -660,12 +746,18 @@ static int quiesce(ctag_handle* h) {
 }
 
 static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
-                                int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out) {
+                                int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out, int ch = 1) {
     // Frames stream through two device slabs: while slab k is processed on the compute stream, slab k+1 is filled over
     // PCIe on the copy stream (main.cpp:29,36,52-54 feed one frame at a time; this is the batched equivalent).  The
     // copies only overlap when `frames` is pinned (ctag_host_alloc / hipHostRegister); pageable memory still works.
     const int sub = std::min(n, std::min(h->max_chunk, h->host_sub));
-    const ptrdiff_t dstride = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;  // packed, 16-byte aligned rows on the device
+    // ch = 3: BGR frames (3 bytes per pixel) are uploaded as they are and converted on the device (k_bgr2gray) into the gray slab
+    const ptrdiff_t rowbytes = (ptrdiff_t)cols * ch;
+    const ptrdiff_t dstride = (rowbytes + 15) & ~(ptrdiff_t)15;  // packed, 16-byte aligned rows on the device
+    if (ch == 3) {
+        const int gr = ensure_gray(h, sub, rows, cols);
+        if (gr != CTAG_OK) return gr;
+    }
     const size_t dframe = (size_t)dstride * rows;
     if (h->d_frames_bytes < dframe * sub * 2) {
         if (quiesce(h) != CTAG_OK) return CTAG_ERR_HIP;
@@ -690,7 +782,7 @@ static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, in
             HIP_TRY(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
         }
     }
-    const bool packed = row_stride == cols && dstride == cols && frame_stride == (ptrdiff_t)rows * cols;
+    const bool packed = row_stride == rowbytes && dstride == rowbytes && frame_stride == (ptrdiff_t)rows * rowbytes;
     const size_t slab_frames = h->d_frames_bytes / dframe / 2;
     const int nsub = (n + sub - 1) / sub;
     auto upload = [&](int k) -> int {  // enqueue the upload of sub-chunk k on the copy stream
@@ -701,7 +793,7 @@ static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, in
             HIP_TRY(hipMemcpyAsync(slab, frames + (ptrdiff_t)f0 * frame_stride, dframe * m, hipMemcpyHostToDevice, h->copy_stream));
         } else {
             for (int i = 0; i < m; i++)
-                HIP_TRY(hipMemcpy2DAsync(slab + dframe * i, dstride, frames + (ptrdiff_t)(f0 + i) * frame_stride, row_stride, cols, rows,
+                HIP_TRY(hipMemcpy2DAsync(slab + dframe * i, dstride, frames + (ptrdiff_t)(f0 + i) * frame_stride, row_stride, (size_t)rowbytes, rows,
                                          hipMemcpyHostToDevice, h->copy_stream));
         }
         HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
@@ -714,7 +806,13 @@ static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, in
         uint8_t* slab = h->d_frames + dframe * slab_frames * slot;
         ctag_frame_result* res = h->d_results + (h->d_results_count / 2) * slot;
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
-        r = detect_device_impl(h, slab, m, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist, res);
+        if (ch == 3) {
+            r = enqueue_bgr2gray(h, slab, m, rows, cols, dstride, (ptrdiff_t)dframe);
+            if (r != CTAG_OK) return r;
+            r = detect_device_impl(h, h->d_gray, m, rows, cols, h->gray_row_stride, h->gray_frame_stride, adaptive_thresh, corner_subpix, subpix_dist, res);
+        } else {
+            r = detect_device_impl(h, slab, m, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist, res);
+        }
         if (r != CTAG_OK) return r;
         HIP_TRY(hipEventRecord(h->ev_done[slot], h->stream));
         // the next upload is enqueued before the result download: a download into pageable memory blocks the host
@@ -733,6 +831,7 @@ int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows,
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
     begin_timings(h);
+    h->last_was_bgr = false;
     const int r = detect_batch_u8_impl(h, frames, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out);
     if (r != CTAG_OK) {  // uploads / kernels may still be in flight: nothing may outlive this call (the caller frees `frames`)
         h->ev_sets_used = 0;
@@ -758,6 +857,47 @@ int ctag_detect_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrd
                    int subpix_dist, ctag_frame_result* out) {
     if (!h || !out) return CTAG_ERR_ARG;
     const int r = ctag_detect_batch_u8(h, gray, 1, rows, cols, row_stride, (ptrdiff_t)row_stride * rows, adaptive_thresh, corner_subpix, subpix_dist, out);
+    if (r != CTAG_OK) return r;
+    return out->status;
+}
+
+int ctag_detect_batch_bgr8_device(ctag_handle* h, const uint8_t* bgr_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                                  int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev) {
+    if (!h || !out_dev) return CTAG_ERR_ARG;
+    begin_timings(h);
+    const int r = detect_bgr_device_impl(h, bgr_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev);
+    if (r != CTAG_OK) {
+        h->ev_sets_used = 0;
+        return r;
+    }
+    return collect_timings(h);
+}
+
+int ctag_detect_batch_bgr8(ctag_handle* h, const uint8_t* bgr, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride, int adaptive_thresh,
+                           int corner_subpix, int subpix_dist, ctag_frame_result* out) {
+    if (!h || !out || row_stride < (ptrdiff_t)cols * 3) return CTAG_ERR_ARG;
+    const int rc = check_args(h, bgr, n, rows, cols, ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15, adaptive_thresh, subpix_dist);
+    if (rc != CTAG_OK) return rc;
+    if (n == 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    begin_timings(h);
+    const int r = detect_batch_u8_impl(h, bgr, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out, 3);
+    if (r != CTAG_OK) {
+        h->ev_sets_used = 0;
+        char keep[sizeof(h->last_error)];
+        std::memcpy(keep, h->last_error, sizeof(keep));
+        (void)quiesce(h);
+        std::memcpy(h->last_error, keep, sizeof(keep));
+        return r;
+    }
+    h->last_was_bgr = true;
+    return collect_timings(h);
+}
+
+int ctag_detect_bgr8(ctag_handle* h, const uint8_t* bgr, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
+                     ctag_frame_result* out) {
+    if (!h || !out) return CTAG_ERR_ARG;
+    const int r = ctag_detect_batch_bgr8(h, bgr, 1, rows, cols, row_stride, (ptrdiff_t)row_stride * rows, adaptive_thresh, corner_subpix, subpix_dist, out);
     if (r != CTAG_OK) return r;
     return out->status;
 }

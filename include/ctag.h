@@ -62,6 +62,19 @@ void ctag_host_free(void* p);
 int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride,
                              ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
                              ctag_frame_result* out_dev);
+/* ---- BGR frames -------------------------------------------------------------------------------------
+ * The reference's stream loop converts every camera frame before detect(): cvtColor(frame, gray, COLOR_BGR2GRAY)
+ * (main.cpp:36,52-54).  These entry points take the 8-bit BGR frames themselves (3 bytes per pixel, B G R order, `row_stride`
+ * >= 3 * cols bytes) and do that conversion on the device with OpenCV's fixed-point weights -- (B*1868 + G*9617 + R*4899 + 8192)
+ * >> 14 -- in front of the same detection chain; a host feed then uploads the camera's bytes as they are instead of spending
+ * a host core per ~1 G pixels/s on the conversion.  Results equal ctag_detect_*_u8 on the converted frames. */
+int ctag_detect_bgr8(ctag_handle* h, const uint8_t* bgr, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int corner_subpix,
+                     int subpix_dist, ctag_frame_result* out);
+int ctag_detect_batch_bgr8(ctag_handle* h, const uint8_t* bgr, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                           int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out);
+int ctag_detect_batch_bgr8_device(ctag_handle* h, const uint8_t* bgr_dev, int n, int rows, int cols, ptrdiff_t row_stride,
+                                  ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
+                                  ctag_frame_result* out_dev);
 int ctag_sync(ctag_handle* h);
 /* HIP stream (hipStream_t) all work of this handle is enqueued on */
 void* ctag_stream(ctag_handle* h);

@@ -73,6 +73,8 @@ void ctago_refine_probe(const uint8_t* img, int rows, int cols, ptrdiff_t stride
                         double* exact, double* fast, double* lit, int32_t* flag);
 
 /* primitive probes for unit tests */
+/* cvtColor(BGR2GRAY) on 8-bit BGR (main.cpp:36,54): OpenCV's fixed-point (B*1868 + G*9617 + R*4899 + 8192) >> 14 */
+void ctago_bgr2gray(const uint8_t* bgr, int rows, int cols, ptrdiff_t row_stride, uint8_t* gray);
 void ctago_resize_half(const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, uint8_t* dst);
 void ctago_threshold(const uint8_t* half, int rows, int cols, int tw, uint8_t* dst);
 int ctago_ccl(const uint8_t* bin, int rows, int cols, int32_t* labels, int32_t* areas, int areas_cap);

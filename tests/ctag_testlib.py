@@ -101,6 +101,7 @@ class Oracle:
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ctago_hardware_concurrency.restype = C.c_int
         L.ctago_resize_half.argtypes = [_p_u8, C.c_int, C.c_int, C.c_ssize_t, _p_u8]
+        L.ctago_bgr2gray.argtypes = [_p_u8, C.c_int, C.c_int, C.c_ssize_t, _p_u8]
         L.ctago_threshold.argtypes = [_p_u8, C.c_int, C.c_int, C.c_int, _p_u8]
         L.ctago_ccl.argtypes = [_p_u8, C.c_int, C.c_int, _p_i32, _p_i32, C.c_int]
         L.ctago_ccl.restype = C.c_int
@@ -184,6 +185,12 @@ class Oracle:
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
         out = np.zeros((gray.shape[0] // 2, gray.shape[1] // 2), np.uint8)
         self.L.ctago_resize_half(_ptr(gray, _p_u8), gray.shape[0], gray.shape[1], gray.strides[0], _ptr(out, _p_u8))
+        return out
+
+    def bgr2gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        out = np.zeros(bgr.shape[:2], np.uint8)
+        self.L.ctago_bgr2gray(_ptr(bgr, _p_u8), bgr.shape[0], bgr.shape[1], bgr.strides[0], _ptr(out, _p_u8))
         return out
 
     def threshold(self, half, tw=5):

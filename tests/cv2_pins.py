@@ -9,6 +9,7 @@ without cv2) and bench.py's opencv_stage_probe runs them on the GPU box and prin
   fitLine(points, line, DIST_L2, 0, 0.01, 0.01)                                   corner_detector.cpp:136 (expand_line)
   fitLine(points, line, DIST_WELSCH, 0, 0.01, 0.01)                               corner_detector.cpp:358
   fastAtan2(y, x)                                                                  corner_detector.cpp:1028-1031
+  cvtColor(frame, gray, COLOR_BGR2GRAY)                                            main.cpp:36,54
 Test infrastructure only (it drives oracle/)."""
 import numpy as np
 
@@ -148,6 +149,23 @@ def pin_fast_atan2(cv2, orc):
             "max_abs_diff_deg": float(np.abs(want - got).max())}
 
 
+def pin_bgr2gray(cv2, orc, test_bmp):
+    rng = np.random.RandomState(9)
+    imgs = [rng.randint(0, 256, (97, 131, 3)).astype(np.uint8), np.stack([test_bmp[:300, :400], test_bmp[100:400, 50:450], test_bmp[200:500, 300:700]], 2)]
+    ramp = np.zeros((256, 3 * 256, 3), np.uint8)  # every value of each channel against two levels of the others
+    for c in range(3):
+        ramp[:, c * 256:(c + 1) * 256, c] = np.arange(256)[None, :]
+        ramp[:128, c * 256:(c + 1) * 256, (c + 1) % 3] = 255
+    imgs.append(ramp)
+    bad = total = 0
+    for im in imgs:
+        want = cv2.cvtColor(im, cv2.COLOR_BGR2GRAY)
+        got = orc.bgr2gray(im)
+        bad += int((want != got).sum())
+        total += int(want.size)
+    return {"call": "cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY) vs ctago_bgr2gray", "pixels": total, "mismatching_pixels": bad}
+
+
 def run_all(orc, test_bmp):
     """Every pin; raises ImportError without cv2.  Returns a JSON-able report."""
     import cv2
@@ -160,4 +178,5 @@ def run_all(orc, test_bmp):
     rep["ccl"] = pin_ccl(cv2, orc, test_bmp)
     rep["fitline"] = pin_fitline(cv2, orc, test_bmp)
     rep["fast_atan2"] = pin_fast_atan2(cv2, orc)
+    rep["bgr2gray"] = pin_bgr2gray(cv2, orc, test_bmp)
     return rep

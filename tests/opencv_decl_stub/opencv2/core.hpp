@@ -43,6 +43,7 @@ public:
     void convertTo(Mat& m, int rtype, double alpha = 1, double beta = 0) const;
     size_t total() const;
     bool empty() const;
+    int channels() const;
     template <typename T> T* ptr(int i0 = 0);
     template <typename T> const T* ptr(int i0 = 0) const;
     template <typename T> T& at(int i0, int i1);

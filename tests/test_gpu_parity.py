@@ -808,6 +808,84 @@ def test_two_rank_rccl_gather_when_two_gpus_are_present(dictionary):
     assert "GATHER_WORKER_OK" in p.stdout
 
 
+def _colourise(gray, seed):
+    """A BGR frame whose channels differ (so that a wrong channel order or weight shows) but whose OpenCV gray value keeps the
+    scene: each channel = gray plus a smooth offset / noise, clipped."""
+    rng = np.random.RandomState(seed)
+    h, w = gray.shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    g16 = gray.astype(np.int32)
+    b = np.clip(g16 + 25 * np.sin(xx / 97.0) + rng.randint(-6, 7, gray.shape), 0, 255)
+    g = np.clip(g16 - 10 * np.cos(yy / 61.0) + rng.randint(-3, 4, gray.shape), 0, 255)
+    r = np.clip(g16 + 18 * np.sin((xx + yy) / 143.0) + rng.randint(-6, 7, gray.shape), 0, 255)
+    return np.stack([b, g, r], 2).astype(np.uint8)
+
+
+def test_bgr_ingest_equals_gray_path(detector, oracle, dictionary, test_bmp):
+    """ctag_detect_*bgr8*: cvtColor(BGR2GRAY) of the reference's stream loop (main.cpp:36,52-54) on the device.  The gray image
+    the device computed equals the oracle's fixed-point conversion byte for byte (incl. odd widths, unaligned rows), and the
+    records equal the oracle's detect() on that gray image -- one frame, a streamed host batch and a device-resident batch."""
+    import torch
+    state, fs = dictionary
+    bgr = _colourise(test_bmp, 1)
+    want_gray = oracle.bgr2gray(bgr)
+    assert np.abs(want_gray.astype(int) - test_bmp.astype(int)).max() < 40 and (want_gray != test_bmp).mean() > 0.5
+    got = detector.detect_bgr(bgr)
+    assert (detector.debug(0, tk.DBG_GRAY).reshape(want_gray.shape) == want_gray).all()
+    assert_same_record(got, oracle.detect_fast(want_gray, state, fs), "colourised test.bmp")
+    assert got["n_markers"] == 5
+    # primary colours / extremes: the weights and the rounding
+    prim = np.zeros((8, 16, 3), np.uint8)
+    prim[0, :, 0] = 255
+    prim[1, :, 1] = 255
+    prim[2, :, 2] = 255
+    prim[3] = 255
+    prim[4, :, :] = np.arange(16)[:, None] * 17
+    prim[5:] = np.random.RandomState(2).randint(0, 256, (3, 16, 3))
+    detector.detect_bgr(prim)
+    g = detector.debug(0, tk.DBG_GRAY).reshape(8, 16)
+    assert (g == oracle.bgr2gray(prim)).all() and g[0, 0] == 29 and g[1, 0] == 150 and g[2, 0] == 76 and g[3, 0] == 255
+    # odd sizes, a row stride that is not a multiple of 4 (the byte path), a strided view
+    for (h, w) in ((301, 403), (64, 67)):
+        a = _colourise(tk.synth_frame_host(state, 3, rows=h, cols=w)[0], 3)
+        assert_same_record(detector.detect_bgr(a), oracle.detect_fast(oracle.bgr2gray(a), state, fs), "bgr %dx%d" % (w, h))
+        assert (detector.debug(0, tk.DBG_GRAY).reshape(h, w) == oracle.bgr2gray(a)).all()
+    # batches: synthetic frames colourised; host (pinned, sub-chunk 3 -> several uploads) and device-resident
+    n, rows, cols = 10, 1080, 1920
+    host = ca.pinned_empty((n, rows, cols, 3), np.uint8)
+    grays = []
+    for f in range(n):
+        host[f] = _colourise(tk.synth_frame_host(state, 200 + f)[0], f)
+        grays.append(oracle.bgr2gray(host[f]))
+    want = [oracle.detect_fast(g, state, fs) for g in grays]
+    detector.set_option(capi.OPT_HOST_SUBCHUNK, 3)
+    try:
+        res = detector.detect_batch_bgr(host)
+    finally:
+        detector.set_option(capi.OPT_HOST_SUBCHUNK, 128)
+    for f in range(n):
+        assert_same_record(res[f], want[f], "bgr host batch frame %d" % f)
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+    out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    detector.set_option(capi.OPT_MAX_CHUNK, 4)  # three chunks through one gray slab
+    try:
+        detector.detect_batch_bgr_device(dev.data_ptr(), n, rows, cols, cols * 3, rows * cols * 3, out.data_ptr())
+        detector.sync()
+    finally:
+        detector.set_option(capi.OPT_MAX_CHUNK, 1024)
+    got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    for f in range(n):
+        assert_same_record(got[f], want[f], "bgr device batch frame %d" % f)
+    assert (detector.debug(1, tk.DBG_GRAY).reshape(rows, cols) == grays[9]).all()  # the last chunk held frames 8, 9
+    with pytest.raises(ca.CtagError):
+        detector.detect_batch_bgr_device(dev.data_ptr(), n, rows, cols, cols * 3 - 1, rows * cols * 3, out.data_ptr())  # stride < 3 * cols
+    # a gray call afterwards leaves no stale gray view
+    detector.detect(test_bmp)
+    with pytest.raises(ca.CtagError):
+        detector.debug(0, tk.DBG_GRAY)
+
+
 def test_cpp_cylindertag_class_demo(oracle, dictionary, test_bmp):
     """The C++ `CylinderTag` host layer (reference class interface) end to end: the demo binary reads test.bmp with the
     C++ BMP reader, calls CylinderTag::detect(img, markers, 5, true, 5) and prints the MarkerInfo vector."""

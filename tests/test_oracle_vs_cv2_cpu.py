@@ -41,3 +41,7 @@ def test_fitline_welsch_equals_cv2(report):
 
 def test_fast_atan2_equals_cv2(report):
     assert report["fast_atan2"]["mismatches"] == 0, report["fast_atan2"]
+
+
+def test_bgr2gray_equals_cv2(report):
+    assert report["bgr2gray"]["mismatching_pixels"] == 0, report["bgr2gray"]
