@@ -21,7 +21,12 @@ int main(int argc, char** argv) {
         const ctag_host::GrayImage g = ctag_host::read_bmp_gray(argv[2]);
         const int at = argc > 3 ? std::atoi(argv[3]) : 5, sp = argc > 4 ? std::atoi(argv[4]) : 1, sd = argc > 5 ? std::atoi(argv[5]) : 5;
         std::vector<MarkerInfo> markers;
-        marker.detect(ctag_host::Mat(g.rows, g.cols, g.px.data()), markers, at, sp != 0, sd);
+#ifdef CTAG_WITH_OPENCV  // the drop-in build of INTEGRATION.md option B: cv::Mat in, cv::Point2f out (oracle/ref_build.sh links and runs it)
+        const cv::Mat img(g.rows, g.cols, CV_8UC1, const_cast<unsigned char*>(g.px.data()));
+#else
+        const ctag_host::Mat img(g.rows, g.cols, g.px.data());
+#endif
+        marker.detect(img, markers, at, sp != 0, sd);
         std::printf("markers %zu\n", markers.size());
         for (const MarkerInfo& m : markers) {
             std::printf("id %d n %zu :", m.markerID, m.cornerLists.size());
@@ -37,11 +42,16 @@ int main(int argc, char** argv) {
             marker.loadModel(argv[6], model);
             marker.loadCamera(argv[7], camera);
             std::vector<PoseInfo> pose;
-            marker.estimatePose(ctag_host::Mat(g.rows, g.cols, g.px.data()), markers, model, camera, pose, false);
+            marker.estimatePose(img, markers, model, camera, pose, false);
             std::printf("poses %zu\n", pose.size());
-            for (const PoseInfo& p : pose)
-                std::printf("pose %d rvec %.17g %.17g %.17g tvec %.17g %.17g %.17g\n", p.markerID, p.rvec[0], p.rvec[1], p.rvec[2], p.tvec[0],
-                            p.tvec[1], p.tvec[2]);
+            for (const PoseInfo& p : pose) {
+#ifdef CTAG_WITH_OPENCV
+                const double *r = p.rvec.ptr<double>(0), *t = p.tvec.ptr<double>(0);
+#else
+                const double *r = p.rvec, *t = p.tvec;
+#endif
+                std::printf("pose %d rvec %.17g %.17g %.17g tvec %.17g %.17g %.17g\n", p.markerID, r[0], r[1], r[2], t[0], t[1], t[2]);
+            }
         }
     } catch (const std::string& s) {
         std::cerr << "error: " << s;

@@ -7,6 +7,7 @@
 #pragma once
 #include <cstddef>
 
+#define CV_8UC1 0
 #define CV_32F 5
 #define CV_64F 6
 

@@ -141,7 +141,10 @@ def test_opencv_branch_of_the_cpp_layer_passes_the_compiler():
     detect(), cv::Mat camera / pose members, cv::Mat1i dictionary: the drop-in build of INTEGRATION.md option A -- goes through
     g++'s syntax and type checks against a declaration-only stand-in for <opencv2/core.hpp> (tests/opencv_decl_stub), because
     this image has no OpenCV; without this the branch had never seen a compiler."""
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DCTAG_WITH_OPENCV", "-I" + os.path.join(ROOT, "tests", "opencv_decl_stub"),
-           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "cylindertag_amd", "csrc", "CylinderTag.cpp")]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stderr[-3000:]
+    for src in (os.path.join("csrc", "CylinderTag.cpp"), os.path.join("examples", "ctag_demo.cpp")):
+        cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DCTAG_WITH_OPENCV", "-I" + os.path.join(ROOT, "tests", "opencv_decl_stub"),
+               "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "cylindertag_amd", src)]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+    # the LINK-level check (real OpenCV, demo run against the stand-alone build's output) lives in oracle/ref_build.sh and runs
+    # wherever pkg-config finds opencv4; tests/test_oracle_ref_cpu.py calls the recipe
