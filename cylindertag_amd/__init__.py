@@ -6,8 +6,8 @@ interface (``csrc/CylinderTag.h``).  This Python module is only the thin ctypes 
 ``bench.py`` use to drive that ABI; it contains no detection logic and no CPU fallback -- if the HIP library is
 missing or no GPU is usable, construction raises.
 """
-from .capi import (CameraC, CtagError, Detector, Model, POSE_DT, load_camera, make_camera, FEATURE_DT, MARKER_DT, RESULT_DT, STAGE_NAMES, build, lib_path, load_library,
+from .capi import (CameraC, ParamsC, default_params, CtagError, Detector, Model, POSE_DT, load_camera, make_camera, FEATURE_DT, MARKER_DT, RESULT_DT, STAGE_NAMES, build, lib_path, load_library,
                    load_marker_file, pinned_empty)
 
-__all__ = ["CameraC", "Model", "POSE_DT", "load_camera", "make_camera", "CtagError", "Detector", "FEATURE_DT", "MARKER_DT", "RESULT_DT", "STAGE_NAMES", "build", "lib_path",
+__all__ = ["CameraC", "ParamsC", "default_params", "Model", "POSE_DT", "load_camera", "make_camera", "CtagError", "Detector", "FEATURE_DT", "MARKER_DT", "RESULT_DT", "STAGE_NAMES", "build", "lib_path",
            "load_library", "load_marker_file", "pinned_empty"]

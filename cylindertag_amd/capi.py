@@ -22,7 +22,7 @@ QUAD_STAGES = ["quad_pack", "quad_edges", "quad_edges_big", "line_sort", "welsch
 OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OPT_WAVE_POINTS = 1, 2, 3, 4, 5, 6
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)
-EXPORTS = ["ctag_create", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
+EXPORTS = ["ctag_create", "ctag_create_ex", "ctag_params_default", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
            "ctag_detect_batch_device", "ctag_detect_bgr8", "ctag_detect_batch_bgr8", "ctag_detect_batch_bgr8_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
            "ctag_stage_name", "ctag_strerror", "ctag_version"]
 # ... and include/ctag_pose.h
@@ -39,6 +39,20 @@ POSE_DT = np.dtype([("status", "<i4"), ("model_index", "<i4"), ("frame", "<i4"),
                     ("n_points", "<i4"), ("iterations", "<i4"), ("rvec", "<f8", (3,)), ("tvec", "<f8", (3,)),
                     ("rvec0", "<f8", (3,)), ("tvec0", "<f8", (3,)), ("cost0", "<f8"), ("cost", "<f8")])
 POSE_OK, POSE_NO_MODEL, POSE_TOO_FEW, POSE_BAD_POS, POSE_DEGENERATE = range(5)
+
+
+class ParamsC(C.Structure):  # ctag_params (include/ctag_types.h): the reference's tunables
+    _fields_ = [("threshold_line", C.c_float), ("threshold_expand", C.c_float), ("threshold_RAC", C.c_float), ("threshold_angle", C.c_float),
+                ("threshold_vertical", C.c_float), ("ID_cr_correspond", C.c_float * 4), ("cr_covariance_left", C.c_float * 4),
+                ("cr_covariance_right", C.c_float * 4), ("dark_cap", C.c_float), ("area_min", C.c_int32), ("area_max_fraction", C.c_double),
+                ("collinear_cost", C.c_double)]
+
+
+def default_params():
+    """ctag_params_default: the reference's values (header/corner_detector.h:90,110,122,135-137,144; corner_detector.cpp:71,88,285)."""
+    p = ParamsC()
+    load_library().ctag_params_default(C.byref(p))
+    return p
 
 
 class CameraC(C.Structure):  # ctag_camera
@@ -84,6 +98,10 @@ def load_library():
     vp, i32p, u8p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
     L.ctag_create.restype = C.c_int
     L.ctag_create.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ctag_create_ex.restype = C.c_int
+    L.ctag_create_ex.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ParamsC), C.POINTER(vp)]
+    L.ctag_params_default.restype = None
+    L.ctag_params_default.argtypes = [C.POINTER(ParamsC)]
     L.ctag_destroy.argtypes = [vp]
     L.ctag_destroy.restype = None
     L.ctag_load_marker_file.restype = C.c_int
@@ -306,13 +324,18 @@ def pinned_empty(shape, dtype=np.uint8):
 class Detector:
     """One ctag_handle (one GPU).  Mirrors the reference's usage: construct with the dictionary, call detect()."""
 
-    def __init__(self, state, feature_size, device=0):
+    def __init__(self, state, feature_size, device=0, params=None):
+        """params: a ParamsC (default_params() edited) for ctag_create_ex; None = the reference's tunables (ctag_create)."""
         self.L = load_library()
         self.state = np.ascontiguousarray(state, dtype=np.int32)
         self.feature_size = int(feature_size)
         h = C.c_void_p()
-        st = self.L.ctag_create(self.state.ctypes.data_as(C.POINTER(C.c_int32)), self.state.shape[0],
-                                self.state.shape[1], self.feature_size, device, C.byref(h))
+        if params is None:
+            st = self.L.ctag_create(self.state.ctypes.data_as(C.POINTER(C.c_int32)), self.state.shape[0],
+                                    self.state.shape[1], self.feature_size, device, C.byref(h))
+        else:
+            st = self.L.ctag_create_ex(self.state.ctypes.data_as(C.POINTER(C.c_int32)), self.state.shape[0],
+                                       self.state.shape[1], self.feature_size, device, C.byref(params), C.byref(h))
         if st != 0:
             raise CtagError(st, "ctag_create")
         self.h = h

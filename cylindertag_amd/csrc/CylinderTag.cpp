@@ -14,15 +14,15 @@ using ctag_host::Mat1i;
 using ctag_host::Point2f;
 using ctag_host::Point3f;
 
-CylinderTag::CylinderTag(const std::string& path, int device_id) {
+CylinderTag::CylinderTag(const std::string& path, int device_id, const ctag_params* params) {
     load_from_file(path);
-    create(device_id);
+    create(device_id, params);
 }
 
-CylinderTag::CylinderTag(const Mat1i& set_state, int feature_size, int device_id) {
+CylinderTag::CylinderTag(const Mat1i& set_state, int feature_size, int device_id, const ctag_params* params) {
     featureSize_ = feature_size;
     load_from_set(set_state);
-    create(device_id);
+    create(device_id, params);
 }
 
 CylinderTag::~CylinderTag() { ctag_destroy(h_); }
@@ -70,9 +70,9 @@ void CylinderTag::check_dictionary(const std::vector<int>& input_state) {
     }
 }
 
-void CylinderTag::create(int device_id) {
+void CylinderTag::create(int device_id, const ctag_params* params) {
     std::vector<int32_t> s(state_.begin(), state_.end());
-    const int st = ctag_create(s.data(), state_rows_, state_cols_, featureSize_, device_id, &h_);
+    const int st = ctag_create_ex(s.data(), state_rows_, state_cols_, featureSize_, device_id, params, &h_);
     if (st != CTAG_OK) throw __FUNCTION__ + std::string(", ") + ctag_strerror(st) + "\n";
 }
 

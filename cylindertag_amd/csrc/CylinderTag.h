@@ -62,6 +62,7 @@ struct Mat1i {
 #endif
 
 struct ctag_handle;
+struct ctag_params;  // include/ctag_types.h: the detector's tunables (the reference's member constants, header/corner_detector.h:90-144)
 
 // reference: header/corner_detector.h:16-22
 struct MarkerInfo {
@@ -102,10 +103,12 @@ struct ModelInfo {
 class CylinderTag {
    public:
     // Load state matrix of CylinderTag from file (reference: CylinderTag.cpp:6-9, 16-41)
-    CylinderTag(const std::string& path, int device_id = 0);
+    // `params` (optional, new): tunables other than the reference's constants -- what a maintainer would otherwise edit in
+    // header/corner_detector.h:90,110,122,135-137,144 -- see ctag_params_default / ctag_create_ex in include/ctag.h
+    CylinderTag(const std::string& path, int device_id = 0, const ctag_params* params = nullptr);
     // Manual input of the state matrix (reference: CylinderTag.cpp:11-14, 43-54).  The reference leaves
     // featureSize unset on this path; it must be given here (default 2 as in CTag_2f12c).
-    CylinderTag(const ctag_host::Mat1i& set_state, int feature_size = 2, int device_id = 0);
+    CylinderTag(const ctag_host::Mat1i& set_state, int feature_size = 2, int device_id = 0, const ctag_params* params = nullptr);
     ~CylinderTag();
     CylinderTag(const CylinderTag&) = delete;
     CylinderTag& operator=(const CylinderTag&) = delete;
@@ -139,7 +142,7 @@ class CylinderTag {
     void load_from_file(const std::string path);
     void load_from_set(const ctag_host::Mat1i& set_state);
     void check_dictionary(const std::vector<int>& state);
-    void create(int device_id);
+    void create(int device_id, const ctag_params* params);
 
     std::vector<int> state_;
     int state_rows_ = 0, state_cols_ = 0;

@@ -33,6 +33,9 @@ struct ctag_handle {
     hipStream_t aux_stream = nullptr;          // side branch of the chain in few-frame calls (launch_quads), joined by events
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<int32_t> dict;
+    ctag_params params{};            // the tunables this handle was created with (ctag_params_default unless ctag_create_ex said otherwise)
+    KParams kp{};                    // ... as the kernels consume them
+    uint8_t* d_thr_table = nullptr;  // adaptive-threshold bound table for params.dark_cap
     int32_t* d_dict = nullptr;
     uint32_t* d_dict_pos = nullptr;  // [dict_rows][64]: columns holding each symbol (k_markers' bit-parallel coverage); null for > 32 columns
     uint8_t* d_pick_table = nullptr;
@@ -120,7 +123,7 @@ static const char* kStageNames[CTAG_NUM_STAGES] = {"decimate",  "threshold_ccl",
 // ---------------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------------
-static FrameGeom make_geom(int rows, int cols, int tw) {
+static FrameGeom make_geom(int rows, int cols, int tw, double area_max_fraction = 0.01) {
     FrameGeom g{};
     g.rows = rows;
     g.cols = cols;
@@ -133,7 +136,7 @@ static FrameGeom make_geom(int rows, int cols, int tw) {
     g.tcols = g.hcols / tw + (g.hcols % tw != 0 ? 1 : 0);
     g.tiles_x = (g.hcols + kTileW - 1) / kTileW;
     g.tiles_y = (g.hrows + kTileH - 1) / kTileH;
-    g.max_area = (int)std::round(0.01 * g.hcols * g.hrows);  // corner_detector.cpp:88
+    g.max_area = (int)std::round(area_max_fraction * g.hcols * g.hrows);  // corner_detector.cpp:88 (0.01 there)
     g.pool_cap = std::max(kPoolCapMin, 256 * g.tiles_x * g.tiles_y);
     return g;
 }
@@ -168,7 +171,8 @@ static void drop_graphs(ctag_handle* h);
 
 static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int frames) {
     if (h->ws.base && h->ws_rows == rows && h->ws_cols == cols && h->ws_cap >= frames) {
-        h->ws.g = make_geom(rows, cols, tw);
+        h->ws.g = make_geom(rows, cols, tw, h->params.area_max_fraction);
+        h->ws.kp = h->kp;
         h->ws.pick_table = h->d_pick_table;
         h->ws.aux_stream = h->aux_stream;
         h->ws.wave_points = h->wave_points;
@@ -184,7 +188,8 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
         h->ws = Workspace{};
     }
     Workspace& W = h->ws;
-    W.g = make_geom(rows, cols, tw);
+    W.g = make_geom(rows, cols, tw, h->params.area_max_fraction);
+    W.kp = h->kp;
     const FrameGeom& g = W.g;
     const size_t F = (size_t)frames;
     const size_t tiles = (size_t)g.tiles_x * g.tiles_y;
@@ -578,9 +583,75 @@ const char* ctag_strerror(int status) {
 }
 const char* ctag_stage_name(int stage) { return (stage >= 0 && stage < CTAG_NUM_STAGES) ? kStageNames[stage] : ""; }
 
+void ctag_params_default(ctag_params* p) {  // header/corner_detector.h:90,110,122,135-137,144; corner_detector.cpp:71,88,285
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->threshold_line = 1.8f;
+    p->threshold_expand = 1.2f;
+    p->threshold_RAC = 0.3f;
+    p->threshold_angle = 5.f;
+    p->threshold_vertical = 0.5f;
+    const float id[4] = {1.47f, 1.54f, 1.61f, 1.68f}, lo[4] = {0.1f, 0.035f, 0.035f, 0.035f}, hi[4] = {0.035f, 0.035f, 0.035f, 0.1f};
+    for (int j = 0; j < 4; j++) {
+        p->ID_cr_correspond[j] = id[j];
+        p->cr_covariance_left[j] = lo[j];
+        p->cr_covariance_right[j] = hi[j];
+    }
+    p->dark_cap = 0.3f;
+    p->area_min = 30;
+    p->area_max_fraction = 0.01;
+    p->collinear_cost = 1.05;
+}
+
+// ctag_params -> KParams (everything but the device table).  The collinearity test compares cost = (float)sqrt((double)c2), c2 the
+// squared integer norm of P0 + P2 - 2 P1, with a double threshold (corner_detector.cpp:285-288 `cost > 1.05`, :337 `cost < 1.05`):
+// as bounds on c2, found by stepping from the threshold's square.
+static bool derive_kparams(const ctag_params& p, KParams* k) {
+    auto ok = [](double v) { return v > 0 && v < 1e30; };
+    if (!ok(p.threshold_line) || !ok(p.threshold_expand) || !ok(p.threshold_RAC) || !ok(p.threshold_angle) || !ok(p.threshold_vertical) || p.area_min < 1 ||
+        !(p.area_max_fraction > 0 && p.area_max_fraction <= 1) || !(p.collinear_cost > 0 && p.collinear_cost < 1e4))
+        return false;
+    for (int j = 0; j < 4; j++)
+        if (!ok(p.ID_cr_correspond[j]) || !(p.cr_covariance_left[j] >= 0) || !(p.cr_covariance_right[j] >= 0)) return false;
+    k->thr_line = p.threshold_line;
+    k->thr_expand = p.threshold_expand;
+    k->rac = p.threshold_RAC;
+    k->angle = p.threshold_angle;
+    k->vertical = p.threshold_vertical;
+    for (int j = 0; j < 4; j++) {
+        k->cr_id[j] = p.ID_cr_correspond[j];
+        k->cr_lo[j] = p.cr_covariance_left[j];
+        k->cr_hi[j] = p.cr_covariance_right[j];
+    }
+    k->dark_cap = p.dark_cap;
+    k->area_min = p.area_min;
+    k->area_max_fraction = p.area_max_fraction;
+    auto cost = [](long long c2) { return (double)(float)std::sqrt((double)c2); };
+    long long c = (long long)(p.collinear_cost * p.collinear_cost);
+    while (c > 0 && cost(c) > p.collinear_cost) c--;       // largest c2 with cost <= threshold ...
+    while (!(cost(c + 1) > p.collinear_cost)) c++;
+    k->c2_far = (int)(c + 1);                                // ... so cost > threshold from c + 1 on
+    long long d = c;
+    while (d >= 0 && !(cost(d) < p.collinear_cost)) d--;     // largest c2 with cost < threshold (-1: none)
+    k->c2_near = (int)d;
+    return true;
+}
+
 int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_size, int device_id, ctag_handle** out) {
+    return ctag_create_ex(state, dict_rows, dict_cols, feature_size, device_id, nullptr, out);
+}
+
+int ctag_create_ex(const int32_t* state, int dict_rows, int dict_cols, int feature_size, int device_id, const ctag_params* params, ctag_handle** out) {
     if (!out) return CTAG_ERR_ARG;
     *out = nullptr;
+    ctag_params prm;
+    ctag_params_default(&prm);
+    if (params) prm = *params;
+    KParams kp{};
+    if (!derive_kparams(prm, &kp)) return CTAG_ERR_ARG;
+    std::vector<uint8_t> thr(256 * 256);
+    if (!build_threshold_table(prm.dark_cap, thr.data(), &kp.thr_dim, &kp.tcap)) return CTAG_ERR_ARG;
+    kp.tcap4 = (uint32_t)kp.tcap * 0x01010101u;
     if (!state || dict_rows < 1 || dict_cols < 1 || (long)dict_rows * dict_cols > kMaxDictCells) return CTAG_ERR_ARG;
     for (long i = 0; i < (long)dict_rows * dict_cols; i++)
         if (!(state[i] >= 0 && state[i] <= 63)) return CTAG_ERR_ARG;  // check_dictionary, CylinderTag.cpp:56-65
@@ -589,6 +660,7 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
     ctag_handle* h = new (std::nothrow) ctag_handle();
     if (!h) return CTAG_ERR_HIP;
     h->device = device_id;
+    h->params = prm;
     h->dict.assign(state, state + (size_t)dict_rows * dict_cols);
     h->dict_rows = dict_rows;
     h->dict_cols = dict_cols;
@@ -613,11 +685,13 @@ int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_
         ok = hipMalloc(reinterpret_cast<void**>(&h->d_pick_table), tab.size()) == hipSuccess &&
              hipMemcpy(h->d_pick_table, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
-    if (!ok) {
-        ctag_destroy(h);
-        return CTAG_ERR_HIP;
+    if (ok) {
+        const size_t tb = (size_t)kp.thr_dim * kp.thr_dim;
+        ok = hipMalloc(reinterpret_cast<void**>(&h->d_thr_table), tb) == hipSuccess && hipMemcpy(h->d_thr_table, thr.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
+        kp.thr_table = h->d_thr_table;
+        h->kp = kp;
     }
-    if (upload_threshold_table() != hipSuccess) {
+    if (!ok) {
         ctag_destroy(h);
         return CTAG_ERR_HIP;
     }
@@ -634,6 +708,7 @@ void ctag_destroy(ctag_handle* h) {
     drop_graphs(h);
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->d_dict) (void)hipFree(h->d_dict);
+    if (h->d_thr_table) (void)hipFree(h->d_thr_table);
     if (h->d_dict_pos) (void)hipFree(h->d_dict_pos);
     if (h->d_pick_table) (void)hipFree(h->d_pick_table);
     if (h->d_frames) (void)hipFree(h->d_frames);

@@ -72,6 +72,21 @@ struct FeatureDev { // K7/K8 output per feature (reference struct featureInfo)
     int32_t pad;
 };
 
+// The detector's tunables as the kernels consume them (include/ctag.h: ctag_params; built once per handle)
+struct KParams {
+    float thr_line, thr_expand, rac, angle, vertical;  // threshold_line / _expand / _RAC / _angle / _vertical
+    float cr_id[4], cr_lo[4], cr_hi[4];                // ID_cr_correspond, cr_covariance_left, cr_covariance_right
+    float dark_cap;
+    int tcap;                 // pixel u is below the cap iff u < tcap (77 for 0.3)
+    uint32_t tcap4;           // tcap in every byte
+    int thr_dim;              // threshold table is thr_dim x thr_dim; mn + mx >= thr_dim means T = tcap
+    const uint8_t* thr_table; // device memory, owned by the handle
+    int area_min;
+    double area_max_fraction;
+    int c2_far;               // squared triplet norm c2 >= c2_far  <=>  (float)sqrt(c2) >  collinear_cost   (2 for 1.05)
+    int c2_near;              // c2 <= c2_near                      <=>  (float)sqrt(c2) <  collinear_cost   (1 for 1.05)
+};
+
 struct FrameGeom {
     int rows, cols;            // full-res
     int hrows, hcols;          // half-res
@@ -127,6 +142,7 @@ struct Workspace {
     hipStream_t aux_stream = nullptr;     // owned by the handle: side branch for few-frame calls (launch_quads)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int wave_points = 0;                  // CTAG_OPT_WAVE_POINTS (0 = automatic)
+    KParams kp{};                         // the handle's tunables
     // features
     void* quad_derived = nullptr;   // [F][kCandCap] x 48 B (K7 scratch)
     int32_t* quad_index = nullptr;  // [F][kCandCap]
@@ -168,7 +184,8 @@ hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams&
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s);
 size_t threshold_ccl_lds_bytes(int tw);
-hipError_t upload_threshold_table();  // once per device before the first K2 launch
+// adaptive-threshold bound table for a dark cap (host): returns false when the cap is outside what K2's packed compares hold
+bool build_threshold_table(float dark_cap, uint8_t* table /* 256*256 */, int* dim, int* tcap);
 void build_pick_table(uint8_t* table);  // kPickN*20*10 bytes
 
 

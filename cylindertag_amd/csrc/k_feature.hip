@@ -56,6 +56,7 @@ struct FeatPtrs {
     FeatureDev* feat1;
     FeatureDev* feat2;
     unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1): clock ticks per phase of k_features, else null
+    float threshold_angle;       // include/ctag.h ctag_params [5]
 };
 
 // developer aid: phase clock of a block (thread 0), summed over blocks into `stamps[base + phase]`
@@ -113,8 +114,7 @@ __device__ void feature_organization(const float* q1, const float* q2, float c1x
 }
 
 // the pair test of featureRecovery (:483-548) for quads i < j; pure in (Di, Dj)
-__device__ __forceinline__ bool feature_pair(const QuadDerived& Di, const QuadDerived& Dj) {
-    const float thr = 5;  // threshold_angle
+__device__ __forceinline__ bool feature_pair(const QuadDerived& Di, const QuadDerived& Dj, float thr /* threshold_angle [5] */) {
     bool tag1 = false, tag2 = false;
     float d1s = 0, d1l = 0, d2s = 0, d2l = 0, ea1 = 0, ea2 = 0;
     const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
             auto consider = [&](int i, int j) {
                 const int at = atomicAdd(&s_npair, 1);
                 if (at < kPairList) s_plist[at] = (uint16_t)(i | (j << 8));
-                else if (feature_pair(s_der[i], s_der[j])) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));  // list full: in place
+                else if (feature_pair(s_der[i], s_der[j], P.threshold_angle)) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));  // list full: in place
             };
             for (int i = 0; i + 1 < Q; i++) {
                 const float xi = s_der[i].cx, yi = s_der[i].cy, ri = s_reach[i];
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         __syncthreads();
         for (int t = tid; t < min(s_npair, kPairList); t += 128) {
             const int i = (int)(s_plist[t] & 0xffu), j = (int)(s_plist[t] >> 8);
-            if (feature_pair(s_der[i], s_der[j])) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));
+            if (feature_pair(s_der[i], s_der[j], P.threshold_angle)) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));
         }
         __syncthreads();
         clk.mark(2);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
             int mine = 0x7fffffff;
             for (int j = i + 1 + tid; j < Q && mine == 0x7fffffff; j += 128) {
                 if (s_vis[j]) continue;
-                if (feature_pair(Di, der[j])) mine = j;
+                if (feature_pair(Di, der[j], P.threshold_angle)) mine = j;
             }
             if (mine != 0x7fffffff) atomicMin(&s_best, mine);
             __syncthreads();
@@ -647,13 +647,12 @@ struct MarkerPtrs {
     ctag_frame_result* out;
     unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1), slots 16..
     const uint32_t* dict_pos;    // [dict_rows][64] columns holding symbol v, bit c = column c; null when the dictionary has > 32 columns
+    KParams kp;                  // tunables: angle, vertical, cross-ratio tables
 };
 
 // featureExtraction for one feature (:1056-1207); C = 8 corners (x,y), swapped in place when direction == 0
-__device__ void feature_ids(float* C, int direction, int& ID_left, int& ID_right, float& crl, float& crr, int& id, int& idl, int& idr) {
-    const float IDc[4] = {1.47f, 1.54f, 1.61f, 1.68f};
-    const float covL[4] = {0.1f, 0.035f, 0.035f, 0.035f};
-    const float covR[4] = {0.035f, 0.035f, 0.035f, 0.1f};
+__device__ void feature_ids(float* C, int direction, int& ID_left, int& ID_right, float& crl, float& crr, int& id, int& idl, int& idr, const float* IDc,
+                            const float* covL, const float* covR) {  // ID_cr_correspond, cr_covariance_left / _right (ctag_params)
     auto Pt = [&](int k) { return P2{C[2 * k], C[2 * k + 1]}; };
     if (!direction) {
         if (C[0] > C[8]) {
@@ -806,7 +805,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
                 if (i == r) continue;  // the middle row pairs with itself: its entries are the first part
             }
             const FeatureDev &A = s_feat[i], &B = s_feat[j];
-            const float threshold_angle = 5, threshold_vertical = 0.5f;
+            const float threshold_angle = P.kp.angle, threshold_vertical = P.kp.vertical;
             const float vlx = A.c[0] - A.c[10], vly = A.c[1] - A.c[11];
             const double reach = 0.3 * dist2p(P2{A.c[0], A.c[1]}, P2{A.c[10], A.c[11]});
             const float vcx = A.center[0] - B.center[0], vcy = A.center[1] - B.center[1];
@@ -1003,7 +1002,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         R.edge_length = (dist2p(P2{F.c[0], F.c[1]}, P2{F.c[2], F.c[3]}) + dist2p(P2{F.c[8], F.c[9]}, P2{F.c[10], F.c[11]}) / 2);
         R.pos = -1;
         int id, idl, idr, nl = kCarry, nr = kCarry;
-        feature_ids(R.corners, s_group[k], nl, nr, R.cr_left, R.cr_right, id, idl, idr);
+        feature_ids(R.corners, s_group[k], nl, nr, R.cr_left, R.cr_right, id, idl, idr, P.kp.cr_id, P.kp.cr_lo, P.kp.cr_hi);
         R.id = id == -2 ? -2 : 0;  // -2: rejected by the edge-length test; 0: ids filled in by the replay
         R.id_left = nl;
         R.id_right = nr;
@@ -1314,7 +1313,7 @@ static unsigned long long* feat_stamps(hipStream_t s, bool report) {
 }
 
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
-    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false)};
+    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false), ws.kp.angle};
     hipLaunchKernelGGL(k_features, dim3(nframes), dim3(128), 0, s, P, nframes, p.feature_size);
     return hipGetLastError();
 }
@@ -1325,7 +1324,7 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     return hipGetLastError();
 }
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s) {
-    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false), p.dict_pos};
+    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false), p.dict_pos, ws.kp};
     hipLaunchKernelGGL(k_markers, dim3(nframes), dim3(64), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
     (void)feat_stamps(s, true);
     return hipGetLastError();

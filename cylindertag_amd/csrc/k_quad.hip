@@ -45,6 +45,9 @@ struct QuadPtrs {
     uint32_t* packs;       // [F][kCandCap] first entry of pack_order | count << 16, longest first
     uint16_t* pack_order;  // [F][kCandCap] candidate indices by descending boundary capacity
     unsigned long long* stamps;  // developer aid (CTAG_QUAD_STAMPS=1): cycles per phase of k_quad_edges, else null
+    // tunables (include/ctag.h: ctag_params; the reference's values in brackets)
+    float thr_line, thr_expand, rac;  // threshold_line [1.8], threshold_expand [1.2], threshold_RAC [0.3]
+    int c2_far, c2_near;              // collinearity cost [1.05] as bounds on the squared integer norm: [2], [1]
 };
 
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
 // All quantities that decide anything are computed from exact sums, so the outcome equals the sequential loop's.
 // Returns nl / nr = points added on the left / right side.  All 8 lanes return the same values.
 template <int SG>
-__device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, int& nl_out,
+__device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, float thr_expand, int& nl_out,
                                                int& nr_out) {
     constexpr unsigned long long kSgMask = SG == 64 ? ~0ull : ((1ull << (SG & 63)) - 1ull);
     long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
@@ -472,7 +475,7 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
             lp[k] = sl == 0 ? line[k] : up;
         }
         const float de = ctm::fabs32(ux(qpt) * lp[1] - uy(qpt) * lp[0] + lp[0] * lp[3] - lp[1] * lp[2]);
-        const unsigned long long failm = ((unsigned long long)__ballot(de > 1.2f) >> sgshift) & kSgMask;
+        const unsigned long long failm = ((unsigned long long)__ballot(de > thr_expand) >> sgshift) & kSgMask;
         const int tf = failm ? (int)(__ffsll(failm) - 1) : 99;
         const int tc = SG <= 8 ? __shfl(cfalse_at, lane0 + SG - 1) : cfalse_at;
         const int te_raw = n - m - 1;  // the add of step te makes Slide.size() == edge_point.size()
@@ -534,8 +537,13 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
 // Every lane of a sub-group executes the serial control flow redundantly (uniform within the sub-group), so no
 // broadcasts are needed; loops over pixels / boundary points are strided over the 8 lanes.
 // =====================================================================================================
-template <int SG, int WORDS, int WAVES, bool DYN>
+// REFPRM: the boundary tunables are the reference's (threshold_line 1.8, threshold_expand 1.2, collinearity 1.05) and compiled in;
+// a handle created with other values (ctag_create_ex) runs the builds that read them from P.  (As kernel arguments in the one
+// build they cost the packed kernel 15 %: 4.9 -> 5.65 ms per 4096 frames -- its register allocation is that tight.)
+template <int SG, int WORDS, int WAVES, bool DYN, bool REFPRM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes, int tier_lo) {
+    const float k_thr_line = REFPRM ? 1.8f : P.thr_line, k_thr_expand = REFPRM ? 1.2f : P.thr_expand;
+    const int k_c2_far = REFPRM ? 2 : P.c2_far, k_c2_near = REFPRM ? 1 : P.c2_near;
     static_assert(SG == 8 || SG == 64, "8 lanes per component (packs) or the whole wave (oversize components)");
     __shared__ uint32_t s_static[DYN ? 1 : WORDS];
     extern __shared__ uint32_t s_dynamic[];
@@ -1231,8 +1239,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 break;
             }
             {
-                int c2 = tri2(init);  // cost > 1.05  <=>  squared norm >= 2
-                while (c2 >= 2 && init < n - 3) {
+                int c2 = tri2(init);  // cost > collinear_cost [1.05]  <=>  squared norm >= c2_far [2]
+                while (c2 >= k_c2_far && init < n - 3) {
                     init++;
                     c2 = tri2(init);
                 }
@@ -1275,20 +1283,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
                 }
                 const int count = end - init - 1;
-                if (bd > 1.8f && count > 1) {
+                if (bd > k_thr_line && count > 1) {
                     end = bi;  // literal index into dist2line
                     continue;
                 }
                 // ---- expand_line (:125-169), speculative over the sub-group's 8 lanes
                 int nl, nr;
-                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, nl, nr);
+                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, k_thr_expand, nl, nr);
                 const int m = end - init + 1 + nl + nr;
                 // the span is a circular arc [a .. b] of m distinct indices
                 const int a = ((init - nl) % n + n) % n;
                 const int b = (end + nr) % n;
                 const bool wrap = a > b;
                 const int span0 = wrap ? n - 1 : b;
-                const int keep = tri2(span0) <= 1 ? 1 : 0;  // cost < 1.05 (:337-339)
+                const int keep = tri2(span0) <= k_c2_near ? 1 : 0;  // cost < collinear_cost [1.05] (:337-339)
                 const int offc = cl_off[cnt_b];
                 for (int k = sl; k < m; k += SG) {  // cluster points in descending index order (:332-334)
                     int idx;
@@ -1793,7 +1801,7 @@ __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int 
             if (rank6[i] == p) c = raw[i];
         cp[p] = c;
     }
-    float rac_min = 0.3f;
+    float rac_min = P.rac;
     int best_id = -1;
     {
         int id = 0;
@@ -1868,7 +1876,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         if (ev5) (void)hipEventRecord(ev5[evi++], s);
     };
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr, ws.kp.thr_line, ws.kp.thr_expand, ws.kp.rac, ws.kp.c2_far, ws.kp.c2_near};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
@@ -1896,28 +1904,40 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     }
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
-    if (small_cfg)
-        hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0);
-    else
-        hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0);
+    const bool refprm = ws.kp.thr_line == 1.8f && ws.kp.thr_expand == 1.2f && ws.kp.c2_far == 2 && ws.kp.c2_near == 1;
+#define CTAG_LAUNCH_PACKED(REF)                                                                                                                              \
+    do {                                                                                                                                                     \
+        if (small_cfg)                                                                                                                                       \
+            hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+        else                                                                                                                                                 \
+            hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0);      \
+    } while (0)
+    if (refprm) CTAG_LAUNCH_PACKED(true);
+    else CTAG_LAUNCH_PACKED(false);
+#undef CTAG_LAUNCH_PACKED
     mark();
     // oversize components, a wave each: working sets up to kWaveWords in a 32 KB build (5 per CU), the rest (up to the 144 KB a
     // 4K frame's longest possible boundary needs three times over) in a build that owns a CU's LDS
     static const int bcols_env = getenv("CTAG_BIG_COLS") ? atoi(getenv("CTAG_BIG_COLS")) : 0;
     const int bcols = bcols_env > 0 ? bcols_env : (latency ? 128 : 4);
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev = dev < 0 || dev >= 64 ? 0 : dev;
-        static bool have[64] = {false};
-        if (!have[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_quad_edges_packed<64, kWaveWordsMax, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kWaveWordsMax * 4);
-            have[dev] = true;
-        }
-    }
-    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWords, 1, false>), dim3(nframes, bcols), dim3(64), 0, sb, P, ws.g, nframes, 0);
-    hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWordsMax, 1, true>), dim3(nframes, latency ? 8 : 2), dim3(64), kWaveWordsMax * 4, sb, P, ws.g, nframes, kWaveWords);
+#define CTAG_LAUNCH_WAVE(REF)                                                                                                                               \
+    do {                                                                                                                                                    \
+        int dev = 0;                                                                                                                                        \
+        (void)hipGetDevice(&dev);                                                                                                                           \
+        dev = dev < 0 || dev >= 64 ? 0 : dev;                                                                                                               \
+        static bool have[64] = {false};                                                                                                                     \
+        if (!have[dev]) {                                                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_quad_edges_packed<64, kWaveWordsMax, 1, true, REF>),                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWaveWordsMax * 4);                                                       \
+            have[dev] = true;                                                                                                                               \
+        }                                                                                                                                                   \
+        hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWords, 1, false, REF>), dim3(nframes, bcols), dim3(64), 0, sb, P, ws.g, nframes, 0);                \
+        hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWordsMax, 1, true, REF>), dim3(nframes, latency ? 8 : 2), dim3(64), kWaveWordsMax * 4, sb, P, ws.g, \
+                           nframes, kWaveWords);                                                                                                            \
+    } while (0)
+    if (refprm) CTAG_LAUNCH_WAVE(true);
+    else CTAG_LAUNCH_WAVE(false);
+#undef CTAG_LAUNCH_WAVE
     if (fork) {
         (void)hipEventRecord(ws.ev_join, sb);
         (void)hipStreamWaitEvent(s, ws.ev_join, 0);

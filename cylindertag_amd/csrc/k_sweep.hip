@@ -530,32 +530,36 @@ __device__ __forceinline__ void lds_union(unsigned* parent, unsigned a, unsigned
 }
 
 // adaptive threshold of one tile as an integer bound: pixel u is foreground iff u < T, where
-// fg <=> float(u)*(1/255) < min(0.3f, (maxF + minF)/2)     (corner_detector.cpp:71)
-__host__ __device__ __forceinline__ int threshold_bound(int mn, int mx) {
+// fg <=> float(u)*(1/255) < min(cap, (maxF + minF)/2), cap = 0.3f in the reference    (corner_detector.cpp:71)
+__host__ __device__ __forceinline__ int threshold_bound(int mn, int mx, float cap) {
     const float k = (float)(1.0 / 255);
     const float a = ((float)mx * k + (float)mn * k) / 2;
-    const float thr = a < 0.3f ? a : 0.3f;
+    const float thr = a < cap ? a : cap;
     int t = (int)(thr * 255.0f);
     t = t < 0 ? 0 : (t > 256 ? 256 : t);
     while (t < 256 && (float)t * k < thr) t++;
     while (t > 0 && !((float)(t - 1) * k < thr)) t--;
     return t;
 }
-// The bound is 77 (the 0.3 cap) once mn + mx >= 154 and otherwise depends on both operands (the two products round
-// separately): a 154 x 154 byte table, built on the host with the function above when a handle is created, replaces the
-// float search in the kernel (most threshold tiles are bright and never touch it).
-constexpr int kThrDim = 154;
-__device__ uint8_t g_thr_table[kThrDim * kThrDim];
-hipError_t upload_threshold_table() {
-    static uint8_t host[kThrDim * kThrDim];
-    for (int mn = 0; mn < kThrDim; mn++)
-        for (int mx = 0; mx < kThrDim; mx++) host[mn * kThrDim + mx] = (uint8_t)threshold_bound(mn, mx);
+// The bound is tcap (77 for the reference's 0.3 cap) once mn + mx >= dim (154 there) and otherwise depends on both operands (the two
+// products round separately): a dim x dim byte table, built on the host with the function above when a handle is created, replaces
+// the float search in the kernel (most threshold tiles are bright and never touch it).  K2's packed-byte compares need tcap < 128.
+bool build_threshold_table(float dark_cap, uint8_t* table, int* dim_out, int* tcap_out) {
+    if (!(dark_cap > 0.f) || !(dark_cap < 0.5f)) return false;
+    const int tcap = threshold_bound(255, 255, dark_cap);  // the bound of a tile brighter than the cap
+    if (tcap < 1 || tcap > 127) return false;
+    int dim = 1;
     for (int mn = 0; mn < 256; mn++)
         for (int mx = mn; mx < 256; mx++)
-            if (mn + mx >= kThrDim && threshold_bound(mn, mx) != 77) return hipErrorAssert;  // the shortcut the kernel relies on
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_thr_table), host, sizeof(host));
+            if (threshold_bound(mn, mx, dark_cap) != tcap) dim = mn + mx + 1 > dim ? mn + mx + 1 : dim;
+    if (dim > 256) return false;
+    for (int mn = 0; mn < dim; mn++)
+        for (int mx = 0; mx < dim; mx++) table[mn * dim + mx] = (uint8_t)threshold_bound(mn, mx, dark_cap);
+    *dim_out = dim;
+    *tcap_out = tcap;
+    return true;
 }
-__device__ __forceinline__ int threshold_lookup(int mn, int mx) { return mn + mx >= kThrDim ? 77 : (int)g_thr_table[mn * kThrDim + mx]; }
+__device__ __forceinline__ int threshold_lookup(int mn, int mx, const KParams& kp) { return mn + mx >= kp.thr_dim ? kp.tcap : (int)kp.thr_table[mn * kp.thr_dim + mx]; }
 
 // geometry of one CCL tile and of the threshold tiles / pixels it needs
 struct TileRegion {
@@ -630,7 +634,7 @@ constexpr int kVPitch = 352;  // column extrema per threshold-tile row: 5 + 320 
 // the tile border (they may grow by seam merging); the other specks keep a label of their own with bit 15 set, which no
 // later stage ever looks up.
 template <int TWC, int RUNCAP, int SLOTCAP, bool BIG>
-__device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P, const FrameGeom& g, int frame0, int tile0) {
+__device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P, const FrameGeom& g, const KParams& kp, int frame0, int tile0) {
     const int tw = TWC ? TWC : g.tw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -724,7 +728,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
             *reinterpret_cast<uint2*>(vmin_s + cr * kVPitch + gq * 8) = mn;
             *reinterpret_cast<uint2*>(vmax_s + cr * kVPitch + gq * 8) = mx;
             // tile rows / columns are multiples of 5 and 8, so an item lies wholly inside the tile or wholly in the ring
-            item_dark[q] = (lt4_bytes(mn.x, 0x4d4d4d4du) | lt4_bytes(mn.y, 0x4d4d4d4du)) != 0u;
+            item_dark[q] = (lt4_bytes(mn.x, kp.tcap4) | lt4_bytes(mn.y, kp.tcap4)) != 0u;
             if (tr0 + cr >= trs0 && tr0 + cr <= trs1 && gx >= tx0 && gx < tx0 + tw_eff) dark = dark || item_dark[q];
         }
     }
@@ -771,7 +775,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
             const int tr = trs0 + r, tc = tcs0 + c;
             int T = 0;
             // a threshold tile whose own minimum is >= 77 has no pixel below any threshold (T <= 77): its T is never needed
-            if (tr >= 1 && tr <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2 && (ext_s[(tr - tr0) * L.ec + (tc - tc0)] & 0xff) < 77) {
+            if (tr >= 1 && tr <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2 && (ext_s[(tr - tr0) * L.ec + (tc - tc0)] & 0xff) < kp.tcap) {
                 int mn = 255, mx = 0;
 #pragma unroll
                 for (int dy = -1; dy <= 1; dy++)
@@ -781,7 +785,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
                         mn = min(mn, e & 0xff);
                         mx = max(mx, e >> 8);
                     }
-                T = threshold_lookup(mn, mx);  // <= 77: the reference caps the threshold at 0.3
+                T = threshold_lookup(mn, mx, kp);  // <= tcap: the reference caps the threshold (at 0.3: 77)
             }
             const int xa = max(tc * tw - tx0, 0), xb = min((tc + 1) * tw - tx0, tw_eff);
             for (int x = xa; x < xb; x++) thr_s[r * (kTileW + 8) + x] = (uint8_t)T;
@@ -866,7 +870,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
                             mn = min(mn, e & 0xff);
                             mx = max(mx, e >> 8);
                         }
-                    T = threshold_bound(mn, mx);  // <= 77: the reference caps the threshold at 0.3
+                    T = threshold_bound(mn, mx, kp.dark_cap);  // <= tcap: the reference caps the threshold (at 0.3: 77)
                 }
                 const int xa = max(tc * tw - tx0, 0), xb = min((tc + 1) * tw - tx0, tw_eff);
                 for (int x = xa; x < xb; x++) thr_s[r * (kTileW + 8) + x] = (uint8_t)T;
@@ -1057,7 +1061,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
         auto keep = [&](int i) -> bool {
             const unsigned rows = st_rows[i];
             const bool border = st_xmin[i] == tx0 || st_xmax[i] == tx0 + tw_eff - 1 || (rows & 1u) != 0u || ((rows >> (th_eff - 1)) & 1u) != 0u;
-            return border || st_area[i] >= 30;
+            return border || st_area[i] >= kp.area_min;
         };
         int mine = 0;
         for (int k = 0; k < per; k++)
@@ -1167,24 +1171,24 @@ __global__ __launch_bounds__(kCclThreads) __attribute__((amdgpu_waves_per_eu(CTA
 #else
 __global__ __launch_bounds__(kCclThreads)
 #endif
-void k_threshold_ccl(SweepPtrs P, FrameGeom g, int nframes) {
+void k_threshold_ccl(SweepPtrs P, FrameGeom g, KParams kp, int nframes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // one tile per block; blocks b and b+8 share an XCD, so a frame's tiles stay on one XCD (map_block)
     int frame0, tile0;
     if (!map_block(blockIdx.x, g.tiles_x * g.tiles_y, nframes, frame0, tile0)) return;
-    ccl_tile<TWC, kRunCap, kSlotCap, false>(smem, P, g, frame0, tile0);
+    ccl_tile<TWC, kRunCap, kSlotCap, false>(smem, P, g, kp, frame0, tile0);
 }
 
 // second pass over the tiles of the overflow list (usually none: the blocks read the count and leave)
 constexpr int kRunCapBig = 4864;   // >= 160 runs per row x 30 rows, a multiple of the block size
 constexpr int kSlotCapBig = 2560;  // >= 160 x 15 isolated pixels
 template <int TWC>
-__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl_big(SweepPtrs P, FrameGeom g) {
+__global__ __launch_bounds__(kCclThreads) void k_threshold_ccl_big(SweepPtrs P, FrameGeom g, KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int count = *P.ovf_count, per_frame = g.tiles_x * g.tiles_y;
     for (int i = blockIdx.x; i < count; i += gridDim.x) {
         const int e = P.ovf_list[i];
-        ccl_tile<TWC, kRunCapBig, kSlotCapBig, true>(smem, P, g, e / per_frame, e % per_frame);
+        ccl_tile<TWC, kRunCapBig, kSlotCapBig, true>(smem, P, g, kp, e / per_frame, e % per_frame);
         __syncthreads();
     }
 }
@@ -1217,14 +1221,14 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s)
     };
     static size_t have_big5[64] = {0}, have_big0[64] = {0}, have_0[64] = {0};
     if (g.tw == 5) {
-        hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
+        hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, ws.kp, nframes);
         want_lds(reinterpret_cast<const void*>(k_threshold_ccl_big<5>), lds_big, have_big5);
-        hipLaunchKernelGGL(k_threshold_ccl_big<5>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g);
+        hipLaunchKernelGGL(k_threshold_ccl_big<5>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g, ws.kp);
     } else {
         want_lds(reinterpret_cast<const void*>(k_threshold_ccl<0>), lds, have_0);
-        hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(kCclThreads), lds, s, P, g, nframes);
+        hipLaunchKernelGGL(k_threshold_ccl<0>, dim3(grid), dim3(kCclThreads), lds, s, P, g, ws.kp, nframes);
         want_lds(reinterpret_cast<const void*>(k_threshold_ccl_big<0>), lds_big, have_big0);
-        hipLaunchKernelGGL(k_threshold_ccl_big<0>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g);
+        hipLaunchKernelGGL(k_threshold_ccl_big<0>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g, ws.kp);
     }
     if (want_stamps) {
         unsigned long long h[16];
@@ -1436,7 +1440,7 @@ hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s) {
 // K5: area filter (corner_detector.cpp:87-91) and OpenCV label order: candidates sorted
 // by the block-raster index of their first 2x2 block.  One block per frame; rank sort in LDS.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, int nframes) {
+__global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, int nframes, int area_min) {
     __shared__ int s_idx[kCandCap];
     __shared__ int s_key[kCandCap];
     __shared__ int s_count;
@@ -1449,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, in
     for (int i = threadIdx.x; i < n; i += 256) {
         if (P.root_of[pool0 + i] == i) {
             const int a = P.area[pool0 + i];
-            if (!(a < 30 || a > g.max_area)) {
+            if (!(a < area_min || a > g.max_area)) {
                 const int at = atomicAdd(&s_count, 1);
                 if (at < kCandCap) {
                     s_idx[at] = i;
@@ -1486,7 +1490,7 @@ __global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, in
     }
 }
 hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s) {
-    hipLaunchKernelGGL(k_candidates, dim3(nframes), dim3(256), 0, s, sweep_ptrs(ws), ws.g, nframes);
+    hipLaunchKernelGGL(k_candidates, dim3(nframes), dim3(256), 0, s, sweep_ptrs(ws), ws.g, nframes, ws.kp.area_min);
     return hipGetLastError();
 }
 

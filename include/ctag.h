@@ -33,6 +33,17 @@ typedef struct ctag_handle ctag_handle;
 int ctag_create(const int32_t* state, int dict_rows, int dict_cols, int feature_size, int device_id, ctag_handle** out);
 void ctag_destroy(ctag_handle* h);
 
+/* The detector's tunables.  In the reference they are member constants of corner_detector
+ * (/root/reference/header/corner_detector.h:90,110,122,135-137,144) and literals of corner_detector.cpp (:71, :88, :285-288,337);
+ * ctag_params_default fills in exactly those values and ctag_create uses them.  ctag_create_ex takes other values -- a
+ * maintainer who edits the reference's constants passes the same numbers here and the results stay identical to the edited
+ * reference (the CPU oracle takes the same struct).  Limits: 0 < dark_cap < 0.5, area_min >= 1, 0 < area_max_fraction <= 1,
+ * finite positive thresholds; else CTAG_ERR_ARG. */
+/* (struct ctag_params: include/ctag_types.h) */
+void ctag_params_default(ctag_params* p);
+int ctag_create_ex(const int32_t* state, int dict_rows, int dict_cols, int feature_size, int device_id, const ctag_params* params,
+                   ctag_handle** out);
+
 /* Parses a .marker text file exactly as CylinderTag::load_from_file does (CylinderTag.cpp:16-41).
  * On success *state is malloc()ed (free with ctag_free). */
 int ctag_load_marker_file(const char* path, int32_t** state, int* dict_rows, int* dict_cols, int* feature_size);

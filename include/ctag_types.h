@@ -60,4 +60,20 @@ typedef struct ctag_frame_result {
     ctag_feature_rec features[CTAG_MAX_FEATURES];
 } ctag_frame_result; /* 16 + 1600 + 10000 = 11616 bytes */
 
+/* The detector's tunables (ctag_create_ex, include/ctag.h); the reference's values in the comments */
+typedef struct ctag_params {
+    float threshold_line;          /* 1.8   split a boundary span while a point lies farther than this from its chord   h:90,  cpp:320-329 */
+    float threshold_expand;        /* 1.2   expand_line accepts a point within this distance of the refitted line       h:90,  cpp:144,156 */
+    float threshold_RAC;           /* 0.3   quadJudgment: |shoelace area - pixel count| / pixel count below this         h:110, cpp:454-463 */
+    float threshold_angle;         /* 5     degrees: featureRecovery (x1, x10) and markerOrganization (x2, x1)           h:122, cpp:488-548,985 */
+    float threshold_vertical;      /* 0.5   markerOrganization: |cos(centre vector, long edge)| below this               h:144, cpp:985 */
+    float ID_cr_correspond[4];     /* 1.47 1.54 1.61 1.68   cross ratio of code 0..3                                     h:135, cpp:1165-1189 */
+    float cr_covariance_left[4];   /* 0.1 0.035 0.035 0.035 interval below ID_cr_correspond[j]                           h:136 */
+    float cr_covariance_right[4];  /* 0.035 0.035 0.035 0.1 interval above                                               h:137 */
+    float dark_cap;                /* 0.3   a pixel is foreground iff p < min(dark_cap, (max + min) / 2), p in [0, 1]    cpp:71 */
+    int32_t area_min;              /* 30    components of fewer pixels are dropped                                       cpp:88 */
+    double area_max_fraction;      /* 0.01  ... and those above round(fraction * cols * rows) of the half-size image     cpp:88 */
+    double collinear_cost;         /* 1.05  |P0 + P2 - 2 P1| of a boundary triplet counts as collinear below this        cpp:285-288,337 */
+} ctag_params;
+
 #endif

@@ -20,6 +20,12 @@ extern "C" {
 
 typedef struct ctago_run ctago_run; /* one traced detect() run */
 
+/* The tunables of every following run (include/ctag_types.h: struct ctag_params -- the reference's member constants
+ * header/corner_detector.h:90,110,122,135-137,144 and literals corner_detector.cpp:71,88,285); NULL = the reference's values.
+ * Not to be called while detections run on other threads. */
+struct ctag_params;
+void ctago_set_params(const struct ctag_params* p);
+
 /* status codes mirror include/ctag.h */
 enum { CTAGO_OK = 0, CTAGO_NO_CORNER = 1, CTAGO_NO_FEATURE = 2, CTAGO_ERR_LIMIT = -3, CTAGO_ERR_ARG = -1 };
 

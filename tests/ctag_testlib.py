@@ -108,6 +108,12 @@ class Oracle:
         L.ctago_fitline_l2.argtypes = [_p_i32, C.c_int, _p_f32]
         L.ctago_fitline_welsch.argtypes = [_p_i32, C.c_int, _p_f32]
         L.ctago_math_probe.argtypes = [C.c_int, C.c_int, _p_f64, _p_f64, _p_f64]
+        L.ctago_set_params.argtypes = [C.c_void_p]
+        L.ctago_set_params.restype = None
+
+    def set_params(self, params=None):
+        """The tunables of every following run: a cylindertag_amd.ParamsC (the struct ctag_create_ex takes), None = the reference's values."""
+        self.L.ctago_set_params(C.byref(params) if params is not None else None)
 
     # ---- full traced run -------------------------------------------------------------------------
     def detect(self, gray, state, feature_size, adaptive_thresh=5, subpix=True, subpix_dist=5):

@@ -53,6 +53,35 @@ def test_result_record_layout_matches_header():
     assert ca.POSE_DT.itemsize == 136 and C.sizeof(capi.CameraC) == 96
 
 
+def test_params_struct_layout_and_reference_defaults(oracle, dictionary, test_bmp):
+    """ctag_params (include/ctag_types.h): the ctypes mirror has the C layout, ctag_params_default gives the reference's constants
+    (header/corner_detector.h:90,110,122,135-137,144; corner_detector.cpp:71,88,285) and the oracle consumes the same struct."""
+    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"ctag_types.h\"\nint main(){printf(\"%zu %zu %zu %zu %zu\", sizeof(ctag_params), " \
+          "offsetof(ctag_params, ID_cr_correspond), offsetof(ctag_params, dark_cap), offsetof(ctag_params, area_max_fraction), offsetof(ctag_params, collinear_cost));}"
+    exe = os.path.join(ROOT, "cylindertag_amd", "_build", "params_layout")
+    subprocess.run(["gcc", "-x", "c", "-I" + os.path.join(ROOT, "include"), "-o", exe, "-"], input=src.encode(), check=True)
+    got = [int(v) for v in subprocess.check_output([exe]).split()]
+    P = capi.ParamsC
+    assert got == [C.sizeof(P), P.ID_cr_correspond.offset, P.dark_cap.offset, P.area_max_fraction.offset, P.collinear_cost.offset]
+    p = ca.default_params()
+    assert (round(p.threshold_line, 6), round(p.threshold_expand, 6), round(p.threshold_RAC, 6), p.threshold_angle, p.threshold_vertical) == (1.8, 1.2, 0.3, 5.0, 0.5)
+    assert [round(v, 6) for v in p.ID_cr_correspond] == [1.47, 1.54, 1.61, 1.68]
+    assert [round(v, 6) for v in p.cr_covariance_left] == [0.1, 0.035, 0.035, 0.035] and [round(v, 6) for v in p.cr_covariance_right] == [0.035, 0.035, 0.035, 0.1]
+    assert (round(p.dark_cap, 6), p.area_min, p.area_max_fraction, p.collinear_cost) == (0.3, 30, 0.01, 1.05)
+    state, fs = dictionary
+    base = oracle.detect_fast(test_bmp, state, fs)
+    oracle.set_params(p)  # the defaults, explicitly
+    try:
+        assert oracle.detect_fast(test_bmp, state, fs).tobytes() == base.tobytes()
+        p.dark_cap = 0.2
+        p.area_min = 60
+        oracle.set_params(p)
+        assert oracle.detect_fast(test_bmp, state, fs).tobytes() != base.tobytes()
+    finally:
+        oracle.set_params(None)
+    assert oracle.detect_fast(test_bmp, state, fs).tobytes() == base.tobytes()
+
+
 def test_marker_loader_matches_reference_format(tmp_path):
     state, fs = ca.load_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
     ref, rfs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))

@@ -886,6 +886,59 @@ def test_bgr_ingest_equals_gray_path(detector, oracle, dictionary, test_bmp):
         detector.debug(0, tk.DBG_GRAY)
 
 
+def test_non_default_params(oracle, dictionary, test_bmp):
+    """ctag_create_ex / ctag_params: the reference's member constants and literals (header/corner_detector.h:90,110,122,135-137,144;
+    corner_detector.cpp:71,88,285) as a struct.  With values other than the reference's, the records still equal the oracle's, which
+    takes the same struct -- every field moved at least once, and in at least one setting the result differs from the default run."""
+    state, fs = dictionary
+    frames = [test_bmp, tk.synth_frame_host(state, 21)[0], tk.synth_frame_host(state, 22)[0]]
+    base = [oracle.detect_fast(f, state, fs) for f in frames]
+
+    def variant(**kw):
+        p = ca.default_params()
+        for k, v in kw.items():
+            if isinstance(v, (list, tuple)):
+                for i, x in enumerate(v):
+                    getattr(p, k)[i] = x
+            else:
+                setattr(p, k, v)
+        return p
+
+    settings = [
+        variant(threshold_line=1.3, threshold_expand=0.9),
+        variant(threshold_line=2.6, threshold_expand=1.7, collinear_cost=1.5),
+        variant(collinear_cost=2.1, threshold_RAC=0.12),
+        variant(threshold_RAC=0.05, threshold_angle=2.0, threshold_vertical=0.2),
+        variant(threshold_angle=9.0, threshold_vertical=0.8),
+        variant(dark_cap=0.2, area_min=60, area_max_fraction=0.002),
+        variant(dark_cap=0.45, area_min=12, area_max_fraction=0.03),
+        variant(dark_cap=0.12),
+        variant(ID_cr_correspond=[1.45, 1.52, 1.63, 1.70], cr_covariance_left=[0.05, 0.02, 0.05, 0.03], cr_covariance_right=[0.03, 0.05, 0.02, 0.06]),
+    ]
+    differs = 0
+    try:
+        for k, p in enumerate(settings):
+            det = tk.Detector(state, fs, params=p)
+            oracle.set_params(p)
+            try:
+                for i, f in enumerate(frames):
+                    want = oracle.detect_fast(f, state, fs)
+                    assert_same_record(det.detect(f), want, "params setting %d frame %d" % (k, i))
+                    differs += want.tobytes() != base[i].tobytes()
+            finally:
+                det.close()
+    finally:
+        oracle.set_params(None)
+    assert differs >= len(settings)  # the settings do change results: the fields are live
+    # the default struct through ctag_create_ex is ctag_create
+    det = tk.Detector(state, fs, params=ca.default_params())
+    assert_same_record(det.detect(test_bmp), base[0], "default params through ctag_create_ex")
+    det.close()
+    for bad in (variant(dark_cap=0.5), variant(dark_cap=0.0), variant(area_min=0), variant(threshold_line=0.0), variant(area_max_fraction=1.5)):
+        with pytest.raises(ca.CtagError):
+            tk.Detector(state, fs, params=bad)
+
+
 def test_cpp_cylindertag_class_demo(oracle, dictionary, test_bmp):
     """The C++ `CylinderTag` host layer (reference class interface) end to end: the demo binary reads test.bmp with the
     C++ BMP reader, calls CylinderTag::detect(img, markers, 5, true, 5) and prints the MarkerInfo vector."""
