@@ -62,6 +62,29 @@ def parse_args():
     return ap.parse_args()
 
 
+def device_copy_rate(dev):
+    """"also report against a measured device-copy kernel".  A plain device-to-device copy of 2 GiB (torch's copy
+    kernel: every byte read once and written once), best of 5 after a warm-up: GB/s of read + written bytes -- what a streaming
+    kernel can reach on this GPU, against the 8 TB/s specification the roofline fraction is priced at."""
+    import torch
+    n = 2 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.fill_(7)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def host_stream_rate(det, frames_dev, m, subpix):
     """Side measurement (never `value`): the same frames handed over as HOST buffers through ctag_detect_batch_u8 --
     pinned memory, uploads double-buffered against detection, results downloaded.  Bounded by PCIe."""
@@ -590,8 +613,16 @@ def main():
                 traffic_source = "replayed from %s (separate rocprofv3 --pmc passes; not collected in this run)" % os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
+        try:
+            copy_gbs = device_copy_rate(dev) if world == 1 else None
+        except Exception:  # noqa: BLE001
+            copy_gbs = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "measured_device_copy": None if not copy_gbs else {
+                        "GB/s": round(copy_gbs, 1), "frac_of_copy": round(achieved / copy_gbs, 5),
+                        "note": "plain device-to-device copy of 2 GiB (read + written bytes), best of 5, measured in this run: the rate a "
+                                "streaming kernel reaches on this GPU; `frac` stays priced at the 8 TB/s specification"},
                     "kernel": "threshold+label sweep = " + "+".join("k_" + k for k in SWEEP_STAGES),
                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * min(n, chunk),
                     "avg_launch_ms": round(sweep_ms / launches, 4), "launches_per_step": launches,
