@@ -268,6 +268,12 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
 #ifndef CTAG_PACK_WAVES
 #define CTAG_PACK_WAVES 2
 #endif
+#ifndef CTAG_SCAN_ROWS4
+#define CTAG_SCAN_ROWS4 0  // 1: the boundary-only build keeps four label rows in flight per lane (measured: 44 spilled registers, 4.03 vs 3.94 ms)
+#endif
+#ifndef CTAG_PACK_SPLIT
+#define CTAG_PACK_SPLIT 1  // the small-configuration packed build as two kernels (boundary, then edge clusters): see k_quad_edges_packed
+#endif
 constexpr int kPackWords = CTAG_PACK_WORDS;  // LDS words shared by the up to 8 components of a wave (large configuration)
 // Two builds of the packed kernel.  The kernel is bound by dependent LDS round trips (24 % of the issue roof at 2 waves per
 // SIMD), so for frames of 1080p class -- boundaries of ~150 points, a pack of 5 components in 10 KB -- the small configuration
@@ -364,16 +370,59 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
 
-// expand_line (corner_detector.cpp:125-169) for one 8-lane sub-group, speculatively: in every round lane t assumes the
-// next t+1 candidate points are all accepted, builds the exact integer moment sums of that prefix and fits its line
-// (fitLine DIST_L2); the point of step t is then tested against the line of step t-1, exactly as the sequential loop
-// does, and the prefix up to the first event (distance test fails, `left == right`, or every point used) is committed.
-// All quantities that decide anything are computed from exact sums, so the outcome equals the sequential loop's.
-// Returns nl / nr = points added on the left / right side.  All 8 lanes return the same values.
+#ifndef CTAG_EXPAND_INLINE
+#define CTAG_EXPAND_INLINE __forceinline__
+#endif
+// ---- expand_line's distance test as a filtered exact predicate ---------------------------------------------------------------------
+// The fitted line of a step is used for ONE thing: `dist_expand > threshold_expand` of the next candidate point
+// (corner_detector.cpp:144,156).  The reference gets there through fitLine(DIST_L2) -- five divisions, atan2, cos, sin in double,
+// rounded to float, then a float dot product (~200 FP64-class instructions per fit on this GPU).  The same decision follows from a
+// cheap double-precision estimate D of the point's distance to the exact least-squares line whenever D is not within `eps` of the
+// threshold; eps bounds |reference's float value - D|:
+//   * the reference's float evaluation of x*vy - y*vx + vx*y0 - vy*x0 on coordinates <= K: 4 products and 3 sums, 9 K 2^-24 in all,
+//     plus the float rounding of x0, y0 (2 K 2^-24);
+//   * its direction: t = (float)atan2(..)/2 (6e-8), the arguments' cancellation error in double (<= 6e-8 once the anisotropy
+//     h / n^2 >= K^2 2^-26, checked below), cos / sin rounded to float (3e-8): 1.5e-7 on each of four terms of size <= K;
+//   * this estimate's own error (v_rcp_f64 / v_rsq_f64 without refinement: 2^-23 relative, on a CENTRED form whose lever is the
+//     distance to the centroid) < 1e-4 K.
+//   Sum < 1.4e-6 K; eps = 3e-6 K.  A test inside the band (or a cluster too isotropic for the bound) sends its sub-group through
+//   the exact fits for that round, so the outcome is the reference's in every case (~1 % of the rounds).
+struct ALine {
+    double c, s, x, y;  // unit direction (cos t, sin t), t in [-pi/2, pi/2], and the centroid
+    bool ok;            // false: anisotropy too small for the error bound
+};
+__device__ __forceinline__ ALine approx_line(long long sx, long long sy, long long sxx, long long syy, long long sxy, int cnt, double k2lim) {
+    const double n = (double)cnt, fx = (double)sx, fy = (double)sy;
+    const double rn = __builtin_amdgcn_rcp(n);
+    const double A = ((double)sxx * n - fx * fx) - ((double)syy * n - fy * fy);  // n^2 (dx2 - dy2)
+    const double B = 2.0 * ((double)sxy * n - fx * fy);                           // n^2 2 dxy
+    const double h2 = A * A + B * B;
+    const double rh = __builtin_amdgcn_rsq(h2);  // 1 / h
+    const double u = ctm::fabs64(A) * rh;        // |cos 2t|
+    const double p = 0.5 + 0.5 * u;              // the larger of cos^2 t, sin^2 t: >= 1/2
+    const double rp = __builtin_amdgcn_rsq(p);
+    const double big = p * rp, small = (0.5 * ctm::fabs64(B) * rh) * rp;
+    const bool bneg = B < 0.0;
+    ALine L;
+    L.c = A >= 0.0 ? big : small;
+    const double sa = A >= 0.0 ? small : big;
+    L.s = bneg ? -sa : sa;
+    L.x = fx * rn;
+    L.y = fy * rn;
+    L.ok = h2 * (rn * rn) * (rn * rn) >= k2lim * k2lim;  // (h / n^2)^2 >= (K^2 2^-26)^2; false for h2 == 0 and for NaN
+    return L;
+}
+
+// expand_line (corner_detector.cpp:125-169) for one sub-group (8 lanes, or the whole wave), speculatively: in every round lane t
+// assumes the next t+1 candidate points are all accepted and builds the exact integer moment sums of that prefix; the point of step t
+// is then tested against the line of step t-1 -- by the filtered predicate above, by the reference's own fit where that is not
+// decisive -- exactly as the sequential loop does, and the prefix up to the first event (distance test fails, `left == right`,
+// or every point used) is committed.  Returns nl / nr = points added on the left / right side.  All lanes return the same values.
 template <int SG>
-__device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, float thr_expand, int& nl_out,
-                                               int& nr_out) {
+__device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, float thr_expand, float kmax,
+                                               int& nl_out, int& nr_out) {
     constexpr unsigned long long kSgMask = SG == 64 ? ~0ull : ((1ull << (SG & 63)) - 1ull);
+    const double thr = (double)thr_expand, eps = 3.0e-6 * (double)kmax, k2lim = (double)kmax * (double)kmax * 1.4901161193847656e-08;  // K^2 2^-26
     long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
     for (int k = init + sl; k <= end; k += SG) {
         const long long x = ux(W[k]), y = uy(W[k]);
@@ -392,92 +441,95 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
         Sxy += __shfl_xor(Sxy, d);
     }
     int m = end - init + 1;
-    float line[4];
-    moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, line);
+    ALine lineA = approx_line(Sx, Sy, Sxx, Syy, Sxy, m, k2lim);  // of the committed prefix
     bool fl = false, fr = false;
     int left = init - 1, right = end + 1, nl = 0, nr = 0;
     while ((!fl || !fr) && (left != right)) {
         const int mode = (!fl && !fr) ? 0 : (!fl ? 1 : 2);  // 0: L,R alternate; 1: left only; 2: right only
-        int l = left, r = right, q_idx = 0, cfalse_at = 99;
-        long long px = 0, py = 0, pxx = 0, pyy = 0, pxy = 0;
-        uint32_t qpt = 0;
-        if constexpr (SG <= 8) {
-            // replay the index bookkeeping of steps 0..sl under the "all accepted" assumption
-            for (int u = 0; u <= sl; u++) {
-                const bool stepL = mode == 0 ? ((u & 1) == 0) : (mode == 1);
-                const bool checkC = mode == 0 ? ((u & 1) == 0) : true;  // `left != right` is tested at the top of an iteration
-                if (checkC && l == r && cfalse_at == 99) cfalse_at = u;
-                int idx;
-                if (stepL) {
-                    idx = (l == -1) ? n - 1 : l;
-                    l = idx - 1;
-                } else {
-                    idx = (r == n) ? 0 : r;
-                    r = idx + 1;
-                }
-                qpt = W[idx];
-                const long long x = ux(qpt), y = uy(qpt);
-                px += x;
-                py += y;
-                pxx += x * x;
-                pyy += y * y;
-                pxy += x * y;
-                q_idx = idx;
+        // The index bookkeeping of steps 0..sl under the "all accepted" assumption, in closed form (a lane per step): before step u the
+        // left cursor has moved kl times and the right one kr times; the k-th left step reads index (left - k) mod n and leaves the raw
+        // cursor at that index - 1, the k-th right step reads (right + k) mod n and leaves index + 1 (`left` is in [-1, n-1], `right`
+        // in [0, n]: -1 and n are the not-yet-wrapped values the reference compares).
+        const bool stepL = mode == 0 ? ((sl & 1) == 0) : (mode == 1);
+        const bool checkC = mode == 0 ? ((sl & 1) == 0) : true;  // `left != right` is tested at the top of an iteration
+        const int kl = mode == 0 ? ((sl + 1) >> 1) : (mode == 1 ? sl : 0);  // left steps among steps 0..sl-1
+        const int kr = mode == 0 ? (sl >> 1) : (mode == 2 ? sl : 0);
+        auto idxL = [&](int k) {
+            if constexpr (SG <= 8) {  // k <= 8 and n >= 3: at most three wraps, no division
+                int x = left - k;
+                x += x < 0 ? n : 0;
+                x += x < 0 ? n : 0;
+                x += x < 0 ? n : 0;
+                return x;
+            } else {
+                return ((left - k) % n + n) % n;
             }
-        } else {
-            // the same bookkeeping in closed form (a lane per step instead of a replay loop per lane): before step u the left
-            // cursor has moved kl times and the right one kr times; the k-th left step reads index (left - k) mod n and leaves
-            // the raw cursor at that index - 1, the k-th right step reads (right + k) mod n and leaves index + 1
-            // (`left` is in [-1, n-1], `right` in [0, n]: -1 and n are the not-yet-wrapped values the reference compares).
-            const bool stepL = mode == 0 ? ((sl & 1) == 0) : (mode == 1);
-            const bool checkC = mode == 0 ? ((sl & 1) == 0) : true;
-            const int kl = mode == 0 ? ((sl + 1) >> 1) : (mode == 1 ? sl : 0);  // left steps among steps 0..sl-1
-            const int kr = mode == 0 ? (sl >> 1) : (mode == 2 ? sl : 0);
-            auto idxL = [&](int k) { return ((left - k) % n + n) % n; };
-            auto idxR = [&](int k) { return (right + k) % n; };
-            const int l_before = kl == 0 ? left : idxL(kl - 1) - 1;
-            const int r_before = kr == 0 ? right : idxR(kr - 1) + 1;
-            const bool cstop = checkC && l_before == r_before;
-            const unsigned long long cm = (unsigned long long)__ballot(cstop) & kSgMask;
-            cfalse_at = cm ? (int)(__ffsll((unsigned long long)cm) - 1) : 99;  // every lane holds the sub-group's first stop
-            q_idx = stepL ? idxL(kl) : idxR(kr);
-            l = stepL ? q_idx - 1 : l_before;
-            r = stepL ? r_before : q_idx + 1;
-            qpt = W[q_idx];
-            // inclusive prefix sums of the five moments over the lanes; 32 bits hold them: coordinates < 2^13 (an 8K frame at
-            // half resolution), products < 2^26, 64 of them < 2^32
-            uint32_t a0 = (uint32_t)ux(qpt), a1 = (uint32_t)uy(qpt), a2 = a0 * a0, a3 = a1 * a1, a4 = a0 * a1;
-#pragma unroll
-            for (int d = 1; d < SG; d <<= 1) {
-                const uint32_t b0 = (uint32_t)__shfl_up((int)a0, d), b1 = (uint32_t)__shfl_up((int)a1, d), b2 = (uint32_t)__shfl_up((int)a2, d),
-                               b3 = (uint32_t)__shfl_up((int)a3, d), b4 = (uint32_t)__shfl_up((int)a4, d);
-                if (sl >= d) {
-                    a0 += b0;
-                    a1 += b1;
-                    a2 += b2;
-                    a3 += b3;
-                    a4 += b4;
-                }
+        };
+        auto idxR = [&](int k) {
+            if constexpr (SG <= 8) {
+                int x = right + k;
+                x -= x >= n ? n : 0;
+                x -= x >= n ? n : 0;
+                x -= x >= n ? n : 0;
+                return x;
+            } else {
+                return (right + k) % n;
             }
-            px = a0;
-            py = a1;
-            pxx = a2;
-            pyy = a3;
-            pxy = a4;
-        }
-        float mine[4];
-        moments_to_line((double)(Sx + px), (double)(Sy + py), (double)(Sxx + pxx), (double)(Syy + pyy), (double)(Sxy + pxy),
-                        (double)(float)(m + sl + 1), mine);
-        float lp[4];
+        };
+        const int l_before = kl == 0 ? left : idxL(kl - 1) - 1;
+        const int r_before = kr == 0 ? right : idxR(kr - 1) + 1;
+        const bool cstop = checkC && l_before == r_before;
+        const unsigned long long cm = ((unsigned long long)__ballot(cstop) >> sgshift) & kSgMask;
+        const int tc = cm ? (int)(__ffsll((unsigned long long)cm) - 1) : 99;  // every lane holds the sub-group's first stop
+        const int q_idx = stepL ? idxL(kl) : idxR(kr);
+        const int l = stepL ? q_idx - 1 : l_before;
+        const int r = stepL ? r_before : q_idx + 1;
+        const uint32_t qpt = W[q_idx];
+        // inclusive prefix sums of the five moments over the lanes; 32 bits hold them: coordinates < 2^13 (an 8K frame at
+        // half resolution), products < 2^26, 64 of them < 2^32
+        uint32_t a0 = (uint32_t)ux(qpt), a1 = (uint32_t)uy(qpt), a2 = a0 * a0, a3 = a1 * a1, a4 = a0 * a1;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float up = __shfl(mine[k], lane0 + ((sl + SG - 1) & (SG - 1)));
-            lp[k] = sl == 0 ? line[k] : up;
+        for (int d = 1; d < SG; d <<= 1) {
+            const uint32_t b0 = (uint32_t)__shfl_up((int)a0, d), b1 = (uint32_t)__shfl_up((int)a1, d), b2 = (uint32_t)__shfl_up((int)a2, d),
+                           b3 = (uint32_t)__shfl_up((int)a3, d), b4 = (uint32_t)__shfl_up((int)a4, d);
+            if (sl >= d) {
+                a0 += b0;
+                a1 += b1;
+                a2 += b2;
+                a3 += b3;
+                a4 += b4;
+            }
         }
-        const float de = ctm::fabs32(ux(qpt) * lp[1] - uy(qpt) * lp[0] + lp[0] * lp[3] - lp[1] * lp[2]);
-        const unsigned long long failm = ((unsigned long long)__ballot(de > thr_expand) >> sgshift) & kSgMask;
+        const long long px = a0, py = a1, pxx = a2, pyy = a3, pxy = a4;
+        // ---- the distance test of step sl against the line of step sl - 1: filtered, exact where the filter is not decisive
+        const ALine mineA = approx_line(Sx + px, Sy + py, Sxx + pxx, Syy + pyy, Sxy + pxy, m + sl + 1, k2lim);
+        const int prev = lane0 + ((sl + SG - 1) & (SG - 1));
+        ALine lpA;
+        lpA.c = __shfl(mineA.c, prev);
+        lpA.s = __shfl(mineA.s, prev);
+        lpA.x = __shfl(mineA.x, prev);
+        lpA.y = __shfl(mineA.y, prev);
+        lpA.ok = __shfl((int)mineA.ok, prev) != 0;
+        if (sl == 0) lpA = lineA;
+        const double D = ctm::fabs64(((double)ux(qpt) - lpA.x) * lpA.s - ((double)uy(qpt) - lpA.y) * lpA.c);
+        bool fail = D > thr;
+        const bool unsure = !lpA.ok || !(ctm::fabs64(D - thr) > eps);
+        if (((unsigned long long)__ballot(unsure) >> sgshift) & kSgMask) {  // uniform within the sub-group
+            float mine[4], base[4];
+            moments_to_line((double)(Sx + px), (double)(Sy + py), (double)(Sxx + pxx), (double)(Syy + pyy), (double)(Sxy + pxy),
+                            (double)(float)(m + sl + 1), mine);
+            moments_to_line((double)Sx, (double)Sy, (double)Sxx, (double)Syy, (double)Sxy, (double)(float)m, base);  // the committed prefix's line
+            float lp[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float up = __shfl(mine[k], prev);
+                lp[k] = sl == 0 ? base[k] : up;
+            }
+            const float de = ctm::fabs32(ux(qpt) * lp[1] - uy(qpt) * lp[0] + lp[0] * lp[3] - lp[1] * lp[2]);
+            fail = de > thr_expand;
+        }
+        const unsigned long long failm = ((unsigned long long)__ballot(fail) >> sgshift) & kSgMask;
         const int tf = failm ? (int)(__ffsll(failm) - 1) : 99;
-        const int tc = SG <= 8 ? __shfl(cfalse_at, lane0 + SG - 1) : cfalse_at;
         const int te_raw = n - m - 1;  // the add of step te makes Slide.size() == edge_point.size()
         const int te = (te_raw >= 0 && te_raw < SG) ? te_raw : 99;
         int accepted;
@@ -501,8 +553,11 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
             Sxx += __shfl(pxx, src);
             Syy += __shfl(pyy, src);
             Sxy += __shfl(pxy, src);
-#pragma unroll
-            for (int k = 0; k < 4; k++) line[k] = __shfl(mine[k], src);
+            lineA.c = __shfl(mineA.c, src);
+            lineA.s = __shfl(mineA.s, src);
+            lineA.x = __shfl(mineA.x, src);
+            lineA.y = __shfl(mineA.y, src);
+            lineA.ok = __shfl((int)mineA.ok, src) != 0;
             left = __shfl(l, src);
             right = __shfl(r, src);
             m += accepted;
@@ -516,9 +571,9 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
             }
         }
         if (failed_step) {
-            const bool stepL = mode == 0 ? ((accepted & 1) == 0) : (mode == 1);
+            const bool stepLf = mode == 0 ? ((accepted & 1) == 0) : (mode == 1);
             const int fidx = __shfl(q_idx, lane0 + accepted);
-            if (stepL) {
+            if (stepLf) {
                 fl = true;
                 left = fidx;  // `left` keeps the tested (already wrapped) index
             } else {
@@ -540,7 +595,12 @@ __device__ __forceinline__ void sg_expand_line(const uint32_t* W, int n, int ini
 // REFPRM: the boundary tunables are the reference's (threshold_line 1.8, threshold_expand 1.2, collinearity 1.05) and compiled in;
 // a handle created with other values (ctag_create_ex) runs the builds that read them from P.  (As kernel arguments in the one
 // build they cost the packed kernel 15 %: 4.9 -> 5.65 ms per 4096 frames -- its register allocation is that tight.)
-template <int SG, int WORDS, int WAVES, bool DYN, bool REFPRM>
+// PHASE: 0 = the whole computation in one kernel; 1 = boundary only (silhouette, ordered traversal, centroid, rotation: the rotated
+// boundary list goes to the component's slot of the cluster pool, its length / centroid / slot to cand_aux); 2 = the split into edge
+// clusters only (reads them back).  The packed builds run as 1 then 2: the two halves want different registers -- dependent LDS
+// round trips with many live indices in the first, FP64 line fits in the second -- and in one kernel at 128 VGPRs each change to
+// one half re-spilled the other (the traversal tripled when the line fits got cheaper).
+template <int SG, int WORDS, int WAVES, bool DYN, bool REFPRM, int PHASE = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes, int tier_lo) {
     const float k_thr_line = REFPRM ? 1.8f : P.thr_line, k_thr_expand = REFPRM ? 1.2f : P.thr_expand;
     const int k_c2_far = REFPRM ? 2 : P.c2_far, k_c2_near = REFPRM ? 1 : P.c2_near;
@@ -620,6 +680,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         uint32_t* rig = bufB;
         const int sgshift = sub * SG;
 
+        int n = 0, n_boundary = 0, p0 = 0;
+        float acx = 0.f, acy = 0.f;
+        if constexpr (PHASE != 2) {
         stamp(6);
         // the component's pixels carry one tile-local label per CCL tile it touches: collect those (tile, label) keys
         // (root entry + its member list built by k_resolve) so the pixel scan needs no gathers
@@ -932,7 +995,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             };
             // label rows in flight per lane (the scan is bound by latency, not by bytes): 4 in the large configuration, 2 in the
             // small one, whose 128-register budget the eight row registers of the deeper pipeline would spill
-            if constexpr (WAVES >= 4) {
+            if constexpr (WAVES >= 4 && !(PHASE == 1 && CTAG_SCAN_ROWS4)) {
                 uint4 r0 = load_row(0), r1 = load_row(1);
                 uint4 s0 = load_row1(0), s1 = load_row1(1);
                 for (int y = 0; y < h; y += 2) {
@@ -1010,7 +1073,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         stamp(0);
         // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): lanes 0..7 of the sub-group test the
         // 8 neighbours (N,NE,E,SE,S,SW,W,NW); the first hit at or after the frame's resume index wins (B7)
-        int n = 0;
+        n = 0;
         {
             const int jd = sl & 7;  // only lanes 0..7 of the sub-group take part (sl < 8 below)
             const int dxl = (int)((0x01A9u >> (2 * jd)) & 3u) - 1, dyl = (int)((0x1A90u >> (2 * jd)) & 3u) - 1;
@@ -1154,7 +1217,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             }
             n = min(n, C);
         }
-        const int n_boundary = n;
+        n_boundary = n;
         if (n == 0) {
             if (sl == 0) {
                 aux->line0 = -1;
@@ -1167,7 +1230,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         SG_SYNC();
         stamp(1);
         // ---- P3: boundary centroid (:250-256), nearest point (:259-263), rotation (:264-275)
-        float acx, acy;
         {
             unsigned long long sx = 0, sy = 0;
             for (int k = sl; k < n; k += SG) {
@@ -1209,7 +1271,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         SG_SYNC();
         stamp(2);
         // cluster space in the frame's pool (upper bound; the clusters are written straight to global memory)
-        int p0 = 0;
+        p0 = 0;
         if (sl == 0) p0 = atomicAdd(&P.clp_used[frame], C + 64);
         p0 = __shfl(p0, lane0);
         if (p0 + C + 64 > kClPool) {
@@ -1221,6 +1283,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 aux->n_boundary = n_boundary;
             }
             continue;
+        }
+        }  // PHASE != 2
+        if constexpr (PHASE == 1) {  // hand the rotated boundary over to the second kernel through the component's cluster-pool slot
+            uint32_t* slot = P.cl_pool + (size_t)frame * kClPool + p0;
+            for (int k = sl; k < n; k += SG) slot[k] = bufB[k];
+            if (sl == 0) {
+                aux->line0 = p0;
+                aux->acx = acx;
+                aux->acy = acy;
+                aux->n_boundary = n_boundary;
+            }
+            continue;
+        }
+        if constexpr (PHASE == 2) {
+            p0 = aux->line0;  // the first kernel left the slot here (-1: it gave up on the component, flags and aux are final)
+            if (p0 < 0) continue;
+            n = n_boundary = aux->n_boundary;
+            acx = aux->acx;
+            acy = aux->acy;
+            const uint32_t* slot = P.cl_pool + (size_t)frame * kClPool + p0;
+            for (int k = sl; k < n; k += SG) bufB[k] = slot[k];
+            SG_SYNC();
         }
         uint32_t* CLg = P.cl_pool + (size_t)frame * kClPool + p0;
         // ---- P4: extended RDP (:278-349), uniform control flow inside the sub-group
@@ -1289,7 +1373,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
                 // ---- expand_line (:125-169), speculative over the sub-group's 8 lanes
                 int nl, nr;
-                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, k_thr_expand, nl, nr);
+                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, k_thr_expand, (float)(g.hcols > g.hrows ? g.hcols : g.hrows), nl, nr);
                 const int m = end - init + 1 + nl + nr;
                 // the span is a circular arc [a .. b] of m distinct indices
                 const int a = ((init - nl) % n + n) % n;
@@ -1908,8 +1992,11 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
 #define CTAG_LAUNCH_PACKED(REF)                                                                                                                              \
     do {                                                                                                                                                     \
         if (small_cfg)                                                                                                                                       \
-            hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
-        else                                                                                                                                                 \
+        {                                                                                                                                                    \
+            hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, CTAG_PACK_SPLIT ? 1 : 0>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+            if (CTAG_PACK_SPLIT)                                                                                                                             \
+                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+        } else                                                                                                                                               \
             hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0);      \
     } while (0)
     if (refprm) CTAG_LAUNCH_PACKED(true);
