@@ -10,7 +10,7 @@ from cylindertag_amd import capi
 from ctag_testlib import Oracle, read_marker_file, GOLDEN
 state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
 src = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
-ns = {"ca": ca, "np": np}
+ns = {"ca": ca, "np": np, "tk": tk}
 exec(src[src.index("def _random_shapes_frame"):src.index("def test_random_shapes_fuzz")], ns)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 rows, cols = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (720, 1152)
