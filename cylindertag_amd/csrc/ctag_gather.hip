@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>  // types only; every entry point is resolved at run time
 
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -91,10 +92,13 @@ struct GatherState {
     char err[256] = {0};
 };
 
+void order_forget(ncclComm_t c);  // below
+
 void gather_state_free(void* p) {
     GatherState* g = static_cast<GatherState*>(p);
     (void)hipSetDevice(g->device);
     if (g->gstream) (void)hipStreamSynchronize(g->gstream);
+    if (g->comm && g->own_comm) order_forget(g->comm);
     if (g->comm && g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
     if (g->d_packed) (void)hipFree(g->d_packed);
     if (g->d_gathered) (void)hipFree(g->d_gathered);
@@ -127,6 +131,51 @@ GatherState* gather_state(ctag_handle* h) {
         *slot = g;
     }
     return static_cast<GatherState*>(*slot);
+}
+
+// Collectives of ONE communicator issued from several streams (two handles sharing it: ctag_comm_attach(b, ctag_comm_native(a), ..))
+// are ordered here explicitly, not left to the library: every collective waits for the event recorded behind the previous
+// collective of the same communicator, whatever stream that one went to.  Per process; a communicator has one entry.
+struct CommOrder {
+    ncclComm_t comm;
+    hipEvent_t last;
+    bool has;
+};
+CommOrder g_order[16];
+std::mutex g_order_mu;
+CommOrder* order_of(ncclComm_t c) {  // caller holds g_order_mu
+    for (CommOrder& o : g_order)
+        if (o.comm == c) return &o;
+    for (CommOrder& o : g_order)
+        if (!o.comm) {
+            if (!o.last && hipEventCreateWithFlags(&o.last, hipEventDisableTiming) != hipSuccess) return nullptr;
+            o.comm = c;
+            o.has = false;
+            return &o;
+        }
+    return nullptr;
+}
+void order_forget(ncclComm_t c) {
+    std::lock_guard<std::mutex> lk(g_order_mu);
+    for (CommOrder& o : g_order)
+        if (o.comm == c) {
+            o.comm = nullptr;
+            o.has = false;
+        }
+}
+// before a collective on `s`: wait for the previous one of this communicator; after it: publish this one
+hipError_t order_before(ncclComm_t c, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_order_mu);
+    CommOrder* o = order_of(c);
+    if (o && o->has) return hipStreamWaitEvent(s, o->last, 0);
+    return hipSuccess;
+}
+hipError_t order_after(ncclComm_t c, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_order_mu);
+    CommOrder* o = order_of(c);
+    if (!o) return hipSuccess;
+    o->has = true;
+    return hipEventRecord(o->last, s);
 }
 
 #define G_HIP(expr)                                                                              \
@@ -389,6 +438,7 @@ int ctag_comm_destroy(ctag_handle* h) {
     if (g->comm) {
         (void)hipSetDevice(g->device);
         (void)hipStreamSynchronize(g->gstream);
+        if (g->own_comm) order_forget(g->comm);
         if (g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
     }
     g->comm = nullptr;
@@ -484,7 +534,11 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
     // local_dev may be overwritten by whatever the caller enqueues next on the main stream: order it behind the pack
     G_HIP(hipEventRecord(g->ev_packed, g->gstream));
     G_HIP(hipStreamWaitEvent(main_s, g->ev_packed, 0));
-    if (g->comm) G_NCCL(R->AllGather(g->d_sizes + g->rank, g->d_sizes, 1, ncclUint64, g->comm, g->gstream));
+    if (g->comm) {
+        G_HIP(order_before(g->comm, g->gstream));
+        G_NCCL(R->AllGather(g->d_sizes + g->rank, g->d_sizes, 1, ncclUint64, g->comm, g->gstream));
+        G_HIP(order_after(g->comm, g->gstream));
+    }
     G_HIP(hipMemcpyAsync(g->h_sizes, g->d_sizes, sizeof(uint64_t) * g->world, hipMemcpyDeviceToHost, g->gstream));
     G_HIP(hipEventRecord(g->ev_sizes, g->gstream));
     g->n_local = n_local;
@@ -519,7 +573,9 @@ int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
     if (g->comm) {
         const int rc = grow(g, &g->d_gathered, &g->gathered_cap, (size_t)width * g->world);
         if (rc != CTAG_OK) return rc;
+        G_HIP(order_before(g->comm, g->gstream));
         G_NCCL(R->AllGather(g->d_packed, g->d_gathered, (size_t)width, ncclUint8, g->comm, g->gstream));
+        G_HIP(order_after(g->comm, g->gstream));
         gathered = g->d_gathered;
     }
     const int rc = enqueue_unpack(g, false, gathered, S, g->n_total, out_dev, g->gstream);
