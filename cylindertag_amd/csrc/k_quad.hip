@@ -271,6 +271,9 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
 #ifndef CTAG_SCAN_ROWS4
 #define CTAG_SCAN_ROWS4 0  // 1: the boundary-only build keeps four label rows in flight per lane (measured: 44 spilled registers, 4.03 vs 3.94 ms)
 #endif
+#ifndef CTAG_PACK_SPLIT_LARGE
+#define CTAG_PACK_SPLIT_LARGE 0  // the same for the large configuration (4K frames)
+#endif
 #ifndef CTAG_PACK_SPLIT
 #define CTAG_PACK_SPLIT 1  // the small-configuration packed build as two kernels (boundary, then edge clusters): see k_quad_edges_packed
 #endif
@@ -1996,8 +1999,11 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
             hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, CTAG_PACK_SPLIT ? 1 : 0>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (CTAG_PACK_SPLIT)                                                                                                                             \
                 hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
-        } else                                                                                                                                               \
-            hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0);      \
+        } else {                                                                                                                                             \
+            hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF, CTAG_PACK_SPLIT_LARGE ? 1 : 0>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+            if (CTAG_PACK_SPLIT_LARGE)                                                                                                                       \
+                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+        }                                                                                                                                                    \
     } while (0)
     if (refprm) CTAG_LAUNCH_PACKED(true);
     else CTAG_LAUNCH_PACKED(false);
