@@ -227,6 +227,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_f1 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
     const size_t o_f2 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
     const size_t o_pre = take(F * sizeof(ctag_frame_result));
+    const size_t o_n0 = take(F * (size_t)CTAG_MAX_FEATURES * 2 * 4 * 128 * 8), o_flong = take(F * 4);
     const size_t o_rzx = take((size_t)g.hcols * 4), o_rza = take((size_t)g.hcols * 8), o_rzy = take((size_t)g.hrows * 4), o_rzb = take((size_t)g.hrows * 8);
     void* base = nullptr;
     HIP_TRY(hipMalloc(&base, off));
@@ -281,6 +282,8 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.feat1 = reinterpret_cast<FeatureDev*>(b + o_f1);
     W.feat2 = reinterpret_cast<FeatureDev*>(b + o_f2);
     W.premarkers = reinterpret_cast<ctag_frame_result*>(b + o_pre);
+    W.refine_n0 = reinterpret_cast<double*>(b + o_n0);
+    W.frame_long = reinterpret_cast<int32_t*>(b + o_flong);
     W.rz_xofs = reinterpret_cast<int32_t*>(b + o_rzx);
     W.rz_alpha = reinterpret_cast<int16_t*>(b + o_rza);
     W.rz_yofs = reinterpret_cast<int32_t*>(b + o_rzy);

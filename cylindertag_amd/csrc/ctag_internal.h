@@ -153,6 +153,8 @@ struct Workspace {
     FeatureDev* feat1 = nullptr;    // after cornerObtain
     FeatureDev* feat2 = nullptr;    // after edgeRefine
     ctag_frame_result* premarkers = nullptr;  // [F] (debug: before decode)
+    double* refine_n0 = nullptr;    // [F][CTAG_MAX_FEATURES * 2][4][128] K8: search kernel -> sums kernel
+    int32_t* frame_long = nullptr;  // [F] K8: the frame has a quad that needs the one-kernel form
     // cubic tap tables of the general (odd-size) decimation: [hcols] / [hcols][4] / [hrows] / [hrows][4]
     int32_t* rz_xofs = nullptr;
     int16_t* rz_alpha = nullptr;

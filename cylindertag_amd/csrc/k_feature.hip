@@ -57,6 +57,7 @@ struct FeatPtrs {
     FeatureDev* feat2;
     unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1): clock ticks per phase of k_features, else null
     float threshold_angle;       // include/ctag.h ctag_params [5]
+    int32_t* frame_long;         // [F] reset here for K8 (k_edge_refine<1> sets it)
 };
 
 // developer aid: phase clock of a block (thread 0), summed over blocks into `stamps[base + phase]`
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
     // frame was dropped, so the frame is reported as such instead of as a (possibly wrong) detection
     if (P.frame_flags[frame] & CTAG_FLAG_POOL_OVERFLOW) status = CTAG_ERR_LIMIT;
     if (tid == 0) {
+        P.frame_long[frame] = 0;
         P.nfeat[frame] = min(nf, CTAG_MAX_FEATURES);
         P.status[frame] = status;
         if (nf > CTAG_MAX_FEATURES) atomicOr(&P.frame_flags[frame], CTAG_FLAG_FEATURE_OVERFLOW);
@@ -413,20 +415,51 @@ struct RefinePtrs {
     const int32_t* status;
     const FeatureDev* feat1;
     FeatureDev* feat2;
+    double* n0;          // [F][CTAG_MAX_FEATURES * 2][4][kRefineSamples]: the search kernel's result per sample (NaN: no edge point), MODE 1 -> 2
+    int32_t* frame_long; // [F] 1: the frame has a quad with an edge of more than kRefineSamples samples (those quads take the one-kernel form)
 };
 constexpr int kRefineSamples = 128;               // samples of an edge searched per pass (the reference's minimum sample count, :615)
 constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: waves 0-1 edge e, waves 2-3 edge e + 1
+#ifndef CTAG_REFINE_SPLIT
+#define CTAG_REFINE_SPLIT 1  // batches: searches and ordered sums as two kernels (k_edge_refine<MODE>)
+#endif
 #ifndef CTAG_REFINE_REGION
 #define CTAG_REFINE_REGION 21504                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
 #endif
 constexpr int kRefineRegion = CTAG_REFINE_REGION;
 
-#ifdef CTAG_REFINE_WAVES
-__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(CTAG_REFINE_WAVES, CTAG_REFINE_WAVES)))
-#else
-__global__ __launch_bounds__(kRefineThreads)
+// MODE 0: the whole of edgeRefine for a (feature, quad) in one block of 256 -- calls of a few frames, and quads with an edge of more
+//         than kRefineSamples samples (edges longer than 1024 px; `only_long`).
+// MODE 1: the searches only (256 threads): per sample n0 = Mn / Mcount goes to P.n0 (NaN: no edge point).  No sample rows in LDS, so
+//         a block is the 21.5 KB pixel box and little else.
+// MODE 2: the ordered sums, line parameters and corners only (ONE wave per quad): rebuilds every sample's point from n0 with the
+//         search's own expressions and continues as MODE 0 does.
+// Batches run 1 then 2 (then 0 for the rare long quads).  In one kernel the serial tail -- 48 chains of 128 dependent FP64 adds on one
+// wave, then divisions / atan2 / sin / cos on 8 lanes -- held a 40 KB, four-wave block while three of its waves idled, at four
+// blocks per CU; apart, the search blocks are smaller and the tails of many quads overlap each other.
+#ifndef CTAG_REFINE_SEARCH_WAVES
+#define CTAG_REFINE_SEARCH_WAVES 5
 #endif
-void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
+// what k_edge_refine<2> needs from global memory for one quad, requested ahead of its use (a looping block asks for the next quad's
+// while it works on the current one's): the search kernel's n0 of the lane's eight samples and, lanes 0-3, a corner
+struct RefinePrefetch {
+    double n0[(4 * kRefineSamples) / 64];
+    float cx, cy;
+};
+__device__ __forceinline__ void refine_prefetch(const RefinePtrs& P, int frame, int qidx, RefinePrefetch& R) {
+    const int tid = threadIdx.x;
+    const double* src = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples);
+#pragma unroll
+    for (int u = 0; u < (4 * kRefineSamples) / 64; u++) R.n0[u] = src[u * 64 + tid];
+    const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + (qidx >> 1);
+    const int c = (qidx & 1) * 4 + (tid & 3);
+    R.cx = F->c[2 * c];
+    R.cy = F->c[2 * c + 1];
+}
+
+template <int MODE>
+__device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long,
+                                            const RefinePrefetch* pre = nullptr) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
     // 16 columns of per-sample values: rows 0-3 x of edge 0-3, 4-7 y, 8-11 weight towards the next corner, 12-15 towards the
@@ -434,8 +467,8 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // pairs: the accumulation reads one element of up to 9 rows per instruction.
     // row 16 holds ones: the factors "1" of the sums Mx = (x * 1) * w, N = (1 * 1) * w are read like any other column, so that
     // every lane of the accumulation walks three unit-stride columns (immediate offsets, no address arithmetic in the loop)
-    __shared__ double s_v[17][kRefineSamples + 1];
-    double (*s_bx)[kRefineSamples + 1] = s_v, (*s_by)[kRefineSamples + 1] = s_v + 4;
+    __shared__ double s_v[MODE == 1 ? 1 : 17][kRefineSamples + 1];
+    double (*s_bx)[kRefineSamples + 1] = s_v, (*s_by)[kRefineSamples + 1] = s_v + (MODE == 1 ? 0 : 4);
     __shared__ double s_nrm[4][2];                // unit normal of each edge
     __shared__ double s_acc[48];
     __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
@@ -443,11 +476,8 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     // staged once with coalesced row loads: the 4 x 128 x 49 scattered byte loads of the searches then gather from LDS
     // instead of going through the texture-address path, which was as busy as the vector ALUs (70 % TA busy,
     // profiles/r02a_before_round2_work_instmix.json).  A box that does not fit stays in global memory (uniform per block).
-    __shared__ __attribute__((aligned(16))) uint8_t s_reg[kRefineRegion];
-    const int frame = blockIdx.y;
-    if (frame >= nframes) return;
-    if (P.status[frame] != CTAG_OK) return;
-    const int fi = blockIdx.x >> 1, quad = blockIdx.x & 1;
+    __shared__ __attribute__((aligned(16))) uint8_t s_reg[MODE == 2 ? 16 : kRefineRegion];
+    const int fi = qidx >> 1, quad = qidx & 1;
     if (fi >= P.nfeat[frame]) return;
     const int tid = threadIdx.x;
     const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi;
@@ -458,11 +488,13 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
     __shared__ int s_ns[4];
     __shared__ int s_box[4];  // x0, y0 of the staged box, its pitch, its rows (0 = not staged)
     if (tid < 4) {
-        s_cx[tid] = F->c[2 * (off + tid)];
-        s_cy[tid] = F->c[2 * (off + tid) + 1];
+        s_cx[tid] = MODE == 2 ? pre->cx : F->c[2 * (off + tid)];
+        s_cy[tid] = MODE == 2 ? pre->cy : F->c[2 * (off + tid) + 1];
     }
-    if (tid < 48) s_acc[tid] = 0.0;
-    if (tid < kRefineSamples + 1) s_v[16][tid] = 1.0;
+    if (MODE != 1 && tid < 48) s_acc[tid] = 0.0;
+    if constexpr (MODE != 1) {
+        for (int k = tid; k < kRefineSamples + 1; k += (int)blockDim.x) s_v[16][k] = 1.0;
+    }
     __syncthreads();
     if (tid < 4) {  // :609-615
         const int a = tid, b = (tid + 1) & 3;
@@ -474,7 +506,8 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         s_nrm[tid][0] = nx / mag;
         s_nrm[tid][1] = ny / mag;
     }
-    if (tid == 64) {  // the box: corners +- (search length + 2), clipped to the image; columns from a multiple of 4
+    if (MODE == 2 && tid == 0) s_box[0] = s_box[1] = s_box[2] = s_box[3] = 0;
+    if (MODE != 2 && tid == 64) {  // the box: corners +- (search length + 2), clipped to the image; columns from a multiple of 4
         const float m = (float)(subpix + 3);
         const float fx0 = fminf(fminf(s_cx[0], s_cx[1]), fminf(s_cx[2], s_cx[3])) - m, fx1 = fmaxf(fmaxf(s_cx[0], s_cx[1]), fmaxf(s_cx[2], s_cx[3])) + m;
         const float fy0 = fminf(fminf(s_cy[0], s_cy[1]), fminf(s_cy[2], s_cy[3])) - m, fy1 = fmaxf(fmaxf(s_cy[0], s_cy[1]), fmaxf(s_cy[2], s_cy[3])) + m;
@@ -496,8 +529,15 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         s_box[3] = staged;  // rows staged, 0 = the box stays in global memory
     }
     __syncthreads();
+    const int max_ns = max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3]));
+    {   // which form takes this quad: an edge of more than kRefineSamples samples needs several passes -> the one-kernel form
+        const bool long_quad = max_ns > kRefineSamples;
+        if (MODE == 1 && long_quad && tid == 0) P.frame_long[frame] = 1;
+        if (MODE != 0 && long_quad) return;
+        if (MODE == 0 && only_long && !long_quad) return;
+    }
     const int box_x0 = s_box[0], box_y0 = s_box[1], box_pitch = s_box[2], box_rows = s_box[3];
-    const bool staged = box_rows > 0;
+    const bool staged = MODE != 2 && box_rows > 0;
     if (staged) {
         // rows of the box, 4 bytes per lane: aligned words when the frame's rows allow it, bytes otherwise.  A thread keeps its
         // column and walks down the rows, four rows requested before the first is stored (the loads of a row-major loop with
@@ -530,9 +570,31 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         __syncthreads();
     }
     const int half = tid >> 7, st = tid & (kRefineSamples - 1);
-    const int max_ns = max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3]));
+    double* const n0_quad = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples);
     for (int sbase = 0; sbase < max_ns; sbase += kRefineSamples) {
         const int s = sbase + st;
+        if constexpr (MODE == 2) {
+            // the samples' points from the search kernel's n0, with the search's own expressions (below): x0 = alpha ax + (1 - alpha) bx, best = x0 + n0 nx
+            // (a lane's eight samples are sm = tid and sm = 64 + tid of the four edges: two position parameters, not eight divisions)
+            const double alpha_lo = (15.0 + tid) / (kRefineSamples + 30), alpha_hi = (15.0 + (64 + tid)) / (kRefineSamples + 30);
+#pragma unroll
+            for (int u = 0; u < (4 * kRefineSamples) / 64; u++) {
+                const int idx = u * 64 + tid;
+                const int edge = idx >> 7, sm = idx & (kRefineSamples - 1);
+                const int a = edge, b = (edge + 1) & 3;
+                const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
+                const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
+                const double alpha = (u & 1) ? alpha_hi : alpha_lo;  // == (15.0 + sm) / (s_ns[edge] + 30): s_ns[edge] == kRefineSamples for every edge of this quad
+                const double x0 = alpha * ax + (1 - alpha) * bx;
+                const double y0 = alpha * ay + (1 - alpha) * by;
+                const double n0 = pre->n0[u];
+                const bool ok = n0 == n0;
+                s_bx[edge][sm] = ok ? x0 + n0 * nx : 0.0;
+                s_by[edge][sm] = ok ? y0 + n0 * ny : 0.0;
+                s_v[8 + edge][sm] = ok ? 1 - alpha : 0.0;
+                s_v[12 + edge][sm] = ok ? alpha : 0.0;
+            }
+        } else
 #pragma nounroll
         for (int epair = 0; epair < 2; epair++) {  // rolled on purpose: one copy of the search loops
             const int edge = 2 * epair + half;
@@ -566,13 +628,19 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
                     bestx = x0 + n0 * nx;
                     besty = y0 + n0 * ny;
                     ok = true;
+                    if constexpr (MODE == 1) n0_quad[edge * kRefineSamples + st] = n0;
                 }
             }
-            s_bx[edge][st] = bestx;  // 0 when !ok
-            s_by[edge][st] = besty;
-            s_v[8 + edge][st] = ok ? 1 - alpha : 0.0;
-            s_v[12 + edge][st] = ok ? alpha : 0.0;
+            if constexpr (MODE == 1) {
+                if (!ok) n0_quad[edge * kRefineSamples + st] = ctm::bits_to_f64(0x7ff8000000000000ULL);  // no edge point (also s >= nsamples: never, ns == 128 here)
+            } else {
+                s_bx[edge][st] = bestx;  // 0 when !ok
+                s_by[edge][st] = besty;
+                s_v[8 + edge][st] = ok ? 1 - alpha : 0.0;
+                s_v[12 + edge][st] = ok ? alpha : 0.0;
+            }
         }
+        if constexpr (MODE == 1) return;  // one pass: every edge of the quad has kRefineSamples samples
         __syncthreads();
         if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
             // every sum has the form (A * B) * w with A, B in {x, y, 1} (x * 1 and 1 * 1 are exact); a sample without an
@@ -585,9 +653,44 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
             double acc = s_acc[tid];
             const int cntS = min(kRefineSamples, s_ns[edge] - sbase);
             int k = 0;
-            for (; k + 16 <= cntS; k += 16) {
+            if constexpr (MODE == 2) {
+                // the sums kernel has registers to spare: the operands of the next eight terms are requested before the current eight
+                // are folded in (left to itself the compiler loads a pair of terms into the same registers every time and waits for the
+                // LDS before each pair: 64 exposed round trips per sum)
+                double ca[8], cb[8], cw[8], na[8], nb[8], nw[8];
 #pragma unroll
-                for (int u = 0; u < 16; u++) acc += (pa[k + u] * pb[k + u]) * pw[k + u];
+                for (int u = 0; u < 8; u++) {
+                    ca[u] = pa[u];
+                    cb[u] = pb[u];
+                    cw[u] = pw[u];
+                }
+                for (; k + 16 <= cntS; k += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        na[u] = pa[k + 8 + u];
+                        nb[u] = pb[k + 8 + u];
+                        nw[u] = pw[k + 8 + u];
+                    }
+                    asm volatile("" ::: "memory");  // the requests above stay above the additions below
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc += (ca[u] * cb[u]) * cw[u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        ca[u] = na[u];
+                        cb[u] = nb[u];
+                        cw[u] = nw[u];
+                    }
+                }
+                if (k + 8 <= cntS) {  // the group already in registers
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc += (ca[u] * cb[u]) * cw[u];
+                    k += 8;
+                }
+            } else {
+                for (; k + 16 <= cntS; k += 16) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) acc += (pa[k + u] * pb[k + u]) * pw[k + u];
+                }
             }
             for (; k < cntS; k++) acc += (pa[k] * pb[k]) * pw[k];
             s_acc[tid] = acc;
@@ -631,6 +734,44 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
             O->c[2 * idx] = F->c[2 * idx];
             O->c[2 * idx + 1] = F->c[2 * idx + 1];
         }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 64 : kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
+void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    if (P.status[frame] != CTAG_OK) return;
+    if constexpr (MODE == 2) {
+        // a few looping blocks per frame: the next quad's inputs are in flight while the current quad's chains of dependent FP64
+        // operations run (a block is one wave and one global round trip used to head every quad)
+        const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
+        int q = (int)blockIdx.x;
+        if (q >= nq) return;
+        RefinePrefetch cur, nxt;
+        refine_prefetch(P, frame, q, cur);
+        for (; q < nq; q += (int)gridDim.x) {
+            const int qn = q + (int)gridDim.x;
+            if (qn < nq) refine_prefetch(P, frame, qn, nxt);
+            refine_quad<2>(P, rows, cols, subpix, frame, q, 0, &cur);
+            __syncthreads();
+            cur = nxt;
+        }
+    } else {
+        refine_quad<MODE>(P, rows, cols, subpix, frame, (int)blockIdx.x, 0);
+    }
+}
+// the quads k_edge_refine<1> / <2> left out (an edge of more than kRefineSamples samples), a few blocks per frame looping over the
+// frame's quads: nothing to do in almost every frame, so it must cost nothing there
+__global__ __launch_bounds__(kRefineThreads) void k_edge_refine_long(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
+    const int frame = blockIdx.y;
+    if (frame >= nframes) return;
+    if (P.status[frame] != CTAG_OK || P.frame_long[frame] == 0) return;
+    const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        refine_quad<0>(P, rows, cols, subpix, frame, q, 1);
+        __syncthreads();
     }
 }
 
@@ -1313,14 +1454,22 @@ static unsigned long long* feat_stamps(hipStream_t s, bool report) {
 }
 
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
-    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false), ws.kp.angle};
+    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false), ws.kp.angle, ws.frame_long};
     hipLaunchKernelGGL(k_features, dim3(nframes), dim3(128), 0, s, P, nframes, p.feature_size);
     return hipGetLastError();
 }
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
     if (!p.corner_subpix) return hipSuccess;
-    RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2};
-    hipLaunchKernelGGL(k_edge_refine, dim3(CTAG_MAX_FEATURES * 2, nframes), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+    RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2, ws.refine_n0, ws.frame_long};
+    const dim3 grid(CTAG_MAX_FEATURES * 2, nframes);
+    static const int refine_sums_gx = getenv("CTAG_REFINE_SUMS_GX") ? atoi(getenv("CTAG_REFINE_SUMS_GX")) : 16;  // looping blocks per frame of k_edge_refine<2>
+    if (nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT) {  // a few frames: one kernel, one launch
+        hipLaunchKernelGGL(k_edge_refine<0>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+    } else {
+        hipLaunchKernelGGL(k_edge_refine<1>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+        hipLaunchKernelGGL(k_edge_refine<2>, dim3(refine_sums_gx, nframes), dim3(64), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+        hipLaunchKernelGGL(k_edge_refine_long, dim3(4, nframes), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+    }
     return hipGetLastError();
 }
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s) {
