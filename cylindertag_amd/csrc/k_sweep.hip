@@ -977,18 +977,23 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     // ---- S7/S8: flatten, compact roots into slots
     int nslots = 0;
     {
+        // thread t owns runs t, t + 256, t + 512, ...: consecutive lanes read consecutive words (as eight consecutive runs per
+        // thread the lanes' addresses were 8 words apart -- a 16-way LDS bank conflict, the largest share of K2's 27 % conflict rate).
+        // Slots are numbered in that (thread, k) order; any numbering is as good as another, later stages use the slot as a name only.
         int roots_mine = 0;
-        const int i0 = tid * (RUNCAP / kCclThreads);
-        if (!overflow && i0 < nruns) {
-            for (int k = 0; k < RUNCAP / kCclThreads; k++) {
-                const int i = i0 + k;
+        constexpr int per_thread = RUNCAP / kCclThreads;
+        if (!overflow) {
+#pragma unroll
+            for (int k = 0; k < per_thread; k++) {
+                const int i = tid + k * kCclThreads;
                 if (i < nruns && parent_s[i] == (unsigned)i) roots_mine++;
             }
         }
         int s = block_excl_scan(roots_mine, misc_s, nslots);
-        if (!overflow && i0 < nruns) {
-            for (int k = 0; k < RUNCAP / kCclThreads; k++) {
-                const int i = i0 + k;
+        if (!overflow) {
+#pragma unroll
+            for (int k = 0; k < per_thread; k++) {
+                const int i = tid + k * kCclThreads;
                 if (i < nruns && parent_s[i] == (unsigned)i) lab_s[i] = (uint16_t)(s++);
             }
         }
