@@ -865,7 +865,114 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
                 }
             };
-            if (bitmap) wave_scan(std::false_type{});
+            // Boxes of up to 256 columns (every component of a 1080p frame's markers): the wave's lanes are (row, column group) pairs --
+            // G column groups of 8 pixels across, 64 / G rows down -- instead of 64 column groups on ONE row, of which a 60-column
+            // component used 8: a batch of 64 / G rows costs one digest (eight table bytes, the bit tricks, a few cross-lane
+            // reductions) instead of 64 / G of them, and the row extents are plain stores (one pass covers the box: no atomics).
+            auto wave_scan_narrow = [&](auto gather_tag, auto groups_tag) {
+                constexpr bool kGather = decltype(gather_tag)::value;
+                constexpr int G = decltype(groups_tag)::value, R = 64 / G;  // column groups across, rows per batch
+                const int xa0 = x_min & ~7;
+                const int cg = lane & (G - 1), rr = lane / G;
+                const int gxf = xa0 + 8 * cg;
+                unsigned valid = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (gxf + q >= x_min && gxf + q < x_end) valid |= 1u << q;
+                const int col = valid ? gxf : xa0;
+                const int tcol = col / kTileW;
+                const int xl0 = gxf - x_min;
+                uint32_t top[4], botp[4], seen[4];  // packed halfwords per column: first row (0xffff none), last row + 1 (0 none)
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    top[d] = 0xffffffffu;
+                    botp[d] = 0u;
+                    seen[d] = 0u;
+                }
+                auto load_row = [&](int y) { return *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y, h - 1)) * g.lp + col); };
+                auto digest = [&](int y, const uint4& v) {  // this lane's row y of the batch (y >= h: nothing)
+                    unsigned bits = 0;
+                    if (y < h) {
+                        const int ty = (y_min + y) / kTileH;
+                        const uint8_t* lut = bitmap ? s_lut + ((ty - mt_y0) * mt_nx + (tcol - mt_x0)) * kLutPitch : s_lut + kMemberTiles * kLutPitch;
+                        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                        unsigned lab[8], mv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            lab[q] = (wv[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                            mv[q] = lut[min(lab[q], 129u)];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            bool in = mv[q] == 1u;
+                            const bool ask = mv[q] == 2u && lab[q] < 0x8000u && ((valid >> q) & 1u);
+                            if constexpr (kGather) {
+                                if (ask) in = rootof[tbase[ty * g.tiles_x + tcol] + (int)lab[q] - 1] == cd.root;
+                            } else {
+                                redo = redo || ask;
+                            }
+                            bits |= (in ? 1u : 0u) << q;
+                        }
+                        bits &= valid;
+                    }
+                    // row extents: first / last foreground column over the row's G lanes
+                    unsigned lo = bits ? (unsigned)(xl0 + __ffs(bits) - 1) : 0xffffffffu, hi = bits ? (unsigned)(xl0 + 32 - __clz(bits)) : 0u;
+#pragma unroll
+                    for (int dd = 1; dd < G; dd <<= 1) {
+                        lo = min(lo, (unsigned)__shfl_xor((int)lo, dd));
+                        hi = max(hi, (unsigned)__shfl_xor((int)hi, dd));
+                    }
+                    if (cg == 0 && y < h) {
+                        lef[y] = lo;
+                        rig[y] = hi;
+                    }
+                    if (bits) {
+                        const uint32_t ypk = (uint32_t)y * 0x10001u, ypk1 = (uint32_t)(y + 1) * 0x10001u;
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            const uint32_t m = ((bits >> (2 * d)) & 1u) * 0xffffu + ((bits >> (2 * d + 1)) & 1u) * 0xffff0000u;
+                            botp[d] = (botp[d] & ~m) | (ypk1 & m);  // this lane's rows ascend: the last one wins
+                            const uint32_t nm = m & ~seen[d];
+                            top[d] = (top[d] & ~nm) | (ypk & nm);
+                            seen[d] |= m;
+                        }
+                    }
+                };
+                uint4 va = load_row(rr), vb;
+                for (int y0 = 0; y0 < h; y0 += 2 * R) {  // two batches in flight
+                    vb = load_row(y0 + R + rr);
+                    digest(y0 + rr, va);
+                    va = load_row(y0 + 2 * R + rr);
+                    digest(y0 + R + rr, vb);
+                }
+                // columns: first row = min, last row + 1 = max over the R lanes that share the column group (packed halfwords)
+#pragma unroll
+                for (int dd = G; dd < 64; dd <<= 1) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t ot = (uint32_t)__shfl_xor((int)top[d], dd), ob = (uint32_t)__shfl_xor((int)botp[d], dd);
+                        top[d] = min(top[d] & 0xffffu, ot & 0xffffu) | (min(top[d] >> 16, ot >> 16) << 16);
+                        botp[d] = max(botp[d] & 0xffffu, ob & 0xffffu) | (max(botp[d] >> 16, ob >> 16) << 16);
+                    }
+                }
+                if (rr == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if ((valid >> q) & 1u) {  // every column of a component's bounding box holds a pixel
+                            const uint32_t t = (top[q >> 1] >> (16 * (q & 1))) & 0xffffu, bp = (botp[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                            tb[xl0 + q + 1] = t == 0xffffu ? 0u : ((t + 2) | ((bp - 1 + 2) << 16));
+                        }
+                    }
+                }
+            };
+            const int span8 = (x_end - (x_min & ~7) + 7) >> 3;  // 8-column groups from the aligned start to the box's end
+            auto scan = [&](auto gather_tag) {
+                if (span8 <= 8) wave_scan_narrow(gather_tag, std::integral_constant<int, 8>{});
+                else if (span8 <= 16) wave_scan_narrow(gather_tag, std::integral_constant<int, 16>{});
+                else if (span8 <= 32) wave_scan_narrow(gather_tag, std::integral_constant<int, 32>{});
+                else wave_scan(gather_tag);
+            };
+            if (bitmap) scan(std::false_type{});
             if (!bitmap || __ballot(redo)) {
                 if (bitmap) {  // start over
                     SG_SYNC();
@@ -876,7 +983,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
                     SG_SYNC();
                 }
-                wave_scan(std::true_type{});
+                scan(std::true_type{});
             }
         } else
         for (int xa = x_min & ~7; xa < x_min + w; xa += 2 * kChunk) {  // one pass per two chunks of the box
