@@ -387,6 +387,47 @@ def test_long_thin_components_take_the_whole_wave_builds(detector, oracle, dicti
         detector.set_option(capi.OPT_KEEP_PREMARKERS, 0)
 
 
+def _zoomed_marker_frame(oracle, state, fs, seed, k):
+    """A 3840x2160 frame holding one planted marker of synthetic frame `seed`, enlarged k times (bilinear)."""
+    from scipy.ndimage import zoom
+    img, _ = tk.synth_frame_host(state, seed)
+    r = oracle.detect_fast(img, state, fs)
+    m = r["markers"][0]
+    c = r["features"][m["first_feature"]:m["first_feature"] + m["n_features"]]["corners"].reshape(-1, 2)
+    x0, y0 = np.maximum(c.min(0) - 12, 0).astype(int)
+    x1, y1 = (c.max(0) + 12).astype(int)
+    up = np.clip(zoom(img[y0:y1, x0:x1].astype(np.float32), k, order=1), 0, 255).astype(np.uint8)
+    big = np.full((2160, 3840), 205, np.uint8)
+    hh, ww = min(2160, up.shape[0]), min(3840, up.shape[1])
+    big[:hh, :ww] = up[:hh, :ww]
+    return big
+
+
+def test_feature_edges_longer_than_1024_px(detector, oracle, dictionary):
+    """edgeRefine (corner_detector.cpp:626-733) samples one point per pixel of an edge; the batch form's two kernels hold 1024
+    samples per edge, and a quad with a longer edge flags its frame for k_edge_refine_long (the one-kernel form, which loops).
+    Markers enlarged 5x in 4K frames have feature edges of 1110-1175 px: as single frames (few-frame path) and inside a batch
+    next to ordinary frames, the records equal the oracle's."""
+    state, fs = dictionary
+    frames = []
+    for i, seed in enumerate((22, 23, 21)):
+        frames.append(_zoomed_marker_frame(oracle, state, fs, seed, 5.0))
+        frames.append(tk.synth_frame_host(state, 40 + i, rows=2160, cols=3840)[0])
+    want = [oracle.detect_fast(f, state, fs) for f in frames]
+    longest = []
+    for w in want[0::2]:
+        c = w["features"][:w["n_features"]]["corners"].reshape(-1, 8, 2)
+        assert len(c) >= 4
+        longest.append(np.linalg.norm(c - np.roll(c, -1, axis=1), axis=2).max())
+    assert min(longest) > 1060, longest
+    assert all(w["n_markers"] >= 1 for w in want)
+    for i in (0, 2):
+        assert_same_record(detector.detect(frames[i]), want[i], "long edges, single frame %d" % i)
+    got = detector.detect_batch(np.stack(frames))
+    for i in range(len(frames)):
+        assert_same_record(got[i], want[i], "long edges, batch frame %d" % i)
+
+
 def test_many_markers_per_frame(detector, oracle, dictionary):
     """6 and 8 planted markers: 71-96 features per frame, i.e. both register halves of k_markers' wave-resident union-find / group
     numbering / rank sort (feature k lives in lane k & 63 of one of two registers) and its feature cap (100) within reach; one frame
@@ -925,6 +966,10 @@ def test_non_default_params(oracle, dictionary, test_bmp):
                     want = oracle.detect_fast(f, state, fs)
                     assert_same_record(det.detect(f), want, "params setting %d frame %d" % (k, i))
                     differs += want.tobytes() != base[i].tobytes()
+                batch = np.stack([tk.synth_frame_host(state, 21 + j)[0] for j in range(6)])  # more than kLatencyFrames: the batch kernels
+                got = det.detect_batch(batch)
+                for j in range(len(batch)):
+                    assert_same_record(got[j], oracle.detect_fast(batch[j], state, fs), "params setting %d batch frame %d" % (k, j))
             finally:
                 det.close()
     finally:
