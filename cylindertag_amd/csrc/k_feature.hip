@@ -759,7 +759,13 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
             cur = nxt;
         }
     } else {
-        refine_quad<MODE>(P, rows, cols, subpix, frame, (int)blockIdx.x, 0);
+        // blocks loop over the frame's quads: a grid of one block per possible quad (2 * CTAG_MAX_FEATURES) would launch more blocks
+        // that find nothing to do than blocks that work
+        const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
+        for (int q = (int)blockIdx.x; q < nq; q += (int)gridDim.x) {
+            refine_quad<MODE>(P, rows, cols, subpix, frame, q, 0);
+            if (q + (int)gridDim.x < nq) __syncthreads();
+        }
     }
 }
 // the quads k_edge_refine<1> / <2> left out (an edge of more than kRefineSamples samples), a few blocks per frame looping over the
@@ -1461,7 +1467,8 @@ hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams&
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
     if (!p.corner_subpix) return hipSuccess;
     RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2, ws.refine_n0, ws.frame_long};
-    const dim3 grid(CTAG_MAX_FEATURES * 2, nframes);
+    static const int refine_gx = getenv("CTAG_REFINE_GX") ? atoi(getenv("CTAG_REFINE_GX")) : 32;  // looping blocks per frame of the other forms
+    const dim3 grid(refine_gx, nframes);
     static const int refine_sums_gx = getenv("CTAG_REFINE_SUMS_GX") ? atoi(getenv("CTAG_REFINE_SUMS_GX")) : 16;  // looping blocks per frame of k_edge_refine<2>
     if (nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT) {  // a few frames: one kernel, one launch
         hipLaunchKernelGGL(k_edge_refine<0>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
