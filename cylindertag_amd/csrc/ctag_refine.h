@@ -1,5 +1,5 @@
-// ctag_refine.h -- the per-sample normal search of edgeRefine (/root/reference/corner_detector.cpp:623-657), in two
-// forms that return THE SAME BITS:
+// ctag_refine.h -- the per-sample normal search of edgeRefine (/root/reference/corner_detector.cpp:623-657), in three
+// forms that return THE SAME BITS (search_mid: at the end of the file):
 //
 //   search_exact   the reference's arithmetic, expression by expression: pixel = ((int)(x0 + m*nx), (int)(y0 + m*ny)) in
 //                  double, running sums Mn += weight*n, Mcount += weight in step order.
@@ -156,6 +156,47 @@ CTR_UNROLL
     Mcount_out = P;
     Mn_out = (range + 0.25) * P - 0.25 * Q;
     return gmin >= 2u * kGuard;
+}
+
+// Middle form: the reference's coordinate expressions in double (so nothing to guard and nothing to decline) with the fast form's
+// prefix-sum moments and staged pixels.  For the samples the fast form cannot take: an axis-aligned edge between corners at x.5
+// puts every fourth step of every sample exactly on a pixel border (half-resolution corners times two: 5 % of the edges of the
+// synthetic frames), where only the reference's own rounding says which pixel it is.  Costs ~1.4 fast searches instead of the
+// ~5 of search_exact (bounds tests, global pixels).  Requires interior(...) and subpix <= kFastMaxSubpix.
+template <int SUBPIX = 0, class Px>
+CTM_HD void search_mid(double x0, double y0, double nx, double ny, int subpix_rt, Px&& px, double& Mn_out, double& Mcount_out, int org_x = 0, int org_y = 0) {
+    const int subpix = SUBPIX > 0 ? SUBPIX : subpix_rt;
+    const double range = subpix;
+    double m = -range - 1;  // multiples of 0.25: exact
+    auto fetch = [&]() -> float {
+        const int x = (int)(x0 + m * nx);
+        const int y = (int)(y0 + m * ny);
+        m += 0.25;
+        return unit(px(x - org_x, y - org_y));
+    };
+    float ring[8];
+CTR_UNROLL
+    for (int u = 0; u < 8; u++) ring[u] = fetch();
+    double P = 0, Q = 0;
+    auto step = [&](float g1, float g2) {
+        const float d = g2 - g1;
+        const float dn = d < 0.f ? d : 0.f;
+        P += (double)(dn * dn);
+        Q += P;
+    };
+    for (int it = 0; it < subpix; it++) {
+        float g[8];
+CTR_UNROLL
+        for (int u = 0; u < 8; u++) g[u] = fetch();
+CTR_UNROLL
+        for (int u = 0; u < 8; u++) {
+            step(g[u], ring[u]);
+            ring[u] = g[u];
+        }
+    }
+    step(fetch(), ring[0]);
+    Mcount_out = P;
+    Mn_out = (range + 0.25) * P - 0.25 * Q;
 }
 
 }  // namespace ctr

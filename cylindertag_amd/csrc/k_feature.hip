@@ -438,7 +438,7 @@ constexpr int kRefineRegion = CTAG_REFINE_REGION;
 // wave, then divisions / atan2 / sin / cos on 8 lanes -- held a 40 KB, four-wave block while three of its waves idled, at four
 // blocks per CU; apart, the search blocks are smaller and the tails of many quads overlap each other.
 #ifndef CTAG_REFINE_SEARCH_WAVES
-#define CTAG_REFINE_SEARCH_WAVES 5
+#define CTAG_REFINE_SEARCH_WAVES 4
 #endif
 // what k_edge_refine<2> needs from global memory for one quad, requested ahead of its use (a looping block asks for the next quad's
 // while it works on the current one's): the search kernel's n0 of the lane's eight samples and, lanes 0-3, a corner
@@ -602,6 +602,7 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
             const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
             const int nsamples = s_ns[edge];
             const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
+            const bool axis = nx == 0.0 || ny == 0.0;
             bool ok = false;
             double bestx = 0, besty = 0, alpha = 0;
             if (s < nsamples) {
@@ -616,8 +617,15 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
                 if (subpix <= ctr::kFastMaxSubpix && ctr::interior(x0, y0, nx, ny, subpix, rows, cols)) {
                     if (staged) {  // the walk runs in box coordinates: the address is one multiply-add
                         auto px_lds = [&](int x, int y) -> unsigned { return s_reg[__umul24((unsigned)y, (unsigned)box_pitch) + (unsigned)x]; };
-                        done = subpix == 5 ? ctr::search_fast<5>(x0, y0, nx, ny, 5, px_lds, Mn, Mcount, box_x0, box_y0)  // main.cpp:39,57
-                                           : ctr::search_fast<0>(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount, box_x0, box_y0);
+                        // an axis-aligned edge (uniform over the two waves of an edge) steps by exactly +-1/4 px: from corners at x.5 every
+                        // fourth step of every sample is on a pixel border, the fast form would decline them all -> middle form at once
+                        if (!axis)
+                            done = subpix == 5 ? ctr::search_fast<5>(x0, y0, nx, ny, 5, px_lds, Mn, Mcount, box_x0, box_y0)  // main.cpp:39,57
+                                               : ctr::search_fast<0>(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount, box_x0, box_y0);
+                        if (!done) {
+                            ctr::search_mid<0>(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount, box_x0, box_y0);
+                            done = true;
+                        }
                     } else {
                         done = ctr::search_fast(x0, y0, nx, ny, subpix, px, Mn, Mcount);
                     }

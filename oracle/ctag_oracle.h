@@ -76,7 +76,7 @@ int ctago_hardware_concurrency(void);
 
 /* probe of the PRODUCT header cylindertag_amd/csrc/ctag_refine.h on the host (see ctag_oracle.cpp) */
 void ctago_refine_probe(const uint8_t* img, int rows, int cols, ptrdiff_t stride, int subpix, int n, const double* xy_nxny,
-                        double* exact, double* fast, double* lit, int32_t* flag);
+                        double* exact, double* fast, double* lit, int32_t* flag, double* mid);
 
 /* primitive probes for unit tests */
 /* cvtColor(BGR2GRAY) on 8-bit BGR (main.cpp:36,54): OpenCV's fixed-point (B*1868 + G*9617 + R*4899 + 8192) >> 14 */

@@ -1,6 +1,6 @@
 """cylindertag_amd/csrc/ctag_refine.h on the host: the fast form of edgeRefine's per-sample normal search (32.32
 fixed-point pixel walk + prefix-sum moments) returns the same BITS as the reference arithmetic (search_exact) and as the
-literal reference loop (corner_detector.cpp:627-649) -- or declines.  The oracle library hosts the probe; the oracle's own
+literal reference loop (corner_detector.cpp:627-649) -- or declines; the middle form (reference coordinates + prefix sums) always does.  The oracle library hosts the probe; the oracle's own
 edgeRefine never calls the product header."""
 import ctypes as C
 import os
@@ -14,13 +14,14 @@ def _probe(oracle, img, subpix, samples):
     img = np.ascontiguousarray(img, np.uint8)
     s = np.ascontiguousarray(samples, np.float64).reshape(-1, 4)
     n = len(s)
-    exact, fast, lit = np.zeros((n, 2)), np.zeros((n, 2)), np.zeros((n, 2))
+    exact, fast, lit, mid = np.zeros((n, 2)), np.zeros((n, 2)), np.zeros((n, 2)), np.zeros((n, 2))
     flag = np.zeros(n, np.int32)
     f = oracle.L.ctago_refine_probe
     f.restype = None
-    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     f(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], subpix, n, s.ctypes.data, exact.ctypes.data, fast.ctypes.data,
-      lit.ctypes.data, flag.ctypes.data)
+      lit.ctypes.data, flag.ctypes.data, mid.ctypes.data)
+    _probe.mid = mid  # {Mn, Mcount} of search_mid where flag >= 0
     return exact, fast, lit, flag
 
 
@@ -58,6 +59,8 @@ def test_fast_search_equals_reference_arithmetic(oracle):
             assert _same_bits(exact, lit).all()                             # ring form == literal loop
             ok = flag == 1
             assert _same_bits(exact[ok], fast[ok]).all()
+            app = flag >= 0                                                  # the middle form never declines
+            assert _same_bits(exact[app], _probe.mid[app]).all() and (flag[:200][app[:200]] == 0).any()
             assert ok.sum() > 0.8 * (flag >= 0).sum() and (flag >= 0).sum() > 0.9 * n * (1 - 40.0 / min(rows, cols))
             total_fast += int(ok.sum())
     assert total_fast > 200000
@@ -73,6 +76,7 @@ def test_guard_band_and_applicability(oracle):
     s[:, 0] += eps
     exact, fast, lit, flag = _probe(oracle, bmp, 5, s)
     assert list(flag[:6]) == [0] * 6 and flag[7] == 1 and _same_bits(exact, lit).all()
+    assert _same_bits(exact, _probe.mid).all()
     assert _same_bits(exact[flag == 1], fast[flag == 1]).all()
     # not interior (search leaves the image) or window too large for the exactness bound: not applicable
     s = np.array([[3.0, 300.0, 1.0, 0.0], [400.0, rows - 2.0, 0.0, 1.0], [400.1, 300.2, np.cos(1.0), np.sin(1.0)]])
