@@ -467,8 +467,11 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
     // pairs: the accumulation reads one element of up to 9 rows per instruction.
     // row 16 holds ones: the factors "1" of the sums Mx = (x * 1) * w, N = (1 * 1) * w are read like any other column, so that
     // every lane of the accumulation walks three unit-stride columns (immediate offsets, no address arithmetic in the loop)
-    __shared__ double s_v[MODE == 1 ? 1 : 17][kRefineSamples + 1];
-    double (*s_bx)[kRefineSamples + 1] = s_v, (*s_by)[kRefineSamples + 1] = s_v + (MODE == 1 ? 0 : 4);
+    // (the sums kernel reads its rows two doubles at a time -- ds_read_b128 moves 16 bytes per lane at twice the rate of the ds_read2_b64 an
+    // 8-byte-aligned row gets -- so its rows are 16-byte aligned: 130 doubles, rows 0-15 then cover the 64 banks exactly once)
+    constexpr int kPitch = MODE == 2 ? kRefineSamples + 2 : kRefineSamples + 1;
+    __shared__ __attribute__((aligned(16))) double s_v[MODE == 1 ? 1 : 17][kPitch];
+    double (*s_bx)[kPitch] = s_v, (*s_by)[kPitch] = s_v + (MODE == 1 ? 0 : 4);
     __shared__ double s_nrm[4][2];                // unit normal of each edge
     __shared__ double s_acc[48];
     __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
@@ -666,18 +669,21 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
                 // are folded in (left to itself the compiler loads a pair of terms into the same registers every time and waits for the
                 // LDS before each pair: 64 exposed round trips per sum)
                 double ca[8], cb[8], cw[8], na[8], nb[8], nw[8];
+                const double2 *pa2 = reinterpret_cast<const double2*>(pa), *pb2 = reinterpret_cast<const double2*>(pb), *pw2 = reinterpret_cast<const double2*>(pw);
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    ca[u] = pa[u];
-                    cb[u] = pb[u];
-                    cw[u] = pw[u];
+                for (int u = 0; u < 4; u++) {
+                    const double2 a = pa2[u], b = pb2[u], w = pw2[u];
+                    ca[2 * u] = a.x, ca[2 * u + 1] = a.y;
+                    cb[2 * u] = b.x, cb[2 * u + 1] = b.y;
+                    cw[2 * u] = w.x, cw[2 * u + 1] = w.y;
                 }
                 for (; k + 16 <= cntS; k += 8) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        na[u] = pa[k + 8 + u];
-                        nb[u] = pb[k + 8 + u];
-                        nw[u] = pw[k + 8 + u];
+                    for (int u = 0; u < 4; u++) {
+                        const double2 a = pa2[(k >> 1) + 4 + u], b = pb2[(k >> 1) + 4 + u], w = pw2[(k >> 1) + 4 + u];
+                        na[2 * u] = a.x, na[2 * u + 1] = a.y;
+                        nb[2 * u] = b.x, nb[2 * u + 1] = b.y;
+                        nw[2 * u] = w.x, nw[2 * u + 1] = w.y;
                     }
                     asm volatile("" ::: "memory");  // the requests above stay above the additions below
 #pragma unroll
