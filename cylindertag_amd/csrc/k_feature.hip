@@ -427,6 +427,10 @@ constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: wa
 #define CTAG_REFINE_REGION 21504                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
 #endif
 constexpr int kRefineRegion = CTAG_REFINE_REGION;
+#ifndef CTAG_REFINE_TAILS
+#define CTAG_REFINE_TAILS 4
+#endif
+constexpr int kRefineTails = CTAG_REFINE_TAILS;  // quads whose tails k_edge_refine<2> runs together (8 lanes each for the lines, 4 for the corners); 4: 19.4 KB of LDS, eight blocks per CU
 
 // MODE 0: the whole of edgeRefine for a (feature, quad) in one block of 256 -- calls of a few frames, and quads with an edge of more
 //         than kRefineSamples samples (edges longer than 1024 px; `only_long`).
@@ -457,9 +461,47 @@ __device__ __forceinline__ void refine_prefetch(const RefinePtrs& P, int frame, 
     R.cy = F->c[2 * c + 1];
 }
 
+// Tail of edgeRefine for one quad, from its 48 ordered sums A[edge * 12 + pass * 6 + {Mx, My, Mxx, Mxy, Myy, N}]:
+// refine_line: the line of (edge, pass) -> L = {Ex, Ey, nx, ny} (:667-678 / :743-754); refine_corner: corner `it` from the lines (:757-776).
+__device__ __forceinline__ void refine_line(const double* A, double* L) {
+    const double Mx = A[0], My = A[1], Mxx = A[2], Mxy = A[3], Myy = A[4], N = A[5];  // (L may be A: everything is read first)
+    const double Ex = Mx / N, Ey = My / N;
+    const double Cxx = Mxx / N - Ex * Ex;
+    const double Cxy = Mxy / N - Ex * Ey;
+    const double Cyy = Myy / N - Ey * Ey;
+    const double normal_theta = .5 * ctm::atan2_32((float)(-2 * Cxy), (float)(Cyy - Cxx));
+    L[0] = Ex;
+    L[1] = Ey;
+    float sn, cs;
+    ctm::sincos32((float)normal_theta, &sn, &cs);  // == sin32, cos32 of the same angle: one reduction, no quadrant divergence
+    L[2] = cs;
+    L[3] = sn;
+}
+// A: the quad's 48-double block after refine_line ran IN PLACE on each (edge, pass) group of six (L = A + edge * 12 + pass * 6)
+__device__ __forceinline__ void refine_corner(const double* A, int it, int off, const FeatureDev* F, FeatureDev* O) {
+    const double* Ln = A + it * 12;                    // edge `it`, weighting towards the next corner
+    const double* Ll = A + ((it + 1) & 3) * 12 + 6;    // the following edge, weighting towards the last corner
+    const double A00 = Ln[3], A01 = -Ll[3];
+    const double A10 = -Ln[2], A11 = Ll[2];
+    const double B0 = -Ln[0] + Ll[0];
+    const double B1 = -Ln[1] + Ll[1];
+    const double det = A00 * A11 - A10 * A01;
+    const double W00 = A11 / det, W01 = -A01 / det;
+    const double L0 = W00 * B0 + W01 * B1;
+    const int idx = ((it + 1) & 3) + off;
+    if (ctm::fabs64(det) > 0.001) {
+        O->c[2 * idx] = (float)(Ln[0] + L0 * A00);
+        O->c[2 * idx + 1] = (float)(Ln[1] + L0 * A10);
+    } else {
+        O->c[2 * idx] = F->c[2 * idx];
+        O->c[2 * idx + 1] = F->c[2 * idx + 1];
+    }
+}
+
 template <int MODE>
-__device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long,
-                                            const RefinePrefetch* pre = nullptr) {
+__device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long,
+                                            const RefinePrefetch* pre = nullptr, double* acc_out = nullptr) {
+    // MODE 2: returns true with the quad's 48 sums in acc_out (the caller runs the tail for several quads at once); else false
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
     // 16 columns of per-sample values: rows 0-3 x of edge 0-3, 4-7 y, 8-11 weight towards the next corner, 12-15 towards the
@@ -474,14 +516,13 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
     double (*s_bx)[kPitch] = s_v, (*s_by)[kPitch] = s_v + (MODE == 1 ? 0 : 4);
     __shared__ double s_nrm[4][2];                // unit normal of each edge
     __shared__ double s_acc[48];
-    __shared__ double s_lines[2][4][4];  // [next/last][edge][Ex,Ey,nx,ny]
     // The pixels the searches of this quad can touch -- the bounding box of its corners grown by the search length --
     // staged once with coalesced row loads: the 4 x 128 x 49 scattered byte loads of the searches then gather from LDS
     // instead of going through the texture-address path, which was as busy as the vector ALUs (70 % TA busy,
     // profiles/r02a_before_round2_work_instmix.json).  A box that does not fit stays in global memory (uniform per block).
     __shared__ __attribute__((aligned(16))) uint8_t s_reg[MODE == 2 ? 16 : kRefineRegion];
     const int fi = qidx >> 1, quad = qidx & 1;
-    if (fi >= P.nfeat[frame]) return;
+    if (fi >= P.nfeat[frame]) return false;
     const int tid = threadIdx.x;
     const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi;
     const uint8_t* __restrict__ img = P.frames + (ptrdiff_t)frame * P.frame_stride;
@@ -494,7 +535,8 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
         s_cx[tid] = MODE == 2 ? pre->cx : F->c[2 * (off + tid)];
         s_cy[tid] = MODE == 2 ? pre->cy : F->c[2 * (off + tid) + 1];
     }
-    if (MODE != 1 && tid < 48) s_acc[tid] = 0.0;
+    double* const accp = MODE == 2 ? acc_out : s_acc;
+    if (MODE != 1 && tid < 48) accp[tid] = 0.0;
     if constexpr (MODE != 1) {
         for (int k = tid; k < kRefineSamples + 1; k += (int)blockDim.x) s_v[16][k] = 1.0;
     }
@@ -536,8 +578,8 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
     {   // which form takes this quad: an edge of more than kRefineSamples samples needs several passes -> the one-kernel form
         const bool long_quad = max_ns > kRefineSamples;
         if (MODE == 1 && long_quad && tid == 0) P.frame_long[frame] = 1;
-        if (MODE != 0 && long_quad) return;
-        if (MODE == 0 && only_long && !long_quad) return;
+        if (MODE != 0 && long_quad) return false;
+        if (MODE == 0 && only_long && !long_quad) return false;
     }
     const int box_x0 = s_box[0], box_y0 = s_box[1], box_pitch = s_box[2], box_rows = s_box[3];
     const bool staged = MODE != 2 && box_rows > 0;
@@ -651,7 +693,7 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
                 s_v[12 + edge][st] = ok ? alpha : 0.0;
             }
         }
-        if constexpr (MODE == 1) return;  // one pass: every edge of the quad has kRefineSamples samples
+        if constexpr (MODE == 1) return false;  // one pass: every edge of the quad has kRefineSamples samples
         __syncthreads();
         if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
             // every sum has the form (A * B) * w with A, B in {x, y, 1} (x * 1 and 1 * 1 are exact); a sample without an
@@ -661,7 +703,7 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
             const double* pa = (which == 0 || which == 2 || which == 3) ? s_bx[edge] : (which == 5 ? s_v[16] : s_by[edge]);
             const double* pb = which == 2 ? s_bx[edge] : ((which == 3 || which == 4) ? s_by[edge] : s_v[16]);
             const double* pw = s_v[8 + 4 * pass + edge];
-            double acc = s_acc[tid];
+            double acc = accp[tid];
             const int cntS = min(kRefineSamples, s_ns[edge] - sbase);
             int k = 0;
             if constexpr (MODE == 2) {
@@ -707,48 +749,18 @@ __device__ __forceinline__ void refine_quad(const RefinePtrs& P, int rows, int c
                 }
             }
             for (; k < cntS; k++) acc += (pa[k] * pb[k]) * pw[k];
-            s_acc[tid] = acc;
+            accp[tid] = acc;
         }
         __syncthreads();
     }
-    if (tid < 8) {  // line of (edge, pass): :667-678 / :743-754
+    if constexpr (MODE == 2) return true;
+    if (tid < 8) {  // line of (edge, pass)
         const int edge = tid >> 1, pass = tid & 1;
-        const double* A = s_acc + edge * 12 + pass * 6;
-        const double Mx = A[0], My = A[1], Mxx = A[2], Mxy = A[3], Myy = A[4], N = A[5];
-        const double Ex = Mx / N, Ey = My / N;
-        const double Cxx = Mxx / N - Ex * Ex;
-        const double Cxy = Mxy / N - Ex * Ey;
-        const double Cyy = Myy / N - Ey * Ey;
-        const double normal_theta = .5 * ctm::atan2_32((float)(-2 * Cxy), (float)(Cyy - Cxx));
-        s_lines[pass][edge][0] = Ex;
-        s_lines[pass][edge][1] = Ey;
-        float sn, cs;
-        ctm::sincos32((float)normal_theta, &sn, &cs);  // == sin32, cos32 of the same angle: one reduction, no quadrant divergence
-        s_lines[pass][edge][2] = cs;
-        s_lines[pass][edge][3] = sn;
+        refine_line(s_acc + edge * 12 + pass * 6, s_acc + edge * 12 + pass * 6);
     }
     __syncthreads();
-    if (tid < 4) {  // :757-776 one refined corner per lane
-        const int it = tid;
-        const double* Ln = s_lines[0][it];
-        const double* Ll = s_lines[1][(it + 1) & 3];
-        const double A00 = Ln[3], A01 = -Ll[3];
-        const double A10 = -Ln[2], A11 = Ll[2];
-        const double B0 = -Ln[0] + Ll[0];
-        const double B1 = -Ln[1] + Ll[1];
-        const double det = A00 * A11 - A10 * A01;
-        const double W00 = A11 / det, W01 = -A01 / det;
-        const double L0 = W00 * B0 + W01 * B1;
-        const int idx = ((it + 1) & 3) + off;
-        FeatureDev* O = P.feat2 + (size_t)frame * CTAG_MAX_FEATURES + fi;
-        if (ctm::fabs64(det) > 0.001) {
-            O->c[2 * idx] = (float)(Ln[0] + L0 * A00);
-            O->c[2 * idx + 1] = (float)(Ln[1] + L0 * A10);
-        } else {
-            O->c[2 * idx] = F->c[2 * idx];
-            O->c[2 * idx + 1] = F->c[2 * idx + 1];
-        }
-    }
+    if (tid < 4) refine_corner(s_acc, tid, off, F, P.feat2 + (size_t)frame * CTAG_MAX_FEATURES + fi);  // one refined corner per lane
+    return true;
 }
 
 template <int MODE>
@@ -763,13 +775,33 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
         int q = (int)blockIdx.x;
         if (q >= nq) return;
+        // the tail of a quad -- five divisions, atan2, sin / cos on 8 lanes, then two divisions on 4 -- is a long dependent chain that
+        // occupies the wave as much as its 128-term sums do: the sums of up to eight quads are kept and their tails run together
+        __shared__ double s_accs[kRefineTails][48];
+        __shared__ int s_q[kRefineTails];
+        const int tid = threadIdx.x;
+        int slot = 0;
         RefinePrefetch cur, nxt;
         refine_prefetch(P, frame, q, cur);
         for (; q < nq; q += (int)gridDim.x) {
             const int qn = q + (int)gridDim.x;
             if (qn < nq) refine_prefetch(P, frame, qn, nxt);
-            refine_quad<2>(P, rows, cols, subpix, frame, q, 0, &cur);
+            const bool have = refine_quad<2>(P, rows, cols, subpix, frame, q, 0, &cur, s_accs[slot]);
+            if (tid == 0) s_q[slot] = have ? q : -1;
+            slot++;
             __syncthreads();
+            if (slot == kRefineTails || qn >= nq) {
+                const int sl = tid >> 3, ep = tid & 7;
+                if (sl < slot && s_q[sl] >= 0) refine_line(s_accs[sl] + (ep >> 1) * 12 + (ep & 1) * 6, s_accs[sl] + (ep >> 1) * 12 + (ep & 1) * 6);
+                __syncthreads();
+                const int sc = tid >> 2;
+                if (sc < slot && s_q[sc] >= 0) {
+                    const int qq = s_q[sc], fi = qq >> 1;
+                    refine_corner(s_accs[sc], tid & 3, (qq & 1) * 4, P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi, P.feat2 + (size_t)frame * CTAG_MAX_FEATURES + fi);
+                }
+                __syncthreads();
+                slot = 0;
+            }
             cur = nxt;
         }
     } else {
@@ -1483,7 +1515,7 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2, ws.refine_n0, ws.frame_long};
     static const int refine_gx = getenv("CTAG_REFINE_GX") ? atoi(getenv("CTAG_REFINE_GX")) : 32;  // looping blocks per frame of the other forms
     const dim3 grid(refine_gx, nframes);
-    static const int refine_sums_gx = getenv("CTAG_REFINE_SUMS_GX") ? atoi(getenv("CTAG_REFINE_SUMS_GX")) : 16;  // looping blocks per frame of k_edge_refine<2>
+    static const int refine_sums_gx = getenv("CTAG_REFINE_SUMS_GX") ? atoi(getenv("CTAG_REFINE_SUMS_GX")) : 12;  // looping blocks per frame of k_edge_refine<2>
     if (nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT) {  // a few frames: one kernel, one launch
         hipLaunchKernelGGL(k_edge_refine<0>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
     } else {
