@@ -33,8 +33,13 @@
 // more registers, which halves the occupancy).  An empty asm that "modifies" the value is the barrier.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CTR_SERIAL(x) asm volatile("" : "+v"(x))
+// The eight pixel requests of a group are issued before the first of them is used: left alone, the scheduler converts each byte
+// as soon as it can, which puts a wait behind every second request (two LDS reads in flight, their latency exposed 25 times per
+// search).  Nothing moves across this point.
+#define CTR_ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define CTR_SERIAL(x) ((void)0)
+#define CTR_ISSUE_FENCE() ((void)0)
 #endif
 
 namespace ctr {
@@ -42,6 +47,10 @@ namespace ctr {
 constexpr int kFastMaxSubpix = 8;            // exactness bound of the prefix-sum form: 8*8+1 = 65 steps
 constexpr uint32_t kGuard = 1u << 10;        // 2^-22 px on either side of an integer, in 2^-32 px units
 
+CTM_HD float clamp01(float x) {  // x for x in [0, 1], 0 below (never above 1 here, never NaN)
+    const float lo = x > 0.f ? x : 0.f;
+    return lo < 1.f ? lo : 1.f;
+}
 CTM_HD float unit(unsigned u8) { return (float)u8 * (float)(1.0 / 255); }  // convertTo(CV_32F, 1/255), CylinderTag.cpp:101
 
 // Reference arithmetic.  `px(x, y)` returns the pixel (0..255) at in-image integer coordinates.  Every pixel on the normal is
@@ -102,39 +111,56 @@ CTM_HD bool interior(double x0, double y0, double nx, double ny, int subpix, int
 // integer part).
 // SUBPIX > 0: the window is a compile-time constant (the group loop unrolls completely and the pixel ring becomes register
 // renaming); SUBPIX == 0: `subpix` at run time.
+// v in 32.32 fixed point (two's complement), rounded to nearest, for |v| < 2^19: adding 1.5 * 2^20 leaves a double whose unit in the
+// last place is 2^-32, so its mantissa IS the fixed-point number (plus 2^19 * 2^32): one FP64 add, an AND and a subtraction -- a
+// device has no double -> int64 conversion and builds one from ~8 double-rate instructions.
+CTM_HD uint64_t to_fix32(double v) {
+    const uint64_t bits = ctm::f64_to_bits(v + 1572864.0);
+    return (bits & 0x000fffffffffffffULL) - 0x0008000000000000ULL;
+}
+// the step of a search (1/4 of the unit normal) in 32.32: the same for every sample of an edge, so a caller may compute it once
+CTM_HD uint64_t fast_step(double n) { return to_fix32(n * 0.25); }
+
 template <int SUBPIX = 0, class Px>
-CTM_HD bool search_fast(double x0, double y0, double nx, double ny, int subpix_rt, Px&& px, double& Mn_out, double& Mcount_out, int org_x = 0, int org_y = 0) {
+CTM_HD bool search_fast(double x0, double y0, double nx, double ny, int subpix_rt, Px&& px, double& Mn_out, double& Mcount_out, int org_x = 0, int org_y = 0,
+                        const uint64_t* step_xy = nullptr /* {fast_step(nx), fast_step(ny)} when the caller has them */) {
     const int subpix = SUBPIX > 0 ? SUBPIX : subpix_rt;
     const double range = subpix;
-    const double two32 = 4294967296.0;
     // start point (m = -range - 1) and step (1/4 of the normal) in 32.32 fixed point, biased by +kGuard so that the low word
-    // of a coordinate within kGuard of an integer reads < 2*kGuard
-    uint64_t X = (uint64_t)(int64_t)((x0 - (range + 1) * nx) * two32) + kGuard - ((uint64_t)(uint32_t)org_x << 32);
-    uint64_t Y = (uint64_t)(int64_t)((y0 - (range + 1) * ny) * two32) + kGuard - ((uint64_t)(uint32_t)org_y << 32);
-    const uint64_t DX = (uint64_t)(int64_t)(nx * (0.25 * two32));
-    const uint64_t DY = (uint64_t)(int64_t)(ny * (0.25 * two32));
+    // of a coordinate within kGuard of an integer reads < 2*kGuard.  (Start and step are rounded to nearest: 2^-33 px each, inside
+    // the 2^-26 px the walk may be off by.)
+    uint64_t X = to_fix32(x0 - (range + 1) * nx) + kGuard - ((uint64_t)(uint32_t)org_x << 32);
+    uint64_t Y = to_fix32(y0 - (range + 1) * ny) + kGuard - ((uint64_t)(uint32_t)org_y << 32);
+    const uint64_t DX = step_xy ? step_xy[0] : fast_step(nx);
+    const uint64_t DY = step_xy ? step_xy[1] : fast_step(ny);
     uint32_t gmin = 0xffffffffu;
-    auto fetch = [&]() -> float {
+    auto fetch = [&]() -> unsigned {  // the pixel, 0..255
         const uint32_t xl = (uint32_t)X, yl = (uint32_t)Y;
         gmin = gmin < xl ? gmin : xl;
         gmin = gmin < yl ? gmin : yl;
-        const float g = unit(px((int)(uint32_t)(X >> 32), (int)(uint32_t)(Y >> 32)));
+        const unsigned v = px((int)(uint32_t)(X >> 32), (int)(uint32_t)(Y >> 32));
         X += DX;
         Y += DY;
         CTR_SERIAL(X);
         CTR_SERIAL(Y);
-        return g;
+        return v;
     };
     float ring[8];
+    {
+        unsigned raw[8];
 CTR_UNROLL
-    for (int u = 0; u < 8; u++) ring[u] = fetch();
+        for (int u = 0; u < 8; u++) raw[u] = fetch();
+        CTR_ISSUE_FENCE();
+CTR_UNROLL
+        for (int u = 0; u < 8; u++) ring[u] = unit(raw[u]);
+    }
     double P = 0, Q = 0;
     auto step = [&](float g1, float g2) {
-        // weight (g2 - g1)^2 when !(g1 < g2), else the step is skipped (:643-645): with d = g2 - g1 that is min(d, 0)^2
-        // (d > 0 -> 0 * 0 = +0, d <= 0 -> d * d), one instruction less than compare + select
-        const float d = g2 - g1;
-        const float dn = d < 0.f ? d : 0.f;
-        P += (double)(dn * dn);
+        // weight (g2 - g1)^2 when !(g1 < g2), else the step is skipped (:643-645): that is e^2 with e = max(g1 - g2, 0) (g1 - g2 is
+        // -(g2 - g1) exactly; g1 < g2 -> 0 * 0 = +0).  e <= 1, so the clamp to [0, 1] below changes nothing -- and is free on the
+        // device: an output modifier of the subtraction (v_sub_f32 ... clamp), where max alone is an instruction
+        const float e = clamp01(g1 - g2);
+        P += (double)(e * e);
         Q += P;
     };
     // nsteps = 8 * subpix + 1: subpix groups of eight steps whose eight pixels are requested together (their addresses do
@@ -143,16 +169,18 @@ CTR_UNROLL
 #pragma unroll SUBPIX > 0 ? SUBPIX : 1
 #endif
     for (int it = 0; it < subpix; it++) {
-        float g[8];
+        unsigned raw[8];
 CTR_UNROLL
-        for (int u = 0; u < 8; u++) g[u] = fetch();
+        for (int u = 0; u < 8; u++) raw[u] = fetch();
+        CTR_ISSUE_FENCE();
 CTR_UNROLL
         for (int u = 0; u < 8; u++) {
-            step(g[u], ring[u]);
-            ring[u] = g[u];
+            const float g = unit(raw[u]);
+            step(g, ring[u]);
+            ring[u] = g;
         }
     }
-    step(fetch(), ring[0]);
+    step(unit(fetch()), ring[0]);
     Mcount_out = P;
     Mn_out = (range + 0.25) * P - 0.25 * Q;
     return gmin >= 2u * kGuard;
@@ -179,9 +207,8 @@ CTR_UNROLL
     for (int u = 0; u < 8; u++) ring[u] = fetch();
     double P = 0, Q = 0;
     auto step = [&](float g1, float g2) {
-        const float d = g2 - g1;
-        const float dn = d < 0.f ? d : 0.f;
-        P += (double)(dn * dn);
+        const float e = clamp01(g1 - g2);
+        P += (double)(e * e);
         Q += P;
     };
     for (int it = 0; it < subpix; it++) {

@@ -500,7 +500,7 @@ __device__ __forceinline__ void refine_corner(const double* A, int it, int off, 
 
 template <int MODE>
 __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long,
-                                            const RefinePrefetch* pre = nullptr, double* acc_out = nullptr) {
+                                            const RefinePrefetch* pre = nullptr, double* acc_out = nullptr, double alpha128 = 0.0) {
     // MODE 2: returns true with the quad's 48 sums in acc_out (the caller runs the tail for several quads at once); else false
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
@@ -515,6 +515,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     __shared__ __attribute__((aligned(16))) double s_v[MODE == 1 ? 1 : 17][kPitch];
     double (*s_bx)[kPitch] = s_v, (*s_by)[kPitch] = s_v + (MODE == 1 ? 0 : 4);
     __shared__ double s_nrm[4][2];                // unit normal of each edge
+    __shared__ uint64_t s_step[4][2];             // ctr::fast_step of the normal's components
     __shared__ double s_acc[48];
     // The pixels the searches of this quad can touch -- the bounding box of its corners grown by the search length --
     // staged once with coalesced row loads: the 4 x 128 x 49 scattered byte loads of the searches then gather from LDS
@@ -550,6 +551,8 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
         s_ns[tid] = (int)ns_d;
         s_nrm[tid][0] = nx / mag;
         s_nrm[tid][1] = ny / mag;
+        s_step[tid][0] = ctr::fast_step(nx / mag);  // the searches' pixel step along this edge's normal, once per edge instead of per sample
+        s_step[tid][1] = ctr::fast_step(ny / mag);
     }
     if (MODE == 2 && tid == 0) s_box[0] = s_box[1] = s_box[2] = s_box[3] = 0;
     if (MODE != 2 && tid == 64) {  // the box: corners +- (search length + 2), clipped to the image; columns from a multiple of 4
@@ -648,10 +651,12 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             const int nsamples = s_ns[edge];
             const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
             const bool axis = nx == 0.0 || ny == 0.0;
+            const uint64_t step_xy[2] = {s_step[edge][0], s_step[edge][1]};
             bool ok = false;
             double bestx = 0, besty = 0, alpha = 0;
             if (s < nsamples) {
-                alpha = (15.0 + s) / (nsamples + 30);
+                // (the search kernel's edges all have kRefineSamples samples: the quotient depends on the thread only, and its caller has it)
+                alpha = MODE == 1 ? alpha128 : (15.0 + s) / (nsamples + 30);
                 const double x0 = alpha * ax + (1 - alpha) * bx;
                 const double y0 = alpha * ay + (1 - alpha) * by;
                 // the normal search of this sample (:623-657): ctag_refine.h -- the fast form where every pixel of the search is
@@ -665,8 +670,8 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
                         // an axis-aligned edge (uniform over the two waves of an edge) steps by exactly +-1/4 px: from corners at x.5 every
                         // fourth step of every sample is on a pixel border, the fast form would decline them all -> middle form at once
                         if (!axis)
-                            done = subpix == 5 ? ctr::search_fast<5>(x0, y0, nx, ny, 5, px_lds, Mn, Mcount, box_x0, box_y0)  // main.cpp:39,57
-                                               : ctr::search_fast<0>(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount, box_x0, box_y0);
+                            done = subpix == 5 ? ctr::search_fast<5>(x0, y0, nx, ny, 5, px_lds, Mn, Mcount, box_x0, box_y0, step_xy)  // main.cpp:39,57
+                                               : ctr::search_fast<0>(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount, box_x0, box_y0, step_xy);
                         if (!done) {
                             ctr::search_mid<0>(x0, y0, nx, ny, subpix, px_lds, Mn, Mcount, box_x0, box_y0);
                             done = true;
@@ -765,15 +770,23 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
 
 template <int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 64 : kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
-void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
-    const int frame = blockIdx.y;
+void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, int per_frame) {
+    // per_frame > 0: a 1-D grid of per_frame blocks per frame in which blocks b and b + 8 -- one XCD -- belong to the same frame: the
+    // boxes of a frame's quads overlap, and on one XCD the shared pixels come out of its L2 instead of HBM
+    int frame = blockIdx.y, bx = blockIdx.x, gx = gridDim.x;
+    if (per_frame > 0) {
+        const int b = blockIdx.x;
+        frame = ((b >> 3) / per_frame) * 8 + (b & 7);
+        bx = (b >> 3) % per_frame;
+        gx = per_frame;
+    }
     if (frame >= nframes) return;
     if (P.status[frame] != CTAG_OK) return;
     if constexpr (MODE == 2) {
         // a few looping blocks per frame: the next quad's inputs are in flight while the current quad's chains of dependent FP64
         // operations run (a block is one wave and one global round trip used to head every quad)
         const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
-        int q = (int)blockIdx.x;
+        int q = bx;
         if (q >= nq) return;
         // the tail of a quad -- five divisions, atan2, sin / cos on 8 lanes, then two divisions on 4 -- is a long dependent chain that
         // occupies the wave as much as its 128-term sums do: the sums of up to eight quads are kept and their tails run together
@@ -783,8 +796,8 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         int slot = 0;
         RefinePrefetch cur, nxt;
         refine_prefetch(P, frame, q, cur);
-        for (; q < nq; q += (int)gridDim.x) {
-            const int qn = q + (int)gridDim.x;
+        for (; q < nq; q += gx) {
+            const int qn = q + gx;
             if (qn < nq) refine_prefetch(P, frame, qn, nxt);
             const bool have = refine_quad<2>(P, rows, cols, subpix, frame, q, 0, &cur, s_accs[slot]);
             if (tid == 0) s_q[slot] = have ? q : -1;
@@ -808,9 +821,10 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes) {
         // blocks loop over the frame's quads: a grid of one block per possible quad (2 * CTAG_MAX_FEATURES) would launch more blocks
         // that find nothing to do than blocks that work
         const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
-        for (int q = (int)blockIdx.x; q < nq; q += (int)gridDim.x) {
-            refine_quad<MODE>(P, rows, cols, subpix, frame, q, 0);
-            if (q + (int)gridDim.x < nq) __syncthreads();
+        const double alpha128 = (15.0 + (double)((int)threadIdx.x & (kRefineSamples - 1))) / (kRefineSamples + 30);  // == (15.0 + s) / (nsamples + 30) at 128 samples
+        for (int q = bx; q < nq; q += gx) {
+            refine_quad<MODE>(P, rows, cols, subpix, frame, q, 0, nullptr, nullptr, alpha128);
+            if (q + gx < nq) __syncthreads();
         }
     }
 }
@@ -1517,10 +1531,14 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     const dim3 grid(refine_gx, nframes);
     static const int refine_sums_gx = getenv("CTAG_REFINE_SUMS_GX") ? atoi(getenv("CTAG_REFINE_SUMS_GX")) : 12;  // looping blocks per frame of k_edge_refine<2>
     if (nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT) {  // a few frames: one kernel, one launch
-        hipLaunchKernelGGL(k_edge_refine<0>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+        hipLaunchKernelGGL(k_edge_refine<0>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
     } else {
-        hipLaunchKernelGGL(k_edge_refine<1>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
-        hipLaunchKernelGGL(k_edge_refine<2>, dim3(refine_sums_gx, nframes), dim3(64), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
+        static const int xcd = getenv("CTAG_REFINE_XCD") ? atoi(getenv("CTAG_REFINE_XCD")) : 1;
+        const int f8 = ((nframes + 7) / 8) * 8;
+        if (xcd & 1) hipLaunchKernelGGL(k_edge_refine<1>, dim3(f8 * refine_gx), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_gx);
+        else hipLaunchKernelGGL(k_edge_refine<1>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
+        if (xcd & 2) hipLaunchKernelGGL(k_edge_refine<2>, dim3(f8 * refine_sums_gx), dim3(64), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_sums_gx);
+        else hipLaunchKernelGGL(k_edge_refine<2>, dim3(refine_sums_gx, nframes), dim3(64), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
         hipLaunchKernelGGL(k_edge_refine_long, dim3(4, nframes), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
     }
     return hipGetLastError();
