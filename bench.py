@@ -268,15 +268,17 @@ ISSUE_KERNELS = {"edge_refine": "ctag::k_edge_refine", "welsch": "ctag::k_welsch
 def issue_rooflines(stage_ms, n_frames):
     """Vector-instruction ISSUE roofline of the kernels that are not memory-bound (86 % of the step): wave-instructions of the
     kernel -- counted by rocprofv3 PMC passes, replayed from profiles/r*_pmc_instmix.json like roofline.traffic -- priced at
-    the SIMD's peak issue rate (2 cycles per wave64 instruction, 4 for FP64 add / mul / fma: MI355X_MICROARCH.md) on 1024
-    SIMDs at 2.4 GHz, against the kernel's time measured in THIS run."""
+    the issue cost MEASURED per instruction class on this GPU (tools/ubench/valu_rate.hip, profiles/r03_valu_issue_cost.txt: 2.1
+    SIMD cycles for f32 add / mul and simple integer / logic instructions, 4.2 for the rest -- fma, min / max, conversions, FP64
+    add / mul / fma --, 8.2 / 16.1 for transcendentals; tools/pmc_instmix.py) on 1024 SIMDs at 2.4 GHz, against the kernel's
+    time measured in THIS run."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instmix.json")))
     if not cands or (ROWS, COLS) != (1080, 1920):
         return None
     prof = json.load(open(cands[-1]))
     out = {"source": "instruction counts replayed from %s (rocprofv3 --pmc, 1024-frame pass); times from this run's HIP events" % os.path.relpath(cands[-1], ROOT),
-           "model": "issue_bound_ms = (2 * (VALU - FP64) + 4 * FP64 wave-instructions) / (1024 SIMDs * 2.4 GHz): the SIMDs' peak issue rate", "kernels": {}}
+           "model": "issue_bound_ms = sum over instruction classes of count * measured SIMD cycles per wave-instruction (2.1 f32 add/mul and simple int, 4.2 others incl. FP64, 8.2 / 16.1 transcendental; int32 at 3.15) / (1024 SIMDs * 2.4 GHz); profiles/r03_valu_issue_cost.txt", "kernels": {}}
     for stage, kname in ISSUE_KERNELS.items():
         hits = [v for k, v in prof["kernels"].items() if k == kname or k.startswith(kname + "<")]  # template arguments vary; several builds of a kernel
         if stage == "quad_edges":  # the packed build runs as two kernels (boundary, edge clusters): both belong to the stage

@@ -423,6 +423,9 @@ constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: wa
 #ifndef CTAG_REFINE_SPLIT
 #define CTAG_REFINE_SPLIT 1  // batches: searches and ordered sums as two kernels (k_edge_refine<MODE>)
 #endif
+#ifndef CTAG_REFINE_STAGE_DEEP
+#define CTAG_REFINE_STAGE_DEEP 12
+#endif
 #ifndef CTAG_REFINE_REGION
 #define CTAG_REFINE_REGION 21504                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
 #endif
@@ -596,24 +599,43 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
         const int r0 = tid / wpr, c4 = (tid - r0 * wpr) * 4;
         const int gx = box_x0 + c4;
         if (rpp > 0 && r0 < rpp) {
-            const bool word_ok = aligned && gx + 3 < cols;
-            auto load = [&](int r) -> uint32_t {
-                const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx;
-                if (word_ok) return *reinterpret_cast<const uint32_t*>(src);
-                uint32_t v = 0;
-                for (int k = 0; k < 4; k++)
-                    if (gx + k < cols) v |= (uint32_t)src[k] << (8 * k);
-                return v;
+            // `load`: the word of row r in this thread's column.  Two forms, chosen per BLOCK: when every word of the box is an aligned word
+            // inside its row (almost always) the loads are plain -- with the general form's per-thread test inside, every load of the
+            // unrolled groups below came out as byte loads + a wait + a word load, one round trip to memory PER ROW (the staging phase
+            // was 64 % of a search block's lifetime).
+            auto stage_rows = [&](auto load) {
+                int r = r0;
+                if constexpr (MODE == 1) {
+                    // the search kernel has its registers free at this point: twelve rows in flight (the usual 10 KB box: 10 per thread)
+                    constexpr int kDeep = CTAG_REFINE_STAGE_DEEP;
+                    for (; r + (kDeep - 1) * rpp < box_rows; r += kDeep * rpp) {
+                        uint32_t v[kDeep];
+#pragma unroll
+                        for (int u = 0; u < kDeep; u++) v[u] = load(r + u * rpp);
+#pragma unroll
+                        for (int u = 0; u < kDeep; u++) *reinterpret_cast<uint32_t*>(s_reg + (r + u * rpp) * box_pitch + c4) = v[u];
+                    }
+                }
+                for (; r + 3 * rpp < box_rows; r += 4 * rpp) {
+                    const uint32_t v0 = load(r), v1 = load(r + rpp), v2 = load(r + 2 * rpp), v3 = load(r + 3 * rpp);
+                    *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = v0;
+                    *reinterpret_cast<uint32_t*>(s_reg + (r + rpp) * box_pitch + c4) = v1;
+                    *reinterpret_cast<uint32_t*>(s_reg + (r + 2 * rpp) * box_pitch + c4) = v2;
+                    *reinterpret_cast<uint32_t*>(s_reg + (r + 3 * rpp) * box_pitch + c4) = v3;
+                }
+                for (; r < box_rows; r += rpp) *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = load(r);
             };
-            int r = r0;
-            for (; r + 3 * rpp < box_rows; r += 4 * rpp) {
-                const uint32_t v0 = load(r), v1 = load(r + rpp), v2 = load(r + 2 * rpp), v3 = load(r + 3 * rpp);
-                *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = v0;
-                *reinterpret_cast<uint32_t*>(s_reg + (r + rpp) * box_pitch + c4) = v1;
-                *reinterpret_cast<uint32_t*>(s_reg + (r + 2 * rpp) * box_pitch + c4) = v2;
-                *reinterpret_cast<uint32_t*>(s_reg + (r + 3 * rpp) * box_pitch + c4) = v3;
+            if (aligned && box_x0 + box_pitch <= cols) {
+                stage_rows([&](int r) -> uint32_t { return *reinterpret_cast<const uint32_t*>(img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx); });
+            } else {
+                stage_rows([&](int r) -> uint32_t {
+                    const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx;
+                    uint32_t v = 0;
+                    for (int k = 0; k < 4; k++)
+                        if (gx + k < cols) v |= (uint32_t)src[k] << (8 * k);
+                    return v;
+                });
             }
-            for (; r < box_rows; r += rpp) *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = load(r);
         }
         __syncthreads();
     }
@@ -1533,7 +1555,7 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     if (nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT) {  // a few frames: one kernel, one launch
         hipLaunchKernelGGL(k_edge_refine<0>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
     } else {
-        static const int xcd = getenv("CTAG_REFINE_XCD") ? atoi(getenv("CTAG_REFINE_XCD")) : 1;
+        static const int xcd = getenv("CTAG_REFINE_XCD") ? atoi(getenv("CTAG_REFINE_XCD")) : 3;
         const int f8 = ((nframes + 7) / 8) * 8;
         if (xcd & 1) hipLaunchKernelGGL(k_edge_refine<1>, dim3(f8 * refine_gx), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_gx);
         else hipLaunchKernelGGL(k_edge_refine<1>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
