@@ -250,6 +250,25 @@ CTM_HD float exp32(float x) {
     const float e = (p * (r * r) + r) + 1.0f;
     return e * bits_to_f32((uint32_t)((int)k + 127) << 23);  // k in [-126, 127] given the clamps: 2^k is a normal float
 }
+// exp32 for the Welsch weights: the argument is -(r c)^2 -- never NaN, never positive -- so of exp32's three range tests only the flush
+// below -87 is left, and the scaling by 2^k is one v_ldexp_f32 on the device instead of add, shift and multiply (the product is a
+// normal float, so e * 2^k == ldexp(e, k) bit for bit).  Same bits as exp32 on its whole domain x <= 0 (tests/test_oracle_cpu.py).
+CTM_HD float exp32_nonpos(float x) {
+    if (x < -87.0f) return 0.0f;
+    const float k = __builtin_rintf(x * 1.44269502162933349609375f);
+    const float r = (x - k * 0.693145751953125f) - k * 1.428606765330187045037746429443359375e-06f;
+    float p = 1.3933733571320772171020508e-03f;
+    p = p * r + 8.3632357418537139892578125e-03f;
+    p = p * r + 4.1666463017463684082031250e-02f;
+    p = p * r + 1.6666576266288757324218750e-01f;
+    p = p * r + 0.5f;
+    const float e = (p * (r * r) + r) + 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ldexpf(e, (int)k);
+#else
+    return e * bits_to_f32((uint32_t)((int)k + 127) << 23);
+#endif
+}
 CTM_HD float sqrt32(float x) { return __builtin_sqrtf(x); }
 CTM_HD double sqrt64(double x) { return __builtin_sqrt(x); }
 // roundf (half away from zero), as std::round(float)

@@ -1550,9 +1550,10 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     if (!p.corner_subpix) return hipSuccess;
     RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2, ws.refine_n0, ws.frame_long};
     static const int refine_gx = getenv("CTAG_REFINE_GX") ? atoi(getenv("CTAG_REFINE_GX")) : 32;  // looping blocks per frame of the other forms
-    const dim3 grid(refine_gx, nframes);
+    const bool few = nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT;
+    const dim3 grid(few ? CTAG_MAX_FEATURES * 2 : refine_gx, nframes);  // a few frames: a block per quad -- the call is as long as its longest block, and looping blocks triple it
     static const int refine_sums_gx = getenv("CTAG_REFINE_SUMS_GX") ? atoi(getenv("CTAG_REFINE_SUMS_GX")) : 12;  // looping blocks per frame of k_edge_refine<2>
-    if (nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT) {  // a few frames: one kernel, one launch
+    if (few) {  // one kernel, one launch
         hipLaunchKernelGGL(k_edge_refine<0>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
     } else {
         static const int xcd = getenv("CTAG_REFINE_XCD") ? atoi(getenv("CTAG_REFINE_XCD")) : 3;

@@ -188,7 +188,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
             const float x = p.x - lx, y = p.y - ly;
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
-            const float wj = ctm::exp32(-r * r * c * c);
+            const float wj = ctm::exp32_nonpos(-r * r * c * c);
             wc[j * 64] = wj;
             sum_w += wj;
         }
@@ -200,7 +200,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
             const float x = p.x - lx, y = p.y - ly;
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
-            sum_w += ctm::exp32(-r * r * c * c);
+            sum_w += ctm::exp32_nonpos(-r * r * c * c);
         }
         if (err < EPS) break;
         double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
@@ -227,7 +227,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
                 pn3 = pts(min(j + 1, n - 1));
                 const float px = p.x, py = p.y;
                 const float r = ctm::fabs32(nx * (px - lx) + ny * (py - ly));
-                const float wj = (float)(ctm::exp32(-r * r * c * c) * inv);
+                const float wj = (float)(ctm::exp32_nonpos(-r * r * c * c) * inv);
                 x += wj * px;
                 y += wj * py;
                 x2 += wj * px * px;
@@ -1813,7 +1813,7 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
                 const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
                 const float r = ctm::fabs32(nx * x + ny * y);
                 s_r[j] = r;
-                s_w[j] = ctm::exp32(-r * r * c * c);
+                s_w[j] = ctm::exp32_nonpos(-r * r * c * c);
             }
             __syncthreads();
             if (lane < 2) {  // err += r and sum_w += w, in point order

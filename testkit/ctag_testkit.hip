@@ -42,6 +42,7 @@ __global__ void k_math_probe(int op, int n, const double* a, const double* b, do
         case 12: r = (float)x / (float)y; break;
         case 13: r = ctm::sqrt32((float)x); break;
         case 14: r = ctm::round32((float)x); break;
+        case 15: r = ctm::exp32_nonpos((float)x); break;  // x <= 0, not NaN
         default: break;
     }
     out[i] = r;
