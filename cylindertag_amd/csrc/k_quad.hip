@@ -303,6 +303,18 @@ __host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int b
     return pack_need(w, h) > pack_words || pack_points(w, h) > big_points;
 }
 
+// packed 16-bit minimum (v_pk_min_u16)
+typedef unsigned short ctag_qus2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t q_pk_min_u16(uint32_t a, uint32_t b) {
+    ctag_qus2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const ctag_qus2 r = __builtin_elementwise_min(x, y);
+    uint32_t o;
+    __builtin_memcpy(&o, &r, 4);
+    return o;
+}
+
 struct CornerPre {
     float x, y, dis, ang;
 };
@@ -999,9 +1011,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 if (gxf + kChunk + q >= x_min && gxf + kChunk + q < x_end) valid1 |= 1u << q;
             }
             const bool ld_ok = valid0 != 0, ld_ok1 = valid1 != 0;
-            unsigned labA0 = 0xffffffffu, labB0 = 0xffffffffu, labA1 = 0xffffffffu, labB1 = 0xffffffffu;
             bool over0 = false, over1 = false;  // more than two labels of this component in one tile: generic test
             int cur_trow = -1;
+            uint32_t LA0 = 0, LB0 = 0, LA1 = 0, LB1 = 0;  // the two tiles' labels of the component as (label | label << 16)
             uint32_t top0[4], bot0[4], seen0[4], top1[4], bot1[4], seen1[4];  // packed halfwords: 8 columns per chunk
 #pragma unroll
             for (int d = 0; d < 4; d++) {
@@ -1053,7 +1065,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
                 return bits & valid;
             };
-            auto note = [&](unsigned bits, int y, uint32_t* tp, uint32_t* bt, uint32_t* sn, int xl0) {
+            // masks of a row's foreground columns: M[d] = 0xffff per label half of word d that is foreground (what note() folds into the
+            // column arrays) -- from the bit form, for the paths that produce bits
+            auto masks_of_bits = [&](unsigned bits, uint32_t (&M)[4]) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) M[d] = ((bits >> (2 * d)) & 1u) * 0xffffu + ((bits >> (2 * d + 1)) & 1u) * 0xffff0000u;
+            };
+            // the common case (at most two labels of the component in the tile) two labels at a time: w ^ (label | label << 16) has a zero
+            // half where a label matches, v_pk_min_u16 against 1 turns "non-zero" into 1, and one 24-bit multiply widens the match flags to
+            // half-word masks -- a third of the instructions of eight compare pairs + selects, then eight bit extracts to rebuild masks
+            // (No test against the box's columns: the lane's eight columns lie in one tile, and a pixel of that tile carrying one of the
+            // component's labels IS a pixel of the component, hence inside its box.  A tile without a label of the component has
+            // LA2 = LB2 = 0xffffffff: label 0xffff does not occur -- specks are 0x8000 | id with id < 4864.)
+            auto fg_masks = [&](const uint4& v, uint32_t LA2, uint32_t LB2, uint32_t (&M)[4]) -> unsigned {
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                uint32_t f[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t na = q_pk_min_u16(wv[d] ^ LA2, 0x00010001u), nb = q_pk_min_u16(wv[d] ^ LB2, 0x00010001u);  // 1 per half that differs
+                    f[d] = (na & nb) ^ 0x00010001u;  // 1 per half that matches a label
+                    M[d] = __umul24(f[d], 0xffffu);
+                }
+                const uint32_t t = f[0] | (f[1] << 2) | (f[2] << 4) | (f[3] << 6);  // even columns in bits 0, 2, 4, 6; odd ones 16 bits up
+                return (t | (t >> 15)) & 0xffu;
+            };
+            auto note = [&](unsigned bits, const uint32_t (&M)[4], int y, uint32_t* tp, uint32_t* bt, uint32_t* sn, int xl0) {
                 if constexpr (SG == 64) {
                     // row extents of a whole-wave component: the lanes are in column order, so the row's first and last foreground
                     // lanes come from one ballot and lane 0 updates the row's words
@@ -1071,7 +1107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const uint32_t ypk = (uint32_t)y * 0x10001u;
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
-                    const uint32_t m = ((bits >> (2 * d)) & 1u) * 0xffffu + ((bits >> (2 * d + 1)) & 1u) * 0xffff0000u;
+                    const uint32_t m = M[d];
                     bt[d] = (bt[d] & ~m) | (ypk & m);
                     const uint32_t nm = m & ~sn[d];
                     tp[d] = (tp[d] & ~nm) | (ypk & nm);
@@ -1097,11 +1133,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const int trow = ((y_min + y) / kTileH) * g.tiles_x;
                 if (trow != cur_trow) {
                     cur_trow = trow;
-                    labels_of_tile(trow + tcol0, labA0, labB0, over0);
-                    labels_of_tile(trow + tcol1, labA1, labB1, over1);
+                    // the tiles' labels in the packed form (label | label << 16) fg_masks takes; 0xffffffff (no label) stays 0xffffffff
+                    unsigned la, lb;
+                    labels_of_tile(trow + tcol0, la, lb, over0);
+                    LA0 = (la & 0xffffu) * 0x10001u, LB0 = (lb & 0xffffu) * 0x10001u;
+                    labels_of_tile(trow + tcol1, la, lb, over1);
+                    LA1 = (la & 0xffffu) * 0x10001u, LB1 = (lb & 0xffffu) * 0x10001u;
                 }
-                note(fg_of(v, labA0, labB0, over0, trow + tcol0, valid0), y, top0, bot0, seen0, gxf - x_min);
-                if (SG == 64 || ld_ok1) note(fg_of(v1, labA1, labB1, over1, trow + tcol1, valid1), y, top1, bot1, seen1, gxf + kChunk - x_min);  // whole wave: note() holds a ballot
+                auto one = [&](const uint4& w, uint32_t LA2, uint32_t LB2, bool over, int tile, unsigned valid, uint32_t* tp, uint32_t* bt, uint32_t* sn, int xl0) {
+                    uint32_t M[4];
+                    unsigned bits;
+                    if (!over) {
+                        bits = fg_masks(w, LA2, LB2, M);
+                    } else {
+                        bits = fg_of(w, 0u, 0u, over, tile, valid);
+                        masks_of_bits(bits, M);
+                    }
+                    note(bits, M, y, tp, bt, sn, xl0);
+                };
+                one(v, LA0, LB0, over0, trow + tcol0, valid0, top0, bot0, seen0, gxf - x_min);
+                if (SG == 64 || ld_ok1) one(v1, LA1, LB1, over1, trow + tcol1, valid1, top1, bot1, seen1, gxf + kChunk - x_min);  // whole wave: note() holds a ballot
             };
             // label rows in flight per lane (the scan is bound by latency, not by bytes): 4 in the large configuration, 2 in the
             // small one, whose 128-register budget the eight row registers of the deeper pipeline would spill
