@@ -213,7 +213,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t o_cand = take(F * kCandCap * sizeof(Candidate));
     const size_t o_quads = take(F * kCandCap * sizeof(QuadOut));
     const size_t o_lcount = take(F * 4), o_clused = take(F * 4), o_llong = take(F * 4);
-    const size_t o_clpool = take(F * kClPool * 4);
+    const size_t o_clpool = take(F * kClPool * 4 + 16);  // + one element: welsch_restart requests one point past a cluster's last
     const size_t o_ldesc = take(F * kLineCap * sizeof(LineDesc));
     const size_t o_lsort = take(F * kLineCap * 4);
     const size_t o_lfit = take(F * kLineCap * 16);

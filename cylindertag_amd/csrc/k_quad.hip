@@ -180,11 +180,13 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
         const float lx = line[2], ly = line[3], nx = line[1], ny = -line[0];
         double sum_w = 0;
         err = 0;
+        // (the point after the last is requested too and never used: the staged rows and the cluster pool are padded by one element, which
+        // spares every trip the clamp of its index -- v_min_i32, sign extension and a 64-bit address per point and pass)
         float2 pn0 = pts(min(0, n - 1));  // next point, loaded one trip ahead
         CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = 0; j < ncache; j++) {
             const float2 p = pn0;
-            pn0 = pts(min(j + 1, n - 1));
+            pn0 = pts(j + 1);
             const float x = p.x - lx, y = p.y - ly;
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
@@ -196,7 +198,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
         CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = ncache; j < n; j++) {
             const float2 p = pn1;
-            pn1 = pts(min(j + 1, n - 1));
+            pn1 = pts(j + 1);
             const float x = p.x - lx, y = p.y - ly;
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
@@ -210,7 +212,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
             CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = 0; j < ncache; j++) {
                 const float2 p = pn2;
-                pn2 = pts(min(j + 1, n - 1));
+                pn2 = pts(j + 1);
                 const float px = p.x, py = p.y;
                 const float wj = (float)(wc[j * 64] * inv);
                 x += wj * px;
@@ -224,7 +226,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
             CTAG_PRAGMA(unroll CTAG_WUNROLL)
         for (int j = ncache; j < n; j++) {
                 const float2 p = pn3;
-                pn3 = pts(min(j + 1, n - 1));
+                pn3 = pts(j + 1);
                 const float px = p.x, py = p.y;
                 const float r = ctm::fabs32(nx * (px - lx) + ny * (py - ly));
                 const float wj = (float)(ctm::exp32_nonpos(-r * r * c * c) * inv);
@@ -239,7 +241,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
             float2 pn4 = pts(min(0, n - 1));  // next point, loaded one trip ahead
             for (int j = 0; j < n; j++) {
                 const float2 p = pn4;
-                pn4 = pts(min(j + 1, n - 1));
+                pn4 = pts(j + 1);
                 const float px = p.x, py = p.y;
                 x += px;
                 y += py;
@@ -1680,6 +1682,7 @@ static_assert(kWCap >= 10 && kWPts < kPickN && 3 * kWPts * 8 >= 64 * 10 * 2, "k_
 struct WelschLds {
     float wc[kWCap * 64];
     float2 pt[3][kWPts];
+    float2 pad;  // pt[2][kWPts]: welsch_restart requests one point past an edge's last
 };
 
 __device__ __forceinline__ void welsch_three(const QuadPtrs& P, WelschLds& S, int frame, int first, int L) {
