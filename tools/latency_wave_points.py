@@ -1,3 +1,4 @@
+"""Single-frame latency against CTAG_OPT_WAVE_POINTS (the boundary capacity above which a component gets a wave of its own in few-frame calls)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
