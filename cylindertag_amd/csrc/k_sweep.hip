@@ -1197,6 +1197,7 @@ __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl_big(SweepPtrs P, 
         __syncthreads();
     }
 }
+static_assert(kSlotCapBig < 0x7fff, "labels are 1..slots or 0x8000 | culled slot: 0xffff never occurs (k_quad's packed label match relies on it)");
 static_assert(2 * kSlotCap <= 256, "FrameGeom::pool_cap = 256 entries per tile holds two first passes");
 static_assert(kRunCapBig % kCclThreads == 0 && kRunCapBig >= (kTileW / 2) * kTileH && kSlotCapBig >= (kTileW / 2) * ((kTileH + 1) / 2), "second-pass caps hold any tile");
 
