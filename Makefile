@@ -8,4 +8,7 @@ clean:
 	$(MAKE) -s -C cylindertag_amd clean
 	$(MAKE) -s -C testkit clean
 	$(MAKE) -s -C oracle clean
-.PHONY: all clean
+# the vector-instruction issue-cost microbenchmark (runs on the GPU box; not part of the product)
+ubench:
+	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/ubench/valu_rate.hip -o tools/ubench/valu_rate
+.PHONY: all clean ubench

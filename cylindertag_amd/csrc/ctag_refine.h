@@ -99,6 +99,7 @@ CTR_UNROLL
 // true when every pixel the search of this sample touches lies at least one pixel inside the image (so no bounds test is
 // needed per pixel and a coordinate in (-1, 0), which truncates to 0, cannot occur)
 CTM_HD bool interior(double x0, double y0, double nx, double ny, int subpix, int rows, int cols) {
+    if (rows >= (1 << 19) || cols >= (1 << 19)) return false;  // to_fix32's range (a frame that large takes the reference arithmetic)
     const double r = (double)subpix + 1.0;
     const double xa = x0 - r * nx, xb = x0 + r * nx, ya = y0 - r * ny, yb = y0 + r * ny;
     const double xlo = xa < xb ? xa : xb, xhi = xa < xb ? xb : xa, ylo = ya < yb ? ya : yb, yhi = ya < yb ? yb : ya;
