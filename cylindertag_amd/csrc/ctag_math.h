@@ -269,6 +269,36 @@ CTM_HD float exp32_nonpos(float x) {
     return e * bits_to_f32((uint32_t)((int)k + 127) << 23);
 #endif
 }
+// Several quotients with ONE denominator (the five moments over their weight in fitLine and in edgeRefine): IEEE division, so a / d
+// on the host; on the device the compiler's own expansion of a double division -- v_rcp_f64, two Newton steps on the reciprocal, then
+// per numerator q = a r, e = a - d q, q + e r (correctly rounded: it is the sequence v_div_fmas / v_div_fixup finish) -- with the
+// reciprocal's part done once instead of once per quotient.  The expansion's v_div_scale / v_div_fixup guard exponents near the ends of
+// the range; left out, so: d and every a / d normal and far from overflow (|d| in [2^-500, 2^500], |a| <= 2^500 |d|, a / d >= 2^-500
+// or zero), which sums of at most a few thousand pixel coordinates times weights in (0, 1] are.  tests: math probe 16 against `/`.
+struct Recip64 {
+    double d, r;
+};
+CTM_HD Recip64 recip64(double d) {
+    Recip64 R;
+    R.d = d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    R.r = r;
+#else
+    R.r = 0.0;
+#endif
+    return R;
+}
+CTM_HD double div64(double a, const Recip64& R) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double q = a * R.r;
+    return __builtin_fma(__builtin_fma(-R.d, q, a), R.r, q);
+#else
+    return a / R.d;
+#endif
+}
 CTM_HD float sqrt32(float x) { return __builtin_sqrtf(x); }
 CTM_HD double sqrt64(double x) { return __builtin_sqrt(x); }
 // roundf (half away from zero), as std::round(float)

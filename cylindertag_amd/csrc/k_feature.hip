@@ -468,10 +468,11 @@ __device__ __forceinline__ void refine_prefetch(const RefinePtrs& P, int frame, 
 // refine_line: the line of (edge, pass) -> L = {Ex, Ey, nx, ny} (:667-678 / :743-754); refine_corner: corner `it` from the lines (:757-776).
 __device__ __forceinline__ void refine_line(const double* A, double* L) {
     const double Mx = A[0], My = A[1], Mxx = A[2], Mxy = A[3], Myy = A[4], N = A[5];  // (L may be A: everything is read first)
-    const double Ex = Mx / N, Ey = My / N;
-    const double Cxx = Mxx / N - Ex * Ex;
-    const double Cxy = Mxy / N - Ex * Ey;
-    const double Cyy = Myy / N - Ey * Ey;
+    const ctm::Recip64 RN = ctm::recip64(N);  // five IEEE quotients by one denominator (ctag_math.h)
+    const double Ex = ctm::div64(Mx, RN), Ey = ctm::div64(My, RN);
+    const double Cxx = ctm::div64(Mxx, RN) - Ex * Ex;
+    const double Cxy = ctm::div64(Mxy, RN) - Ex * Ey;
+    const double Cyy = ctm::div64(Myy, RN) - Ey * Ey;
     const double normal_theta = .5 * ctm::atan2_32((float)(-2 * Cxy), (float)(Cyy - Cxx));
     L[0] = Ex;
     L[1] = Ey;

@@ -56,11 +56,12 @@ __device__ __forceinline__ int uy(uint32_t p) { return (int)(p >> 16); }
 
 // fitLine2D_wods tail: moments -> (vx, vy, x0, y0)   [SURVEY App. A.5]
 __device__ __forceinline__ void moments_to_line(double x, double y, double x2, double y2, double xy, double w, float* line) {
-    x /= w;
-    y /= w;
-    x2 /= w;
-    y2 /= w;
-    xy /= w;
+    const ctm::Recip64 W = ctm::recip64(w);  // five IEEE quotients by one denominator: its reciprocal refined once (ctag_math.h)
+    x = ctm::div64(x, W);
+    y = ctm::div64(y, W);
+    x2 = ctm::div64(x2, W);
+    y2 = ctm::div64(y2, W);
+    xy = ctm::div64(xy, W);
     const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
     const float t = (float)ctm::atan2_64(2 * dxy, dx2 - dy2) / 2;
     double sn, cs;

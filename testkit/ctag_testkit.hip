@@ -43,6 +43,7 @@ __global__ void k_math_probe(int op, int n, const double* a, const double* b, do
         case 13: r = ctm::sqrt32((float)x); break;
         case 14: r = ctm::round32((float)x); break;
         case 15: r = ctm::exp32_nonpos((float)x); break;  // x <= 0, not NaN
+        case 16: r = ctm::div64(x, ctm::recip64(y)); break;  // x / y through the shared-reciprocal form (device) or `/` (host)
         default: break;
     }
     out[i] = r;

@@ -33,13 +33,17 @@ def test_device_math_is_bit_identical_to_host(detector, oracle):
     rng = np.random.RandomState(11)
     a = np.concatenate([rng.uniform(-1e3, 1e3, 40000), rng.uniform(-1, 1, 20000), [0.0, -0.0, 1.0, -1.0, 1e-30, 3.5e4]])
     b = np.concatenate([rng.uniform(-1e3, 1e3, 40000), rng.uniform(-1, 1, 20000), [1.0, -1.0, 0.0, 0.0, 1e30, -2.5]])
-    for op in range(16):
+    for op in range(17):
         x, y = a, b
         if op in (3, 8):
             x = np.clip(a, -100, 80) if op == 3 else np.clip(a, -120, 80)
         if op == 15:  # the Welsch weights' form of exp32: non-positive arguments only
             x = np.concatenate([-np.abs(np.clip(a, -120, 120)), -np.exp(rng.uniform(-30, 4.8, 60000))])
             y = np.zeros_like(x)
+        if op == 16:  # quotients through a shared reciprocal (ctm::div64): moments over weights, and harder ranges than the kernels see
+            w = np.exp(rng.uniform(-40, 40, 300000))
+            x = np.concatenate([rng.uniform(-4e3, 4e3, 300000) * w, np.exp(rng.uniform(-200, 200, 300000)) * rng.choice([-1.0, 1.0], 300000), np.zeros(1000)])
+            y = np.concatenate([w, np.exp(rng.uniform(-200, 200, 300000)) * rng.choice([-1.0, 1.0], 300000), w[:1000]])
         if op == 4:
             x = np.clip(a, -1, 1).astype(np.float32).astype(np.float64)
         if op in (11, 13):
