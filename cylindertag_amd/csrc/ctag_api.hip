@@ -430,7 +430,7 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
         evs = h->ev.data() + (size_t)h->ev_sets_used * (CTAG_NUM_STAGES + 1);
         h->ev_sets_used++;
     }
-    static const bool stamps = getenv("CTAG_CCL_STAMPS") != nullptr || getenv("CTAG_QUAD_STAMPS") != nullptr;  // developer aids that synchronise inside the chain
+    static const bool stamps = getenv("CTAG_CCL_STAMPS") != nullptr || getenv("CTAG_QUAD_STAMPS") != nullptr || getenv("CTAG_FEAT_STAMPS") != nullptr;  // developer aids that synchronise inside the chain (no graph capture around them)
     bool graph = h->use_graph == 1;
     if (h->use_graph == 2 && n <= kLatencyFrames) {  // one frame per call in a loop (main.cpp:52-59): same staging buffers, same sizes every time
         ctag_handle::GraphEntry& k = h->last_key;
