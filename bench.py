@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--size", default="1920x1080", help="frame size WxH; the headline metric is 1920x1080 (other sizes are side measurements)")
     ap.add_argument("--no-subpix", action="store_true")
     ap.add_argument("--latency-calls", type=int, default=200, help="single-frame ctag_detect_u8 calls of the latency side measurement, 0 = skip")
+    ap.add_argument("--pipelined-steps", type=int, default=6, help="steps of the two-handle side measurement at N = 1, 0 = skip")
     ap.add_argument("--allow-torch-gather", action="store_true",
                     help="N > 1: if the library's RCCL gather (ctag_gather, the C ABI) cannot come up, fall back to torch.distributed's all_gather "
                          "of the fixed records instead of failing.  Without this flag such a run exits non-zero: the line must not hide a gather failure")
@@ -83,6 +84,38 @@ def device_copy_rate(dev):
         best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     del a, b
     return best
+
+
+def pipelined_steps_rate(det, state, fs, dev_index, frames_dev, n, chunk, subpix, out_buf, steps):
+    """Side measurement (never `value`): the same steps alternating between TWO handles (streams, workspaces), so that the tail of a
+    step's kernels -- a few long boundary / Welsch blocks -- overlaps the head of the next step.  This is how `--gpus N > 1` runs its
+    steps; the N = 1 line stays on one handle so that its per-kernel HIP-event times are not stretched by a neighbouring stream."""
+    import torch
+    import testkit as tk
+    from cylindertag_amd import capi
+    det2 = tk.Detector(state, fs, device=dev_index)
+    try:
+        det2.set_option(capi.OPT_MAX_CHUNK, chunk)
+        out2 = torch.empty_like(out_buf)
+        pair = ((det, out_buf), (det2, out2))
+
+        def run(k):
+            d, o = pair[k % 2]
+            d.detect_batch_device(frames_dev.data_ptr(), n, ROWS, COLS, COLS, ROWS * COLS, o.data_ptr(), 5, subpix, 5)
+        for k in range(2):
+            run(k)
+        det.sync(); det2.sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            run(k)
+        det.sync(); det2.sync()
+        dt = time.perf_counter() - t0
+        same = bool(torch.equal(out_buf[:n], out2[:n]))
+        return {"value": round(n * steps / dt, 1), "unit": "frames/s", "handles": 2, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+                "records_equal_between_handles": same,
+                "note": "consecutive steps alternate between two handles; the headline `value` is one handle, one stream"}
+    finally:
+        det2.close()
 
 
 def host_stream_rate(det, frames_dev, m, subpix):
@@ -684,6 +717,8 @@ def main():
             out["parity"] = None
         if world == 1 and args.cpu_frames > 0 and frames is not None:
             side("opencv_stage_probe", lambda: opencv_stage_probe(frames[:16].cpu().numpy()))
+        if world == 1 and args.pipelined_steps > 0 and frames is not None:
+            side("pipelined_two_handles", lambda: pipelined_steps_rate(det, state, fs, dev_index, frames, n, chunk, subpix, local_bufs[0], args.pipelined_steps))
         if world == 1 and args.host_frames > 0:
             side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
             side("pcie_inclusive_bgr", lambda: host_stream_rate_bgr(det, frames, min(args.host_frames // 2, n), subpix))
