@@ -174,7 +174,7 @@ def _random_shapes_frame(state, seed, rows=720, cols=1152):
     rectangles and quads of many sizes (incl. long bars wider than 128 half-res px and blobs near the 1 % area limit),
     rings, L-shapes, stacked quad pairs (feature candidates), tiny specks, some touching the frame border or a marker."""
     rng = np.random.RandomState(1000 + seed)
-    base = tk.synth_frame_host(state, 500 + seed)[0]
+    base = tk.synth_frame_host(state, 500 + seed, rows=max(1080, rows), cols=max(1920, cols))[0]  # (larger frames: a larger synthetic base)
     y0, x0 = rng.randint(0, base.shape[0] - rows + 1), rng.randint(0, base.shape[1] - cols + 1)
     img = base[y0:y0 + rows, x0:x0 + cols].astype(np.float32)
     yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
