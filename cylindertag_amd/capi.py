@@ -23,7 +23,7 @@ OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OP
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)
 EXPORTS = ["ctag_create", "ctag_create_ex", "ctag_params_default", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
-           "ctag_detect_batch_device", "ctag_detect_bgr8", "ctag_detect_batch_bgr8", "ctag_detect_batch_bgr8_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings",
+           "ctag_detect_batch_device", "ctag_detect_bgr8", "ctag_detect_batch_bgr8", "ctag_detect_batch_bgr8_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings", "ctag_get_counters",
            "ctag_stage_name", "ctag_strerror", "ctag_version"]
 # ... and include/ctag_pose.h
 POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag_model_get_view", "ctag_camera_load",
@@ -42,7 +42,7 @@ POSE_OK, POSE_NO_MODEL, POSE_TOO_FEW, POSE_BAD_POS, POSE_DEGENERATE = range(5)
 
 
 class ParamsC(C.Structure):  # ctag_params (include/ctag_types.h): the reference's tunables
-    _fields_ = [("threshold_line", C.c_float), ("threshold_expand", C.c_float), ("threshold_RAC", C.c_float), ("threshold_angle", C.c_float),
+    _fields_ = [("struct_size", C.c_uint32), ("threshold_line", C.c_float), ("threshold_expand", C.c_float), ("threshold_RAC", C.c_float), ("threshold_angle", C.c_float),
                 ("threshold_vertical", C.c_float), ("ID_cr_correspond", C.c_float * 4), ("cr_covariance_left", C.c_float * 4),
                 ("cr_covariance_right", C.c_float * 4), ("dark_cap", C.c_float), ("area_min", C.c_int32), ("area_max_fraction", C.c_double),
                 ("collinear_cost", C.c_double)]
@@ -53,6 +53,14 @@ def default_params():
     p = ParamsC()
     load_library().ctag_params_default(C.byref(p))
     return p
+
+
+COUNTER_NAMES = ["components", "candidates", "quads", "features", "markers"]
+PENDING = -5  # CTAG_PENDING
+
+
+class CountersC(C.Structure):  # ctag_counters (include/ctag_types.h)
+    _fields_ = [("frames", C.c_int64), ("sum", C.c_int64 * 5), ("max", C.c_int32 * 5), ("reruns", C.c_int32)]
 
 
 class CameraC(C.Structure):  # ctag_camera
@@ -132,6 +140,8 @@ def load_library():
     L.ctag_stream.argtypes = [vp]
     L.ctag_set_option.restype = C.c_int
     L.ctag_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.ctag_get_counters.restype = C.c_int
+    L.ctag_get_counters.argtypes = [vp, C.POINTER(CountersC)]
     L.ctag_get_timings.restype = C.c_int
     L.ctag_get_timings.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.ctag_stage_name.restype = C.c_char_p
@@ -423,6 +433,18 @@ class Detector:
 
     def stream(self):
         return self.L.ctag_stream(self.h)
+
+    def counters(self):
+        """Per-frame counts of the last chunk: {name: (mean, max)} for components / candidates / quads / features / markers, plus
+        'frames' and 'reruns' (frames completed through the any-frame workspace since the handle was created)."""
+        c = CountersC()
+        st = self.L.ctag_get_counters(self.h, C.byref(c))
+        if st != 0:
+            raise CtagError(st, "ctag_get_counters")
+        out = {"frames": int(c.frames), "reruns": int(c.reruns)}
+        for k, name in enumerate(COUNTER_NAMES):
+            out[name] = (c.sum[k] / c.frames if c.frames else 0.0, int(c.max[k]))
+        return out
 
     def timings(self):
         buf = (C.c_float * len(STAGE_NAMES))()

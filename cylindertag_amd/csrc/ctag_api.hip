@@ -40,8 +40,29 @@ struct ctag_handle {
     uint32_t* d_dict_pos = nullptr;  // [dict_rows][64]: columns holding each symbol (k_markers' bit-parallel coverage); null for > 32 columns
     uint8_t* d_pick_table = nullptr;
     int dict_rows = 0, dict_cols = 0, feature_size = 0;
-    Workspace ws;
-    int ws_rows = 0, ws_cols = 0, ws_tw = 0, ws_cap = 0;
+    // Two workspaces: `batch` holds chunks of frames with pools sized for what a frame of its size ordinarily needs (make_caps);
+    // `big` holds ONE frame with pools no frame of that size can exhaust -- a frame that overflowed a batch pool (thousands of
+    // blobs, fine texture: CTAG_FLAG_POOL_OVERFLOW -> CTAG_PENDING) is run again there (rerun_frame).  `big` is allocated on first use.
+    struct WsSlot {
+        Workspace ws;
+        int rows = 0, cols = 0, tw = 0, cap = 0;
+        double* n0_buf = nullptr;   // refine_n0, allocated when a chunk of more than kLatencyFrames frames first runs with corner_subpix
+        size_t n0_frames = 0;
+    };
+    WsSlot batch, big;
+    const Workspace* last_ws = nullptr;  // whichever ran last (handle_view)
+    const ctag_frame_result* last_out = nullptr;  // ... and where its records went (ctag_get_counters)
+    // frames of device-memory calls that wait for the any-frame pass (k_markers appends, finish_pending drains)
+    PendingRec* d_pending = nullptr;
+    int32_t* d_pending_count = nullptr;
+    int pending_cap = 65536;
+    bool pending_dirty = false;      // a device-memory call was enqueued since the list was last read
+    uint8_t* d_big_frame = nullptr;  // private copy of a pending frame (host-memory calls upload it again; BGR frames are converted into d_big_gray)
+    size_t d_big_frame_bytes = 0;
+    uint8_t* d_big_gray = nullptr;
+    size_t d_big_gray_bytes = 0;
+    ctag_frame_result* d_big_result = nullptr;
+    int reruns = 0;                  // frames completed through the any-frame workspace so far (ctag_get_counters)
     int max_chunk = 1024;
     int wave_points = 0;  // CTAG_OPT_WAVE_POINTS
     bool timing = false;
@@ -76,6 +97,7 @@ struct ctag_handle {
         const void* ws_base = nullptr;
         int n = 0, rows = 0, cols = 0, tw = 0, subpix = 0, dist = 0, keep_pre = 0;
         ptrdiff_t row_stride = 0, frame_stride = 0;
+        const void* pend_src = nullptr;  // PendingCtx::src baked into k_markers' arguments (null: no list)
         hipGraphExec_t exec = nullptr;
         uint64_t last_use = 0;
     };
@@ -105,7 +127,7 @@ bool handle_timing(const ctag_handle* h) { return h->timing; }
 int handle_device(const ctag_handle* h) { return h->device; }
 void handle_view(const ctag_handle* h, HandleView* out) {
     out->device = h->device;
-    out->ws = h->ws.base ? &h->ws : nullptr;
+    out->ws = h->last_ws && h->last_ws->base ? h->last_ws : nullptr;
     out->last_chunk_frames = h->last_chunk_frames;
     out->keep_pre = h->keep_pre;
     out->dict = h->dict.data();
@@ -168,31 +190,91 @@ static void build_resize_tables(int src, int dst, std::vector<int32_t>& ofs, std
 }
 
 static void drop_graphs(ctag_handle* h);
+static int finish_pending(ctag_handle* h);
 
-static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int frames) {
-    if (h->ws.base && h->ws_rows == rows && h->ws_cols == cols && h->ws_cap >= frames) {
-        h->ws.g = make_geom(rows, cols, tw, h->params.area_max_fraction);
-        h->ws.kp = h->kp;
-        h->ws.pick_table = h->d_pick_table;
-        h->ws.aux_stream = h->aux_stream;
-        h->ws.wave_points = h->wave_points;
-        h->ws.ev_fork = h->ev_fork;
-        h->ws.ev_join = h->ev_join;
-        h->ws_tw = tw;
-        return CTAG_OK;
+// Pool sizes of a workspace.  Batch: what a frame of this size ordinarily needs, scaled with its area so that a 4K frame is not held
+// to a 1080p frame's numbers (at 1080p: 2048 candidates, 262 144 cluster points -- a camera frame uses a few hundred / ~50 K).
+// Big: bounds no frame can exceed --
+//   candidates: components of >= area_min pixels: hw / area_min;
+//   cluster points: a component of a pixels has w + h <= 2a, so its reservation min(2(w + h), wh) + 65 <= 4a + 65: 4 hw + 65 candidates;
+//   component pool: a 320x30 label tile publishes every component only in the first pass (<= 128); the second publishes the ones
+//   of >= area_min pixels (<= 9600 / area_min) or touching the tile border (<= 348 non-adjacent border pixels), at most kSlotCapBig.
+struct Caps {
+    int pool_cap, cand_cap;
+    uint32_t cl_cap;
+};
+static Caps make_caps(const FrameGeom& g, const ctag_params& prm, bool big) {
+    const long long hw = (long long)g.hrows * g.hcols;
+    Caps c{};
+    if (!big) {
+        c.pool_cap = g.pool_cap;
+        c.cand_cap = (int)std::max<long long>(kCandCapMin, ((hw / 256 + 63) / 64) * 64);
+        c.cl_cap = (uint32_t)std::max<long long>(kClPoolMin, ((hw / 2 + 1023) / 1024) * 1024);
+    } else {
+        const int amin = std::max(prm.area_min, 1);
+        const long long per_tile = std::min<long long>(kSlotCapBig, 352 + (kTileW * kTileH) / amin);
+        c.pool_cap = (int)std::max<long long>(g.pool_cap, per_tile * g.tiles_x * g.tiles_y);
+        const long long cand = ((hw / amin + 1 + 63) / 64) * 64;
+        c.cand_cap = (int)std::max<long long>(kCandCapMin, cand);
+        c.cl_cap = (uint32_t)std::max<long long>(kClPoolMin, 4 * hw + 65 * cand + 1024);
     }
-    if (h->ws.base) {
+    return c;
+}
+
+static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, int cols, int tw, int frames, bool big, bool need_n0) {
+    auto refresh = [&](Workspace& W) {
+        const Caps c = make_caps(make_geom(rows, cols, tw, h->params.area_max_fraction), h->params, big);
+        W.g = make_geom(rows, cols, tw, h->params.area_max_fraction);
+        W.g.pool_cap = c.pool_cap;
+        W.kp = h->kp;
+        W.pick_table = h->d_pick_table;
+        W.aux_stream = h->aux_stream;
+        W.wave_points = h->wave_points;
+        W.ev_fork = h->ev_fork;
+        W.ev_join = h->ev_join;
+        W.big = big;
+    };
+    auto ensure_n0 = [&]() -> int {  // the searches -> sums hand-over of k_edge_refine<1> / <2>: 0.8 MB per frame, batches with corner_subpix only
+        if (!need_n0 || S.n0_frames >= (size_t)S.cap) {
+            S.ws.refine_n0 = S.n0_buf;
+            return CTAG_OK;
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        drop_graphs(h);
+        if (S.n0_buf) HIP_TRY(hipFree(S.n0_buf));
+        S.n0_buf = nullptr;
+        S.n0_frames = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.n0_buf), (size_t)S.cap * CTAG_MAX_FEATURES * 2 * 4 * 128 * 8));
+        S.n0_frames = (size_t)S.cap;
+        S.ws.refine_n0 = S.n0_buf;
+        return CTAG_OK;
+    };
+    if (S.ws.base && S.rows == rows && S.cols == cols && S.cap >= frames) {
+        refresh(S.ws);
+        S.tw = tw;
+        return ensure_n0();
+    }
+    if (S.ws.base) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         drop_graphs(h);  // they hold pointers into the old workspace
-        HIP_TRY(hipFree(h->ws.base));
-        h->ws = Workspace{};
+        HIP_TRY(hipFree(S.ws.base));
+        if (S.n0_buf) HIP_TRY(hipFree(S.n0_buf));
+        S.n0_buf = nullptr;
+        S.n0_frames = 0;
+        if (h->last_ws == &S.ws) h->last_ws = nullptr;
+        S.ws = Workspace{};
+        S.cap = 0;
     }
-    Workspace& W = h->ws;
-    W.g = make_geom(rows, cols, tw, h->params.area_max_fraction);
-    W.kp = h->kp;
+    Workspace& W = S.ws;
+    refresh(W);
+    const Caps caps = make_caps(W.g, h->params, big);
+    W.cand_cap = caps.cand_cap;
+    W.line_cap = 4 * caps.cand_cap;
+    W.cl_cap = caps.cl_cap;
     const FrameGeom& g = W.g;
     const size_t F = (size_t)frames;
     const size_t tiles = (size_t)g.tiles_x * g.tiles_y;
+    const size_t CC = (size_t)W.cand_cap, LC = (size_t)W.line_cap;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -209,25 +291,25 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     const size_t pool = F * (size_t)g.pool_cap * 4;
     const size_t o_parent = take(pool), o_root = take(pool), o_area = take(pool), o_xmin = take(pool), o_ymin = take(pool),
                  o_xmax = take(pool), o_ymax = take(pool), o_key = take(pool), o_ptile = take(pool), o_mhead = take(pool), o_mnext = take(pool);
-    const size_t o_ncand = take(F * 4);
-    const size_t o_cand = take(F * kCandCap * sizeof(Candidate));
-    const size_t o_quads = take(F * kCandCap * sizeof(QuadOut));
+    const size_t o_ncand = take(F * 4), o_nroots = take(F * 4);
+    const size_t o_cand = take(F * CC * sizeof(Candidate));
+    const size_t o_quads = take(F * CC * sizeof(QuadOut));
     const size_t o_lcount = take(F * 4), o_clused = take(F * 4), o_llong = take(F * 4);
-    const size_t o_clpool = take(F * kClPool * 4 + 16);  // + one element: welsch_restart requests one point past a cluster's last
-    const size_t o_ldesc = take(F * kLineCap * sizeof(LineDesc));
-    const size_t o_lsort = take(F * kLineCap * 4);
-    const size_t o_lfit = take(F * kLineCap * 16);
-    const size_t o_aux = take(F * kCandCap * sizeof(CandAux));
-    const size_t o_npk = take(F * 4), o_pk = take(F * kCandCap * 4), o_pord = take(F * kCandCap * 2);
+    const size_t o_clpool = take(F * (size_t)W.cl_cap * 4 + 16);  // + one element: welsch_restart requests one point past a cluster's last
+    const size_t o_ldesc = take(F * LC * sizeof(LineDesc));
+    const size_t o_lsort = take(F * LC * 4);
+    const size_t o_lfit = take(F * LC * 16);
+    const size_t o_aux = take(F * CC * sizeof(CandAux));
+    const size_t o_npk = take(F * 8), o_pk = take(F * CC * 4), o_pord = take(F * CC * 4);
     const size_t o_wrs = take(std::min<size_t>(F, kLatencyFrames) * kLatLines * 20 * 6 * 4);
-    const size_t o_der = take(F * kCandCap * 48);
-    const size_t o_qidx = take(F * kCandCap * 4);
+    const size_t o_der = take(F * kQuadStride * 48);
+    const size_t o_qidx = take(F * kQuadStride * 4);
     const size_t o_nq = take(F * 4), o_nf = take(F * 4), o_st = take(F * 4);
     const size_t o_f0 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
     const size_t o_f1 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
     const size_t o_f2 = take(F * CTAG_MAX_FEATURES * sizeof(FeatureDev));
     const size_t o_pre = take(F * sizeof(ctag_frame_result));
-    const size_t o_n0 = take(F * (size_t)CTAG_MAX_FEATURES * 2 * 4 * 128 * 8), o_flong = take(F * 4);
+    const size_t o_flong = take(F * 4);
     const size_t o_rzx = take((size_t)g.hcols * 4), o_rza = take((size_t)g.hcols * 8), o_rzy = take((size_t)g.hrows * 4), o_rzb = take((size_t)g.hrows * 8);
     void* base = nullptr;
     HIP_TRY(hipMalloc(&base, off));
@@ -254,6 +336,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.member_head = reinterpret_cast<int32_t*>(b + o_mhead);
     W.member_next = reinterpret_cast<int32_t*>(b + o_mnext);
     W.ncand = reinterpret_cast<int32_t*>(b + o_ncand);
+    W.nroots = reinterpret_cast<int32_t*>(b + o_nroots);
     W.cand = reinterpret_cast<Candidate*>(b + o_cand);
     W.quads = reinterpret_cast<QuadOut*>(b + o_quads);
     W.line_count = reinterpret_cast<int32_t*>(b + o_lcount);
@@ -266,13 +349,8 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.cand_aux = reinterpret_cast<CandAux*>(b + o_aux);
     W.npacks = reinterpret_cast<int32_t*>(b + o_npk);
     W.packs = reinterpret_cast<uint32_t*>(b + o_pk);
-    W.pack_order = reinterpret_cast<uint16_t*>(b + o_pord);
+    W.pack_order = reinterpret_cast<uint32_t*>(b + o_pord);
     W.welsch_rs = reinterpret_cast<float*>(b + o_wrs);
-    W.pick_table = h->d_pick_table;
-    W.aux_stream = h->aux_stream;
-    W.wave_points = h->wave_points;
-    W.ev_fork = h->ev_fork;
-    W.ev_join = h->ev_join;
     W.quad_derived = b + o_der;
     W.quad_index = reinterpret_cast<int32_t*>(b + o_qidx);
     W.nquads = reinterpret_cast<int32_t*>(b + o_nq);
@@ -282,7 +360,7 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
     W.feat1 = reinterpret_cast<FeatureDev*>(b + o_f1);
     W.feat2 = reinterpret_cast<FeatureDev*>(b + o_f2);
     W.premarkers = reinterpret_cast<ctag_frame_result*>(b + o_pre);
-    W.refine_n0 = reinterpret_cast<double*>(b + o_n0);
+    W.refine_n0 = nullptr;
     W.frame_long = reinterpret_cast<int32_t*>(b + o_flong);
     W.rz_xofs = reinterpret_cast<int32_t*>(b + o_rzx);
     W.rz_alpha = reinterpret_cast<int16_t*>(b + o_rza);
@@ -298,11 +376,11 @@ static int ensure_workspace(ctag_handle* h, int rows, int cols, int tw, int fram
         HIP_TRY(hipMemcpy(W.rz_yofs, yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(W.rz_beta, be.data(), be.size() * 2, hipMemcpyHostToDevice));
     }
-    h->ws_rows = rows;
-    h->ws_cols = cols;
-    h->ws_tw = tw;
-    h->ws_cap = frames;
-    return CTAG_OK;
+    S.rows = rows;
+    S.cols = cols;
+    S.tw = tw;
+    S.cap = frames;
+    return ensure_n0();
 }
 
 static int check_args(ctag_handle* h, const void* frames, int n, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int subpix_dist) {
@@ -314,10 +392,11 @@ static int check_args(ctag_handle* h, const void* frames, int n, int rows, int c
 }
 
 // enqueue the whole pipeline for `n` device-resident frames (n <= workspace capacity); evs: CTAG_NUM_STAGES + 1 timing events or null
-static int enqueue_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
-                         ctag_frame_result* out_dev, hipEvent_t* evs) {
-    const Workspace& ws = h->ws;
+static int enqueue_chunk(ctag_handle* h, const Workspace& ws, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                         const DetectParams& p, ctag_frame_result* out_dev, hipEvent_t* evs, const PendingCtx& pend) {
     hipStream_t s = h->stream;
+    h->last_ws = &ws;
+    h->last_out = out_dev;
     HIP_TRY(launch_zero_counters(n, ws, s));
     int st = 0;
     auto mark = [&](int i) -> hipError_t { return evs ? hipEventRecord(evs[i], s) : hipSuccess; };
@@ -341,7 +420,7 @@ static int enqueue_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdi
     HIP_TRY(mark(++st));
     Workspace wtmp = ws;
     if (!h->keep_pre) wtmp.premarkers = nullptr;
-    HIP_TRY(launch_markers(n, wtmp, p, out_dev, s));
+    HIP_TRY(launch_markers(n, wtmp, p, out_dev, pend, s));
     HIP_TRY(mark(++st));
     return CTAG_OK;
 }
@@ -362,17 +441,18 @@ static void drop_graphs(ctag_handle* h) {
 // replay (or first capture) the chunk as a hipGraph; any failure disables the graph path for this handle and the caller
 // falls back to direct launches -- results are the same either way
 static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
-                            ctag_frame_result* out_dev) {
+                            ctag_frame_result* out_dev, const PendingCtx& pend) {
+    const Workspace& W = h->batch.ws;
     constexpr size_t kMaxGraphs = 8;
     ctag_handle::GraphEntry* hit = nullptr;
     for (auto& g : h->graphs)
-        if (g.frames == frames_dev && g.out == out_dev && g.ws_base == h->ws.base && g.n == n && g.rows == h->ws.g.rows && g.cols == h->ws.g.cols &&
+        if (g.frames == frames_dev && g.out == out_dev && g.ws_base == W.base && g.n == n && g.rows == W.g.rows && g.cols == W.g.cols &&
             g.tw == p.adaptive_thresh && g.subpix == p.corner_subpix && g.dist == p.subpix_dist && g.keep_pre == (h->keep_pre ? 1 : 0) &&
-            g.row_stride == row_stride && g.frame_stride == frame_stride)
+            g.row_stride == row_stride && g.frame_stride == frame_stride && g.pend_src == (pend.list ? (const void*)pend.src : nullptr))
             hit = &g;
     if (!hit) {
         if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) != hipSuccess) return false;
-        const int r = enqueue_chunk(h, frames_dev, n, row_stride, frame_stride, p, out_dev, nullptr);
+        const int r = enqueue_chunk(h, W, frames_dev, n, row_stride, frame_stride, p, out_dev, nullptr, pend);
         hipGraph_t graph = nullptr;
         const hipError_t e = hipStreamEndCapture(h->stream, &graph);
         if (r != CTAG_OK || e != hipSuccess || !graph) {
@@ -398,10 +478,11 @@ static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, pt
         ctag_handle::GraphEntry g;
         g.frames = frames_dev;
         g.out = out_dev;
-        g.ws_base = h->ws.base;
+        g.ws_base = W.base;
         g.n = n;
-        g.rows = h->ws.g.rows;
-        g.cols = h->ws.g.cols;
+        g.rows = W.g.rows;
+        g.cols = W.g.cols;
+        g.pend_src = pend.list ? (const void*)pend.src : nullptr;
         g.tw = p.adaptive_thresh;
         g.subpix = p.corner_subpix;
         g.dist = p.subpix_dist;
@@ -413,12 +494,16 @@ static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, pt
         hit = &h->graphs.back();
     }
     hit->last_use = ++h->graph_clock;
+    h->last_ws = &W;
+    h->last_out = out_dev;
     return hipGraphLaunch(hit->exec, h->stream) == hipSuccess;
 }
 
 static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride, const DetectParams& p,
-                     ctag_frame_result* out_dev) {
+                     ctag_frame_result* out_dev, const PendingCtx& pend) {
+    const Workspace& W = h->batch.ws;
     h->last_chunk_frames = n;
+    if (pend.list) h->pending_dirty = true;
     hipEvent_t* evs = nullptr;
     if (h->timing) {
         const size_t need = (size_t)(h->ev_sets_used + 1) * (CTAG_NUM_STAGES + 1);
@@ -434,18 +519,20 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
     bool graph = h->use_graph == 1;
     if (h->use_graph == 2 && n <= kLatencyFrames) {  // one frame per call in a loop (main.cpp:52-59): same staging buffers, same sizes every time
         ctag_handle::GraphEntry& k = h->last_key;
-        graph = k.frames == frames_dev && k.out == out_dev && k.ws_base == h->ws.base && k.n == n && k.rows == h->ws.g.rows && k.cols == h->ws.g.cols &&
+        const void* psrc = pend.list ? (const void*)pend.src : nullptr;
+        graph = k.frames == frames_dev && k.out == out_dev && k.ws_base == W.base && k.n == n && k.rows == W.g.rows && k.cols == W.g.cols &&
                 k.tw == p.adaptive_thresh && k.subpix == p.corner_subpix && k.dist == p.subpix_dist && k.keep_pre == (h->keep_pre ? 1 : 0) &&
-                k.row_stride == row_stride && k.frame_stride == frame_stride;
-        k.frames = frames_dev, k.out = out_dev, k.ws_base = h->ws.base, k.n = n, k.rows = h->ws.g.rows, k.cols = h->ws.g.cols, k.tw = p.adaptive_thresh,
-        k.subpix = p.corner_subpix, k.dist = p.subpix_dist, k.keep_pre = h->keep_pre ? 1 : 0, k.row_stride = row_stride, k.frame_stride = frame_stride;
+                k.row_stride == row_stride && k.frame_stride == frame_stride && k.pend_src == psrc;
+        k.frames = frames_dev, k.out = out_dev, k.ws_base = W.base, k.n = n, k.rows = W.g.rows, k.cols = W.g.cols, k.tw = p.adaptive_thresh,
+        k.subpix = p.corner_subpix, k.dist = p.subpix_dist, k.keep_pre = h->keep_pre ? 1 : 0, k.row_stride = row_stride, k.frame_stride = frame_stride,
+        k.pend_src = psrc;
     }
     if (!evs && graph && !stamps) {
-        if (run_chunk_graph(h, frames_dev, n, row_stride, frame_stride, p, out_dev)) return CTAG_OK;
+        if (run_chunk_graph(h, frames_dev, n, row_stride, frame_stride, p, out_dev, pend)) return CTAG_OK;
         h->use_graph = 0;  // capture / instantiate / launch failed: direct launches from now on
         drop_graphs(h);
     }
-    return enqueue_chunk(h, frames_dev, n, row_stride, frame_stride, p, out_dev, evs);
+    return enqueue_chunk(h, W, frames_dev, n, row_stride, frame_stride, p, out_dev, evs, pend);
 }
 
 // public entry points call begin_timings() before their first chunk and collect_timings() after their last
@@ -466,22 +553,31 @@ static int collect_timings(ctag_handle* h) {
             h->stage_ms[i] += ms;
         }
     }
-    return CTAG_OK;
+    return finish_pending(h);  // the call has waited anyway: frames that need the any-frame pass are completed now (outside the stage times)
 }
 
+// pend: where the frames of this call live in the CALLER's device memory (what a frame that needs the any-frame pass is read from
+// again: `frames_dev` itself for gray calls, the BGR source for colour calls), or null for host-memory calls -- their frames
+// pass through staging slabs that are reused, and they find CTAG_PENDING records in the results they download
 static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
-                              int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev) {
+                              int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev, const PendingCtx* pend) {
     const int rc = check_args(h, frames_dev, n, rows, cols, row_stride, adaptive_thresh, subpix_dist);
     if (rc != CTAG_OK) return rc;
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
     const int chunk = std::min(n, h->max_chunk);
-    const int wr = ensure_workspace(h, rows, cols, adaptive_thresh, std::max(chunk, h->ws_rows == rows && h->ws_cols == cols ? h->ws_cap : 0));
+    const int wr = ensure_workspace(h, h->batch, rows, cols, adaptive_thresh, std::max(chunk, h->batch.rows == rows && h->batch.cols == cols ? h->batch.cap : 0),
+                                    false, corner_subpix != 0 && chunk > kLatencyFrames);
     if (wr != CTAG_OK) return wr;
     DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int m = std::min(chunk, n - f0);
-        const int r = run_chunk(h, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0);
+        PendingCtx pc{};
+        if (pend) {
+            pc = *pend;
+            pc.src = pend->src + (ptrdiff_t)f0 * pend->frame_stride;
+        }
+        const int r = run_chunk(h, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0, pc);
         if (r != CTAG_OK) return r;
     }
     return CTAG_OK;
@@ -535,11 +631,99 @@ static int ensure_gray(ctag_handle* h, int frames, int rows, int cols) {
     return CTAG_OK;
 }
 
-static int enqueue_bgr2gray(ctag_handle* h, const uint8_t* bgr_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride) {
+static int enqueue_bgr2gray(ctag_handle* h, const uint8_t* bgr_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride, uint8_t* gray = nullptr) {
     const int aligned = ((reinterpret_cast<uintptr_t>(bgr_dev) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 3u) == 0 ? 1 : 0;
-    hipLaunchKernelGGL(k_bgr2gray, dim3((cols + 1023) / 1024, rows, n), dim3(256), 0, h->stream, bgr_dev, frame_stride, row_stride, h->d_gray, h->gray_frame_stride,
-                       h->gray_row_stride, rows, cols, aligned);
+    const ptrdiff_t pitch = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;  // == gray_row_stride of the chunk slab
+    hipLaunchKernelGGL(k_bgr2gray, dim3((cols + 1023) / 1024, rows, n), dim3(256), 0, h->stream, bgr_dev, frame_stride, row_stride, gray ? gray : h->d_gray,
+                       gray ? pitch * rows : h->gray_frame_stride, gray ? pitch : h->gray_row_stride, rows, cols, aligned);
     HIP_TRY(hipGetLastError());
+    return CTAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the any-frame pass: frames that exceeded a pool of the batch workspace
+// ---------------------------------------------------------------------------------------------------
+static int grow(ctag_handle* h, uint8_t** buf, size_t* have, size_t need) {
+    if (*have >= need) return CTAG_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(buf), need));
+    *have = need;
+    return CTAG_OK;
+}
+
+// One frame in device memory (gray, or BGR for ch == 3) through the workspace whose pools hold any frame of its size; the record
+// goes to out_dev.  Enqueued on the handle's stream; the caller waits.  The reference has none of the batch workspace's limits
+// (corner_detector.cpp:81-107 keeps every component of [area_min, 1 %], :171-405 walks them all), so neither does a result.
+static int rerun_frame(ctag_handle* h, const uint8_t* src_dev, int ch, int rows, int cols, ptrdiff_t row_stride, int tw, int subpix, int dist,
+                       ctag_frame_result* out_dev) {
+    const int wr = ensure_workspace(h, h->big, rows, cols, tw, 1, true, false);
+    if (wr != CTAG_OK) return wr;
+    const uint8_t* gray = src_dev;
+    ptrdiff_t gstride = row_stride;
+    if (ch == 3) {
+        const ptrdiff_t pitch = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;
+        const int gr = grow(h, &h->d_big_gray, &h->d_big_gray_bytes, (size_t)pitch * rows);
+        if (gr != CTAG_OK) return gr;
+        const int r = enqueue_bgr2gray(h, src_dev, 1, rows, cols, row_stride, 0, h->d_big_gray);
+        if (r != CTAG_OK) return r;
+        gray = h->d_big_gray;
+        gstride = pitch;
+    }
+    DetectParams p{tw, subpix, dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
+    h->last_chunk_frames = 1;
+    h->reruns++;
+    return enqueue_chunk(h, h->big.ws, gray, 1, gstride, (ptrdiff_t)gstride * rows, p, out_dev, nullptr, PendingCtx{});
+}
+
+// drain the list device-memory calls left (see handle_finish_pending, ctag_internal.h)
+static int finish_pending(ctag_handle* h) {
+    if (!h->pending_dirty) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int count = 0;
+    HIP_TRY(hipMemcpy(&count, h->d_pending_count, 4, hipMemcpyDeviceToHost));
+    h->pending_dirty = false;
+    if (count <= 0) return CTAG_OK;
+    const int take = std::min(count, h->pending_cap);
+    std::vector<PendingRec> recs((size_t)take);
+    HIP_TRY(hipMemcpy(recs.data(), h->d_pending, sizeof(PendingRec) * (size_t)take, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->d_pending_count, 0, 4));
+    for (const PendingRec& r : recs) {
+        const int rc = rerun_frame(h, r.src, r.ch, r.rows, r.cols, (ptrdiff_t)r.row_stride, r.tw, r.subpix, r.dist, r.out);
+        if (rc != CTAG_OK) return rc;
+    }
+    if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (count > h->pending_cap) {  // more than the list holds between two synchronisation points: the surplus keeps CTAG_PENDING
+        std::snprintf(h->last_error, sizeof(h->last_error), "%d frames waited for the any-frame pass, the list holds %d: synchronise more often", count,
+                      h->pending_cap);
+        return CTAG_ERR_LIMIT;
+    }
+    return CTAG_OK;
+}
+namespace ctag {
+int handle_finish_pending(ctag_handle* h) { return h ? finish_pending(h) : CTAG_ERR_ARG; }
+}  // namespace ctag
+
+// host-memory calls: the records are on the host already; a CTAG_PENDING one is completed from the caller's own frame
+static int rerun_host_frames(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride, int ch, int tw,
+                             int subpix, int dist, ctag_frame_result* out) {
+    for (int i = 0; i < n; i++) {
+        if (out[i].status != CTAG_PENDING) continue;
+        const ptrdiff_t rowbytes = (ptrdiff_t)cols * ch, dstride = (rowbytes + 15) & ~(ptrdiff_t)15;
+        int r = grow(h, &h->d_big_frame, &h->d_big_frame_bytes, (size_t)dstride * rows);
+        if (r != CTAG_OK) return r;
+        if (!h->d_big_result) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_big_result), sizeof(ctag_frame_result)));
+        HIP_TRY(hipMemcpy2DAsync(h->d_big_frame, dstride, frames + (ptrdiff_t)i * frame_stride, row_stride, (size_t)rowbytes, rows, hipMemcpyHostToDevice, h->stream));
+        r = rerun_frame(h, h->d_big_frame, ch, rows, cols, dstride, tw, subpix, dist, h->d_big_result);
+        if (r != CTAG_OK) return r;
+        HIP_TRY(hipMemcpyAsync(out + i, h->d_big_result, sizeof(ctag_frame_result), hipMemcpyDeviceToHost, h->stream));
+        if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return CTAG_OK;
 }
 
@@ -558,7 +742,9 @@ static int detect_bgr_device_impl(ctag_handle* h, const uint8_t* bgr_dev, int n,
         const int m = std::min(chunk, n - f0);
         int r = enqueue_bgr2gray(h, bgr_dev + (ptrdiff_t)f0 * frame_stride, m, rows, cols, row_stride, frame_stride);
         if (r != CTAG_OK) return r;
-        r = detect_device_impl(h, h->d_gray, m, rows, cols, h->gray_row_stride, h->gray_frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev + f0);
+        const PendingCtx pc{h->d_pending, h->d_pending_count, h->pending_cap, bgr_dev + (ptrdiff_t)f0 * frame_stride, (int64_t)frame_stride, (int64_t)row_stride,
+                            rows, cols, 3, adaptive_thresh, corner_subpix, subpix_dist};
+        r = detect_device_impl(h, h->d_gray, m, rows, cols, h->gray_row_stride, h->gray_frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev + f0, &pc);
         if (r != CTAG_OK) return r;
     }
     h->last_was_bgr = true;
@@ -570,7 +756,7 @@ static int detect_bgr_device_impl(ctag_handle* h, const uint8_t* bgr_dev, int n,
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
-int ctag_version(void) { return 100; }
+int ctag_version(void) { return 110; }  // 110: ctag_params carries struct_size; CTAG_PENDING; test scaffolding left the product ABI (was 100)
 
 const char* ctag_strerror(int status) {
     switch (status) {
@@ -580,6 +766,7 @@ const char* ctag_strerror(int status) {
         case CTAG_ERR_ARG: return "invalid argument";
         case CTAG_ERR_HIP: return "HIP runtime error (no usable gfx950 device?)";
         case CTAG_ERR_LIMIT: return "frame exceeds a fixed-array limit of the reference";
+        case CTAG_PENDING: return "frame waits for the any-frame pass (ctag_sync completes it)";
         case CTAG_ERR_UNSUPPORTED: return "unsupported configuration";
         default: return "unknown status";
     }
@@ -589,6 +776,7 @@ const char* ctag_stage_name(int stage) { return (stage >= 0 && stage < CTAG_NUM_
 void ctag_params_default(ctag_params* p) {  // header/corner_detector.h:90,110,122,135-137,144; corner_detector.cpp:71,88,285
     if (!p) return;
     std::memset(p, 0, sizeof(*p));
+    p->struct_size = (uint32_t)sizeof(*p);
     p->threshold_line = 1.8f;
     p->threshold_expand = 1.2f;
     p->threshold_RAC = 0.3f;
@@ -649,7 +837,10 @@ int ctag_create_ex(const int32_t* state, int dict_rows, int dict_cols, int featu
     *out = nullptr;
     ctag_params prm;
     ctag_params_default(&prm);
-    if (params) prm = *params;
+    if (params) {
+        if (params->struct_size != sizeof(ctag_params)) return CTAG_ERR_ARG;  // built against another version of include/ctag_types.h
+        prm = *params;
+    }
     KParams kp{};
     if (!derive_kparams(prm, &kp)) return CTAG_ERR_ARG;
     std::vector<uint8_t> thr(256 * 256);
@@ -694,6 +885,8 @@ int ctag_create_ex(const int32_t* state, int dict_rows, int dict_cols, int featu
         kp.thr_table = h->d_thr_table;
         h->kp = kp;
     }
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_pending), sizeof(PendingRec) * (size_t)h->pending_cap) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_pending_count), 256) == hipSuccess && hipMemset(h->d_pending_count, 0, 256) == hipSuccess;
     if (!ok) {
         ctag_destroy(h);
         return CTAG_ERR_HIP;
@@ -709,7 +902,15 @@ void ctag_destroy(ctag_handle* h) {
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
-    if (h->ws.base) (void)hipFree(h->ws.base);
+    for (ctag_handle::WsSlot* S : {&h->batch, &h->big}) {
+        if (S->ws.base) (void)hipFree(S->ws.base);
+        if (S->n0_buf) (void)hipFree(S->n0_buf);
+    }
+    if (h->d_pending) (void)hipFree(h->d_pending);
+    if (h->d_pending_count) (void)hipFree(h->d_pending_count);
+    if (h->d_big_frame) (void)hipFree(h->d_big_frame);
+    if (h->d_big_gray) (void)hipFree(h->d_big_gray);
+    if (h->d_big_result) (void)hipFree(h->d_big_result);
     if (h->d_dict) (void)hipFree(h->d_dict);
     if (h->d_thr_table) (void)hipFree(h->d_thr_table);
     if (h->d_dict_pos) (void)hipFree(h->d_dict_pos);
@@ -793,10 +994,35 @@ int ctag_get_timings(ctag_handle* h, float* ms, int capacity) {
     return n;
 }
 
+int ctag_get_counters(ctag_handle* h, ctag_counters* out) {
+    if (!h || !out) return CTAG_ERR_ARG;
+    std::memset(out, 0, sizeof(*out));
+    out->reruns = h->reruns;
+    if (!h->last_ws || !h->last_ws->base || h->last_chunk_frames <= 0) return CTAG_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int fr = finish_pending(h);
+    if (fr != CTAG_OK) return fr;
+    out->reruns = h->reruns;
+    long long* d = reinterpret_cast<long long*>(h->d_pending_count + 16);  // 80 bytes of the 256-byte counter block
+    HIP_TRY(launch_counters(h->last_chunk_frames, *h->last_ws, h->last_out, d, h->stream));
+    long long v[10];
+    HIP_TRY(hipMemcpyAsync(v, d, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    out->frames = h->last_chunk_frames;
+    for (int k = 0; k < 5; k++) {
+        out->sum[k] = v[k];
+        out->max[k] = (int32_t)v[5 + k];
+    }
+    return CTAG_OK;
+}
+
 void* ctag_stream(ctag_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int ctag_sync(ctag_handle* h) {
     if (!h) return CTAG_ERR_ARG;
+    h->last_error[0] = 0;
+    const int r = finish_pending(h);  // frames that wait for the any-frame pass (CTAG_PENDING) are completed here
+    if (r != CTAG_OK) return r;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return CTAG_OK;
 }
@@ -806,12 +1032,14 @@ int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, i
     if (!h || !out_dev) return CTAG_ERR_ARG;
     begin_timings(h);
     h->last_was_bgr = false;
-    const int r = detect_device_impl(h, frames_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev);
+    const PendingCtx pc{h->d_pending, h->d_pending_count, h->pending_cap, frames_dev, (int64_t)frame_stride, (int64_t)row_stride,
+                        rows, cols, 1, adaptive_thresh, corner_subpix, subpix_dist};
+    const int r = detect_device_impl(h, frames_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev, &pc);
     if (r != CTAG_OK) {
         h->ev_sets_used = 0;
         return r;
     }
-    return collect_timings(h);  // with CTAG_OPT_TIMING the call waits for its last chunk; otherwise it returns at once
+    return collect_timings(h);  // with CTAG_OPT_TIMING the call waits for its last chunk (and completes CTAG_PENDING frames); otherwise it returns at once
 }
 
 // both streams idle: every exit of the host-batch path that leaves copies or kernels in flight goes through here, and so does
@@ -887,9 +1115,9 @@ static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, in
         if (ch == 3) {
             r = enqueue_bgr2gray(h, slab, m, rows, cols, dstride, (ptrdiff_t)dframe);
             if (r != CTAG_OK) return r;
-            r = detect_device_impl(h, h->d_gray, m, rows, cols, h->gray_row_stride, h->gray_frame_stride, adaptive_thresh, corner_subpix, subpix_dist, res);
+            r = detect_device_impl(h, h->d_gray, m, rows, cols, h->gray_row_stride, h->gray_frame_stride, adaptive_thresh, corner_subpix, subpix_dist, res, nullptr);
         } else {
-            r = detect_device_impl(h, slab, m, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist, res);
+            r = detect_device_impl(h, slab, m, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist, res, nullptr);
         }
         if (r != CTAG_OK) return r;
         HIP_TRY(hipEventRecord(h->ev_done[slot], h->stream));
@@ -898,7 +1126,8 @@ static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, in
         HIP_TRY(hipMemcpyAsync(out + f0, res, sizeof(ctag_frame_result) * m, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return CTAG_OK;
+    // a frame that exceeded a pool of the batch workspace came back CTAG_PENDING: complete it through the any-frame workspace
+    return rerun_host_frames(h, frames, n, rows, cols, row_stride, frame_stride, ch, adaptive_thresh, corner_subpix, subpix_dist, out);
 }
 
 int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,

@@ -396,6 +396,10 @@ int ctag_pack_results(ctag_handle* h, const ctag_frame_result* results_dev, int 
     if (!g) return CTAG_ERR_HIP;
     g->err[0] = 0;
     G_HIP(hipSetDevice(g->device));
+    {   // records of frames that wait for the any-frame pass (CTAG_PENDING) are completed before they are packed
+        const int fr = ctag::handle_finish_pending(h);
+        if (fr != CTAG_OK) return fr;
+    }
     hipStream_t s = static_cast<hipStream_t>(ctag_stream(h));
     const int r = enqueue_pack(g, true, results_dev, n, static_cast<unsigned char*>(packed_dev), packed_bytes_host ? g->d_sizes + kSoloSlot : nullptr, s);
     if (r != CTAG_OK) return r;
@@ -518,6 +522,10 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
         return CTAG_ERR_ARG;
     }
     G_HIP(hipSetDevice(g->device));
+    {   // records of frames that wait for the any-frame pass (CTAG_PENDING) are completed before they are packed
+        const int fr = ctag::handle_finish_pending(h);
+        if (fr != CTAG_OK) return fr;
+    }
     hipStream_t main_s = static_cast<hipStream_t>(ctag_stream(h));
     const int n_max = (n_total + g->world - 1) / g->world;
     // the payload all-gather sends the largest packed size ROUNDED UP to 256 bytes from this buffer

@@ -30,16 +30,24 @@ constexpr int kTileWords = kTileW / 64;
 #endif
 constexpr int kRunCap = CTAG_RUN_CAP;           // row-runs per tile the first CCL pass holds in LDS; a tile with more takes the second pass
 constexpr int kSlotCap = 128;           // tile-local components a tile publishes in the first CCL pass; a tile with more takes the second pass
+constexpr int kRunCapBig = 4864;        // second CCL pass (k_threshold_ccl_big): >= 160 runs per row x 30 rows, a multiple of the block size
+constexpr int kSlotCapBig = 2560;       // ... and >= 160 x 15 isolated pixels: its caps hold any tile
 constexpr int kPoolCapMin = 8192;       // tile-local components per frame (global pool): max(this, 256 per CCL tile), FrameGeom::pool_cap
-constexpr int kCandCap = 2048;          // max area-filtered candidates per frame
+// Pools of the stages behind the label sweep are sized per workspace (Workspace::cand_cap / line_cap / cl_cap): the batch
+// workspace holds what a frame of its size ordinarily needs (make_caps, ctag_api.hip); a frame that needs more is flagged
+// CTAG_FLAG_POOL_OVERFLOW, reported CTAG_PENDING and run again, alone, through a workspace whose pools hold ANY frame of
+// that size (Workspace::big) -- the reference has no such limits (corner_detector.cpp:81-107,171-405).
+constexpr int kCandCapMin = 2048;       // area-filtered candidates per frame the batch workspace holds at least
+constexpr int kLdsCand = 2048;          // candidates k_candidates / k_pack sort in LDS; more take their global-memory paths
+constexpr int kLdsLines = 8192;         // fitted edges k_line_sort ranks in LDS; more take a counting sort
+constexpr int kQuadStride = 1024;       // accepted quads per frame K7 keeps (CTAG_MAX_QUADS = 1000: more is the reference's UB)
 constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range [1, 32]
 
 // ---- K6 limits ----------------------------------------------------------------------------------------------
 constexpr int kLatencyFrames = 4;           // calls with at most this many frames are tuned for the latency of the call (launch_quads, hipGraph replay)
 constexpr int kLatLines = 2048;             // edges per frame / points per edge the one-wave-per-restart Welsch kernel of such calls holds;
 constexpr int kLatPoints = 1024;            // a frame beyond either takes the batch kernel
-constexpr int kLineCap = 4 * kCandCap;     // fitted edges per frame (4 per candidate that survives the RDP split)
-constexpr int kClPool = 262144;           // edge-cluster points per frame (a candidate reserves its boundary capacity + 64)
+constexpr int kClPoolMin = 262144;        // edge-cluster points per frame the batch workspace holds at least (a candidate reserves its boundary capacity + 64)
 constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table
 constexpr int kMaxDictCells = 2048;       // dictionary rows*cols supported by K9 (reference dictionary: 41*12)
 
@@ -87,6 +95,24 @@ struct KParams {
     int c2_near;              // c2 <= c2_near                      <=>  (float)sqrt(c2) <  collinear_cost   (1 for 1.05)
 };
 
+// A frame of a DEVICE-memory call that exceeded the batch workspace's pools: everything the library needs to run it again
+// through the any-frame workspace at the handle's next synchronisation point (ctag_sync and every call that waits).
+struct PendingRec {
+    const uint8_t* src;        // the frame in the caller's device memory (gray, or BGR when ch == 3)
+    ctag_frame_result* out;    // its record
+    int64_t row_stride;
+    int32_t rows, cols, ch;
+    int32_t tw, subpix, dist;
+};
+struct PendingCtx {            // per chunk, by value to k_markers; list == nullptr: no list (host-memory calls find CTAG_PENDING in the records)
+    PendingRec* list;
+    int32_t* count;
+    int32_t cap;
+    const uint8_t* src;        // first frame of the chunk in the caller's memory
+    int64_t frame_stride, row_stride;
+    int32_t rows, cols, ch, tw, subpix, dist;
+};
+
 struct FrameGeom {
     int rows, cols;            // full-res
     int hrows, hcols;          // half-res
@@ -124,19 +150,24 @@ struct Workspace {
     int32_t* member_next = nullptr;
     // candidates
     int32_t* ncand = nullptr;       // [F]
-    Candidate* cand = nullptr;      // [F][kCandCap]
-    QuadOut* quads = nullptr;       // [F][kCandCap]
+    int32_t* nroots = nullptr;      // [F]              connected components the label sweep published (ctag_get_counters)
+    int cand_cap = 0;               // candidates per frame this workspace holds
+    int line_cap = 0;               // fitted edges per frame (4 per candidate)
+    uint32_t cl_cap = 0;            // edge-cluster points per frame
+    bool big = false;               // the any-frame workspace (one frame, worst-case pools): an overflow here is final (CTAG_ERR_LIMIT)
+    Candidate* cand = nullptr;      // [F][cand_cap]
+    QuadOut* quads = nullptr;       // [F][cand_cap]
     int32_t* line_count = nullptr;  // [F]
     int32_t* clp_used = nullptr;    // [F]
-    uint32_t* cl_pool = nullptr;    // [F][kClPool]
-    LineDesc* line_desc = nullptr;  // [F][kLineCap]
-    int32_t* line_sorted = nullptr; // [F][kLineCap]
+    uint32_t* cl_pool = nullptr;    // [F][cl_cap]
+    LineDesc* line_desc = nullptr;  // [F][line_cap]
+    int32_t* line_sorted = nullptr; // [F][line_cap]
     int32_t* line_long = nullptr;   // [F] edges of more than 10 points (the first ranks of line_sorted)
-    float* line_fit = nullptr;      // [F][kLineCap][4]
-    CandAux* cand_aux = nullptr;    // [F][kCandCap]
-    int32_t* npacks = nullptr;      // [F]
-    uint32_t* packs = nullptr;      // [F][kCandCap]
-    uint16_t* pack_order = nullptr; // [F][kCandCap]
+    float* line_fit = nullptr;      // [F][line_cap][4]
+    CandAux* cand_aux = nullptr;    // [F][cand_cap]   (k_candidates' sort scratch before K6 writes it)
+    int32_t* npacks = nullptr;      // [F][2]          packs, oversize components
+    uint32_t* packs = nullptr;      // [F][cand_cap]
+    uint32_t* pack_order = nullptr; // [F][cand_cap]
     float* welsch_rs = nullptr;     // [min(F, kLatencyFrames)][kLatLines][20][6]: line + err (as a double) of every restart, few-frame calls only
     const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
     hipStream_t aux_stream = nullptr;     // owned by the handle: side branch for few-frame calls (launch_quads)
@@ -144,8 +175,8 @@ struct Workspace {
     int wave_points = 0;                  // CTAG_OPT_WAVE_POINTS (0 = automatic)
     KParams kp{};                         // the handle's tunables
     // features
-    void* quad_derived = nullptr;   // [F][kCandCap] x 48 B (K7 scratch)
-    int32_t* quad_index = nullptr;  // [F][kCandCap]
+    void* quad_derived = nullptr;   // [F][kQuadStride] x 48 B (K7 scratch)
+    int32_t* quad_index = nullptr;  // [F][kQuadStride]
     int32_t* nquads = nullptr;      // [F]
     int32_t* nfeat = nullptr;       // [F]
     int32_t* status = nullptr;      // [F]
@@ -184,7 +215,9 @@ hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEvent_t* ev5 = nullptr);  // ev5: 5 events, one after each kernel but the last
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
-hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s);
+// sums and maxima over the frames of the last chunk: components, candidates, quads, features, markers -> out10 (device, 5 x int64 sums then 5 x int64 maxima)
+hipError_t launch_counters(int nframes, const Workspace& ws, const ctag_frame_result* results, long long* out10, hipStream_t s);
+hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, const PendingCtx& pend, hipStream_t s);
 size_t threshold_ccl_lds_bytes(int tw);
 // adaptive-threshold bound table for a dark cap (host): returns false when the cap is outside what K2's packed compares hold
 bool build_threshold_table(float dark_cap, uint8_t* table /* 256*256 */, int* dim, int* tcap);
@@ -196,6 +229,9 @@ void** handle_pose_slot(struct ::ctag_handle* h, void (*free_fn)(void*));
 // ... and for the multi-GPU gather layer (ctag_gather.hip)
 void** handle_gather_slot(struct ::ctag_handle* h, void (*free_fn)(void*));
 bool handle_timing(const struct ::ctag_handle* h);
+// completes the frames of earlier device-memory calls that wait for the any-frame workspace (CTAG_PENDING records); waits for the
+// handle's stream when there may be any.  Every entry point that reads result records on the device calls it first.
+int handle_finish_pending(struct ::ctag_handle* h);
 int handle_device(const struct ::ctag_handle* h);
 
 // Private window for libctag_testkit.so (include/ctag_testkit.h: parity probes, synthetic frames).  Not declared in any

@@ -46,8 +46,8 @@ static_assert(sizeof(QuadDerived) == 48, "workspace carve in ctag_api.hip");
 struct FeatPtrs {
     const int32_t* ncand;
     const QuadOut* quads;
-    QuadDerived* derived;  // [F][kCandCap]
-    int32_t* quad_index;   // [F][kCandCap] accepted-quad -> candidate index
+    QuadDerived* derived;  // [F][kQuadStride]
+    int32_t* quad_index;   // [F][kQuadStride] accepted-quad -> candidate index (the first kQuadStride of them: more than CTAG_MAX_QUADS ends the frame)
     int32_t* nquads;
     int32_t* nfeat;
     int32_t* status;
@@ -58,7 +58,9 @@ struct FeatPtrs {
     unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1): clock ticks per phase of k_features, else null
     float threshold_angle;       // include/ctag.h ctag_params [5]
     int32_t* frame_long;         // [F] reset here for K8 (k_edge_refine<1> sets it)
+    int cand_cap;                // candidates per frame the workspace holds (stride of `quads`)
 };
+static_assert(kQuadStride > CTAG_MAX_QUADS, "K7 keeps every quad of a frame it goes on with");
 
 // developer aid: phase clock of a block (thread 0), summed over blocks into `stamps[base + phase]`
 struct PhaseClock {
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
     if (frame >= nframes) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nc = P.ncand[frame];
-    const QuadOut* quads = P.quads + (size_t)frame * kCandCap;
-    QuadDerived* der = P.derived + (size_t)frame * kCandCap;
-    int32_t* qidx = P.quad_index + (size_t)frame * kCandCap;
+    const QuadOut* quads = P.quads + (size_t)frame * P.cand_cap;
+    QuadDerived* der = P.derived + (size_t)frame * kQuadStride;
+    int32_t* qidx = P.quad_index + (size_t)frame * kQuadStride;
     FeatureDev* f0 = P.feat0 + (size_t)frame * CTAG_MAX_FEATURES;
     FeatureDev* f1 = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES;
     FeatureDev* f2 = P.feat2 + (size_t)frame * CTAG_MAX_FEATURES;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         if (lane == 63) s_scan[wave] = inc;
         __syncthreads();
         const int pre = (wave == 1 ? s_scan[0] : 0) + inc - v;
-        if (v) qidx[Q + pre] = i;
+        if (v && Q + pre < kQuadStride) qidx[Q + pre] = i;
         Q += s_scan[0] + s_scan[1];
         __syncthreads();
     }
@@ -878,6 +880,8 @@ struct MarkerPtrs {
     unsigned long long* stamps;  // developer aid (CTAG_FEAT_STAMPS=1), slots 16..
     const uint32_t* dict_pos;    // [dict_rows][64] columns holding symbol v, bit c = column c; null when the dictionary has > 32 columns
     KParams kp;                  // tunables: angle, vertical, cross-ratio tables
+    PendingCtx pend;             // frames that exceeded this workspace's pools (device-memory calls list them for the any-frame pass)
+    int big;                     // this IS the any-frame workspace: an overflow is final
 };
 
 // featureExtraction for one feature (:1056-1207); C = 8 corners (x,y), swapped in place when direction == 0
@@ -998,12 +1002,34 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     const int nf = P.nfeat[frame];
     if (status != CTAG_OK || nf == 0) {
         if (tid == 0) {
-            out->status = status;
+            int st = status;
+            if ((flags & CTAG_FLAG_POOL_OVERFLOW) && !P.big) {
+                // the batch workspace's pools were too small for this frame: not a result yet -- the library runs it again through the
+                // workspace that holds any frame (finish_pending, ctag_api.hip); device-memory calls leave what that takes in a list
+                st = CTAG_PENDING;
+                if (P.pend.list) {
+                    const int at = atomicAdd(P.pend.count, 1);
+                    if (at < P.pend.cap) {
+                        PendingRec r;
+                        r.src = P.pend.src + (int64_t)frame * P.pend.frame_stride;
+                        r.out = out;
+                        r.row_stride = P.pend.row_stride;
+                        r.rows = P.pend.rows;
+                        r.cols = P.pend.cols;
+                        r.ch = P.pend.ch;
+                        r.tw = P.pend.tw;
+                        r.subpix = P.pend.subpix;
+                        r.dist = P.pend.dist;
+                        P.pend.list[at] = r;
+                    }
+                }
+            }
+            out->status = st;
             out->n_markers = 0;
             out->n_features = 0;
             out->flags = flags;
             if (P.pre) {
-                P.pre[frame].status = status;
+                P.pre[frame].status = st;
                 P.pre[frame].n_markers = 0;
                 P.pre[frame].n_features = 0;
                 P.pre[frame].flags = flags;
@@ -1543,7 +1569,7 @@ static unsigned long long* feat_stamps(hipStream_t s, bool report) {
 }
 
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
-    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false), ws.kp.angle, ws.frame_long};
+    FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false), ws.kp.angle, ws.frame_long, ws.cand_cap};
     hipLaunchKernelGGL(k_features, dim3(nframes), dim3(128), 0, s, P, nframes, p.feature_size);
     return hipGetLastError();
 }
@@ -1567,8 +1593,8 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     }
     return hipGetLastError();
 }
-hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, hipStream_t s) {
-    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false), p.dict_pos, ws.kp};
+hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, const PendingCtx& pend, hipStream_t s) {
+    MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false), p.dict_pos, ws.kp, pend, ws.big ? 1 : 0};
     hipLaunchKernelGGL(k_markers, dim3(nframes), dim3(64), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
     (void)feat_stamps(s, true);
     return hipGetLastError();

@@ -1051,6 +1051,10 @@ int ctag_pose_batch_device(ctag_handle* h, const ctag_frame_result* results_dev,
     if (model_to_device(model, dev) != CTAG_OK) return CTAG_ERR_HIP;
     PoseState* st = pose_state(h);
     if (!st) return CTAG_ERR_HIP;
+    {   // records of frames that wait for the any-frame pass (CTAG_PENDING) are completed before they are read
+        const int fr = ctag::handle_finish_pending(h);
+        if (fr != CTAG_OK) return fr;
+    }
     hipStream_t s = static_cast<hipStream_t>(ctag_stream(h));
     ctag::PoseCam cam;
     cam.fx = (double)camera->K[0];

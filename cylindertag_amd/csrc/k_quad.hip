@@ -31,23 +31,26 @@ struct QuadPtrs {
     // edge clusters handed from k_quad_edges to k_welsch / k_quad_final
     int32_t* line_count;   // [F]
     int32_t* clp_used;     // [F]
-    uint32_t* cl_pool;     // [F][kClPool] packed (x | y << 16) points, in the order the reference pushes them
-    LineDesc* line_desc;   // [F][kLineCap]
-    int32_t* line_sorted;  // [F][kLineCap] line ids by descending point count
+    uint32_t* cl_pool;     // [F][cl_cap] packed (x | y << 16) points, in the order the reference pushes them
+    LineDesc* line_desc;   // [F][line_cap]
+    int32_t* line_sorted;  // [F][line_cap] line ids by descending point count
     int32_t* line_long;    // [F] edges of more than kWShort points = the first ranks of line_sorted
-    float* line_fit;       // [F][kLineCap][4]
-    CandAux* cand_aux;     // [F][kCandCap]
+    float* line_fit;       // [F][line_cap][4]
+    CandAux* cand_aux;     // [F][cand_cap]
     const uint8_t* pick_table;  // [kPickN][20][10] cv::RNG initial samples of fitLine2D for every point count < kPickN
     const int32_t* pool_tile;    // [F][pool_cap]
     const int32_t* member_head;  // [F][pool_cap]
     const int32_t* member_next;  // [F][pool_cap]
-    int32_t* npacks;       // [F]
-    uint32_t* packs;       // [F][kCandCap] first entry of pack_order | count << 16, longest first
-    uint16_t* pack_order;  // [F][kCandCap] candidate indices by descending boundary capacity
+    int32_t* npacks;       // [F][2] packs, oversize components
+    uint32_t* packs;       // [F][cand_cap] first entry of pack_order | count << 24, longest first
+    uint32_t* pack_order;  // [F][cand_cap] candidate indices by descending boundary capacity
     unsigned long long* stamps;  // developer aid (CTAG_QUAD_STAMPS=1): cycles per phase of k_quad_edges, else null
     // tunables (include/ctag.h: ctag_params; the reference's values in brackets)
     float thr_line, thr_expand, rac;  // threshold_line [1.8], threshold_expand [1.2], threshold_RAC [0.3]
     int c2_far, c2_near;              // collinearity cost [1.05] as bounds on the squared integer norm: [2], [1]
+    // pool sizes of this workspace (ctag_internal.h: Workspace::cand_cap / line_cap / cl_cap)
+    int cand_cap, line_cap;
+    uint32_t cl_cap;
 };
 
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
@@ -331,18 +334,80 @@ struct CornerPre {
 // One block per frame; rank sort in LDS like k_candidates.  Oversize components are skipped; the whole-wave builds take them.
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words) {
-    __shared__ int s_key[kCandCap];
-    __shared__ int s_need[kCandCap];
-    __shared__ uint16_t s_ord[kCandCap];
+    __shared__ int s_key[kLdsCand + 2];
+    __shared__ int s_need[kLdsCand];
+    __shared__ uint16_t s_ord[kLdsCand];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    const int nc = min(P.ncand[frame], kCandCap);
-    const Candidate* cand = P.cand + (size_t)frame * kCandCap;
-    uint16_t* order = P.pack_order + (size_t)frame * kCandCap;
+    const int nc = min(P.ncand[frame], P.cand_cap);
+    const Candidate* cand = P.cand + (size_t)frame * P.cand_cap;
+    uint32_t* order = P.pack_order + (size_t)frame * P.cand_cap;
+    uint32_t* packs = P.packs + (size_t)frame * P.cand_cap;
+    auto key_of = [&](const Candidate& c) {
+        const int w = c.x_max - c.x_min + 1, h = c.y_max - c.y_min + 1;
+        return pack_big(c.x_min, w, h, big_points, pack_words) ? -1 : pack_points(w, h);  // -1: not packed, sorts last
+    };
+    if (nc > kLdsCand) {
+        // A frame of thousands of blobs (more candidates than the LDS arrays hold).  The order is scheduling only -- results do not
+        // depend on it beyond "oversize components last" -- so a counting sort by boundary capacity (descending, capacities of 2047
+        // and more in one bucket, ties in arrival order) replaces the rank sort, and the pack builder reads the ordered
+        // candidates 64 at a time instead of from LDS.
+        constexpr int kB = kLdsCand;  // buckets 0..kB-1: capacity kB-1-b (longest first); bucket kB: oversize
+        auto bucket_of = [&](int key) { return key < 0 ? kB : kB - 1 - min(key, kB - 1); };
+        for (int b = threadIdx.x; b <= kB; b += 64) s_key[b] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc; i += 64) atomicAdd(&s_key[bucket_of(key_of(cand[i]))], 1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int b = 0; b <= kB; b++) {
+                const int v = s_key[b];
+                s_key[b] = run;
+                run += v;
+            }
+            s_key[kB + 1] = run;
+        }
+        __syncthreads();
+        const int first_big = s_key[kB];  // oversize components: entries [first_big, nc) of `order`
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc; i += 64) order[atomicAdd(&s_key[bucket_of(key_of(cand[i]))], 1)] = (uint32_t)i;
+        __syncthreads();
+        int np = 0, first = -1, cnt = 0, words = 0;  // uniform across the wave
+        for (int r0 = 0; r0 < first_big; r0 += 64) {
+            const int r = r0 + (int)threadIdx.x;
+            int need = 0;
+            if (r < first_big) {
+                const Candidate c = cand[order[r]];
+                need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
+            }
+            const int m = min(64, first_big - r0);
+            for (int k = 0; k < m; k++) {
+                const int nk = __shfl(need, k);
+                if (cnt > 0 && (cnt == max_per_pack || words + nk > pack_words)) {
+                    if (threadIdx.x == 0) packs[np] = (uint32_t)first | ((uint32_t)cnt << 24);
+                    np++;
+                    cnt = 0;
+                    words = 0;
+                }
+                if (cnt == 0) first = r0 + k;
+                cnt++;
+                words += nk;
+            }
+        }
+        if (cnt > 0) {
+            if (threadIdx.x == 0) packs[np] = (uint32_t)first | ((uint32_t)cnt << 24);
+            np++;
+        }
+        if (threadIdx.x == 0) {
+            P.npacks[2 * frame] = np;
+            P.npacks[2 * frame + 1] = nc - first_big;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < nc; i += 64) {
         const Candidate c = cand[i];
         const int w = c.x_max - c.x_min + 1, h = c.y_max - c.y_min + 1;
-        s_key[i] = pack_big(c.x_min, w, h, big_points, pack_words) ? -1 : pack_points(w, h);  // -1: not packed, sorts last
+        s_key[i] = key_of(c);
         s_need[i] = pack_need(w, h);  // for the pack builder below: one lane walks the sorted list, it should not wait for global memory
     }
     __syncthreads();
@@ -358,14 +423,13 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
     __syncthreads();
     for (int i = threadIdx.x; i < nc; i += 64) order[i] = s_ord[i];
     if (threadIdx.x == 0) {
-        uint32_t* packs = P.packs + (size_t)frame * kCandCap;
         int np = 0, first = -1, cnt = 0, words = 0;
         for (int r = 0; r < nc; r++) {
             const int i = s_ord[r];
             if (s_key[i] < 0) break;  // the rest is oversize
             const int need = s_need[i];
             if (cnt > 0 && (cnt == max_per_pack || words + need > pack_words)) {  // a pack = consecutive entries of `order`
-                packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
+                packs[np++] = (uint32_t)first | ((uint32_t)cnt << 24);
                 cnt = 0;
                 words = 0;
             }
@@ -373,10 +437,11 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
             cnt++;
             words += need;
         }
-        if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 16);
+        if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 24);
         int nbig = 0;  // the oversize components sort last: entries [nc - nbig, nc) of `order`, the whole-wave builds walk only those
         for (int r = nc - 1; r >= 0 && s_key[s_ord[r]] < 0; r--) nbig++;
-        P.npacks[frame] = np | (nbig << 16);
+        P.npacks[2 * frame] = np;
+        P.npacks[2 * frame + 1] = nbig;
     }
 }
 
@@ -630,8 +695,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     if (frame >= nframes) return;
     const int lane = threadIdx.x, sub = lane / SG, sl = lane % SG, lane0 = lane - sl;
     // SG == 8: the frame's packs; SG == 64: the oversize tail of k_pack's order, one component per wave
-    const int nc = min(P.ncand[frame], kCandCap);
-    const int npk = SG == 8 ? (P.npacks[frame] & 0xffff) : (P.npacks[frame] >> 16);
+    const int nc = min(P.ncand[frame], P.cand_cap);
+    const int npk = P.npacks[2 * frame + (SG == 8 ? 0 : 1)];
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
@@ -650,16 +715,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         stamp(-1);
         int first, cnt;
         if constexpr (SG == 8) {
-            const uint32_t pw = P.packs[(size_t)frame * kCandCap + pk];
-            first = (int)(pw & 0xffffu);
-            cnt = (int)(pw >> 16);
+            const uint32_t pw = P.packs[(size_t)frame * P.cand_cap + pk];
+            first = (int)(pw & 0xffffffu);
+            cnt = (int)(pw >> 24);
         } else {
             first = nc - npk + pk;
             cnt = 1;
         }
         const bool act = sub < cnt;
-        const int ci = P.pack_order[(size_t)frame * kCandCap + first + (act ? sub : 0)];
-        const Candidate cd = P.cand[(size_t)frame * kCandCap + ci];
+        const int ci = (int)P.pack_order[(size_t)frame * P.cand_cap + first + (act ? sub : 0)];
+        const Candidate cd = P.cand[(size_t)frame * P.cand_cap + ci];
         const int x_min = cd.x_min, y_min = cd.y_min;
         const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
         const int C = pack_points(w, h);
@@ -671,7 +736,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             if (k < sub) off += v;
         }
         if (!act) continue;
-        CandAux* aux = P.cand_aux + (size_t)frame * kCandCap + ci;
+        CandAux* aux = P.cand_aux + (size_t)frame * P.cand_cap + ci;
         if constexpr (SG == 64) {
             // two builds share the oversize components by working-set size: (tier_lo, WORDS] is this one's
             if (need <= tier_lo) continue;
@@ -1438,7 +1503,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         p0 = 0;
         if (sl == 0) p0 = atomicAdd(&P.clp_used[frame], C + 64);
         p0 = __shfl(p0, lane0);
-        if (p0 + C + 64 > kClPool) {
+        if ((uint32_t)(p0 + C + 64) > P.cl_cap) {
             if (sl == 0) {
                 atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
                 aux->line0 = -1;
@@ -1450,7 +1515,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
         }  // PHASE != 2
         if constexpr (PHASE == 1) {  // hand the rotated boundary over to the second kernel through the component's cluster-pool slot
-            uint32_t* slot = P.cl_pool + (size_t)frame * kClPool + p0;
+            uint32_t* slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;
             for (int k = sl; k < n; k += SG) slot[k] = bufB[k];
             if (sl == 0) {
                 aux->line0 = p0;
@@ -1466,11 +1531,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             n = n_boundary = aux->n_boundary;
             acx = aux->acx;
             acy = aux->acy;
-            const uint32_t* slot = P.cl_pool + (size_t)frame * kClPool + p0;
+            const uint32_t* slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;
             for (int k = sl; k < n; k += SG) bufB[k] = slot[k];
             SG_SYNC();
         }
-        uint32_t* CLg = P.cl_pool + (size_t)frame * kClPool + p0;
+        uint32_t* CLg = P.cl_pool + (size_t)frame * P.cl_cap + p0;
         // ---- P4: extended RDP (:278-349), uniform control flow inside the sub-group
         uint32_t* W = bufB;
         uint32_t* Wn = bufA;
@@ -1592,7 +1657,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         if (ok) {
             if (sl == 0) l0 = atomicAdd(&P.line_count[frame], 4);
             l0 = __shfl(l0, lane0);
-            if (l0 + 4 > kLineCap) {
+            if (l0 + 4 > P.line_cap) {
                 ok = false;
                 if (sl == 0) atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
             }
@@ -1601,7 +1666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             LineDesc d;
             d.off = (uint32_t)(p0 + cl_off[sl]);
             d.n = cl_off[sl + 1] - cl_off[sl];
-            P.line_desc[(size_t)frame * kLineCap + l0 + sl] = d;
+            P.line_desc[(size_t)frame * P.line_cap + l0 + sl] = d;
         }
         if (sl == 0) {
             aux->line0 = ok ? l0 : -1;
@@ -1623,14 +1688,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 constexpr int kWShort = 10;
 constexpr int kLineSortThreads = 1024;  // a rank sort: L / threads passes of L comparisons each; one frame has ~400 edges
 __global__ __launch_bounds__(kLineSortThreads) void k_line_sort(QuadPtrs P, int nframes) {
-    __shared__ int s_n[kLineCap];
+    __shared__ int s_n[kLdsLines];
     __shared__ int s_long;
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    const int L = min(P.line_count[frame], kLineCap);
-    const LineDesc* d = P.line_desc + (size_t)frame * kLineCap;
+    const int L = min(P.line_count[frame], P.line_cap);
+    const LineDesc* d = P.line_desc + (size_t)frame * P.line_cap;
+    int32_t* out = P.line_sorted + (size_t)frame * P.line_cap;
     if (threadIdx.x == 0) s_long = 0;
     __syncthreads();
+    if (L > kLdsLines) {
+        // More edges than the LDS array holds (a frame of thousands of blobs): counting sort by point count, descending, counts of
+        // kB - 1 and more in one bucket.  What the consumers rely on still holds: ranks [0, line_long) are the edges of more
+        // than kWShort points; below the shared bucket the order is exact, and everything in it is longer than any length a
+        // consumer compares with (kWPts, kLatPoints).
+        constexpr int kB = 2048;
+        static_assert(kB - 1 > kLatPoints && kB + 1 <= kLdsLines, "shared bucket");
+        auto bucket_of = [&](int n) { return kB - 1 - min(n, kB - 1); };
+        for (int b = threadIdx.x; b <= kB; b += kLineSortThreads) s_n[b] = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int i = threadIdx.x; i < L; i += kLineSortThreads) {
+            const int n = d[i].n;
+            atomicAdd(&s_n[bucket_of(n)], 1);
+            mine += n > kWShort ? 1 : 0;
+        }
+        if (mine) atomicAdd(&s_long, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            P.line_long[frame] = s_long;
+            int run = 0;
+            for (int b = 0; b < kB; b++) {
+                const int v = s_n[b];
+                s_n[b] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L; i += kLineSortThreads) out[atomicAdd(&s_n[bucket_of(d[i].n)], 1)] = i;
+        return;
+    }
     int mine = 0;
     for (int i = threadIdx.x; i < L; i += kLineSortThreads) {
         const int n = d[i].n;
@@ -1640,7 +1737,6 @@ __global__ __launch_bounds__(kLineSortThreads) void k_line_sort(QuadPtrs P, int 
     if (mine) atomicAdd(&s_long, mine);
     __syncthreads();
     if (threadIdx.x == 0) P.line_long[frame] = s_long;  // ranks [0, s_long) of the sorted list hold the edges of more than kWShort points
-    int32_t* out = P.line_sorted + (size_t)frame * kLineCap;
     for (int i = threadIdx.x; i < L; i += kLineSortThreads) {
         const int ni = s_n[i];
         int rank = 0;
@@ -1672,7 +1768,7 @@ __device__ __forceinline__ void welsch_select(const QuadPtrs& P, int frame, int 
             if (r.err < EPS) break;
         }
     }
-    float* o = P.line_fit + ((size_t)frame * kLineCap + lid) * 4;
+    float* o = P.line_fit + ((size_t)frame * P.line_cap + lid) * 4;
     for (int q = 0; q < 4; q++) o[q] = best[q];
 }
 
@@ -1693,10 +1789,10 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, WelschLds& S, in
     int lid = 0, n = 0;
     const uint32_t* pts = nullptr;
     if (active) {
-        lid = P.line_sorted[(size_t)frame * kLineCap + first + grp];
-        const LineDesc d = P.line_desc[(size_t)frame * kLineCap + lid];
+        lid = P.line_sorted[(size_t)frame * P.line_cap + first + grp];
+        const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
         n = d.n;
-        pts = P.cl_pool + (size_t)frame * kClPool + d.off;
+        pts = P.cl_pool + (size_t)frame * P.cl_cap + d.off;
     }
     // the triple's edges are sorted by descending length: the first one decides whether all three fit the staged form
     const int n_first = __shfl(n, 0, 64);
@@ -1747,10 +1843,10 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, WelschLds& S, in
 __device__ __forceinline__ void welsch_short(const QuadPtrs& P, WelschLds& S, int frame, int first, int L) {
     const int lane = threadIdx.x;
     if (first + lane >= L) return;
-    const int lid = P.line_sorted[(size_t)frame * kLineCap + first + lane];
-    const LineDesc d = P.line_desc[(size_t)frame * kLineCap + lid];
+    const int lid = P.line_sorted[(size_t)frame * P.line_cap + first + lane];
+    const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
     const int n = d.n;  // 2 <= n <= kWShort <= kWCap: every weight stays in LDS
-    welsch_restart(GlobalPts{P.cl_pool + (size_t)frame * kClPool + d.off}, n, AllPicks{}, n, n * 1.1920928955078125e-07, S.wc + lane, 64, S.wc + lane);
+    welsch_restart(GlobalPts{P.cl_pool + (size_t)frame * P.cl_cap + d.off}, n, AllPicks{}, n, n * 1.1920928955078125e-07, S.wc + lane, 64, S.wc + lane);
     welsch_select(P, frame, lid, n, S.wc + lane, 0, 64, 1);
 }
 
@@ -1764,8 +1860,8 @@ __device__ __forceinline__ void welsch_short(const QuadPtrs& P, WelschLds& S, in
 __device__ __forceinline__ bool welsch_lat_takes(const QuadPtrs& P, int frame, int L) {
     if (L > kLatLines) return false;
     if (L == 0) return true;
-    const int longest = P.line_sorted[(size_t)frame * kLineCap];  // sorted by descending point count
-    return P.line_desc[(size_t)frame * kLineCap + longest].n <= kLatPoints;
+    const int longest = P.line_sorted[(size_t)frame * P.line_cap];  // sorted by descending point count
+    return P.line_desc[(size_t)frame * P.line_cap + longest].n <= kLatPoints;
 }
 
 // a += src[j] for j = 0 .. n-1 in that order; eight terms are loaded ahead of the additions that wait for one another
@@ -1794,17 +1890,17 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
     __shared__ uint16_t s_pk[10];
     const int frame = blockIdx.z, k = blockIdx.y, lane = threadIdx.x;
     if (frame >= nframes) return;
-    const int L = min(P.line_count[frame], kLineCap);
+    const int L = min(P.line_count[frame], P.line_cap);
     if (!welsch_lat_takes(P, frame, L)) return;
     const float c = 1 / 2.9846f;
     for (int rank = blockIdx.x; rank < L; rank += gridDim.x) {
         __syncthreads();  // single wave: the previous edge is done with the arrays
-        const int lid = P.line_sorted[(size_t)frame * kLineCap + rank];
-        const LineDesc d = P.line_desc[(size_t)frame * kLineCap + lid];
+        const int lid = P.line_sorted[(size_t)frame * P.line_cap + rank];
+        const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
         const int n = d.n;
         if (n <= LO) break;     // block-uniform; the rest of the list is shorter still: the other build's
         if (n > NP) continue;
-        const uint32_t* pts = P.cl_pool + (size_t)frame * kClPool + d.off;
+        const uint32_t* pts = P.cl_pool + (size_t)frame * P.cl_cap + d.off;
         for (int j = lane; j < n; j += 64) s_p[j] = pts[j];
         const int npick = min(n, 10);
         if (lane == 0) {  // the restart's initial sample (ascending), as welsch_three builds it
@@ -1927,8 +2023,8 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
 
 // fitLine2D's choice among the restarts of the edge of sorted rank `rank`: the first restart below EPS ends the search, else the first minimum wins
 __device__ __forceinline__ void welsch_pick(const QuadPtrs& P, int frame, int rank, const float* rs) {
-    const int lid = P.line_sorted[(size_t)frame * kLineCap + rank];
-    const int n = P.line_desc[(size_t)frame * kLineCap + lid].n;
+    const int lid = P.line_sorted[(size_t)frame * P.line_cap + rank];
+    const int n = P.line_desc[(size_t)frame * P.line_cap + lid].n;
     const double EPS = n * 1.1920928955078125e-07;
     double min_err = 1.7976931348623157e308;
     float best[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1941,7 +2037,7 @@ __device__ __forceinline__ void welsch_pick(const QuadPtrs& P, int frame, int ra
             if (e < EPS) break;
         }
     }
-    float* o = P.line_fit + ((size_t)frame * kLineCap + lid) * 4;
+    float* o = P.line_fit + ((size_t)frame * P.line_cap + lid) * 4;
     for (int q = 0; q < 4; q++) o[q] = best[q];
 }
 
@@ -1959,7 +2055,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_
     // the load stays balanced without the column rotation the other layout needed.
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    const int L = min(P.line_count[frame], kLineCap);
+    const int L = min(P.line_count[frame], P.line_cap);
     if (lat_rs && welsch_lat_takes(P, frame, L)) {  // few-frame call: k_welsch_lat has run the restarts of this frame's edges; pick per edge
         for (int rank = (int)blockIdx.y * 64 + (int)threadIdx.x; rank < L; rank += (int)gridDim.y * 64) welsch_pick(P, frame, rank, lat_rs);
         return;
@@ -1983,23 +2079,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_
 // K6c: per candidate, the six pairwise intersections of its four fitted edges, angular sort and the best
 // 4-subset by RAC (corner_detector.cpp:362-403, :420-463).  One thread per candidate.
 // =====================================================================================================
+__device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeom& g, int frame, int ci);
 __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int nframes) {
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
-    const int ci = (int)((blockIdx.x + frame) % gridDim.x) * 64 + threadIdx.x;  // column rotated by frame: spreads the few busy blocks over the XCDs
-    if (ci >= P.ncand[frame]) return;
-    const CandAux aux = P.cand_aux[(size_t)frame * kCandCap + ci];
-    QuadOut* out = P.quads + (size_t)frame * kCandCap + ci;
+    const int nc = min(P.ncand[frame], P.cand_cap);
+    // column rotated by frame: spreads the few busy blocks over the XCDs; a block loops when a frame has more candidates than the grid has threads
+    for (int ci = (int)((blockIdx.x + frame) % gridDim.x) * 64 + threadIdx.x; ci < nc; ci += (int)gridDim.x * 64) quad_final_one(P, g, frame, ci);
+}
+__device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeom& g, int frame, int ci) {
+    const CandAux aux = P.cand_aux[(size_t)frame * P.cand_cap + ci];
+    QuadOut* out = P.quads + (size_t)frame * P.cand_cap + ci;
     out->n_boundary = aux.n_boundary;
     if (aux.line0 < 0) {
         out->valid = 0;
         return;
     }
-    const int areaPx = P.cand[(size_t)frame * kCandCap + ci].area;
+    const int areaPx = P.cand[(size_t)frame * P.cand_cap + ci].area;
     const float acx = aux.acx, acy = aux.acy;
     float lf[4][4];
     {
-        const float* src = P.line_fit + ((size_t)frame * kLineCap + aux.line0) * 4;
+        const float* src = P.line_fit + ((size_t)frame * P.line_cap + aux.line0) * 4;
         for (int j = 0; j < 4; j++)
             for (int q = 0; q < 4; q++) lf[j][q] = src[j * 4 + q];
     }
@@ -2125,7 +2225,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         if (ev5) (void)hipEventRecord(ev5[evi++], s);
     };
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr, ws.kp.thr_line, ws.kp.thr_expand, ws.kp.rac, ws.kp.c2_far, ws.kp.c2_near};
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr, ws.kp.thr_line, ws.kp.thr_expand, ws.kp.rac, ws.kp.c2_far, ws.kp.c2_near,
+               ws.cand_cap, ws.line_cap, ws.cl_cap};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
@@ -2200,8 +2301,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(kLineSortThreads), 0, s, P, nframes);
     mark();
-    static const int welsch_gs = getenv("CTAG_WELSCH_GS") ? atoi(getenv("CTAG_WELSCH_GS")) : 4;   // blocks per frame for the edges of <= 10 points, 64 per wave
-    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? atoi(getenv("CTAG_WELSCH_GX")) : 72;   // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144 -> 72 once the short edges left: fewer empty blocks)
+    static const int welsch_gs = getenv("CTAG_WELSCH_GS") ? std::max(1, atoi(getenv("CTAG_WELSCH_GS"))) : 4;   // blocks per frame for the edges of <= 10 points, 64 per wave
+    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? std::max(1, atoi(getenv("CTAG_WELSCH_GX"))) : 72;   // (both at least 1: the grid's two row ranges each own a class of edges)   // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144 -> 72 once the short edges left: fewer empty blocks)
     if (latency && ws.welsch_rs) {  // one wave per (edge, restart); frames it declines (more edges / longer edges than it holds) fall through to k_welsch
         if (fork) {  // the long edges beside the short ones
             (void)hipEventRecord(ws.ev_fork, s);
@@ -2216,7 +2317,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     }
     hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx + welsch_gs), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr, welsch_gx);
     mark();
-    hipLaunchKernelGGL(k_quad_final, dim3(kCandCap / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    hipLaunchKernelGGL(k_quad_final, dim3(std::min(ws.cand_cap, kLdsCand) / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);

@@ -403,7 +403,10 @@ struct SweepPtrs {
     int32_t* member_head;  // per root: head of the list of its non-root members (K4), -1 = none
     int32_t* member_next;
     int32_t* ncand;
+    int32_t* nroots;
     Candidate* cand;
+    int cand_cap;          // candidates per frame the workspace holds
+    int2* cand_scratch;    // [F][cand_cap] (pool index, key) of a frame with more candidates than k_candidates sorts in LDS (cand_aux, unused until K6)
     int32_t* ovf_count;    // tiles the LDS-sized pass could not finish (too many runs / components, or the frame's pool filled up) ...
     int32_t* ovf_list;     // ... as frame * tiles_per_frame + tile: k_threshold_ccl_big takes them
     unsigned long long* stamps;  // developer aid (CTAG_CCL_STAMPS=1): cycles per phase of k_threshold_ccl, else null
@@ -411,7 +414,8 @@ struct SweepPtrs {
 };
 static SweepPtrs sweep_ptrs(const Workspace& ws) {
     return SweepPtrs{ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
-                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.cand, ws.ovf_count, ws.ovf_list, nullptr,
+                     ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.nroots, ws.cand, ws.cand_cap,
+                     reinterpret_cast<int2*>(ws.cand_aux), ws.ovf_count, ws.ovf_list, nullptr,
                      (size_t)(reinterpret_cast<const char*>(ws.root_of) - reinterpret_cast<const char*>(ws.parent))};
 }
 
@@ -1185,8 +1189,6 @@ void k_threshold_ccl(SweepPtrs P, FrameGeom g, KParams kp, int nframes) {
 }
 
 // second pass over the tiles of the overflow list (usually none: the blocks read the count and leave)
-constexpr int kRunCapBig = 4864;   // >= 160 runs per row x 30 rows, a multiple of the block size
-constexpr int kSlotCapBig = 2560;  // >= 160 x 15 isolated pixels
 template <int TWC>
 __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl_big(SweepPtrs P, FrameGeom g, KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1446,31 +1448,39 @@ hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s) {
 // K5: area filter (corner_detector.cpp:87-91) and OpenCV label order: candidates sorted
 // by the block-raster index of their first 2x2 block.  One block per frame; rank sort in LDS.
 // =====================================================================================================
+static_assert(sizeof(CandAux) >= sizeof(int2), "k_candidates borrows cand_aux as (pool index, key) scratch");
 __global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, int nframes, int area_min) {
-    __shared__ int s_idx[kCandCap];
-    __shared__ int s_key[kCandCap];
-    __shared__ int s_count;
+    __shared__ int s_idx[kLdsCand];
+    __shared__ int s_key[kLdsCand];
+    __shared__ int s_count, s_roots;
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    if (threadIdx.x == 0) s_count = 0;
+    if (threadIdx.x == 0) s_count = s_roots = 0;
     __syncthreads();
     const int n = min(P.frame_ncomp[frame], g.pool_cap);
     const size_t pool0 = (size_t)frame * g.pool_cap;
+    int my_roots = 0;
+    int2* scratch = P.cand_scratch + (size_t)frame * P.cand_cap;
     for (int i = threadIdx.x; i < n; i += 256) {
         if (P.root_of[pool0 + i] == i) {
+            my_roots++;
             const int a = P.area[pool0 + i];
             if (!(a < area_min || a > g.max_area)) {
                 const int at = atomicAdd(&s_count, 1);
-                if (at < kCandCap) {
+                if (at < kLdsCand) {
                     s_idx[at] = i;
                     s_key[at] = P.key[pool0 + i];
+                } else if (at < P.cand_cap) {
+                    scratch[at] = make_int2(i, P.key[pool0 + i]);
                 }
             }
         }
     }
+    if (my_roots) atomicAdd(&s_roots, my_roots);
     __syncthreads();
+    if (threadIdx.x == 0) P.nroots[frame] = s_roots;
     int c = s_count;
-    if (c > kCandCap) {
+    if (c > P.cand_cap) {  // more candidates than this workspace holds: the frame goes through the any-frame workspace (ctag_api.hip)
         if (threadIdx.x == 0) {
             atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
             P.ncand[frame] = 0;
@@ -1479,12 +1489,8 @@ __global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, in
     }
     if (P.frame_flags[frame] & CTAG_FLAG_POOL_OVERFLOW) c = 0;
     if (threadIdx.x == 0) P.ncand[frame] = c;
-    Candidate* out = P.cand + (size_t)frame * kCandCap;
-    for (int i = threadIdx.x; i < c; i += 256) {
-        const int k = s_key[i];
-        int rank = 0;
-        for (int j = 0; j < c; j++) rank += (s_key[j] < k) ? 1 : 0;
-        const int idx = s_idx[i];
+    Candidate* out = P.cand + (size_t)frame * P.cand_cap;
+    auto emit = [&](int idx, int rank) {
         Candidate cd;
         cd.root = idx;
         cd.area = P.area[pool0 + idx];
@@ -1493,8 +1499,81 @@ __global__ __launch_bounds__(256) void k_candidates(SweepPtrs P, FrameGeom g, in
         cd.x_max = (int16_t)P.xmax[pool0 + idx];
         cd.y_max = (int16_t)P.ymax[pool0 + idx];
         out[rank] = cd;
+    };
+    if (c <= kLdsCand) {
+        for (int i = threadIdx.x; i < c; i += 256) {
+            const int k = s_key[i];
+            int rank = 0;
+            for (int j = 0; j < c; j++) rank += (s_key[j] < k) ? 1 : 0;
+            emit(s_idx[i], rank);
+        }
+        return;
+    }
+    // More candidates than the LDS arrays hold (a frame of thousands of blobs): the same rank sort with the (index, key) pairs in
+    // global memory, the keys passing through LDS a tile at a time; a thread ranks four of its candidates per sweep over the keys.
+    // A key is the block-raster index of a component's first 2x2 block: no two components share one.
+    for (int i = threadIdx.x; i < kLdsCand; i += 256) scratch[i] = make_int2(s_idx[i], s_key[i]);
+    __syncthreads();
+    for (int i0 = 0; i0 < c; i0 += 4 * 256) {
+        int2 mine[4];
+        int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 256 + threadIdx.x;
+            mine[u] = i < c ? scratch[i] : make_int2(-1, 0x7fffffff);
+        }
+        for (int t0 = 0; t0 < c; t0 += kLdsCand) {
+            const int tn = min(kLdsCand, c - t0);
+            __syncthreads();
+            for (int j = threadIdx.x; j < tn; j += 256) s_key[j] = scratch[t0 + j].y;
+            __syncthreads();
+            for (int j = 0; j < tn; j++) {
+                const int kj = s_key[j];
+#pragma unroll
+                for (int u = 0; u < 4; u++) rank[u] += (kj < mine[u].y) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (mine[u].x >= 0) emit(mine[u].x, rank[u]);
     }
 }
+// ctag_get_counters: sums and maxima of the per-frame counts over the frames of a chunk (one block; on demand, never in a timed chain)
+__global__ __launch_bounds__(256) void k_counters(const int32_t* nroots, const int32_t* ncand, const int32_t* nquads, const int32_t* nfeat, const int32_t* status,
+                                                  const ctag_frame_result* results, int nframes, long long* out10) {
+    __shared__ long long s_sum[5];
+    __shared__ int s_max[5];
+    if (threadIdx.x < 5) {
+        s_sum[threadIdx.x] = 0;
+        s_max[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    long long sum[5] = {0, 0, 0, 0, 0};
+    int mx[5] = {0, 0, 0, 0, 0};
+    for (int f = threadIdx.x; f < nframes; f += 256) {
+        const int v[5] = {nroots[f], ncand[f], nquads[f], status[f] == CTAG_OK || status[f] == CTAG_NO_FEATURE ? nfeat[f] : 0, results ? results[f].n_markers : 0};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            sum[k] += v[k];
+            mx[k] = max(mx[k], v[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&s_sum[k]), (unsigned long long)sum[k]);
+        atomicMax(&s_max[k], mx[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        out10[threadIdx.x] = s_sum[threadIdx.x];
+        out10[5 + threadIdx.x] = s_max[threadIdx.x];
+    }
+}
+hipError_t launch_counters(int nframes, const Workspace& ws, const ctag_frame_result* results, long long* out10, hipStream_t s) {
+    hipLaunchKernelGGL(k_counters, dim3(1), dim3(256), 0, s, ws.nroots, ws.ncand, ws.nquads, ws.nfeat, ws.status, results, nframes, out10);
+    return hipGetLastError();
+}
+
 hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s) {
     hipLaunchKernelGGL(k_candidates, dim3(nframes), dim3(256), 0, s, sweep_ptrs(ws), ws.g, nframes, ws.kp.area_min);
     return hipGetLastError();

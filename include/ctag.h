@@ -37,7 +37,8 @@ void ctag_destroy(ctag_handle* h);
  * (/root/reference/header/corner_detector.h:90,110,122,135-137,144) and literals of corner_detector.cpp (:71, :88, :285-288,337);
  * ctag_params_default fills in exactly those values and ctag_create uses them.  ctag_create_ex takes other values -- a
  * maintainer who edits the reference's constants passes the same numbers here and the results stay identical to the edited
- * reference (the CPU oracle takes the same struct).  Limits: 0 < dark_cap < 0.5, area_min >= 1, 0 < area_max_fraction <= 1,
+ * reference (the CPU oracle takes the same struct).  Always start from ctag_params_default: it fills in struct_size, which
+ * ctag_create_ex checks against the library's own sizeof(ctag_params).  Limits: 0 < dark_cap < 0.5, area_min >= 1, 0 < area_max_fraction <= 1,
  * finite positive thresholds; else CTAG_ERR_ARG. */
 /* (struct ctag_params: include/ctag_types.h) */
 void ctag_params_default(ctag_params* p);
@@ -69,7 +70,16 @@ void ctag_host_free(void* p);
 
 /* A batch of frames already resident in DEVICE memory; results are written to DEVICE memory `out_dev`
  * (n records).  Work is enqueued on the handle's stream and this call returns without waiting; use
- * ctag_sync() or stream ordering.  This is the entry point the throughput bench times. */
+ * ctag_sync() (or stream ordering, see below).  This is the entry point the throughput bench times.
+ *
+ * Frames that need more than the batch workspace's pools.  The reference keeps EVERY component of 30 px .. 1 % of the frame
+ * and walks them all (corner_detector.cpp:81-107,171-405); the batch workspace holds what a frame ordinarily needs (at
+ * 1080p: 2048 such components, 262 144 reserved boundary points; scaled with the frame's area).  A frame beyond that --
+ * thousands of blobs, fine texture -- is not failed: it is run again, alone, through a workspace whose pools no frame of
+ * its size can exhaust, and its record is the reference's like any other.  Host-memory calls (ctag_detect_u8 / _batch_u8 /
+ * _bgr8) do that before they return.  Device-memory calls do it at the handle's next synchronisation point: ctag_sync(), a call
+ * with CTAG_OPT_TIMING on, ctag_pose_batch_device, ctag_pack_results / ctag_gather_begin; a caller that relies on stream ordering
+ * alone sees such a frame's record with status CTAG_PENDING until then (the source frames must stay valid that long). */
 int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride,
                              ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
                              ctag_frame_result* out_dev);
@@ -112,6 +122,10 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value);
 #define CTAG_NUM_STAGES 14
 int ctag_get_timings(ctag_handle* h, float* ms, int capacity);
 const char* ctag_stage_name(int stage);
+/* Per-frame counts of the LAST chunk the handle processed (at most CTAG_OPT_MAX_CHUNK frames; one small kernel, waits for the
+ * stream): sums and maxima of components / candidates / quads / features / markers -- the numbers behind the reference's two
+ * log lines (CylinderTag.cpp:88,94) -- and how many frames have needed the any-frame workspace so far. */
+int ctag_get_counters(ctag_handle* h, ctag_counters* out);
 const char* ctag_strerror(int status);
 int ctag_version(void);
 

@@ -24,12 +24,17 @@
 #define CTAG_ERR_HIP (-2)
 #define CTAG_ERR_LIMIT (-3) /* frame exceeded a fixed-array limit the reference would overflow (UB there) */
 #define CTAG_ERR_UNSUPPORTED (-4)
+#define CTAG_PENDING (-5) /* DEVICE-memory calls only, and only until the handle's next synchronisation point (ctag_sync, or any call
+                             that waits): the frame needs larger pools than the batch workspace holds -- thousands of blobs, fine
+                             texture -- and is completed there through a workspace that holds any frame.  Host-memory calls
+                             never return it. */
 
 /* flags (bit set) */
 #define CTAG_FLAG_QUAD_OVERFLOW 1u     /* > CTAG_MAX_QUADS quads */
 #define CTAG_FLAG_FEATURE_OVERFLOW 2u  /* > CTAG_MAX_FEATURES features */
 #define CTAG_FLAG_CODE_OVERFLOW 4u     /* a marker's code position reached CTAG_MAX_CODE_POS (marker dropped) */
-#define CTAG_FLAG_POOL_OVERFLOW 8u     /* GPU component pool exhausted (frame far outside the domain) */
+#define CTAG_FLAG_POOL_OVERFLOW 8u     /* a pool of the batch workspace was exhausted: the frame is CTAG_PENDING, then completed (flag cleared);
+                                          with CTAG_ERR_LIMIT: a component larger than any 8K frame can hold (frames beyond 7680x4320 only) */
 #define CTAG_FLAG_ERASE_CLAMPED 16u    /* reference UB: vector::erase past end, defined as no-op */
 
 typedef struct ctag_feature_rec {
@@ -60,8 +65,21 @@ typedef struct ctag_frame_result {
     ctag_feature_rec features[CTAG_MAX_FEATURES];
 } ctag_frame_result; /* 16 + 1600 + 10000 = 11616 bytes */
 
+/* What the frames of the last chunk held, stage by stage (ctag_get_counters, include/ctag.h).  Index: 0 connected components the label
+ * sweep published (every component of >= area_min pixels is among them), 1 candidates (area within [area_min, 1 %],
+ * corner_detector.cpp:88), 2 quads (edgeExtraction's output, :171-405), 3 features (:465-559), 4 markers in the record. */
+#define CTAG_NUM_COUNTERS 5
+typedef struct ctag_counters {
+    int64_t frames;                  /* frames of the chunk */
+    int64_t sum[CTAG_NUM_COUNTERS];  /* over those frames */
+    int32_t max[CTAG_NUM_COUNTERS];
+    int32_t reruns;                  /* frames this handle has completed through the any-frame workspace so far (CTAG_PENDING) */
+} ctag_counters;
+
 /* The detector's tunables (ctag_create_ex, include/ctag.h); the reference's values in the comments */
 typedef struct ctag_params {
+    uint32_t struct_size;          /* sizeof(ctag_params) of the header the caller was compiled with: ctag_params_default fills it in,
+                                      ctag_create_ex refuses a struct of another size (a later library version may append fields) */
     float threshold_line;          /* 1.8   split a boundary span while a point lies farther than this from its chord   h:90,  cpp:320-329 */
     float threshold_expand;        /* 1.2   expand_line accepts a point within this distance of the refitted line       h:90,  cpp:144,156 */
     float threshold_RAC;           /* 0.3   quadJudgment: |shoelace area - pixel count| / pixel count below this         h:110, cpp:454-463 */

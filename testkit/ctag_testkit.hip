@@ -170,8 +170,8 @@ long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t cap
             if (dst && cap >= (size_t)nc * 8 && nc > 0) {
                 std::vector<Candidate> c(nc);
                 std::vector<QuadOut> q(nc);
-                if (!d2h(c.data(), W.cand + (size_t)frame * kCandCap, sizeof(Candidate) * nc)) return -2;
-                if (!d2h(q.data(), W.quads + (size_t)frame * kCandCap, sizeof(QuadOut) * nc)) return -2;
+                if (!d2h(c.data(), W.cand + (size_t)frame * W.cand_cap, sizeof(Candidate) * nc)) return -2;
+                if (!d2h(q.data(), W.quads + (size_t)frame * W.cand_cap, sizeof(QuadOut) * nc)) return -2;
                 if (what == CTAG_DBG_CANDIDATES) {
                     int32_t* o = static_cast<int32_t*>(dst);
                     for (int i = 0; i < nc; i++) {
@@ -219,10 +219,10 @@ long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t cap
         case CTAG_DBG_LINES: {
             int nl = 0;
             if (!d2h(&nl, W.line_count + frame, 4)) return -2;
-            nl = std::min(nl, kLineCap);
+            nl = std::min(nl, W.line_cap);
             if (dst && cap >= (size_t)nl && nl > 0) {
                 std::vector<LineDesc> d(nl);
-                if (!d2h(d.data(), W.line_desc + (size_t)frame * kLineCap, sizeof(LineDesc) * nl)) return -2;
+                if (!d2h(d.data(), W.line_desc + (size_t)frame * W.line_cap, sizeof(LineDesc) * nl)) return -2;
                 int32_t* o = static_cast<int32_t*>(dst);
                 for (int i = 0; i < nl; i++) o[i] = d[i].n;
             }
