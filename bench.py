@@ -631,6 +631,31 @@ def main():
         det.set_option(capi.OPT_TIMING, 0)
     launches = (n + chunk - 1) // chunk
     stage_ms = dict(stage_ms)
+    # what the frames held (ctag_get_counters: the last chunk of this rank's last step) -- SURVEY.md 5's metrics row
+    try:
+        frame_counters = det.counters()
+    except Exception as e:  # noqa: BLE001
+        frame_counters = {"error": "%s: %s" % (type(e).__name__, e)}
+    # N > 1: what the exchange costs by itself -- one more gather of the last step's records, alone on the GPU, wall clock from
+    # ctag_gather_begin to the end of ctag_gather_wait (max over ranks) -- and every rank's per-kernel times, so that a SCALE
+    # record says where a step went
+    gather_ms, rank_stage_ms = None, None
+    if world > 1:
+        cpu_side = dist.get_backend() != "nccl"
+        if comm is not None:
+            fence()
+            g0 = time.perf_counter()
+            comm.begin(local_bufs[last % len(local_bufs)][:n], n_total)
+            comm.end(gathered[(last + 1) % 2])
+            comm.wait()
+            det.sync()
+            g = torch.tensor([(time.perf_counter() - g0) * 1e3], dtype=torch.float64, device="cpu" if cpu_side else dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            gather_ms = round(float(g.item()), 3)
+        mine = torch.tensor([stage_ms[k] for k in ca.STAGE_NAMES], dtype=torch.float64, device="cpu" if cpu_side else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_stage_ms = [{k: round(float(v), 3) for k, v in zip(ca.STAGE_NAMES, t.tolist())} for t in allr]
     stage_ms["quad"] = sum(stage_ms[k] for k in capi.QUAD_STAGES)  # a4 edgeExtraction: the six kernels of the quad stage
 
     # ---- outcome of the last step: the job's result list in frame order (gathered when N > 1)
@@ -682,7 +707,15 @@ def main():
                "roofline": roofline,
                "issue_roofline": issue_rooflines(stage_ms, n),
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
+               "frame_counters": frame_counters if "error" in frame_counters else {
+                   "frames": frame_counters["frames"], "any_frame_reruns": frame_counters["reruns"],
+                   **{k: {"mean": round(frame_counters[k][0], 2), "max": frame_counters[k][1]} for k in capi.COUNTER_NAMES},
+                   "note": "per-frame counts of the last chunk of the last step (ctag_get_counters): components the label sweep published, "
+                           "candidates (area in [30 px, 1 %]), quads, features, decoded markers"},
                "frames_ok": ok_frames, "markers_decoded_last_step": markers_found, "results_sha256": sha}
+        if world > 1:
+            out["gather_ms"] = gather_ms
+            out["rank_stage_ms"] = rank_stage_ms
         if comm is not None:
             lb, pb = det.gather_last_bytes()
             out["config"]["gather_bytes"] = {"packed_local": lb, "padded_per_rank": pb, "fixed_records_per_rank": n * rec_bytes}
