@@ -51,6 +51,9 @@ struct ctag_handle {
     };
     WsSlot batch, big;
     const Workspace* last_ws = nullptr;  // whichever ran last (handle_view)
+    bool last_fused = false;  // the last chunk took the fused sweep: its workspace holds the threshold mask, not the half-size image
+    const uint8_t* last_frames = nullptr;  // ... and the frames it read (the test kit decimates them again for CTAG_DBG_HALF)
+    ptrdiff_t last_row_stride = 0, last_frame_stride = 0;
     const ctag_frame_result* last_out = nullptr;  // ... and where its records went (ctag_get_counters)
     // frames of device-memory calls that wait for the any-frame pass (k_markers appends, finish_pending drains)
     PendingRec* d_pending = nullptr;
@@ -65,6 +68,7 @@ struct ctag_handle {
     int reruns = 0;                  // frames completed through the any-frame workspace so far (ctag_get_counters)
     int max_chunk = 1024;
     int wave_points = 0;  // CTAG_OPT_WAVE_POINTS
+    int fuse_mode = -1;   // CTAG_OPT_FUSED_SWEEP
     bool timing = false;
     bool keep_pre = false;
     // timing (CTAG_OPT_TIMING): one set of CTAG_NUM_STAGES + 1 events per chunk of a public call, read back ONCE after the
@@ -133,6 +137,11 @@ void handle_view(const ctag_handle* h, HandleView* out) {
     out->dict = h->dict.data();
     out->dict_rows = h->dict_rows;
     out->dict_cols = h->dict_cols;
+    out->fused = h->last_fused;
+    out->frames = h->last_frames;
+    out->row_stride = h->last_row_stride;
+    out->frame_stride = h->last_frame_stride;
+    out->stream = h->stream;
     out->gray = h->last_was_bgr ? h->d_gray : nullptr;
     out->gray_row_stride = h->gray_row_stride;
     out->gray_frame_stride = h->gray_frame_stride;
@@ -230,6 +239,7 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
         W.pick_table = h->d_pick_table;
         W.aux_stream = h->aux_stream;
         W.wave_points = h->wave_points;
+        W.fuse_mode = h->fuse_mode;
         W.ev_fork = h->ev_fork;
         W.ev_join = h->ev_join;
         W.big = big;
@@ -397,13 +407,18 @@ static int enqueue_chunk(ctag_handle* h, const Workspace& ws, const uint8_t* fra
     hipStream_t s = h->stream;
     h->last_ws = &ws;
     h->last_out = out_dev;
+    h->last_frames = frames_dev;
+    h->last_row_stride = row_stride;
+    h->last_frame_stride = frame_stride;
     HIP_TRY(launch_zero_counters(n, ws, s));
     int st = 0;
     auto mark = [&](int i) -> hipError_t { return evs ? hipEventRecord(evs[i], s) : hipSuccess; };
     HIP_TRY(mark(0));
-    HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s));
+    const bool fused = sweep_fused(frames_dev, frame_stride, row_stride, n, ws);  // threshold where the pixels are computed: 1 bit per pixel to K2, no `half`
+    h->last_fused = fused;
+    HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s, fused));
     HIP_TRY(mark(++st));
-    HIP_TRY(launch_threshold_ccl(n, ws, s));
+    HIP_TRY(launch_threshold_ccl(n, ws, s, fused));
     HIP_TRY(mark(++st));
     HIP_TRY(launch_seam_merge(n, ws, s));
     HIP_TRY(mark(++st));
@@ -496,6 +511,10 @@ static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, pt
     hit->last_use = ++h->graph_clock;
     h->last_ws = &W;
     h->last_out = out_dev;
+    h->last_frames = frames_dev;
+    h->last_row_stride = row_stride;
+    h->last_frame_stride = frame_stride;
+    h->last_fused = sweep_fused(frames_dev, frame_stride, row_stride, n, W);
     return hipGraphLaunch(hit->exec, h->stream) == hipSuccess;
 }
 
@@ -978,6 +997,11 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
             if (value < 0 || value > 0x7fffffff) return CTAG_ERR_ARG;
             h->wave_points = (int)value;
             drop_graphs(h);  // a captured chain holds the old value
+            return CTAG_OK;
+        case CTAG_OPT_FUSED_SWEEP:
+            if (value < 0 || value > 2) return CTAG_ERR_ARG;
+            h->fuse_mode = (int)value;
+            drop_graphs(h);
             return CTAG_OK;
         case CTAG_OPT_HOST_SUBCHUNK:
             if (value < 1 || value > (1 << 20)) return CTAG_ERR_ARG;

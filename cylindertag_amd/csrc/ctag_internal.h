@@ -173,6 +173,7 @@ struct Workspace {
     hipStream_t aux_stream = nullptr;     // owned by the handle: side branch for few-frame calls (launch_quads)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int wave_points = 0;                  // CTAG_OPT_WAVE_POINTS (0 = automatic)
+    int fuse_mode = -1;                   // CTAG_OPT_FUSED_SWEEP (-1 = not set: CTAG_FUSED_SWEEP from the environment, else 1)
     KParams kp{};                         // the handle's tunables
     // features
     void* quad_derived = nullptr;   // [F][kQuadStride] x 48 B (K7 scratch)
@@ -207,8 +208,10 @@ struct DetectParams {
 
 // kernel launchers (each enqueues on `s`, returns hipGetLastError())
 hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s);  // frame_ncomp, frame_flags, line_count, clp_used, ovf_count
-hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s);
-hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s);
+// fused: k_decimate_mask + the mask front end of K2 (1 bit per pixel between them, no `half`) -- sweep_fused says when that form applies
+bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws);
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused = false);
+hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s, bool fused = false);
 hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s);
@@ -243,6 +246,10 @@ struct HandleView {
     bool keep_pre;
     const int32_t* dict;            // host copy of the dictionary
     int dict_rows, dict_cols;
+    bool fused;                     // the last chunk took the fused sweep: ws->half holds the threshold mask (1 bit per pixel), not the half-size image
+    const uint8_t* frames;          // the frames the last chunk read (device memory) and their strides
+    ptrdiff_t row_stride, frame_stride;
+    hipStream_t stream;
     const uint8_t* gray;            // device gray frames of the last BGR call (null otherwise)
     ptrdiff_t gray_row_stride, gray_frame_stride;
 };

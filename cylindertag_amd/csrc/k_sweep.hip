@@ -24,6 +24,12 @@ __device__ __forceinline__ bool map_block(int b, int per_frame, int nframes, int
 }
 static inline int grid_for(int nframes, int per_frame) { return ((nframes + 7) / 8) * 8 * per_frame; }
 
+// the fused sweep (k_decimate_mask below)
+constexpr int kFuseCols = 960;     // half-resolution columns per wave
+constexpr int kFuseLanes = 60;     // ... = 60 lanes x 16 pixels
+constexpr int kFuseTiles = kFuseCols / 5;
+static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s);
+
 // =====================================================================================================
 // K1: bicubic 2x decimation, u8 -> u8.  OpenCV resize(INTER_CUBIC) for an exact 2x scale has the fixed
 // taps [-192, 1216, 1216, -192]/2048 at source positions 2x-1..2x+2 (index-clamped at the borders); the
@@ -345,8 +351,23 @@ __global__ __launch_bounds__(256) void k_decimate_general(const uint8_t* __restr
     half[((size_t)frame * g.hrows + y) * g.hp + x] = (uint8_t)min(max(out, 0), 255);
 }
 
-hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s) {
+// The fused sweep (k_decimate_mask + the mask front end of K2) takes batches of frames whose half size is a multiple of 960 x 135
+// (1080p, 4K, 8K) with the reference's 5x5 window and 16-byte aligned rows; everything else keeps the two-kernel form with `half`.
+// CTAG_FUSED_SWEEP=0 (developer aid, A/B) turns it off.
+bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws) {
+    static const int env_mode = getenv("CTAG_FUSED_SWEEP") ? atoi(getenv("CTAG_FUSED_SWEEP")) : -1;
+    const int env = ws.fuse_mode >= 0 ? ws.fuse_mode : env_mode >= 0 ? env_mode : 1;  // CTAG_OPT_FUSED_SWEEP: 0 never, 1 batches (default), 2 whenever the frame size allows
     const FrameGeom& g = ws.g;
+    if (!env || (g.rows & 1) || (g.cols & 1) || g.tw != 5 || g.hcols % kFuseCols != 0 || g.hrows % 135 != 0) return false;
+    if ((((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) != 0) return false;
+    const int bands = g.hrows / 135;
+    if (env < 2 && (long)nframes * (g.hcols / kFuseCols) * bands < 2048) return false;  // few frames: short bands and the latency-tuned kernels (launch_decimate)
+    return bands % 4 == 0;
+}
+
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused) {
+    const FrameGeom& g = ws.g;
+    if (fused) return launch_decimate_mask(frames, frame_stride, row_stride, nframes, ws, s);
     if ((g.rows & 1) || (g.cols & 1) || getenv("CTAG_GENERAL_RESIZE")) {  // env: developer aid, runs even sizes through the general kernel
         hipLaunchKernelGGL(k_decimate_general, dim3((g.hcols + 255) / 256, g.hrows, nframes), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g,
                            nframes, ws.rz_xofs, ws.rz_alpha, ws.rz_yofs, ws.rz_beta);
@@ -387,6 +408,7 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
 // =====================================================================================================
 struct SweepPtrs {
     const uint8_t* half;
+    const uint8_t* mask;   // k_decimate_mask's 1 bit per half-resolution pixel, rows of hcols / 8 bytes (the fused sweep: `half` is not written then)
     uint16_t* labels;
     int32_t* tile_base;
     int32_t* frame_ncomp;
@@ -413,7 +435,7 @@ struct SweepPtrs {
     size_t pool_stride;    // bytes between consecutive pool arrays (parent, root_of, area, xmin, ymin, xmax, ymax, key, pool_tile, member_head, member_next)
 };
 static SweepPtrs sweep_ptrs(const Workspace& ws) {
-    return SweepPtrs{ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
+    return SweepPtrs{ws.half, ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
                      ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.nroots, ws.cand, ws.cand_cap,
                      reinterpret_cast<int2*>(ws.cand_aux), ws.ovf_count, ws.ovf_list, nullptr,
                      (size_t)(reinterpret_cast<const char*>(ws.root_of) - reinterpret_cast<const char*>(ws.parent))};
@@ -630,6 +652,246 @@ __device__ __forceinline__ int div_small(int n, int m16) { return (int)(((unsign
 __device__ __forceinline__ int recip16(int d) { return (65536 + d - 1) / d; }
 constexpr int kVPitch = 352;  // column extrema per threshold-tile row: 5 + 320 + 5 columns from an 8-aligned start
 
+// =====================================================================================================
+// K1 + the front half of K2 in one kernel (batches of 1080p-class frames, 5x5 window): decimate AND threshold, 1 bit per pixel out.
+// k_decimate_wide holds every half-resolution pixel in registers with half of its vector slots idle, and K2 spent half of its
+// cycles fetching those pixels back (its front end: stage, 5x5 extrema, 3x3 dilation, compare).  Here a wave slides down its band
+// like k_decimate_wide, and per threshold-tile row (5 output rows) it
+//   * keeps the rows' pixels in an LDS ring (10 rows) and their per-column min / max in registers,
+//   * at the end of the tile row publishes the column extrema, reduces them to tile extrema (5 columns each; a ring of 3 tile rows),
+//   * and can then finish the PREVIOUS tile row: 3x3 min-of-min / max-of-max (corner_detector.cpp:54-67, interior tiles only: B1),
+//     the threshold bound (threshold_lookup, :71), pixel < bound on packed bytes, 16 mask bits per lane and row.
+// The half-resolution image is never written (518 KB written + read per 1080p frame); the mask is 65 KB.  A band needs the
+// extrema of the tile rows just above and below it: those 2 x 5 output rows are decimated again (extrema only: +7 % source reads,
+// which the neighbouring band's wave reads at about the same time on the same XCD).  A wave covers 960 half-resolution columns --
+// 60 lanes x 16 pixels, a multiple of the 5-pixel tile -- and lanes 60 / 61 decimate the 16 columns right / left of the span for
+// the tile column just outside it (4K frames: two waves per row).  Frames with hcols % 960 == 0, hrows % 135 == 0 (1080p, 4K, 8K).
+// =====================================================================================================
+struct FuseLds {                   // per wave: 12 960 bytes, four waves per block, three blocks per CU
+    uint4 ring[10][kFuseLanes];    // the pixels of the tile row being built and of the one waiting for its lower neighbour
+    uint8_t vmin[16 + kFuseCols + 16], vmax[16 + kFuseCols + 16];  // column extrema of the finished tile row: [16 + column - X0]
+    uint16_t ext[3][kFuseTiles + 4];  // tile extrema min | max << 8 of three tile rows: tile k = -1 .. 192 of the span at [k + 1]
+    uint8_t tt[kFuseTiles];        // threshold bound of the tiles of the row being emitted
+};
+// A source row as the lane loaded it: 32 pixels, nothing else.  The neighbours' pixels the horizontal pass needs (one to the left, two
+// to the right) are fetched from the lanes next door when the row is CONSUMED (wave_shr / wave_shl DPP moves, no LDS): a shuffle at
+// load time makes the wave wait for every row it has just requested, which leaves one row in flight per wave (k_decimate_wide does
+// that and leans on four waves per SIMD; this kernel has three and keeps four rows in flight instead).  No byte loads either: at
+// the image border the edge pixel repeats (index clamp), at the seam between two waves of a 4K row the halo lanes hold the pixels.
+struct Raw32 {
+    uint32_t w[8];
+};
+__device__ __forceinline__ Raw32 load_row_fuse(const uint8_t* __restrict__ rowp, int x0) {  // every lane loads (inactive ones an in-row dummy): no branch around the loads
+    Raw32 r;
+    const uint4 a = *reinterpret_cast<const uint4*>(rowp + x0), b = *reinterpret_cast<const uint4*>(rowp + x0 + 16);
+    r.w[0] = a.x, r.w[1] = a.y, r.w[2] = a.z, r.w[3] = a.w;
+    r.w[4] = b.x, r.w[5] = b.y, r.w[6] = b.z, r.w[7] = b.w;
+    return r;
+}
+// lane i <- lane i - 1 / lane i + 1 across the whole wave (DPP wave_shr:1 / wave_shl:1)
+__device__ __forceinline__ uint32_t wave_from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+// left_edge: lane 0 is at the image's left border; right_edge: lane 59 at its right border (else lanes 61 / 60 hold the pixels beyond)
+__device__ __forceinline__ void hpass_fuse(const Raw32& r, int lane, bool left_edge, bool right_edge, uint32_t q[8]) {
+    Raw34 t;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.w[i] = r.w[i];
+    uint32_t left = wave_from_prev(r.w[7] >> 24);
+    uint32_t right2 = wave_from_next(r.w[0] & 0xffffu);
+    const uint32_t last61 = (uint32_t)__builtin_amdgcn_readlane((int)(r.w[7] >> 24), 61), first0 = (uint32_t)__builtin_amdgcn_readlane((int)(r.w[0] & 0xffffu), 0);
+    if (lane == 0) left = left_edge ? (r.w[0] & 0xffu) : last61;
+    if (lane == 59 && right_edge) right2 = (r.w[7] >> 24) * 0x0101u;
+    if (lane == 61) right2 = first0;  // (the halo lanes' outer neighbours only reach pixels nobody reads)
+    t.left = left;
+    t.right2 = right2;
+    hpass_wide(t, q);
+}
+template <int BAND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_decimate_mask(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
+                                                                                                    uint8_t* __restrict__ mask, FrameGeom g, KParams kp, int nframes, int xblocks,
+                                                                                                    int yblocks) {
+    static_assert(BAND % 5 == 0, "a band is whole threshold-tile rows");
+    __shared__ FuseLds S4[4];
+    int frame, idx;
+    if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
+    const int bx = idx % xblocks, by = idx / xblocks;
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const int band = by * 4 + wy;
+    const int y_begin = band * BAND;
+    if (y_begin >= g.hrows) return;  // wave-uniform
+    FuseLds& S = S4[wy];
+    const int X0 = bx * kFuseCols;
+    const int hx0 = lane < kFuseLanes ? X0 + 16 * lane : lane == 60 ? X0 + kFuseCols : X0 - 16;
+    const bool active = lane < kFuseLanes || (lane == 60 && X0 + kFuseCols < g.hcols) || (lane == 61 && X0 > 0);
+    const int x0 = active ? hx0 * 2 : 0;  // inactive lanes load the row's first bytes and drop them
+    const bool left_edge = X0 == 0, right_edge = X0 + kFuseCols >= g.hcols;
+    const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
+    const int mpitch = g.hcols >> 3;
+    uint8_t* __restrict__ mrow0 = mask + (size_t)frame * g.hrows * mpitch + (X0 >> 3) + 2 * lane;
+    const int rmax = g.rows - 1;
+    auto rowp = [&](int r) { return src + (ptrdiff_t)min(max(r, 0), rmax) * row_stride; };
+    // the lane's 16 pixels lie in the tiles j0 .. j0 + 3 of the span; sel[k] picks, for pixels 4k .. 4k + 3, their tile's byte of a packed word
+    const int j0 = (16 * lane) / 5;
+    uint32_t sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v |= (uint32_t)((16 * lane + 4 * k + q) / 5 - j0) << (8 * q);
+        sel[k] = v;
+    }
+    const int ys = max(y_begin - 5, 0), ye = min(y_begin + BAND + 5, g.hrows);  // the band plus one tile row above and below (extrema only)
+    const int e_lo = y_begin / 5, e_hi = min(y_begin + BAND, g.hrows) / 5;     // tile rows this wave emits: [e_lo, e_hi)
+    const int tc0 = X0 / 5;
+    uint32_t mnE[4], mnO[4], mxE[4], mxO[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        mnE[k] = mnO[k] = 0x00ff00ffu;
+        mxE[k] = mxO[k] = 0u;
+    }
+    int rit = 0, slot = ys % 10;
+    // one wave, LDS only: its accesses are served in order, so a wait for LDS (NOT for the source rows in flight) orders them
+    auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto tile_row_done = [&](int gt) {  // the five rows of threshold-tile row gt are in the ring, their column extrema in registers
+        if (active) {
+            const uint4 mn = make_uint4(mnE[0] | (mnO[0] << 8), mnE[1] | (mnO[1] << 8), mnE[2] | (mnO[2] << 8), mnE[3] | (mnO[3] << 8));
+            const uint4 mx = make_uint4(mxE[0] | (mxO[0] << 8), mxE[1] | (mxO[1] << 8), mxE[2] | (mxO[2] << 8), mxE[3] | (mxO[3] << 8));
+            const int at = lane < kFuseLanes ? 16 + 16 * lane : lane == 60 ? 16 + kFuseCols : 0;
+            *reinterpret_cast<uint4*>(S.vmin + at) = mn;
+            *reinterpret_cast<uint4*>(S.vmax + at) = mx;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            mnE[k] = mnO[k] = 0x00ff00ffu;
+            mxE[k] = mxO[k] = 0u;
+        }
+        wave_sync();
+        const int r3 = gt % 3;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = lane + 64 * q;  // tile j - 1 of the span
+            if (j < kFuseTiles + 2) {
+                const uint8_t* a = S.vmin + 11 + 5 * j;
+                const uint8_t* b = S.vmax + 11 + 5 * j;
+                const int mn = min(min(min((int)a[0], (int)a[1]), min((int)a[2], (int)a[3])), (int)a[4]);
+                const int mx = max(max(max((int)b[0], (int)b[1]), max((int)b[2], (int)b[3])), (int)b[4]);
+                S.ext[r3][j] = (uint16_t)(mn | (mx << 8));
+            }
+        }
+        wave_sync();
+    };
+    auto emit_tile_row = [&](int e) {  // tile row e's pixels are in the ring and the tile extrema of rows e - 1, e, e + 1 (as far as they exist) in `ext`
+        if (e < e_lo || e >= e_hi) return;  // wave-uniform
+        const int ra = (e + 2) % 3, rb = e % 3, rc = (e + 1) % 3;  // rows e - 1, e, e + 1 of the ring
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int j = lane + 64 * q;
+            if (j < kFuseTiles) {
+                int T = 0;
+                const int tc = tc0 + j;
+                // 3x3 min-of-min / max-of-max for interior tiles, zero elsewhere (corner_detector.cpp:54-67, B1); a tile whose own minimum
+                // is >= tcap has no pixel below any bound (T <= tcap)
+                if (e >= 1 && e <= g.trows - 2 && tc >= 1 && tc <= g.tcols - 2 && (S.ext[rb][j + 1] & 0xff) < kp.tcap) {
+                    int mn = 255, mx = 0;
+#pragma unroll
+                    for (int dx = 0; dx < 3; dx++) {
+                        const int ea = S.ext[ra][j + dx], eb = S.ext[rb][j + dx], ec = S.ext[rc][j + dx];
+                        mn = min(mn, min(min(ea & 0xff, eb & 0xff), ec & 0xff));
+                        mx = max(mx, max(max(ea >> 8, eb >> 8), ec >> 8));
+                    }
+                    // the bound from its definition, not from the table K2 reads: a global load inside this branch would make the wave
+                    // wait for every source row it has in flight at each tile row (the table is built from the same function)
+                    T = mn + mx >= kp.thr_dim ? kp.tcap : threshold_bound(mn, mx, kp.dark_cap);
+                }
+                S.tt[j] = (uint8_t)T;
+            }
+        }
+        wave_sync();
+        if (lane < kFuseLanes) {
+            const uint32_t T4 = (uint32_t)S.tt[j0] | ((uint32_t)S.tt[j0 + 1] << 8) | ((uint32_t)S.tt[j0 + 2] << 16) | ((uint32_t)S.tt[min(j0 + 3, kFuseTiles - 1)] << 24);
+            uint8_t* mp = mrow0 + (size_t)(5 * e) * mpitch;
+            if (T4 == 0u) {
+#pragma unroll
+                for (int r = 0; r < 5; r++) *reinterpret_cast<uint16_t*>(mp + (size_t)r * mpitch) = (uint16_t)0;
+            } else {
+                const uint32_t t0 = __builtin_amdgcn_perm(0u, T4, sel[0]), t1 = __builtin_amdgcn_perm(0u, T4, sel[1]), t2 = __builtin_amdgcn_perm(0u, T4, sel[2]),
+                               t3 = __builtin_amdgcn_perm(0u, T4, sel[3]);
+                const int s0 = (e & 1) * 5;  // 5 e mod 10
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    const uint4 px = S.ring[s0 + r][lane];
+                    const uint32_t bits = lt4_bytes(px.x, t0) | (lt4_bytes(px.y, t1) << 4) | (lt4_bytes(px.z, t2) << 8) | (lt4_bytes(px.w, t3) << 12);
+                    *reinterpret_cast<uint16_t*>(mp + (size_t)r * mpitch) = (uint16_t)bits;
+                }
+            }
+        }
+        // (the ring slots just read are overwritten two tile rows from now; LDS serves a wave's accesses in order)
+    };
+    auto row_done = [&](int y, const uint32_t (&o)[4]) {
+        if (lane < kFuseLanes) S.ring[slot][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t e = o[k] & 0x00ff00ffu, od = (o[k] >> 8) & 0x00ff00ffu;
+            mnE[k] = pk_min_u16(mnE[k], e);
+            mnO[k] = pk_min_u16(mnO[k], od);
+            mxE[k] = pk_max_u16(mxE[k], e);
+            mxO[k] = pk_max_u16(mxO[k], od);
+        }
+        slot = slot == 9 ? 0 : slot + 1;
+        if (++rit == 5) {
+            rit = 0;
+            tile_row_done(y / 5);
+            emit_tile_row(y / 5 - 1);  // its lower neighbour is known now
+        }
+    };
+    uint32_t qa[8], qb[8], qc[8], qd[8];
+    auto hp = [&](const Raw32& r, uint32_t (&q)[8]) { hpass_fuse(r, lane, left_edge, right_edge, q); };
+    {
+        const Raw32 ra = load_row_fuse(rowp(2 * ys - 1), x0);
+        const Raw32 rb = load_row_fuse(rowp(2 * ys), x0);
+        const Raw32 rc = load_row_fuse(rowp(2 * ys + 1), x0);
+        const Raw32 rd = load_row_fuse(rowp(2 * ys + 2), x0);
+        hp(ra, qa);
+        hp(rb, qb);
+        hp(rc, qc);
+        hp(rd, qd);
+    }
+    auto emit = [&](int y, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = vpack4(vpass2(a[2 * k], b[2 * k], c[2 * k], d[2 * k], 0), vpass2(a[2 * k + 1], b[2 * k + 1], c[2 * k + 1], d[2 * k + 1], 0));
+        row_done(y, o);
+    };
+    Raw32 n0 = load_row_fuse(rowp(2 * ys + 3), x0);
+    Raw32 n1 = load_row_fuse(rowp(2 * ys + 4), x0);
+    for (int y = ys; y < ye; y += 2) {
+        const Raw32 m0 = load_row_fuse(rowp(2 * y + 5), x0);
+        const Raw32 m1 = load_row_fuse(rowp(2 * y + 6), x0);
+        emit(y, qa, qb, qc, qd);
+        uint32_t qe[8], qf[8];
+        hp(n0, qe);
+        hp(n1, qf);
+        if (y + 1 < ye) emit(y + 1, qc, qd, qe, qf);  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            qa[i] = qe[i];
+            qb[i] = qf[i];
+        }
+        n0 = load_row_fuse(rowp(2 * y + 7), x0);
+        n1 = load_row_fuse(rowp(2 * y + 8), x0);
+        hp(m0, qc);
+        hp(m1, qd);
+    }
+    if (ye == g.hrows) emit_tile_row(g.trows - 1);  // the frame's last tile row has no lower neighbour: a border row (bound 0)
+}
+
+static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s) {
+    const FrameGeom& g = ws.g;
+    const int xb = g.hcols / kFuseCols, yblocks = g.hrows / 135 / 4;
+    hipLaunchKernelGGL((k_decimate_mask<135>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+    return hipGetLastError();
+}
+
 // One 320x30 tile.  RUNCAP / SLOTCAP: row runs / components of the tile held in LDS.  BIG = false is the pass every tile
 // takes first (2048 runs, 640 components, 8 tiles per CU); a tile that does not fit -- dense speckle, fine texture -- or
 // whose components no longer fit the frame's pool is handed on through the overflow list instead of failing the frame, and
@@ -637,7 +899,7 @@ constexpr int kVPitch = 352;  // column extrema per threshold-tile row: 5 + 320 
 // tile per CU, and only the components that can matter are published -- area >= 30 (corner_detector.cpp:88) or touching
 // the tile border (they may grow by seam merging); the other specks keep a label of their own with bit 15 set, which no
 // later stage ever looks up.
-template <int TWC, int RUNCAP, int SLOTCAP, bool BIG>
+template <int TWC, int RUNCAP, int SLOTCAP, bool BIG, bool MASKIN = false>
 __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P, const FrameGeom& g, const KParams& kp, int frame0, int tile0) {
     const int tw = TWC ? TWC : g.tw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -676,7 +938,39 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     (void)tr1;
     (void)py0;
     (void)lx0;
-  if constexpr (TWC == 5) {
+    // a tile without foreground: its labels are zero and it owns no component -- exactly what the phases below would produce
+    auto empty_tile = [&]() {
+        uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+        constexpr int groups = kTileW / 8;
+        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
+            const int r = i / groups, gq = i - r * groups;
+            if (r < th_eff && gq * 8 < tw_eff) *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
+    };
+  if constexpr (MASKIN) {
+    // ---- the fused sweep: k_decimate_mask thresholded the pixels where they were computed; the row masks arrive as 64-bit words
+    // (hcols is a multiple of the tile width there, rows of hcols / 8 bytes: every word is aligned and inside the frame's columns)
+    (void)tcs0, (void)tcs1, (void)trs0, (void)trs1, (void)tc0, (void)tr0, (void)hr_s, (void)ext_s, (void)thr_s;
+    uint64_t m = 0ull;
+    if (tid < kTileH * kTileWords) {
+        const int r = tid / kTileWords, w = tid - r * kTileWords;
+        const int mp = g.hcols >> 3;
+        if (r < th_eff) m = *reinterpret_cast<const uint64_t*>(P.mask + ((size_t)frame * g.hrows + ty0 + r) * mp + (tx0 >> 3) + 8 * w);
+        mask_s[tid] = m;
+    }
+    {
+        const unsigned long long any = __ballot(m != 0ull);
+        if (lane == 0) misc_s[12 + wave] = any != 0ull ? 1 : 0;
+    }
+    CCL_SYNC();
+    stamp(0);
+    if ((misc_s[12] | misc_s[13] | misc_s[14] | misc_s[15]) == 0) {
+        empty_tile();
+        return;
+    }
+    stamp(3);
+  } else if constexpr (TWC == 5) {
     // ---- front end for the 5x5 window: no LDS staging.  An item is (threshold-tile row, 8-pixel column group); the thread
     // loads its 5 x 8 pixels straight into registers, reduces them vertically on packed bytes and leaves one min / max per
     // COLUMN in LDS; a thread per threshold tile then combines 5 columns.  The pixels stay in registers for the compare.
@@ -746,13 +1040,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     // so a tile whose pixels are all >= 77 has no foreground whatever its thresholds turn out to be: its labels are zero
     // and it owns no component.  Exactly what the phases below would produce, without running them.
     if ((misc_s[12] | misc_s[13] | misc_s[14] | misc_s[15]) == 0) {
-        uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
-        constexpr int groups = kTileW / 8;
-        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
-            const int r = i / groups, gq = i - r * groups;
-            if (r < th_eff && gq * 8 < tw_eff) *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(0u, 0u, 0u, 0u);
-        }
-        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
+        empty_tile();
         return;
     }
     // ---- per-threshold-tile min / max (corner_detector.cpp:42-53): 5 column extrema each
@@ -1174,7 +1462,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
   }
 }
 
-template <int TWC>
+template <int TWC, bool MASKIN = false>
 #ifdef CTAG_CCL_WAVES
 __global__ __launch_bounds__(kCclThreads) __attribute__((amdgpu_waves_per_eu(CTAG_CCL_WAVES, CTAG_CCL_WAVES)))
 #else
@@ -1185,17 +1473,17 @@ void k_threshold_ccl(SweepPtrs P, FrameGeom g, KParams kp, int nframes) {
     // one tile per block; blocks b and b+8 share an XCD, so a frame's tiles stay on one XCD (map_block)
     int frame0, tile0;
     if (!map_block(blockIdx.x, g.tiles_x * g.tiles_y, nframes, frame0, tile0)) return;
-    ccl_tile<TWC, kRunCap, kSlotCap, false>(smem, P, g, kp, frame0, tile0);
+    ccl_tile<TWC, kRunCap, kSlotCap, false, MASKIN>(smem, P, g, kp, frame0, tile0);
 }
 
 // second pass over the tiles of the overflow list (usually none: the blocks read the count and leave)
-template <int TWC>
+template <int TWC, bool MASKIN = false>
 __global__ __launch_bounds__(kCclThreads) void k_threshold_ccl_big(SweepPtrs P, FrameGeom g, KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int count = *P.ovf_count, per_frame = g.tiles_x * g.tiles_y;
     for (int i = blockIdx.x; i < count; i += gridDim.x) {
         const int e = P.ovf_list[i];
-        ccl_tile<TWC, kRunCapBig, kSlotCapBig, true>(smem, P, g, kp, e / per_frame, e % per_frame);
+        ccl_tile<TWC, kRunCapBig, kSlotCapBig, true, MASKIN>(smem, P, g, kp, e / per_frame, e % per_frame);
         __syncthreads();
     }
 }
@@ -1203,7 +1491,7 @@ static_assert(kSlotCapBig < 0x7fff, "labels are 1..slots or 0x8000 | culled slot
 static_assert(2 * kSlotCap <= 256, "FrameGeom::pool_cap = 256 entries per tile holds two first passes");
 static_assert(kRunCapBig % kCclThreads == 0 && kRunCapBig >= (kTileW / 2) * kTileH && kSlotCapBig >= (kTileW / 2) * ((kTileH + 1) / 2), "second-pass caps hold any tile");
 
-hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s) {
+hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s, bool fused) {
     const FrameGeom& g = ws.g;
     const size_t lds = threshold_ccl_lds_bytes(g.tw);
     const int grid = grid_for(nframes, g.tiles_x * g.tiles_y);  // one 320x30 tile per block
@@ -1227,8 +1515,12 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s)
             have[dev] = bytes;
         }
     };
-    static size_t have_big5[64] = {0}, have_big0[64] = {0}, have_0[64] = {0};
-    if (g.tw == 5) {
+    static size_t have_big5[64] = {0}, have_big0[64] = {0}, have_0[64] = {0}, have_big5m[64] = {0};
+    if (fused) {
+        hipLaunchKernelGGL((k_threshold_ccl<5, true>), dim3(grid), dim3(kCclThreads), lds, s, P, g, ws.kp, nframes);
+        want_lds(reinterpret_cast<const void*>(k_threshold_ccl_big<5, true>), lds_big, have_big5m);
+        hipLaunchKernelGGL((k_threshold_ccl_big<5, true>), dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g, ws.kp);
+    } else if (g.tw == 5) {
         hipLaunchKernelGGL(k_threshold_ccl<5>, dim3(grid), dim3(kCclThreads), lds, s, P, g, ws.kp, nframes);
         want_lds(reinterpret_cast<const void*>(k_threshold_ccl_big<5>), lds_big, have_big5);
         hipLaunchKernelGGL(k_threshold_ccl_big<5>, dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g, ws.kp);

@@ -31,6 +31,7 @@ extern "C" {
 #define CTAG_DBG_FEATURES2 7  /* float  [nfeat*19]      after edgeRefine */
 #define CTAG_DBG_PREMARKERS 8 /* ctag_frame_result      markers before decoding (needs CTAG_OPT_KEEP_PREMARKERS) */
 #define CTAG_DBG_GRAY 9       /* uint8  [rows*cols]     gray image the BGR entry points computed (ctag_detect_batch_bgr8...) */
+#define CTAG_DBG_MASK 11      /* uint8  [hrows*hcols]   0 / 1: the adaptive-threshold mask of the fused sweep (k_decimate_mask); -1 when the last chunk took the two-kernel form */
 #define CTAG_DBG_LINES 10     /* int32  [nlines]        point count of every edge cluster handed to the Welsch fit (a4) */
 /* returns the number of ELEMENTS available (copies min(available, capacity) elements), < 0 on error */
 long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t capacity_elems);

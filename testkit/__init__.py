@@ -18,7 +18,7 @@ TRUTH3D_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("_pad",
                        ("radius", "<f8", (8,))])
 TRUTH_DT = np.dtype([("n_markers", "<i4"), ("dict_row", "<i4", (8,)), ("strip_len", "<f4", (8,)),
                      ("corners", "<f4", (8, 8))])
-DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS, DBG_GRAY, DBG_LINES = range(1, 11)
+DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURES1, DBG_FEATURES2, DBG_PREMARKERS, DBG_GRAY, DBG_LINES, DBG_MASK = range(1, 12)
 SYNTH_SEED = 0x4354616753594E00  # "CTagSYN\0", SURVEY.md 8(d)
 
 # every symbol include/ctag_testkit.h declares (tests check the library exports all of them)
@@ -152,7 +152,7 @@ class Detector(ca.Detector):
         n = self.T.ctag_debug_fetch(self.h, frame, what, None, 0)
         if n < 0:
             raise CtagError(-1, "ctag_debug_fetch(%d)" % what)
-        if what in (DBG_HALF, DBG_GRAY):
+        if what in (DBG_HALF, DBG_GRAY, DBG_MASK):
             a = np.zeros(n, np.uint8)
         elif what in (DBG_LABELS, DBG_CANDIDATES, DBG_LINES):
             a = np.zeros(n, np.int32)

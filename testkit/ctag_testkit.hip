@@ -137,7 +137,34 @@ long ctag_debug_fetch(ctag_handle* h, int frame, int what, void* dst, size_t cap
         case CTAG_DBG_HALF: {
             const size_t n = (size_t)g.hrows * g.hcols;
             if (dst && cap >= n) {
-                if (hipMemcpy2D(dst, g.hcols, W.half + (size_t)frame * g.hrows * g.hp, g.hp, g.hcols, g.hrows, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+                if (v.fused) {
+                    // the fused sweep never writes the half-size image (its place holds the threshold mask): decimate this frame again with
+                    // the stand-alone kernel into a scratch image (the fused kernel's own pixels are checked through CTAG_DBG_MASK / labels)
+                    if (!v.frames) return -1;
+                    Workspace T = W;
+                    uint8_t* tmp = nullptr;
+                    if (hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)g.hrows * g.hp + 256) != hipSuccess) return -2;
+                    T.half = tmp;
+                    bool ok = launch_decimate(v.frames + (ptrdiff_t)frame * v.frame_stride, v.frame_stride, v.row_stride, 1, T, s, false) == hipSuccess &&
+                              hipStreamSynchronize(s) == hipSuccess;
+                    ok = ok && hipMemcpy2D(dst, g.hcols, tmp, g.hp, g.hcols, g.hrows, hipMemcpyDeviceToHost) == hipSuccess;
+                    (void)hipFree(tmp);
+                    if (!ok) return -2;
+                } else if (hipMemcpy2D(dst, g.hcols, W.half + (size_t)frame * g.hrows * g.hp, g.hp, g.hcols, g.hrows, hipMemcpyDeviceToHost) != hipSuccess) {
+                    return -2;
+                }
+            }
+            return (long)n;
+        }
+        case CTAG_DBG_MASK: {
+            if (!v.fused) return -1;
+            const size_t n = (size_t)g.hrows * g.hcols;
+            if (dst && cap >= n) {
+                const size_t mb = (size_t)g.hrows * (g.hcols >> 3);
+                std::vector<uint8_t> bits(mb);
+                if (!d2h(bits.data(), W.half + (size_t)frame * mb, mb)) return -2;
+                uint8_t* o = static_cast<uint8_t*>(dst);
+                for (size_t i = 0; i < n; i++) o[i] = (bits[i >> 3] >> (i & 7)) & 1u;
             }
             return (long)n;
         }

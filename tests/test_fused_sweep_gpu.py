@@ -1,0 +1,70 @@
+"""GPU parity of the fused sweep (-m gpu): k_decimate_mask thresholds the half-size pixels where it computes them and hands K2 one bit
+per pixel (no half-size image in HBM).  CTAG_OPT_FUSED_SWEEP = 2 forces that form for any number of frames of a size that allows it
+(half size a multiple of 960 x 135: 1080p, 4K); the mask must equal the oracle's adaptiveThreshold output (corner_detector.cpp:28-79)
+bit for bit, and everything behind it the oracle's stage by stage."""
+import numpy as np
+import pytest
+
+import cylindertag_amd as ca
+import testkit as tk
+from cylindertag_amd import capi
+from clutter import blob_field
+from test_gpu_parity import _stage_check, assert_same_record
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fused(detector):
+    detector.set_option(capi.OPT_FUSED_SWEEP, 2)
+    yield detector
+    detector.set_option(capi.OPT_FUSED_SWEEP, 1)
+
+
+def _mask_check(det, oracle, state, fs, img, what):
+    o, r, lab = _stage_check(det, oracle, state, fs, img, what)
+    mask = det.debug(0, tk.DBG_MASK).reshape(o["binary"].shape)
+    assert (mask == (o["binary"] > 0)).all(), what + ": threshold mask"
+    assert (det.debug(0, tk.DBG_HALF).reshape(o["half"].shape) == o["half"]).all(), what  # the stand-alone decimation, for the record
+    return o, r
+
+
+def test_fused_mask_equals_adaptive_threshold_1080p(fused, oracle, dictionary, test_bmp):
+    state, fs = dictionary
+    rng = np.random.RandomState(17)
+    yy, xx = np.mgrid[0:1080, 0:1920]
+    cases = [("test.bmp rows 60..1139", test_bmp[60:1140]),
+             ("synthetic frame 2", tk.synth_frame_host(state, 2)[0]),
+             ("blob field", blob_field(tk.synth_frame_host(state, 3)[0])[0]),
+             # thresholds of every kind: ramps through the 0.3 cap (77) with noise, so that tile bounds come from the table, from the cap and from 0
+             ("ramp + noise", np.clip(xx * (150.0 / 1920) + yy * (40.0 / 1080) + rng.randint(-30, 31, (1080, 1920)), 0, 255).astype(np.uint8)),
+             ("dark noise", np.clip(rng.normal(40, 25, (1080, 1920)), 0, 255).astype(np.uint8)),
+             ("checker of 5-pixel tiles", (((yy // 10 + xx // 10) & 1) * 120 + 20 + rng.randint(0, 3, (1080, 1920))).astype(np.uint8)),
+             ("all dark", np.zeros((1080, 1920), np.uint8)), ("all bright", np.full((1080, 1920), 230, np.uint8))]
+    for name, img in cases:
+        _mask_check(fused, oracle, state, fs, np.ascontiguousarray(img), name)
+
+
+def test_fused_mask_4k_two_waves_per_row(fused, oracle, dictionary):
+    """3840x2160: two waves per half-size row; the tile column on either side of column 960 comes from the halo lanes."""
+    state, fs = dictionary
+    rng = np.random.RandomState(23)
+    img = tk.synth_frame_host(state, 1, 2160, 3840)[0].copy()
+    img[:, 1880:1960] = np.clip(rng.normal(60, 30, (2160, 80)), 0, 255).astype(np.uint8)  # texture across the seam between the waves
+    _mask_check(fused, oracle, state, fs, img, "4K frame with a noise band across the wave seam")
+    noise = np.clip(rng.normal(70, 40, (2160, 3840)), 0, 255).astype(np.uint8)
+    _mask_check(fused, oracle, state, fs, noise, "4K noise")
+
+
+def test_fused_and_two_kernel_sweeps_give_the_same_records(detector, oracle, dictionary, test_bmp):
+    state, fs = dictionary
+    frames = np.stack([tk.synth_frame_host(state, 100 + f)[0] for f in range(24)] + [test_bmp[60:1140]])
+    want, _ = oracle.detect_many(frames, state, fs)
+    try:
+        for mode in (0, 2):
+            detector.set_option(capi.OPT_FUSED_SWEEP, mode)
+            got = detector.detect_batch(frames)
+            for k in range(len(frames)):
+                assert_same_record(got[k], want[k], "mode %d frame %d" % (mode, k))
+    finally:
+        detector.set_option(capi.OPT_FUSED_SWEEP, 1)
