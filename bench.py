@@ -113,7 +113,7 @@ def pipelined_steps_rate(det, state, fs, dev_index, frames_dev, n, chunk, subpix
         same = bool(torch.equal(out_buf[:n], out2[:n]))
         return {"value": round(n * steps / dt, 1), "unit": "frames/s", "handles": 2, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
                 "records_equal_between_handles": same,
-                "note": "consecutive steps alternate between two handles; the headline `value` is one handle, one stream"}
+                "note": "consecutive steps alternate between two handles (each running its chunks on two internal streams); the headline `value` is one handle"}
     finally:
         det2.close()
 
@@ -599,23 +599,32 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # Per-kernel device time: HIP events recorded by the library on ITS stream around every kernel (torch.cuda.Event
-    # would only see torch's current stream).  At N = 1 they bracket the kernels of the timed steps themselves (reading
-    # them back costs one event synchronisation per chunk, inside the timed region); at N > 1 that synchronisation would
-    # serialise the detect / gather pipeline, so the timed steps run without it and ONE extra untimed step collects them.
-    timed_with_events = world == 1
+    # The timed steps run as the library runs any device-memory batch: every chunk as two halves on two internal streams
+    # (CTAG_OPT_STREAMS, default 2), no events.  Per-kernel device time comes from the SAME number of extra steps behind the timed
+    # region with CTAG_OPT_TIMING on -- HIP events recorded by the library on ITS stream around every kernel (torch.cuda.Event would
+    # only see torch's current stream), which keeps those steps on ONE stream: between two interleaved streams an event pair around
+    # a kernel would time the neighbour's kernels as well.  (At N > 1 one extra step: it would serialise the detect / gather pipeline.)
+    timed_with_events = False
     acc = {k: 0.0 for k in ca.STAGE_NAMES}
-    if timed_with_events:
-        det.set_option(capi.OPT_TIMING, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if timed_with_events:
-            for k, v in det.timings().items():
-                acc[k] += v
     fence()
     dt = time.perf_counter() - t0
-    det.set_option(capi.OPT_TIMING, 0)
+    single_stream_dt = None
+    if world == 1:
+        det.set_option(capi.OPT_TIMING, 1)
+        step()  # warm: the one-stream workspace
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            for k, v in det.timings().items():
+                acc[k] += v
+        fence()
+        single_stream_dt = time.perf_counter() - t1
+        det.set_option(capi.OPT_TIMING, 0)
+        timed_with_events = True
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -693,7 +702,9 @@ def main():
                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * min(n, chunk),
                     "avg_launch_ms": round(sweep_ms / launches, 4), "launches_per_step": launches,
                     "frames_per_launch": min(n, chunk),
-                    "timing": "HIP events on the library's stream, " + ("timed steps" if timed_with_events else "one extra untimed step on rank 0 (N > 1)")}
+                    "timing": "HIP events on the library's stream, " + ("%d one-stream steps right behind the timed region (the timed steps run the halves of a "
+                                                                             "chunk on two streams, where an event pair would time the neighbour's kernels too)" % args.steps
+                                                                             if timed_with_events else "one extra untimed step on rank 0 (N > 1)")}
         out = {"metric": "frames/sec detect() %dx%d" % (COLS, ROWS), "value": round(n_total * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
@@ -703,7 +714,12 @@ def main():
                                       % (n_total, world, args.markers, "true" if subpix else "false"),
                           "frames_per_step": n_total, "frames_per_gpu": n, "chunk": chunk, "parallelism": "frames sharded, dp%d" % world,
                           "gather": gather_impl,
-                          "pipelining": ("steps alternate between %d handles (streams)" % len(dets)) if len(dets) > 1 else "one handle, one stream"},
+                          "pipelining": ("steps alternate between %d handles (streams)" % len(dets)) if len(dets) > 1 else
+                          "one handle; the library runs the two halves of a chunk on two internal streams (CTAG_OPT_STREAMS = 2, its default)"},
+               "one_stream": None if single_stream_dt is None else {
+                   "value": round(n_total * args.steps / single_stream_dt, 2), "unit": "frames/s", "ms_per_step": round(single_stream_dt / args.steps * 1e3, 3),
+                   "note": "the same steps with CTAG_OPT_TIMING on (one stream, per-kernel HIP events read back every step): the steps `stage_ms_per_step` and "
+                           "`roofline` are measured on"},
                "roofline": roofline,
                "issue_roofline": issue_rooflines(stage_ms, n),
                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},

@@ -50,6 +50,13 @@ struct ctag_handle {
         size_t n0_frames = 0;
     };
     WsSlot batch, big;
+    // CTAG_OPT_STREAMS = 2 (default): a chunk of a device-memory batch runs as two halves on two streams (`stream` + `stream2`, workspaces
+    // `batch` + `batch2`), so that the tail of one half's kernels -- a few long boundary / Welsch blocks -- overlaps the other half's next
+    // kernel.  stream2 forks from `stream` at the head of a call and joins it at the end: callers still order against `stream` alone.
+    WsSlot batch2;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    int streams = 2;
     const Workspace* last_ws = nullptr;  // whichever ran last (handle_view)
     bool last_fused = false;  // the last chunk took the fused sweep: its workspace holds the threshold mask, not the half-size image
     const uint8_t* last_frames = nullptr;  // ... and the frames it read (the test kit decimates them again for CTAG_DBG_HALF)
@@ -249,6 +256,7 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
             S.ws.refine_n0 = S.n0_buf;
             return CTAG_OK;
         }
+        if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
         HIP_TRY(hipStreamSynchronize(h->stream));
         drop_graphs(h);
         if (S.n0_buf) HIP_TRY(hipFree(S.n0_buf));
@@ -265,6 +273,7 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
         return ensure_n0();
     }
     if (S.ws.base) {
+        if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
         HIP_TRY(hipStreamSynchronize(h->stream));
         drop_graphs(h);  // they hold pointers into the old workspace
         HIP_TRY(hipFree(S.ws.base));
@@ -293,7 +302,7 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
     };
     const size_t o_half = take(F * g.hrows * g.hp + 256);
     const size_t o_labels = take(F * g.hrows * g.lp * 2 + 256);
-    const size_t o_tbase = take(F * tiles * 4);
+    const size_t o_tbase = take(F * tiles * 4), o_tdirty = take(F * tiles * 4);
     const size_t o_ncomp = take(F * 4);
     const size_t o_flags = take(F * 4);
     const size_t o_ovfc = take(256);
@@ -330,6 +339,11 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
     W.half = reinterpret_cast<uint8_t*>(b + o_half);
     W.labels = reinterpret_cast<uint16_t*>(b + o_labels);
     W.tile_base = reinterpret_cast<int32_t*>(b + o_tbase);
+    W.tile_dirty = reinterpret_cast<int32_t*>(b + o_tdirty);
+    // the label image's invariant: a tile whose tile_dirty is 0 holds zeros
+    HIP_TRY(hipMemsetAsync(W.labels, 0, F * g.hrows * g.lp * 2 + 256, h->stream));
+    HIP_TRY(hipMemsetAsync(W.tile_dirty, 0, F * tiles * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(W.tile_base, 0, F * tiles * 4, h->stream));  // the fused sweep leaves the entries of tiles without foreground alone: they must stay valid offsets
     W.frame_ncomp = reinterpret_cast<int32_t*>(b + o_ncomp);
     W.frame_flags = reinterpret_cast<uint32_t*>(b + o_flags);
     W.ovf_count = reinterpret_cast<int32_t*>(b + o_ovfc);
@@ -403,8 +417,8 @@ static int check_args(ctag_handle* h, const void* frames, int n, int rows, int c
 
 // enqueue the whole pipeline for `n` device-resident frames (n <= workspace capacity); evs: CTAG_NUM_STAGES + 1 timing events or null
 static int enqueue_chunk(ctag_handle* h, const Workspace& ws, const uint8_t* frames_dev, int n, ptrdiff_t row_stride, ptrdiff_t frame_stride,
-                         const DetectParams& p, ctag_frame_result* out_dev, hipEvent_t* evs, const PendingCtx& pend) {
-    hipStream_t s = h->stream;
+                         const DetectParams& p, ctag_frame_result* out_dev, hipEvent_t* evs, const PendingCtx& pend, hipStream_t s = nullptr) {
+    if (!s) s = h->stream;
     h->last_ws = &ws;
     h->last_out = out_dev;
     h->last_frames = frames_dev;
@@ -585,10 +599,41 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
     const int chunk = std::min(n, h->max_chunk);
+    DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
+    static const int two_min = getenv("CTAG_STREAMS_MIN") ? std::max(2 * kLatencyFrames + 2, atoi(getenv("CTAG_STREAMS_MIN"))) : 256;
+    if (h->streams >= 2 && !h->timing && chunk >= two_min && h->stream2) {
+        // two halves of every chunk side by side (see WsSlot batch2).  With CTAG_OPT_TIMING the chunk stays on one stream: the HIP events
+        // around a kernel would otherwise time the other stream's kernels as well.
+        const int piece = (chunk + 1) / 2;
+        ctag_handle::WsSlot* slot[2] = {&h->batch, &h->batch2};
+        for (int k = 0; k < 2; k++) {
+            const int wr = ensure_workspace(h, *slot[k], rows, cols, adaptive_thresh, std::max(piece, slot[k]->rows == rows && slot[k]->cols == cols ? slot[k]->cap : 0),
+                                            false, corner_subpix != 0);
+            if (wr != CTAG_OK) return wr;
+        }
+        HIP_TRY(hipEventRecord(h->ev_fork2, h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork2, 0));
+        int k = 0;
+        for (int f0 = 0; f0 < n; f0 += piece, k ^= 1) {
+            const int m = std::min(piece, n - f0);
+            PendingCtx pc{};
+            if (pend) {
+                pc = *pend;
+                pc.src = pend->src + (ptrdiff_t)f0 * pend->frame_stride;
+                h->pending_dirty = true;
+            }
+            h->last_chunk_frames = m;
+            const int r = enqueue_chunk(h, slot[k]->ws, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0, nullptr, pc,
+                                        k ? h->stream2 : h->stream);
+            if (r != CTAG_OK) return r;
+        }
+        HIP_TRY(hipEventRecord(h->ev_join2, h->stream2));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join2, 0));
+        return CTAG_OK;
+    }
     const int wr = ensure_workspace(h, h->batch, rows, cols, adaptive_thresh, std::max(chunk, h->batch.rows == rows && h->batch.cols == cols ? h->batch.cap : 0),
                                     false, corner_subpix != 0 && chunk > kLatencyFrames);
     if (wr != CTAG_OK) return wr;
-    DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int m = std::min(chunk, n - f0);
         PendingCtx pc{};
@@ -881,6 +926,9 @@ int ctag_create_ex(const int32_t* state, int dict_rows, int dict_cols, int featu
     bool ok = hipSetDevice(device_id) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_dict), h->dict.size() * 4) == hipSuccess;
@@ -921,7 +969,10 @@ void ctag_destroy(ctag_handle* h) {
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
-    for (ctag_handle::WsSlot* S : {&h->batch, &h->big}) {
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
+    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
+    for (ctag_handle::WsSlot* S : {&h->batch, &h->batch2, &h->big}) {
         if (S->ws.base) (void)hipFree(S->ws.base);
         if (S->n0_buf) (void)hipFree(S->n0_buf);
     }
@@ -949,6 +1000,7 @@ void ctag_destroy(ctag_handle* h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -997,6 +1049,10 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
             if (value < 0 || value > 0x7fffffff) return CTAG_ERR_ARG;
             h->wave_points = (int)value;
             drop_graphs(h);  // a captured chain holds the old value
+            return CTAG_OK;
+        case CTAG_OPT_STREAMS:
+            if (value < 1 || value > 2) return CTAG_ERR_ARG;
+            h->streams = (int)value;
             return CTAG_OK;
         case CTAG_OPT_FUSED_SWEEP:
             if (value < 0 || value > 2) return CTAG_ERR_ARG;
@@ -1070,6 +1126,7 @@ int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, i
 // every reallocation of the staging slabs (an upload still running on copy_stream must not lose its destination)
 static int quiesce(ctag_handle* h) {
     if (h->copy_stream) HIP_TRY(hipStreamSynchronize(h->copy_stream));
+    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
     if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));  // side branch of few-frame calls
     HIP_TRY(hipStreamSynchronize(h->stream));
     return CTAG_OK;

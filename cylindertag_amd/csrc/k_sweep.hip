@@ -411,6 +411,8 @@ struct SweepPtrs {
     const uint8_t* mask;   // k_decimate_mask's 1 bit per half-resolution pixel, rows of hcols / 8 bytes (the fused sweep: `half` is not written then)
     uint16_t* labels;
     int32_t* tile_base;
+    int32_t* tile_dirty;   // [F][tiles] 1: the tile's label pixels are not all zero.  The label image starts out zeroed and a tile without foreground
+                           // whose labels are zero already is not written again: background is most of a frame, and its 2 bytes per pixel were most of K2's traffic
     int32_t* frame_ncomp;
     uint32_t* frame_flags;
     uint32_t* parent;
@@ -435,7 +437,7 @@ struct SweepPtrs {
     size_t pool_stride;    // bytes between consecutive pool arrays (parent, root_of, area, xmin, ymin, xmax, ymax, key, pool_tile, member_head, member_next)
 };
 static SweepPtrs sweep_ptrs(const Workspace& ws) {
-    return SweepPtrs{ws.half, ws.half, ws.labels, ws.tile_base, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
+    return SweepPtrs{ws.half, ws.half, ws.labels, ws.tile_base, ws.tile_dirty, ws.frame_ncomp, ws.frame_flags, ws.parent, ws.root_of,
                      ws.area, ws.xmin, ws.ymin, ws.xmax, ws.ymax, ws.key, ws.pool_tile, ws.member_head, ws.member_next, ws.ncand, ws.nroots, ws.cand, ws.cand_cap,
                      reinterpret_cast<int2*>(ws.cand_aux), ws.ovf_count, ws.ovf_list, nullptr,
                      (size_t)(reinterpret_cast<const char*>(ws.root_of) - reinterpret_cast<const char*>(ws.parent))};
@@ -706,17 +708,17 @@ __device__ __forceinline__ void hpass_fuse(const Raw32& r, int lane, bool left_e
     t.right2 = right2;
     hpass_wide(t, q);
 }
-template <int BAND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_decimate_mask(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
+template <int BAND, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_decimate_mask(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
                                                                                                     uint8_t* __restrict__ mask, FrameGeom g, KParams kp, int nframes, int xblocks,
                                                                                                     int yblocks) {
     static_assert(BAND % 5 == 0, "a band is whole threshold-tile rows");
-    __shared__ FuseLds S4[4];
+    __shared__ FuseLds S4[WAVES];
     int frame, idx;
     if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
     const int bx = idx % xblocks, by = idx / xblocks;
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
-    const int band = by * 4 + wy;
+    const int band = by * WAVES + wy;
     const int y_begin = band * BAND;
     if (y_begin >= g.hrows) return;  // wave-uniform
     FuseLds& S = S4[wy];
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int mpitch = g.hcols >> 3;
     uint8_t* __restrict__ mrow0 = mask + (size_t)frame * g.hrows * mpitch + (X0 >> 3) + 2 * lane;
     const int rmax = g.rows - 1;
-    auto rowp = [&](int r) { return src + (ptrdiff_t)min(max(r, 0), rmax) * row_stride; };
+    auto rowp = [&](int r) __attribute__((always_inline)) { return src + (ptrdiff_t)min(max(r, 0), rmax) * row_stride; };
     // the lane's 16 pixels lie in the tiles j0 .. j0 + 3 of the span; sel[k] picks, for pixels 4k .. 4k + 3, their tile's byte of a packed word
     const int j0 = (16 * lane) / 5;
     uint32_t sel[4];
@@ -751,8 +753,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     int rit = 0, slot = ys % 10;
     // one wave, LDS only: its accesses are served in order, so a wait for LDS (NOT for the source rows in flight) orders them
-    auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    auto tile_row_done = [&](int gt) {  // the five rows of threshold-tile row gt are in the ring, their column extrema in registers
+    auto wave_sync = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto tile_row_done = [&](int gt) __attribute__((always_inline)) {  // the five rows of threshold-tile row gt are in the ring, their column extrema in registers
         if (active) {
             const uint4 mn = make_uint4(mnE[0] | (mnO[0] << 8), mnE[1] | (mnO[1] << 8), mnE[2] | (mnO[2] << 8), mnE[3] | (mnO[3] << 8));
             const uint4 mx = make_uint4(mxE[0] | (mxO[0] << 8), mxE[1] | (mxO[1] << 8), mxE[2] | (mxO[2] << 8), mxE[3] | (mxO[3] << 8));
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         wave_sync();
     };
-    auto emit_tile_row = [&](int e) {  // tile row e's pixels are in the ring and the tile extrema of rows e - 1, e, e + 1 (as far as they exist) in `ext`
+    auto emit_tile_row = [&](int e) __attribute__((always_inline)) {  // tile row e's pixels are in the ring and the tile extrema of rows e - 1, e, e + 1 (as far as they exist) in `ext`
         if (e < e_lo || e >= e_hi) return;  // wave-uniform
         const int ra = (e + 2) % 3, rb = e % 3, rc = (e + 1) % 3;  // rows e - 1, e, e + 1 of the ring
 #pragma unroll
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         // (the ring slots just read are overwritten two tile rows from now; LDS serves a wave's accesses in order)
     };
-    auto row_done = [&](int y, const uint32_t (&o)[4]) {
+    auto row_done = [&](int y, const uint32_t (&o)[4]) __attribute__((always_inline)) {
         if (lane < kFuseLanes) S.ring[slot][lane] = make_uint4(o[0], o[1], o[2], o[3]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     };
     uint32_t qa[8], qb[8], qc[8], qd[8];
-    auto hp = [&](const Raw32& r, uint32_t (&q)[8]) { hpass_fuse(r, lane, left_edge, right_edge, q); };
+    auto hp = [&](const Raw32& r, uint32_t (&q)[8]) __attribute__((always_inline)) { hpass_fuse(r, lane, left_edge, right_edge, q); };
     {
         const Raw32 ra = load_row_fuse(rowp(2 * ys - 1), x0);
         const Raw32 rb = load_row_fuse(rowp(2 * ys), x0);
@@ -856,7 +858,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         hp(rc, qc);
         hp(rd, qd);
     }
-    auto emit = [&](int y, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
+    auto emit = [&](int y, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) __attribute__((always_inline)) {
         uint32_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) o[k] = vpack4(vpass2(a[2 * k], b[2 * k], c[2 * k], d[2 * k], 0), vpass2(a[2 * k + 1], b[2 * k + 1], c[2 * k + 1], d[2 * k + 1], 0));
@@ -887,8 +889,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s) {
     const FrameGeom& g = ws.g;
-    const int xb = g.hcols / kFuseCols, yblocks = g.hrows / 135 / 4;
-    hipLaunchKernelGGL((k_decimate_mask<135>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+    const int xb = g.hcols / kFuseCols;
+    static const int band_env = getenv("CTAG_FUSE_BAND") ? atoi(getenv("CTAG_FUSE_BAND")) : 135;  // developer aid (A/B): 270-row bands in two-wave blocks
+    if (band_env == 270 && g.hrows % 540 == 0) {
+        const int yblocks = g.hrows / 270 / 2;
+        hipLaunchKernelGGL((k_decimate_mask<270, 2>), dim3(grid_for(nframes, xb * yblocks)), dim3(128), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+    } else {
+        const int yblocks = g.hrows / 135 / 4;
+        hipLaunchKernelGGL((k_decimate_mask<135, 4>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+    }
     return hipGetLastError();
 }
 
@@ -939,14 +948,21 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     (void)py0;
     (void)lx0;
     // a tile without foreground: its labels are zero and it owns no component -- exactly what the phases below would produce
+    int32_t* const dirty_p = P.tile_dirty + (size_t)frame * g.tiles_x * g.tiles_y + tile;
+    const int was_dirty = *dirty_p;  // requested with the tile's first loads; block-uniform
     auto empty_tile = [&]() {
-        uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
-        constexpr int groups = kTileW / 8;
-        for (int i = tid; i < kTileH * groups; i += kCclThreads) {
-            const int r = i / groups, gq = i - r * groups;
-            if (r < th_eff && gq * 8 < tw_eff) *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(0u, 0u, 0u, 0u);
+        if (was_dirty) {  // left over from the frame this slot held before: back to zeros
+            uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+            constexpr int groups = kTileW / 8;
+            for (int i = tid; i < kTileH * groups; i += kCclThreads) {
+                const int r = i / groups, gq = i - r * groups;
+                if (r < th_eff && gq * 8 < tw_eff) *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
-        if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
+        if (tid == 0) {
+            P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = 0;
+            if (was_dirty) *dirty_p = 0;
+        }
     };
   if constexpr (MASKIN) {
     // ---- the fused sweep: k_decimate_mask thresholded the pixels where they were computed; the row masks arrive as 64-bit words
@@ -1423,7 +1439,10 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
         hand_over();
         return;
     }
-    if (tid == 0) P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
+    if (tid == 0) {
+        P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
+        if (!was_dirty) *dirty_p = 1;  // S11 wrote labels
+    }
     {
         const size_t pool0 = (size_t)frame * g.pool_cap;
         for (int i = tid; i < nslots; i += kCclThreads) {
@@ -1517,6 +1536,9 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s,
     };
     static size_t have_big5[64] = {0}, have_big0[64] = {0}, have_0[64] = {0}, have_big5m[64] = {0};
     if (fused) {
+        // (measured and not kept: K2 over work lists of the tiles with foreground, flagged by k_decimate_mask -- as looping blocks 1.33-1.55 ms, as a
+        // block per list entry 1.36 ms per 4096 frames against 1.25 ms for a block per tile: the blocks of background tiles load, look and leave in the
+        // shadow of their neighbours' label phases, while the lists cost two more dependent loads per tile and 0.1 ms of atomics in K1)
         hipLaunchKernelGGL((k_threshold_ccl<5, true>), dim3(grid), dim3(kCclThreads), lds, s, P, g, ws.kp, nframes);
         want_lds(reinterpret_cast<const void*>(k_threshold_ccl_big<5, true>), lds_big, have_big5m);
         hipLaunchKernelGGL((k_threshold_ccl_big<5, true>), dim3(grid_big), dim3(kCclThreads), lds_big, s, P, g, ws.kp);

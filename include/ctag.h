@@ -111,6 +111,10 @@ void* ctag_stream(ctag_handle* h);
 #define CTAG_OPT_WAVE_POINTS 6     /* components whose boundary can hold more than this many points get a wave of their own instead of 8 lanes of a
                                       shared one (the longest boundary decides how long a one-frame call takes); 0 = automatic: 96 for calls of
                                       up to 4 frames, never for batches.  Results do not depend on it. */
+#define CTAG_OPT_STREAMS 8         /* 2 (default): a chunk of >= 256 frames of a device-memory call runs as two halves on two internal streams and workspaces -- the
+                                      tail of one half's kernels overlaps the other half's next kernel; the second stream forks from and joins the handle's stream
+                                      inside the call, so callers order against ctag_stream() as before.  1: one stream.  A call with CTAG_OPT_TIMING on
+                                      always uses one stream (the per-kernel events would time the neighbour's kernels too).  Results do not depend on it. */
 #define CTAG_OPT_FUSED_SWEEP 7     /* the threshold + label sweep as k_decimate_mask -> k_threshold_ccl (thresholds where the half-size pixels are computed, hands
                                       1 bit per pixel on; frames whose half size is a multiple of 960 x 135 -- 1080p, 4K, 8K -- with adaptiveThresh 5):
                                       0 never, 1 (default) batches of 512 frames' worth of bands and more, 2 whenever the frame size allows.  Results do not depend on it. */
