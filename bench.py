@@ -55,6 +55,9 @@ def parse_args():
                     help="frames of the detect()+estimatePose side measurement on camera content, 0 = skip; never `value`")
     ap.add_argument("--size", default="1920x1080", help="frame size WxH; the headline metric is 1920x1080 (other sizes are side measurements)")
     ap.add_argument("--no-subpix", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="CTAG_OPT_STREAMS of the timed steps: 2 (the library's default) runs the halves of a chunk on two internal streams; 1 for profiler runs "
+                         "(every launch then covers a whole chunk)")
     ap.add_argument("--latency-calls", type=int, default=200, help="single-frame ctag_detect_u8 calls of the latency side measurement, 0 = skip")
     ap.add_argument("--pipelined-steps", type=int, default=6, help="steps of the two-handle side measurement at N = 1, 0 = skip")
     ap.add_argument("--allow-torch-gather", action="store_true",
@@ -295,7 +298,7 @@ def pose_side_3d(det, state, m, dev, frames_cap):
 
 
 ISSUE_KERNELS = {"edge_refine": "ctag::k_edge_refine", "welsch": "ctag::k_welsch", "quad_edges": "ctag::k_quad_edges_packed",
-                 "threshold_ccl": "ctag::k_threshold_ccl<5>"}
+                 "threshold_ccl": "ctag::k_threshold_ccl<5"}
 
 
 def issue_rooflines(stage_ms, n_frames):
@@ -313,7 +316,7 @@ def issue_rooflines(stage_ms, n_frames):
     out = {"source": "instruction counts replayed from %s (rocprofv3 --pmc, 1024-frame pass); times from this run's HIP events" % os.path.relpath(cands[-1], ROOT),
            "model": "issue_bound_ms = sum over instruction classes of count * measured SIMD cycles per wave-instruction (2.1 f32 add/mul and simple int, 4.2 others incl. FP64, 8.2 / 16.1 transcendental; int32 at 3.15) / (1024 SIMDs * 2.4 GHz); profiles/r03_valu_issue_cost.txt", "kernels": {}}
     for stage, kname in ISSUE_KERNELS.items():
-        hits = [v for k, v in prof["kernels"].items() if k == kname or k.startswith(kname + "<")]  # template arguments vary; several builds of a kernel
+        hits = [v for k, v in prof["kernels"].items() if k == kname or k.startswith(kname + "<") or (kname.endswith("<5") and k.startswith(kname))]  # template arguments vary; several builds of a kernel
         if stage == "quad_edges":  # the packed build runs as two kernels (boundary, edge clusters): both belong to the stage
             hits = [v for k, v in prof["kernels"].items() if k.startswith(kname + "<8,")]
             work = hits
@@ -487,6 +490,7 @@ def main():
 
     state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
     det = tk.Detector(state, fs, device=dev_index)
+    det.set_option(capi.OPT_STREAMS, args.streams)
     subpix = not args.no_subpix
 
     # ---- the job: n_total frames per step; this rank owns frames [lo, hi) of it
@@ -715,7 +719,8 @@ def main():
                           "frames_per_step": n_total, "frames_per_gpu": n, "chunk": chunk, "parallelism": "frames sharded, dp%d" % world,
                           "gather": gather_impl,
                           "pipelining": ("steps alternate between %d handles (streams)" % len(dets)) if len(dets) > 1 else
-                          "one handle; the library runs the two halves of a chunk on two internal streams (CTAG_OPT_STREAMS = 2, its default)"},
+                          ("one handle; the library runs the two halves of a chunk on two internal streams (CTAG_OPT_STREAMS = 2, its default)" if args.streams == 2 else
+                           "one handle, one stream (--streams 1)")},
                "one_stream": None if single_stream_dt is None else {
                    "value": round(n_total * args.steps / single_stream_dt, 2), "unit": "frames/s", "ms_per_step": round(single_stream_dt / args.steps * 1e3, 3),
                    "note": "the same steps with CTAG_OPT_TIMING on (one stream, per-kernel HIP events read back every step): the steps `stage_ms_per_step` and "

@@ -17,7 +17,7 @@ def main(fetch_dir, write_dir, frames_per_launch, tag):
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     detail, total = {}, 0.0
     for k in SWEEP:
-        base = lambda name: name.split("(")[0].split("<")[0].replace("void ", "").replace("ctag::", "").replace("k_decimate_wide", "k_decimate")  # noqa: E731  (k_threshold_ccl, not ..._big; both builds of K1)
+        base = lambda name: name.split("(")[0].split("<")[0].replace("void ", "").replace("ctag::", "").replace("k_decimate_wide", "k_decimate").replace("k_decimate_mask", "k_decimate")  # noqa: E731  (k_threshold_ccl, not ..._big; both builds of K1)
         fk = [v for name, vals in fe.items() if base(name) == k for v in vals]
         wk = [v for name, vals in wr.items() if base(name) == k for v in vals]
         if not fk or not wk:

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 bash tools/pmc_instmix.sh ${TAG} > gpurun_out/instmix.log 2>&1; tail -3 gpurun_out/instmix.log
 cp profiles/${TAG}_pmc_instmix.json gpurun_out/${TAG}_pmc_instmix.json
 rm -rf gpurun_out/ks gpurun_out/ksl
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 bench.py --cpu-frames 0 --host-frames 0 --pose-frames 0 --latency-calls 0 > gpurun_out/ks_bench.log 2>&1; tail -1 gpurun_out/ks_bench.log | cut -c1-200
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 bench.py --streams 1 --pipelined-steps 0 --cpu-frames 0 --host-frames 0 --pose-frames 0 --latency-calls 0 > gpurun_out/ks_bench.log 2>&1; tail -1 gpurun_out/ks_bench.log | cut -c1-200
 find gpurun_out/ks -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_kernel_stats_bench4096.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ksl -- python3 tools/latency.py > gpurun_out/ksl.log 2>&1; tail -3 gpurun_out/ksl.log
 find gpurun_out/ksl -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_latency_kernel_stats.csv
