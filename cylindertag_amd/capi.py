@@ -19,11 +19,11 @@ STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates
                "line_sort", "welsch", "quad_final", "features", "edge_refine", "markers"]
 QUAD_STAGES = ["quad_pack", "quad_edges", "quad_edges_big", "line_sort", "welsch", "quad_final"]  # a4: edgeExtraction
 
-OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OPT_WAVE_POINTS, OPT_FUSED_SWEEP, OPT_STREAMS = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OPT_WAVE_POINTS, OPT_FUSED_SWEEP, OPT_STREAMS, OPT_EXPAND_EXACT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)
 EXPORTS = ["ctag_create", "ctag_create_ex", "ctag_params_default", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",
-           "ctag_detect_batch_device", "ctag_detect_bgr8", "ctag_detect_batch_bgr8", "ctag_detect_batch_bgr8_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings", "ctag_get_counters",
+           "ctag_detect_batch_device", "ctag_detect_bgr8", "ctag_detect_batch_bgr8", "ctag_detect_batch_bgr8_device", "ctag_host_alloc", "ctag_host_free", "ctag_sync", "ctag_stream", "ctag_set_option", "ctag_get_timings", "ctag_get_counters", "ctag_submit_u8", "ctag_collect",
            "ctag_stage_name", "ctag_strerror", "ctag_version"]
 # ... and include/ctag_pose.h
 POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag_model_get_view", "ctag_camera_load",
@@ -140,6 +140,10 @@ def load_library():
     L.ctag_stream.argtypes = [vp]
     L.ctag_set_option.restype = C.c_int
     L.ctag_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.ctag_submit_u8.restype = C.c_int
+    L.ctag_submit_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+    L.ctag_collect.restype = C.c_int
+    L.ctag_collect.argtypes = [vp, vp]
     L.ctag_get_counters.restype = C.c_int
     L.ctag_get_counters.argtypes = [vp, C.POINTER(CountersC)]
     L.ctag_get_timings.restype = C.c_int
@@ -374,6 +378,21 @@ class Detector:
                                    adaptive_thresh, int(subpix), subpix_dist, res.ctypes.data)
         if st < 0:
             raise CtagError(st, "ctag_detect_u8")
+        return res[0]
+
+    def submit(self, gray, adaptive_thresh=5, subpix=True, subpix_dist=5):
+        """ctag_submit_u8: start one frame without waiting (at most two in flight); `gray` must stay alive until its collect()."""
+        assert gray.dtype == np.uint8 and gray.ndim == 2 and gray.strides[1] == 1
+        st = self.L.ctag_submit_u8(self.h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0], adaptive_thresh, int(subpix), subpix_dist)
+        if st != 0:
+            raise CtagError(st, "ctag_submit_u8")
+
+    def collect(self, out=None):
+        """ctag_collect: the record of the oldest submitted frame."""
+        res = np.zeros(1, RESULT_DT) if out is None else out
+        st = self.L.ctag_collect(self.h, res.ctypes.data)
+        if st < 0:
+            raise CtagError(st, "ctag_collect")
         return res[0]
 
     def detect_batch(self, frames, adaptive_thresh=5, subpix=True, subpix_dist=5, out=None):

@@ -73,6 +73,21 @@ struct ctag_handle {
     size_t d_big_gray_bytes = 0;
     ctag_frame_result* d_big_result = nullptr;
     int reruns = 0;                  // frames completed through the any-frame workspace so far (ctag_get_counters)
+    // ctag_submit_u8 / ctag_collect: frames in flight, one per call (a camera loop, main.cpp:44-61).  Slot k: a device slab for the frame (filled on
+    // copy_stream), a device record and its pinned host copy; `up` = upload done, `done` = record downloaded
+    struct AsyncSlot {
+        uint8_t* d_frame = nullptr;
+        size_t d_bytes = 0;
+        ctag_frame_result* d_res = nullptr;
+        ctag_frame_result* h_res = nullptr;
+        hipEvent_t up = nullptr, done = nullptr;
+        const uint8_t* host = nullptr;  // the caller's frame (valid until its ctag_collect: a pending frame is uploaded again from it)
+        int rows = 0, cols = 0, ch = 1, tw = 0, subpix = 0, dist = 0;
+        ptrdiff_t row_stride = 0;
+    };
+    static constexpr int kAsyncDepth = 2;
+    AsyncSlot aslot[kAsyncDepth];
+    int a_head = 0, a_count = 0;     // oldest slot in flight, slots in flight
     int max_chunk = 1024;
     int wave_points = 0;  // CTAG_OPT_WAVE_POINTS
     int fuse_mode = -1;   // CTAG_OPT_FUSED_SWEEP
@@ -870,6 +885,7 @@ static bool derive_kparams(const ctag_params& p, KParams* k) {
         if (!ok(p.ID_cr_correspond[j]) || !(p.cr_covariance_left[j] >= 0) || !(p.cr_covariance_right[j] >= 0)) return false;
     k->thr_line = p.threshold_line;
     k->thr_expand = p.threshold_expand;
+    k->expand_eps = 3.0e-6f;
     k->rac = p.threshold_RAC;
     k->angle = p.threshold_angle;
     k->vertical = p.threshold_vertical;
@@ -981,6 +997,13 @@ void ctag_destroy(ctag_handle* h) {
     if (h->d_big_frame) (void)hipFree(h->d_big_frame);
     if (h->d_big_gray) (void)hipFree(h->d_big_gray);
     if (h->d_big_result) (void)hipFree(h->d_big_result);
+    for (auto& A : h->aslot) {
+        if (A.d_frame) (void)hipFree(A.d_frame);
+        if (A.d_res) (void)hipFree(A.d_res);
+        if (A.h_res) (void)hipHostFree(A.h_res);
+        if (A.up) (void)hipEventDestroy(A.up);
+        if (A.done) (void)hipEventDestroy(A.done);
+    }
     if (h->d_dict) (void)hipFree(h->d_dict);
     if (h->d_thr_table) (void)hipFree(h->d_thr_table);
     if (h->d_dict_pos) (void)hipFree(h->d_dict_pos);
@@ -1049,6 +1072,10 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
             if (value < 0 || value > 0x7fffffff) return CTAG_ERR_ARG;
             h->wave_points = (int)value;
             drop_graphs(h);  // a captured chain holds the old value
+            return CTAG_OK;
+        case CTAG_OPT_EXPAND_EXACT:
+            h->kp.expand_eps = value ? INFINITY : 3.0e-6f;
+            drop_graphs(h);
             return CTAG_OK;
         case CTAG_OPT_STREAMS:
             if (value < 1 || value > 2) return CTAG_ERR_ARG;
@@ -1230,6 +1257,75 @@ int ctag_detect_batch_u8(ctag_handle* h, const uint8_t* frames, int n, int rows,
         return r;
     }
     return collect_timings(h);
+}
+
+// ---- one frame per call, not waited for (include/ctag.h) ----------------------------------------------------------------------------
+int ctag_submit_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int corner_subpix, int subpix_dist) {
+    if (!h) return CTAG_ERR_ARG;
+    h->last_error[0] = 0;
+    const int rc = check_args(h, gray, 1, rows, cols, row_stride, adaptive_thresh, subpix_dist);
+    if (rc != CTAG_OK) return rc;
+    if (h->a_count >= ctag_handle::kAsyncDepth) return CTAG_ERR_ARG;  // collect first
+    HIP_TRY(hipSetDevice(h->device));
+    ctag_handle::AsyncSlot& A = h->aslot[(h->a_head + h->a_count) % ctag_handle::kAsyncDepth];
+    const ptrdiff_t dstride = ((ptrdiff_t)cols + 15) & ~(ptrdiff_t)15;
+    const size_t need = (size_t)dstride * rows;
+    if (!h->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
+        }
+    }
+    if (!A.up) {
+        HIP_TRY(hipEventCreateWithFlags(&A.up, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&A.done, hipEventDisableTiming));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&A.d_res), sizeof(ctag_frame_result)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&A.h_res), sizeof(ctag_frame_result), hipHostMallocDefault));
+    }
+    if (A.d_bytes < need) {  // the slot is free: nothing reads its slab
+        drop_graphs(h);      // ... but a captured chain may hold its address
+        if (A.d_frame) HIP_TRY(hipFree(A.d_frame));
+        A.d_frame = nullptr;
+        A.d_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&A.d_frame), need));
+        A.d_bytes = need;
+    }
+    A.host = gray, A.rows = rows, A.cols = cols, A.ch = 1, A.row_stride = row_stride, A.tw = adaptive_thresh, A.subpix = corner_subpix, A.dist = subpix_dist;
+    // the upload runs on the copy stream while the previous frame's kernels run on the compute stream (the slab's previous reader finished before its
+    // ctag_collect returned); the detection waits for it; the record comes back into pinned memory behind the detection
+    HIP_TRY(hipMemcpy2DAsync(A.d_frame, dstride, gray, row_stride, (size_t)cols, rows, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipEventRecord(A.up, h->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, A.up, 0));
+    h->last_was_bgr = false;
+    begin_timings(h);
+    const int r = detect_device_impl(h, A.d_frame, 1, rows, cols, dstride, (ptrdiff_t)need, adaptive_thresh, corner_subpix, subpix_dist, A.d_res, nullptr);
+    h->ev_sets_used = 0;
+    if (r != CTAG_OK) {
+        (void)quiesce(h);
+        return r;
+    }
+    HIP_TRY(hipMemcpyAsync(A.h_res, A.d_res, sizeof(ctag_frame_result), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(A.done, h->stream));
+    h->a_count++;
+    return CTAG_OK;
+}
+
+int ctag_collect(ctag_handle* h, ctag_frame_result* out) {
+    if (!h || !out) return CTAG_ERR_ARG;
+    h->last_error[0] = 0;
+    if (h->a_count <= 0) return CTAG_ERR_ARG;  // nothing in flight
+    HIP_TRY(hipSetDevice(h->device));
+    ctag_handle::AsyncSlot& A = h->aslot[h->a_head];
+    HIP_TRY(hipEventSynchronize(A.done));
+    h->a_head = (h->a_head + 1) % ctag_handle::kAsyncDepth;
+    h->a_count--;
+    *out = *A.h_res;
+    if (out->status == CTAG_PENDING) {  // needs the any-frame workspace: from the caller's frame, like every host-memory call
+        const int r = rerun_host_frames(h, A.host, 1, A.rows, A.cols, A.row_stride, 0, A.ch, A.tw, A.subpix, A.dist, out);
+        if (r != CTAG_OK) return r;
+    }
+    return out->status;
 }
 
 void* ctag_host_alloc(size_t bytes) {

@@ -92,13 +92,13 @@ struct GatherState {
     char err[256] = {0};
 };
 
-void order_forget(ncclComm_t c);  // below
+void order_unref(ncclComm_t c, bool wait_for_last);  // below
 
 void gather_state_free(void* p) {
     GatherState* g = static_cast<GatherState*>(p);
     (void)hipSetDevice(g->device);
     if (g->gstream) (void)hipStreamSynchronize(g->gstream);
-    if (g->comm && g->own_comm) order_forget(g->comm);
+    if (g->comm) order_unref(g->comm, g->own_comm);
     if (g->comm && g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
     if (g->d_packed) (void)hipFree(g->d_packed);
     if (g->d_gathered) (void)hipFree(g->d_gathered);
@@ -135,45 +135,61 @@ GatherState* gather_state(ctag_handle* h) {
 
 // Collectives of ONE communicator issued from several streams (two handles sharing it: ctag_comm_attach(b, ctag_comm_native(a), ..))
 // are ordered here explicitly, not left to the library: every collective waits for the event recorded behind the previous
-// collective of the same communicator, whatever stream that one went to.  Per process; a communicator has one entry.
+// collective of the same communicator, whatever stream that one went to.  Per process; a communicator has one entry, counted by the
+// handles that use it (its owner + the attached ones).  The lock is held from the wait to the record: two threads driving two handles
+// on one communicator cannot both wait for the same predecessor and then issue in either order (round-3 ADVICE).
 struct CommOrder {
     ncclComm_t comm;
-    hipEvent_t last;
+    hipEvent_t last;   // created when the entry is taken (on the device that is current then: a communicator lives on one device), destroyed with it
     bool has;
+    int refs;
 };
 CommOrder g_order[16];
 std::mutex g_order_mu;
-CommOrder* order_of(ncclComm_t c) {  // caller holds g_order_mu
+CommOrder* order_find(ncclComm_t c) {  // caller holds g_order_mu
     for (CommOrder& o : g_order)
         if (o.comm == c) return &o;
-    for (CommOrder& o : g_order)
-        if (!o.comm) {
-            if (!o.last && hipEventCreateWithFlags(&o.last, hipEventDisableTiming) != hipSuccess) return nullptr;
-            o.comm = c;
-            o.has = false;
-            return &o;
-        }
     return nullptr;
 }
-void order_forget(ncclComm_t c) {
+// a handle starts / stops using communicator c; false: the table is full (16 communicators per process)
+bool order_ref(ncclComm_t c) {
     std::lock_guard<std::mutex> lk(g_order_mu);
+    if (CommOrder* o = order_find(c)) {
+        o->refs++;
+        return true;
+    }
     for (CommOrder& o : g_order)
-        if (o.comm == c) {
-            o.comm = nullptr;
+        if (!o.comm) {
+            if (hipEventCreateWithFlags(&o.last, hipEventDisableTiming) != hipSuccess) return false;
+            o.comm = c;
             o.has = false;
+            o.refs = 1;
+            return true;
         }
+    return false;
 }
-// before a collective on `s`: wait for the previous one of this communicator; after it: publish this one
-hipError_t order_before(ncclComm_t c, hipStream_t s) {
+void order_unref(ncclComm_t c, bool wait_for_last) {
     std::lock_guard<std::mutex> lk(g_order_mu);
-    CommOrder* o = order_of(c);
-    if (o && o->has) return hipStreamWaitEvent(s, o->last, 0);
-    return hipSuccess;
+    CommOrder* o = order_find(c);
+    if (!o) return;
+    if (wait_for_last && o->has) (void)hipEventSynchronize(o->last);  // the owner is about to destroy the communicator: nothing issued on it may still run
+    if (--o->refs <= 0) {
+        if (o->last) (void)hipEventDestroy(o->last);
+        *o = CommOrder{};
+    }
 }
-hipError_t order_after(ncclComm_t c, hipStream_t s) {
+// one collective on `s`, ordered behind the previous one of this communicator and published for the next, under ONE lock
+template <class F>
+hipError_t ordered_collective(ncclComm_t c, hipStream_t s, F issue, ncclResult_t* nr) {
     std::lock_guard<std::mutex> lk(g_order_mu);
-    CommOrder* o = order_of(c);
-    if (!o) return hipSuccess;
+    CommOrder* o = order_find(c);
+    if (!o) return hipErrorInvalidValue;  // ctag_comm_init / _attach registers every communicator
+    if (o->has) {
+        const hipError_t e = hipStreamWaitEvent(s, o->last, 0);
+        if (e != hipSuccess) return e;
+    }
+    *nr = issue();
+    if (*nr != ncclSuccess) return hipSuccess;
     o->has = true;
     return hipEventRecord(o->last, s);
 }
@@ -442,7 +458,7 @@ int ctag_comm_destroy(ctag_handle* h) {
     if (g->comm) {
         (void)hipSetDevice(g->device);
         (void)hipStreamSynchronize(g->gstream);
-        if (g->own_comm) order_forget(g->comm);
+        order_unref(g->comm, g->own_comm);  // the owner waits for the communicator's last collective, whichever handle issued it
         if (g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
     }
     g->comm = nullptr;
@@ -468,6 +484,12 @@ int ctag_comm_init(ctag_handle* h, const void* id_bytes, int rank, int world) {
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
     G_NCCL(R->CommInitRank(&g->comm, world, id, rank));
+    if (!order_ref(g->comm)) {
+        (void)R->CommDestroy(g->comm);
+        g->comm = nullptr;
+        std::snprintf(g->err, sizeof(g->err), "more than 16 communicators in this process");
+        return CTAG_ERR_LIMIT;
+    }
     g->own_comm = true;
     g->rank = rank;
     g->world = world;
@@ -485,6 +507,13 @@ int ctag_comm_attach(ctag_handle* h, void* nccl_comm, int rank, int world) {
         return CTAG_ERR_HIP;
     }
     (void)ctag_comm_destroy(h);
+    G_HIP(hipSetDevice(g->device));
+    if (!order_ref(static_cast<ncclComm_t>(nccl_comm))) {
+        std::snprintf(g->err, sizeof(g->err), "more than 16 communicators in this process");
+        return CTAG_ERR_LIMIT;
+    }
+    // the communicator stays its owner's: the owner must outlive every collective issued through an attached handle (its ctag_comm_destroy /
+    // ctag_destroy waits for the last one issued, on any handle, before it destroys the communicator; nothing may be issued afterwards)
     g->comm = static_cast<ncclComm_t>(nccl_comm);
     g->own_comm = false;
     g->rank = rank;
@@ -543,9 +572,9 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
     G_HIP(hipEventRecord(g->ev_packed, g->gstream));
     G_HIP(hipStreamWaitEvent(main_s, g->ev_packed, 0));
     if (g->comm) {
-        G_HIP(order_before(g->comm, g->gstream));
-        G_NCCL(R->AllGather(g->d_sizes + g->rank, g->d_sizes, 1, ncclUint64, g->comm, g->gstream));
-        G_HIP(order_after(g->comm, g->gstream));
+        ncclResult_t nr = ncclSuccess;
+        G_HIP(ordered_collective(g->comm, g->gstream, [&] { return R->AllGather(g->d_sizes + g->rank, g->d_sizes, 1, ncclUint64, g->comm, g->gstream); }, &nr));
+        G_NCCL(nr);
     }
     G_HIP(hipMemcpyAsync(g->h_sizes, g->d_sizes, sizeof(uint64_t) * g->world, hipMemcpyDeviceToHost, g->gstream));
     G_HIP(hipEventRecord(g->ev_sizes, g->gstream));
@@ -581,9 +610,9 @@ int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
     if (g->comm) {
         const int rc = grow(g, &g->d_gathered, &g->gathered_cap, (size_t)width * g->world);
         if (rc != CTAG_OK) return rc;
-        G_HIP(order_before(g->comm, g->gstream));
-        G_NCCL(R->AllGather(g->d_packed, g->d_gathered, (size_t)width, ncclUint8, g->comm, g->gstream));
-        G_HIP(order_after(g->comm, g->gstream));
+        ncclResult_t nr = ncclSuccess;
+        G_HIP(ordered_collective(g->comm, g->gstream, [&] { return R->AllGather(g->d_packed, g->d_gathered, (size_t)width, ncclUint8, g->comm, g->gstream); }, &nr));
+        G_NCCL(nr);
         gathered = g->d_gathered;
     }
     const int rc = enqueue_unpack(g, false, gathered, S, g->n_total, out_dev, g->gstream);

@@ -93,6 +93,7 @@ struct KParams {
     double area_max_fraction;
     int c2_far;               // squared triplet norm c2 >= c2_far  <=>  (float)sqrt(c2) >  collinear_cost   (2 for 1.05)
     int c2_near;              // c2 <= c2_near                      <=>  (float)sqrt(c2) <  collinear_cost   (1 for 1.05)
+    float expand_eps;         // expand_line's filter band (k_quad.hip: sg_expand_line): 3e-6, or +inf with CTAG_OPT_EXPAND_EXACT
 };
 
 // A frame of a DEVICE-memory call that exceeded the batch workspace's pools: everything the library needs to run it again

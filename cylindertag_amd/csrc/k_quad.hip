@@ -51,6 +51,7 @@ struct QuadPtrs {
     // pool sizes of this workspace (ctag_internal.h: Workspace::cand_cap / line_cap / cl_cap)
     int cand_cap, line_cap;
     uint32_t cl_cap;
+    float expand_eps;                 // half-width of expand_line's filter band in units of the frame extent [3e-6]; +inf: always the exact fits (builds that read P)
 };
 
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
@@ -466,10 +467,13 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
 //     plus the float rounding of x0, y0 (2 K 2^-24);
 //   * its direction: t = (float)atan2(..)/2 (6e-8), the arguments' cancellation error in double (<= 6e-8 once the anisotropy
 //     h / n^2 >= K^2 2^-26, checked below), cos / sin rounded to float (3e-8): 1.5e-7 on each of four terms of size <= K;
-//   * this estimate's own error (v_rcp_f64 / v_rsq_f64 without refinement: 2^-23 relative, on a CENTRED form whose lever is the
-//     distance to the centroid) < 1e-4 K.
-//   Sum < 1.4e-6 K; eps = 3e-6 K.  A test inside the band (or a cluster too isotropic for the bound) sends its sub-group through
-//   the exact fits for that round, so the outcome is the reference's in every case (~1 % of the rounds).
+//   * this estimate's own error: v_rcp_f64 / v_rsq_f64 without refinement are good to 2^-23 relative, and they enter the centroid (rn) and
+//     the direction (rh, rp) of a CENTRED form whose lever is the distance to the centroid, <= K: about 4 x 2^-23 K ~ 0.5e-6 .. 1e-6 K.
+//   Sum ~ 2e-6 K; eps = 3e-6 K, a margin of about 1.4.  A test inside the band (or a cluster too isotropic for the bound) sends its
+//   sub-group through the exact fits for that round, so the outcome is the reference's in every case (~1 % of the rounds).
+//   CTAG_OPT_EXPAND_EXACT (developer aid) widens the band to infinity -- every round takes the exact fits -- and
+//   tests/test_gpu_parity.py::test_expand_line_filter... holds the two against each other and against the oracle on frames, fuzz
+//   and non-default threshold_expand.
 struct ALine {
     double c, s, x, y;  // unit direction (cos t, sin t), t in [-pi/2, pi/2], and the centroid
     bool ok;            // false: anisotropy too small for the error bound
@@ -502,10 +506,10 @@ __device__ __forceinline__ ALine approx_line(long long sx, long long sy, long lo
 // decisive -- exactly as the sequential loop does, and the prefix up to the first event (distance test fails, `left == right`,
 // or every point used) is committed.  Returns nl / nr = points added on the left / right side.  All lanes return the same values.
 template <int SG>
-__device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, float thr_expand, float kmax,
+__device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, float thr_expand, float kmax, float eps_scale,
                                                int& nl_out, int& nr_out) {
     constexpr unsigned long long kSgMask = SG == 64 ? ~0ull : ((1ull << (SG & 63)) - 1ull);
-    const double thr = (double)thr_expand, eps = 3.0e-6 * (double)kmax, k2lim = (double)kmax * (double)kmax * 1.4901161193847656e-08;  // K^2 2^-26
+    const double thr = (double)thr_expand, eps = (double)eps_scale * (double)kmax, k2lim = (double)kmax * (double)kmax * 1.4901161193847656e-08;  // K^2 2^-26
     long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
     for (int k = init + sl; k <= end; k += SG) {
         const long long x = ux(W[k]), y = uy(W[k]);
@@ -1602,7 +1606,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
                 // ---- expand_line (:125-169), speculative over the sub-group's 8 lanes
                 int nl, nr;
-                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, k_thr_expand, (float)(g.hcols > g.hrows ? g.hcols : g.hrows), nl, nr);
+                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, k_thr_expand, (float)(g.hcols > g.hrows ? g.hcols : g.hrows), REFPRM ? 3.0e-6f : P.expand_eps, nl,
+                                   nr);
                 const int m = end - init + 1 + nl + nr;
                 // the span is a circular arc [a .. b] of m distinct indices
                 const int a = ((init - nl) % n + n) % n;
@@ -2226,7 +2231,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     };
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.frame_flags,
                ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr, ws.kp.thr_line, ws.kp.thr_expand, ws.kp.rac, ws.kp.c2_far, ws.kp.c2_near,
-               ws.cand_cap, ws.line_cap, ws.cl_cap};
+               ws.cand_cap, ws.line_cap, ws.cl_cap, ws.kp.expand_eps};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
@@ -2254,7 +2259,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     }
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
-    const bool refprm = ws.kp.thr_line == 1.8f && ws.kp.thr_expand == 1.2f && ws.kp.c2_far == 2 && ws.kp.c2_near == 1;
+    const bool refprm = ws.kp.thr_line == 1.8f && ws.kp.thr_expand == 1.2f && ws.kp.c2_far == 2 && ws.kp.c2_near == 1 && ws.kp.expand_eps == 3.0e-6f;
 #define CTAG_LAUNCH_PACKED(REF)                                                                                                                              \
     do {                                                                                                                                                     \
         if (small_cfg)                                                                                                                                       \

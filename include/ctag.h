@@ -96,6 +96,15 @@ int ctag_detect_batch_bgr8(ctag_handle* h, const uint8_t* bgr, int n, int rows, 
 int ctag_detect_batch_bgr8_device(ctag_handle* h, const uint8_t* bgr_dev, int n, int rows, int cols, ptrdiff_t row_stride,
                                   ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
                                   ctag_frame_result* out_dev);
+/* ---- one frame per call, not waited for ------------------------------------------------------------------------------------------
+ * The reference's camera loop (main.cpp:44-61) calls detect() on every frame and waits.  With this pair the upload of frame k + 1
+ * overlaps the detection of frame k: ctag_submit_u8 starts the upload (its own stream) and enqueues the detection behind it,
+ * ctag_collect waits for the OLDEST submitted frame and returns its record and status (as ctag_detect_u8 would).  Up to two frames may
+ * be in flight (a third submit returns CTAG_ERR_ARG until one is collected); a frame buffer must stay valid until its collect
+ * returns (page-locked memory, ctag_host_alloc, makes the upload asynchronous). */
+int ctag_submit_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrdiff_t row_stride, int adaptive_thresh, int corner_subpix,
+                   int subpix_dist);
+int ctag_collect(ctag_handle* h, ctag_frame_result* out);
 int ctag_sync(ctag_handle* h);
 /* HIP stream (hipStream_t) all work of this handle is enqueued on */
 void* ctag_stream(ctag_handle* h);
@@ -115,6 +124,9 @@ void* ctag_stream(ctag_handle* h);
                                       tail of one half's kernels overlaps the other half's next kernel; the second stream forks from and joins the handle's stream
                                       inside the call, so callers order against ctag_stream() as before.  1: one stream.  A call with CTAG_OPT_TIMING on
                                       always uses one stream (the per-kernel events would time the neighbour's kernels too).  Results do not depend on it. */
+#define CTAG_OPT_EXPAND_EXACT 9    /* developer aid: 1 makes expand_line (corner_detector.cpp:125-169) refit the line with the reference's own arithmetic at EVERY step
+                                      instead of deciding most distance tests from a filtered estimate (k_quad.hip).  Results do not depend on it -- that is what
+                                      the option exists to check. */
 #define CTAG_OPT_FUSED_SWEEP 7     /* the threshold + label sweep as k_decimate_mask -> k_threshold_ccl (thresholds where the half-size pixels are computed, hands
                                       1 bit per pixel on; frames whose half size is a multiple of 960 x 135 -- 1080p, 4K, 8K -- with adaptiveThresh 5):
                                       0 never, 1 (default) batches of 512 frames' worth of bands and more, 2 whenever the frame size allows.  Results do not depend on it. */

@@ -1030,3 +1030,38 @@ def test_4k_frame(detector, oracle, dictionary):
     got, want = detector.detect(frame), oracle.detect_fast(frame, state, fs)
     assert_same_record(got, want, "4K synthetic frame")
     assert sorted(int(m["marker_id"]) for m in want["markers"][:want["n_markers"]]) == sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
+
+
+def test_expand_line_filter_equals_exact_path(oracle, dictionary, test_bmp):
+    """expand_line's distance test is decided from a filtered double-precision estimate unless the estimate lies within a band of the
+    threshold (k_quad.hip: sg_expand_line).  CTAG_OPT_EXPAND_EXACT widens the band to infinity -- the reference's own refit at every
+    step -- and both forms must give the oracle's quads, stage by stage, on camera content, synthetic frames, noise and with
+    threshold_expand / threshold_line away from the reference's values."""
+    state, fs = dictionary
+    rng = np.random.RandomState(77)
+    frames = [test_bmp[60:1140]] + [tk.synth_frame_host(state, 300 + k)[0] for k in range(12)]
+    frames.append(np.clip(rng.normal(120, 60, (1080, 1920)), 0, 255).astype(np.uint8))
+    batch = np.stack(frames)
+    for kw in ({}, {"threshold_expand": 0.7, "threshold_line": 1.4}, {"threshold_expand": 2.2, "threshold_line": 2.5}):
+        p = ca.default_params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        oracle.set_params(p)
+        try:
+            want, _ = oracle.detect_many(batch, state, fs)
+            for exact in (0, 1):
+                det = tk.Detector(state, fs, params=p)
+                det.set_option(capi.OPT_EXPAND_EXACT, exact)
+                try:
+                    got = det.detect_batch(batch)
+                    for k in range(len(batch)):
+                        assert_same_record(got[k], want[k], "expand %s exact=%d frame %d" % (kw, exact, k))
+                    one = det.detect(batch[0])  # the few-frame builds (whole-wave components) too
+                    assert_same_record(one, want[0], "expand %s exact=%d single" % (kw, exact))
+                    o = oracle.detect(batch[3], state, fs)
+                    det.detect(batch[3])
+                    assert det.debug(0, tk.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
+                finally:
+                    det.close()
+        finally:
+            oracle.set_params(None)
