@@ -773,7 +773,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         stamp(6);
         // the component's pixels carry one tile-local label per CCL tile it touches: collect those (tile, label) keys
         // (root entry + its member list built by k_resolve) so the pixel scan needs no gathers
-        constexpr int kMaxKeys = 8;
+#ifndef CTAG_KEYS_LARGE
+#define CTAG_KEYS_LARGE 16
+#endif
+        // (tile, label) keys a lane keeps: a component with more members falls back to the gather test for every pixel.  The packs of 4K
+        // frames hold components that cross four or five 30-row label tiles: eight keys were not enough for most of them
+#ifndef CTAG_KEYS_SMALL
+#define CTAG_KEYS_SMALL 8
+#endif
+        constexpr int kMaxKeys = (SG == 8 && WORDS > kPackWordsSmall) ? CTAG_KEYS_LARGE : CTAG_KEYS_SMALL;  // (4K, measured: 8 keys 5.47 ms, 12: 4.46, 16: 4.08, 24: 4.16 per 1024 frames)
         uint32_t mykey[kMaxKeys];
         bool many = false;
         {
@@ -1191,12 +1199,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     atomicMax(&rig[y], (unsigned)(xl0 + 32 - __clz(bits)));
                 }
             };
+#ifndef CTAG_SCAN_UNCOND
+#define CTAG_SCAN_UNCOND 1
+#endif
+            // Unconditional loads from clamped addresses, the lanes / rows outside the box zeroed by a select: a load inside a branch makes the
+            // compiler wait for EVERY load in flight where the branch rejoins, and the rows "in flight" arrived one at a time
+            const int gx0 = ld_ok ? gxf : (x_min & ~7), gx1 = ld_ok1 ? gxf + kChunk : (x_min & ~7);
             auto load_row = [&](int y) {
+                if (CTAG_SCAN_UNCOND) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y, h - 1)) * g.lp + gx0);
+                    return ld_ok ? v : make_uint4(0, 0, 0, 0);
+                }
                 uint4 r = make_uint4(0, 0, 0, 0);
                 if (ld_ok && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf);
                 return r;
             };
             auto load_row1 = [&](int y) {
+                if (CTAG_SCAN_UNCOND) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y, h - 1)) * g.lp + gx1);
+                    return ld_ok1 ? v : make_uint4(0, 0, 0, 0);
+                }
                 uint4 r = make_uint4(0, 0, 0, 0);
                 if (ld_ok1 && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf + kChunk);
                 return r;
