@@ -305,9 +305,13 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
 // box in passes of 128 columns); the rest are "big" and get a wave of their own (k_quad_edges_packed<64, ...>)
 // big_points: in latency mode (a few frames per call) components with a long boundary also go there -- a whole wave per
 // component instead of 8 lanes shortens the critical path of the call; 0x7fffffff otherwise
-__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points, int pack_words) {
+// scan_words > 0: the silhouettes of the packed components come from the scan-only kernel (PHASE 3 below), which holds w + 3 h + 4
+// words of a component in LDS; one that needs more is "big" too (the whole-wave builds scan for themselves)
+constexpr int kScanWords = 2048;
+__host__ __device__ __forceinline__ int scan_need(int w, int h) { return w + 3 * h + 4; }
+__host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points, int pack_words, int scan_words = 0) {
     (void)x_min;
-    return pack_need(w, h) > pack_words || pack_points(w, h) > big_points;
+    return pack_need(w, h) > pack_words || pack_points(w, h) > big_points || (scan_words > 0 && scan_need(w, h) > scan_words);
 }
 
 // packed 16-bit minimum (v_pk_min_u16)
@@ -334,7 +338,7 @@ struct CornerPre {
 // anywhere and were the kernel's tail: a 150-point boundary is ~0.3 ms of dependent LDS round trips).
 // One block per frame; rank sort in LDS like k_candidates.  Oversize components are skipped; the whole-wave builds take them.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words) {
+__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words, int scan_words) {
     __shared__ int s_key[kLdsCand + 2];
     __shared__ int s_need[kLdsCand];
     __shared__ uint16_t s_ord[kLdsCand];
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
     uint32_t* packs = P.packs + (size_t)frame * P.cand_cap;
     auto key_of = [&](const Candidate& c) {
         const int w = c.x_max - c.x_min + 1, h = c.y_max - c.y_min + 1;
-        return pack_big(c.x_min, w, h, big_points, pack_words) ? -1 : pack_points(w, h);  // -1: not packed, sorts last
+        return pack_big(c.x_min, w, h, big_points, pack_words, scan_words) ? -1 : pack_points(w, h);  // -1: not packed, sorts last
     };
     if (nc > kLdsCand) {
         // A frame of thousands of blobs (more candidates than the LDS arrays hold).  The order is scheduling only -- results do not
@@ -687,8 +691,15 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
 // clusters only (reads them back).  The packed builds run as 1 then 2: the two halves want different registers -- dependent LDS
 // round trips with many live indices in the first, FP64 line fits in the second -- and in one kernel at 128 VGPRs each change to
 // one half re-spilled the other (the traversal tripled when the line fits got cheaper).
-template <int SG, int WORDS, int WAVES, bool DYN, bool REFPRM, int PHASE = 0>
+// PHASE 3 (batches; always the whole wave on one component): the silhouette scan ALONE, for every PACKED component of the frame -- tb / lr go to the
+// component's cluster-pool slot (reserved here), and the packed builds run with PRESCAN = true: they load the two arrays instead of
+// scanning.  The scan is the part of the boundary stage that waits for global memory (label rows); as a kernel of its own it keeps 64
+// lanes on one component's rows (the packed build has 8), needs 11 KB of LDS and few registers -- three and a half waves per SIMD
+// where the 4K packed build runs two -- and the builds behind it lose their largest phase (43-56 % of their cycles).
+template <int SG, int WORDS, int WAVES, bool DYN, bool REFPRM, int PHASE = 0, bool PRESCAN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_quad_edges_packed(QuadPtrs P, FrameGeom g, int nframes, int tier_lo) {
+    static_assert(PHASE != 3 || (SG == 64 && !PRESCAN), "the scan-only build is a whole-wave build");
+    static_assert(!PRESCAN || (SG == 8 && PHASE != 2), "PRESCAN: a packed build that would otherwise scan");
     const float k_thr_line = REFPRM ? 1.8f : P.thr_line, k_thr_expand = REFPRM ? 1.2f : P.thr_expand;
     const int k_c2_far = REFPRM ? 2 : P.c2_far, k_c2_near = REFPRM ? 1 : P.c2_near;
     static_assert(SG == 8 || SG == 64, "8 lanes per component (packs) or the whole wave (oversize components)");
@@ -700,7 +711,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     const int lane = threadIdx.x, sub = lane / SG, sl = lane % SG, lane0 = lane - sl;
     // SG == 8: the frame's packs; SG == 64: the oversize tail of k_pack's order, one component per wave
     const int nc = min(P.ncand[frame], P.cand_cap);
-    const int npk = P.npacks[2 * frame + (SG == 8 ? 0 : 1)];
+    const int npk = PHASE == 3 ? nc - P.npacks[2 * frame + 1]  // every packed component: entries [0, nc - oversize) of k_pack's order
+                               : P.npacks[2 * frame + (SG == 8 ? 0 : 1)];
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
@@ -722,6 +734,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             const uint32_t pw = P.packs[(size_t)frame * P.cand_cap + pk];
             first = (int)(pw & 0xffffffu);
             cnt = (int)(pw >> 24);
+        } else if constexpr (PHASE == 3) {
+            first = pk;
+            cnt = 1;
         } else {
             first = nc - npk + pk;
             cnt = 1;
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         const int x_min = cd.x_min, y_min = cd.y_min;
         const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
         const int C = pack_points(w, h);
-        const int need = act ? pack_need(w, h) : 0;
+        const int need = act ? (PHASE == 3 ? scan_need(w, h) : pack_need(w, h)) : 0;
         int off = 0;
 #pragma unroll
         for (int k = 0; k < 64 / SG; k++) {
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
         if (!act) continue;
         CandAux* aux = P.cand_aux + (size_t)frame * P.cand_cap + ci;
-        if constexpr (SG == 64) {
+        if constexpr (SG == 64 && PHASE != 3) {
             // two builds share the oversize components by working-set size: (tier_lo, WORDS] is this one's
             if (need <= tier_lo) continue;
             if (need > WORDS) {
@@ -762,14 +777,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         uint32_t* tb = mem;               // w + 2 words
         uint32_t* lr = tb + w + 2;        // h + 2 words
         uint32_t* bufA = lr + h + 2;      // C words
-        uint32_t* bufB = bufA + C;        // C + 1 words
+        uint32_t* bufB = bufA + (PHASE == 3 ? h : C);  // C + 1 words (scan only: the row extents, h words each)
         uint32_t* lef = bufA;             // P1 only: row extents by atomics (h <= C words each)
         uint32_t* rig = bufB;
         const int sgshift = sub * SG;
 
         int n = 0, n_boundary = 0, p0 = 0;
         float acx = 0.f, acy = 0.f;
-        if constexpr (PHASE != 2) {
+        if constexpr (PHASE != 2 && !PRESCAN) {
         stamp(6);
         // the component's pixels carry one tile-local label per CCL tile it touches: collect those (tile, label) keys
         // (root entry + its member list built by k_resolve) so the pixel scan needs no gathers
@@ -807,7 +822,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // asks root_of of pool entry tile_base + l - 1; a 1 for a label the tile does not have is harmless, no pixel carries
         // it).  Entry 0 (background) is 0, entry 129 -- where larger labels are clamped to -- says "ask root_of": labels above 128
         // exist only in tiles that took the second CCL pass.  One more table, all "ask", serves boxes over more than 96 tiles.
-        constexpr int kMemberTiles = 96, kLutPitch = 132;
+        constexpr int kMemberTiles = PHASE == 3 ? 24 : 96, kLutPitch = 132;
         __shared__ uint8_t s_lut[SG == 64 ? (kMemberTiles + 1) * kLutPitch : 4];
         const int mt_x0 = x_min / kTileW, mt_y0 = y_min / kTileH;
         const int mt_nx = (x_min + w - 1) / kTileW - mt_x0 + 1, mt_ny = (y_min + h - 1) / kTileH - mt_y0 + 1;
@@ -1305,6 +1320,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             }
         }
         SG_SYNC();
+        }  // the scan
+        if constexpr (PHASE == 3) {
+            // the component's cluster space (what the packed builds reserve after their traversal) and, in it for now, the silhouette:
+            // w + h + 4 <= C + 64 words
+            if (sl == 0) p0 = atomicAdd(&P.clp_used[frame], C + 64);
+            p0 = __shfl(p0, lane0);
+            if ((uint32_t)(p0 + C + 64) > P.cl_cap) {
+                if (sl == 0) {
+                    atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+                    aux->line0 = -1;
+                    aux->acx = 0.f;
+                    aux->acy = 0.f;
+                    aux->n_boundary = 0;
+                }
+                continue;
+            }
+            uint32_t* slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;
+            for (int x = sl; x < w + 2; x += SG) slot[x] = tb[x];
+            for (int y = sl; y < h + 2; y += SG) slot[w + 2 + y] = lr[y];
+            if (sl == 0) {
+                aux->line0 = p0;
+                aux->acx = 0.f;
+                aux->acy = 0.f;
+                aux->n_boundary = 0;
+            }
+            continue;
+        }
+        if constexpr (PHASE != 2) {
+        if constexpr (PRESCAN) {
+            p0 = aux->line0;  // the scan-only kernel left the component's slot here (-1: the frame's cluster pool is exhausted, flags and aux are final)
+            if (p0 < 0) continue;
+            const uint32_t* slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;
+            for (int x = sl; x < w + 2; x += SG) tb[x] = slot[x];
+            for (int y = sl; y < h + 2; y += SG) lr[y] = slot[w + 2 + y];
+            SG_SYNC();
+        }
         // distinct silhouette pixels: two per column (one where top == bottom) plus the row ends that head no column list.  The
         // traversal below visits every listed pixel at most once, so once it has appended this many points nothing is left to
         // find and the rest of its work -- unwinding a stack as deep as the boundary is long, a full neighbour test per frame --
@@ -1525,6 +1576,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
         SG_SYNC();
         stamp(2);
+        if constexpr (!PRESCAN) {
         // cluster space in the frame's pool (upper bound; the clusters are written straight to global memory)
         p0 = 0;
         if (sl == 0) p0 = atomicAdd(&P.clp_used[frame], C + 64);
@@ -1538,6 +1590,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 aux->n_boundary = n_boundary;
             }
             continue;
+        }
         }
         }  // PHASE != 2
         if constexpr (PHASE == 1) {  // hand the rotated boundary over to the second kernel through the component's cluster-pool slot
@@ -2268,7 +2321,13 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     const int big_points = ws.wave_points > 0 ? ws.wave_points : big_env > 0 ? big_env : (latency ? kLatencyBigPoints : 0x7fffffff);
     const bool small_cfg = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;  // up to 1920x1200 frames
     const int pack_words = small_cfg ? kPackWordsSmall : kPackWords;
-    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words);
+    // batches: the silhouettes of the packed components come from a kernel of their own (PHASE 3 of k_quad_edges_packed); CTAG_PRESCAN=0 (developer aid) keeps the scan in the packed builds
+    static const int prescan_env = getenv("CTAG_PRESCAN") ? atoi(getenv("CTAG_PRESCAN")) : 1;
+    // (measured: 4K frames, quad_edges 4.07 -> 2.78 ms per 1024 frames; 1080p frames 3.88 -> 4.01 per 4096 -- there a component's box is ~75 x 20, the
+    // packed build's eight components per wave amortise the chain of dependent loads a component costs better than a wave per component does)
+    const bool small_frames = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;
+    const bool prescan = !latency && (prescan_env == 2 || (prescan_env == 1 && !small_frames));
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words, prescan ? kScanWords : 0);
     mark();
     // A few frames per call (the reference's one detect() per camera frame): the call is as long as its slowest component,
     // so the packs and the whole-wave components run side by side (second stream, fork/join by events)
@@ -2282,9 +2341,23 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     static const int pack_gx_env = getenv("CTAG_PACK_GX") ? atoi(getenv("CTAG_PACK_GX")) : 0;
     const int pack_gx = pack_gx_env > 0 ? pack_gx_env : 32;
     const bool refprm = ws.kp.thr_line == 1.8f && ws.kp.thr_expand == 1.2f && ws.kp.c2_far == 2 && ws.kp.c2_near == 1 && ws.kp.expand_eps == 3.0e-6f;
+#ifndef CTAG_SCAN_WAVES
+#define CTAG_SCAN_WAVES 4
+#endif
+    static const int scan_gx = getenv("CTAG_SCAN_GX") ? std::max(1, atoi(getenv("CTAG_SCAN_GX"))) : 48;
 #define CTAG_LAUNCH_PACKED(REF)                                                                                                                              \
     do {                                                                                                                                                     \
-        if (small_cfg)                                                                                                                                       \
+        if (prescan) {                                                                                                                                       \
+            hipLaunchKernelGGL((k_quad_edges_packed<64, kScanWords, CTAG_SCAN_WAVES, false, true, 3>), dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+            if (small_cfg) {                                                                                                                                 \
+                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 1, true>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+            } else {                                                                                                                                         \
+                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF, CTAG_PACK_SPLIT_LARGE ? 1 : 0, true>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+                if (CTAG_PACK_SPLIT_LARGE)                                                                                                                   \
+                    hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+            }                                                                                                                                                \
+        } else if (small_cfg)                                                                                                                                \
         {                                                                                                                                                    \
             hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, CTAG_PACK_SPLIT ? 1 : 0>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (CTAG_PACK_SPLIT)                                                                                                                             \
