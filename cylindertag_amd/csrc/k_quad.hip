@@ -2324,7 +2324,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     // batches: the silhouettes of the packed components come from a kernel of their own (PHASE 3 of k_quad_edges_packed); CTAG_PRESCAN=0 (developer aid) keeps the scan in the packed builds
     static const int prescan_env = getenv("CTAG_PRESCAN") ? atoi(getenv("CTAG_PRESCAN")) : 1;
     // (measured: 4K frames, quad_edges 4.07 -> 2.78 ms per 1024 frames; 1080p frames 3.88 -> 4.01 per 4096 -- there a component's box is ~75 x 20, the
-    // packed build's eight components per wave amortise the chain of dependent loads a component costs better than a wave per component does)
+    // packed build's eight components per wave amortise the chain of dependent loads a component costs better than a wave per component does; a
+    // scan-only kernel with the packs' own 8 x 8 lanes at 4 / 5 / 6 waves per SIMD: 4.09 / 4.11 / 4.14 -- the scan is not what the small build waits for)
     const bool small_frames = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;
     const bool prescan = !latency && (prescan_env == 2 || (prescan_env == 1 && !small_frames));
     hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words, prescan ? kScanWords : 0);
