@@ -740,6 +740,8 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
                 // the sums kernel has registers to spare: the operands of the next eight terms are requested before the current eight
                 // are folded in (left to itself the compiler loads a pair of terms into the same registers every time and waits for the
                 // LDS before each pair: 64 exposed round trips per sum)
+                // (measured and not kept, round 4: lanes whose factor is the constant 1 -- 24 of the 48 lanes' B, 8 lanes' A -- sitting out that
+                // ds_read_b128: the exec-masked reads cost more than the bank cycles they save, edge_refine 5.03 -> 5.54 ms per 4096 frames)
                 double ca[8], cb[8], cw[8], na[8], nb[8], nw[8];
                 const double2 *pa2 = reinterpret_cast<const double2*>(pa), *pb2 = reinterpret_cast<const double2*>(pb), *pw2 = reinterpret_cast<const double2*>(pw);
 #pragma unroll
