@@ -619,6 +619,8 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
     if (h->streams >= 2 && !h->timing && chunk >= two_min && h->stream2) {
         // two halves of every chunk side by side (see WsSlot batch2).  With CTAG_OPT_TIMING the chunk stays on one stream: the HIP events
         // around a kernel would otherwise time the other stream's kernels as well.
+        // (measured, round 4: pieces of 1024 / 512 frames instead of half a chunk 226 / 203 K frames/s against 231 K; the second stream half a
+        // piece out of phase -- one stream in its memory-bound sweep while the other computes -- 216-227 K: the kernels' tails want large pieces)
         const int piece = (chunk + 1) / 2;
         ctag_handle::WsSlot* slot[2] = {&h->batch, &h->batch2};
         for (int k = 0; k < 2; k++) {
