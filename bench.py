@@ -55,7 +55,7 @@ def parse_args():
                     help="frames of the detect()+estimatePose side measurement on camera content, 0 = skip; never `value`")
     ap.add_argument("--size", default="1920x1080", help="frame size WxH; the headline metric is 1920x1080 (other sizes are side measurements)")
     ap.add_argument("--no-subpix", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="CTAG_OPT_STREAMS of the timed steps: 2 (the library's default) runs the halves of a chunk on two internal streams; 1 for profiler runs "
                          "(every launch then covers a whole chunk)")
     ap.add_argument("--latency-calls", type=int, default=200, help="single-frame ctag_detect_u8 calls of the latency side measurement, 0 = skip")
@@ -508,7 +508,8 @@ def main():
 
     state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
     det = tk.Detector(state, fs, device=dev_index)
-    det.set_option(capi.OPT_STREAMS, args.streams)
+    if args.streams:  # 0: the library's default
+        det.set_option(capi.OPT_STREAMS, args.streams)
     subpix = not args.no_subpix
 
     # ---- the job: n_total frames per step; this rank owns frames [lo, hi) of it
@@ -737,8 +738,8 @@ def main():
                           "frames_per_step": n_total, "frames_per_gpu": n, "chunk": chunk, "parallelism": "frames sharded, dp%d" % world,
                           "gather": gather_impl,
                           "pipelining": ("steps alternate between %d handles (streams)" % len(dets)) if len(dets) > 1 else
-                          ("one handle; the library runs the two halves of a chunk on two internal streams (CTAG_OPT_STREAMS = 2, its default)" if args.streams == 2 else
-                           "one handle, one stream (--streams 1)")},
+                          ("one handle; the library runs the parts of a chunk on its internal streams (CTAG_OPT_STREAMS: library default)" if args.streams == 0 else
+                           "one handle, CTAG_OPT_STREAMS = %d (--streams)" % args.streams)},
                "one_stream": None if single_stream_dt is None else {
                    "value": round(n_total * args.steps / single_stream_dt, 2), "unit": "frames/s", "ms_per_step": round(single_stream_dt / args.steps * 1e3, 3),
                    "note": "the same steps with CTAG_OPT_TIMING on (one stream, per-kernel HIP events read back every step): the steps `stage_ms_per_step` and "

@@ -53,9 +53,12 @@ struct ctag_handle {
     // CTAG_OPT_STREAMS = 2 (default): a chunk of a device-memory batch runs as two halves on two streams (`stream` + `stream2`, workspaces
     // `batch` + `batch2`), so that the tail of one half's kernels -- a few long boundary / Welsch blocks -- overlaps the other half's next
     // kernel.  stream2 forks from `stream` at the head of a call and joins it at the end: callers still order against `stream` alone.
-    WsSlot batch2;
+    static constexpr int kMaxStreams = 4;
+    WsSlot batchx[kMaxStreams - 1];                 // workspaces of the extra streams (stream k > 0 uses batchx[k - 1])
+    hipStream_t streamx[kMaxStreams - 1] = {};      // (stream2 = streamx[0])
+    hipEvent_t ev_joinx[kMaxStreams - 1] = {};
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr;
     int streams = 2;
     const Workspace* last_ws = nullptr;  // whichever ran last (handle_view)
     bool last_fused = false;  // the last chunk took the fused sweep: its workspace holds the threshold mask, not the half-size image
@@ -271,7 +274,8 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
             S.ws.refine_n0 = S.n0_buf;
             return CTAG_OK;
         }
-        if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
+        for (hipStream_t x : h->streamx)
+            if (x) HIP_TRY(hipStreamSynchronize(x));
         HIP_TRY(hipStreamSynchronize(h->stream));
         drop_graphs(h);
         if (S.n0_buf) HIP_TRY(hipFree(S.n0_buf));
@@ -288,7 +292,8 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
         return ensure_n0();
     }
     if (S.ws.base) {
-        if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
+        for (hipStream_t x : h->streamx)
+            if (x) HIP_TRY(hipStreamSynchronize(x));
         HIP_TRY(hipStreamSynchronize(h->stream));
         drop_graphs(h);  // they hold pointers into the old workspace
         HIP_TRY(hipFree(S.ws.base));
@@ -617,21 +622,22 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
     DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
     static const int two_min = getenv("CTAG_STREAMS_MIN") ? std::max(2 * kLatencyFrames + 2, atoi(getenv("CTAG_STREAMS_MIN"))) : 256;
     if (h->streams >= 2 && !h->timing && chunk >= two_min && h->stream2) {
+        const int ns = std::min(h->streams, (int)ctag_handle::kMaxStreams);
         // two halves of every chunk side by side (see WsSlot batch2).  With CTAG_OPT_TIMING the chunk stays on one stream: the HIP events
         // around a kernel would otherwise time the other stream's kernels as well.
         // (measured, round 4: pieces of 1024 / 512 frames instead of half a chunk 226 / 203 K frames/s against 231 K; the second stream half a
         // piece out of phase -- one stream in its memory-bound sweep while the other computes -- 216-227 K: the kernels' tails want large pieces)
-        const int piece = (chunk + 1) / 2;
-        ctag_handle::WsSlot* slot[2] = {&h->batch, &h->batch2};
-        for (int k = 0; k < 2; k++) {
+        const int piece = (chunk + ns - 1) / ns;
+        ctag_handle::WsSlot* slot[ctag_handle::kMaxStreams] = {&h->batch, &h->batchx[0], &h->batchx[1], &h->batchx[2]};
+        for (int k = 0; k < ns; k++) {
             const int wr = ensure_workspace(h, *slot[k], rows, cols, adaptive_thresh, std::max(piece, slot[k]->rows == rows && slot[k]->cols == cols ? slot[k]->cap : 0),
                                             false, corner_subpix != 0);
             if (wr != CTAG_OK) return wr;
         }
         HIP_TRY(hipEventRecord(h->ev_fork2, h->stream));
-        HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork2, 0));
+        for (int k = 1; k < ns; k++) HIP_TRY(hipStreamWaitEvent(h->streamx[k - 1], h->ev_fork2, 0));
         int k = 0;
-        for (int f0 = 0; f0 < n; f0 += piece, k ^= 1) {
+        for (int f0 = 0; f0 < n; f0 += piece, k = (k + 1) % ns) {
             const int m = std::min(piece, n - f0);
             PendingCtx pc{};
             if (pend) {
@@ -641,11 +647,13 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
             }
             h->last_chunk_frames = m;
             const int r = enqueue_chunk(h, slot[k]->ws, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0, nullptr, pc,
-                                        k ? h->stream2 : h->stream);
+                                        k ? h->streamx[k - 1] : h->stream);
             if (r != CTAG_OK) return r;
         }
-        HIP_TRY(hipEventRecord(h->ev_join2, h->stream2));
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join2, 0));
+        for (int j = 1; j < ns; j++) {
+            HIP_TRY(hipEventRecord(h->ev_joinx[j - 1], h->streamx[j - 1]));
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_joinx[j - 1], 0));
+        }
         return CTAG_OK;
     }
     const int wr = ensure_workspace(h, h->batch, rows, cols, adaptive_thresh, std::max(chunk, h->batch.rows == rows && h->batch.cols == cols ? h->batch.cap : 0),
@@ -944,9 +952,12 @@ int ctag_create_ex(const int32_t* state, int dict_rows, int dict_cols, int featu
     bool ok = hipSetDevice(device_id) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < ctag_handle::kMaxStreams - 1; k++) {
+        ok = ok && hipStreamCreateWithFlags(&h->streamx[k], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->ev_joinx[k], hipEventDisableTiming) == hipSuccess;
+    }
+    h->stream2 = h->streamx[0];
     ok = ok && hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&h->d_dict), h->dict.size() * 4) == hipSuccess;
@@ -987,10 +998,12 @@ void ctag_destroy(ctag_handle* h) {
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (int k = 0; k < ctag_handle::kMaxStreams - 1; k++) {
+        if (h->streamx[k]) (void)hipStreamSynchronize(h->streamx[k]);
+        if (h->ev_joinx[k]) (void)hipEventDestroy(h->ev_joinx[k]);
+    }
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
-    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
-    for (ctag_handle::WsSlot* S : {&h->batch, &h->batch2, &h->big}) {
+    for (ctag_handle::WsSlot* S : {&h->batch, &h->batchx[0], &h->batchx[1], &h->batchx[2], &h->big}) {
         if (S->ws.base) (void)hipFree(S->ws.base);
         if (S->n0_buf) (void)hipFree(S->n0_buf);
     }
@@ -1025,7 +1038,8 @@ void ctag_destroy(ctag_handle* h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    for (int k = 0; k < ctag_handle::kMaxStreams - 1; k++)
+        if (h->streamx[k]) (void)hipStreamDestroy(h->streamx[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1080,7 +1094,7 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
             drop_graphs(h);
             return CTAG_OK;
         case CTAG_OPT_STREAMS:
-            if (value < 1 || value > 2) return CTAG_ERR_ARG;
+            if (value < 1 || value > ctag_handle::kMaxStreams) return CTAG_ERR_ARG;
             h->streams = (int)value;
             return CTAG_OK;
         case CTAG_OPT_FUSED_SWEEP:
@@ -1155,7 +1169,8 @@ int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, i
 // every reallocation of the staging slabs (an upload still running on copy_stream must not lose its destination)
 static int quiesce(ctag_handle* h) {
     if (h->copy_stream) HIP_TRY(hipStreamSynchronize(h->copy_stream));
-    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
+    for (hipStream_t x : h->streamx)
+        if (x) HIP_TRY(hipStreamSynchronize(x));
     if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));  // side branch of few-frame calls
     HIP_TRY(hipStreamSynchronize(h->stream));
     return CTAG_OK;
