@@ -3,8 +3,9 @@
 # runs with --kernel-trace only) of one 1024-frame bench pass, summarised by tools/pmc_instmix.py into profiles/<tag>_pmc_instmix.json
 # usage: tools/pmc_instmix.sh r02a
 TAG=${1:-r02}
+SIZE=${2:-1920x1080}   # tools/pmc_instmix.sh r04_4k 3840x2160 -> profiles/r04_4k_pmc_instmix.json
 export TMPDIR=/tmp
-B="python3 bench.py --frames 1024 --chunk 1024 --steps 1 --warmup 1 --streams 1 --pipelined-steps 0 --cpu-frames 0 --host-frames 0 --pose-frames 0 --latency-calls 0"
+B="python3 bench.py --size $SIZE --frames 1024 --chunk 1024 --steps 1 --warmup 1 --streams 1 --pipelined-steps 0 --cpu-frames 0 --host-frames 0 --pose-frames 0 --latency-calls 0"
 P1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 P2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT"
 P3="SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
