@@ -246,32 +246,25 @@ __device__ __forceinline__ int pxw(const Raw34& r, int k) {  // k in [-1, 33]
     if (k >= 32) return (int)((r.right2 >> (8 * (k - 32))) & 0xff);
     return (int)((r.w[k >> 2] >> (8 * (k & 3))) & 0xff);
 }
-// The same sums on PACKED 16-bit lanes (the fused kernel is bound by its vector instructions: 0.80 of the SIMD cycles busy): a word's
-// even bytes E = (p0, p2) and odd bytes O = (p1, p3) as u16 pairs give S = E + O = (p0 + p1, p2 + p3), the 19x terms of (q0, q1); the 3x
-// terms (p[-1] + p2, p1 + p4) are two funnel shifts over neighbouring words' O and E and one add; then 19 S - 3 T as a packed multiply
-// and multiply-add: 8 instead of ~15 vector instructions per word, and the result is already the packed int16 pair the vertical
-// pass takes.  Values lie in [-1530, 9690]: no 16-bit lane overflows.
+// One v_dot4_i32_i8 per horizontal-pass value (the fused kernel is bound by its vector instructions: 0.80-0.83 of the SIMD cycles busy):
+// q0 = 19 (p0 + p1) - 3 (p[-1] + p2) is the dot product of the four consecutive bytes (p[-1], p0, p1, p2) with (-3, 19, 19, -3), q1 the
+// same of (p1, p2, p3, p4).  The instruction's bytes are SIGNED: the pixels go in as p - 128 (one xor per word) and the accumulator starts
+// at 128 x (the weights' sum 32) = 4096.  The byte quadruples are funnel shifts over neighbouring words.  Six vector instructions per
+// word (xor, two v_alignbit, two dots, one v_perm to pair the results as the int16 halves the vertical pass takes) instead of ~15 with byte
+// extracts and 9 on packed 16-bit lanes.  Same integers: values lie in [-1530, 9690].
 __device__ __forceinline__ void hpass_wide(const Raw34& r, uint32_t q[8]) {
-    uint32_t E[9], O[9];  // O[j]: odd bytes of word j - 1 (O[0]: only p[-1] in the upper lane); E[j]: even bytes of word j (E[8]: only p[32] in the lower lane)
-    O[0] = r.left << 16;
-    E[8] = r.right2 & 0xffu;
+    uint32_t x[10];  // x[j + 1]: word j with every pixel - 128; x[0]: p[-1] in the top byte; x[9]: p[32] in the low byte
+    x[0] = (r.left ^ 0x80u) << 24;
+    x[9] = (r.right2 ^ 0x80u) & 0xffu;
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j + 1] = r.w[j] ^ 0x80808080u;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        E[j] = r.w[j] & 0x00ff00ffu;
-        O[j + 1] = (r.w[j] >> 8) & 0x00ff00ffu;
-    }
-    const ctag_s2 k19 = {(short)19, (short)19}, k3 = {(short)-3, (short)-3};
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t S = pk_add_s16(E[j], O[j + 1]);
-        const uint32_t A = __builtin_amdgcn_alignbit(O[j + 1], O[j], 16);  // (p[4j - 1], p[4j + 1])
-        const uint32_t B = __builtin_amdgcn_alignbit(E[j + 1], E[j], 16);  // (p[4j + 2], p[4j + 4])
-        const uint32_t T = pk_add_s16(A, B);
-        ctag_s2 s, t;
-        __builtin_memcpy(&s, &S, 4);
-        __builtin_memcpy(&t, &T, 4);
-        const ctag_s2 v = s * k19 + t * k3;
-        __builtin_memcpy(&q[j], &v, 4);
+        const uint32_t a = __builtin_amdgcn_alignbit(x[j + 1], x[j], 24);      // (p[4j - 1], p[4j], p[4j + 1], p[4j + 2])
+        const uint32_t b = __builtin_amdgcn_alignbit(x[j + 2], x[j + 1], 8);   // (p[4j + 1], p[4j + 2], p[4j + 3], p[4j + 4])
+        const int q0 = __builtin_amdgcn_sdot4((int)a, (int)0xfd1313fdu, 4096, false);
+        const int q1 = __builtin_amdgcn_sdot4((int)b, (int)0xfd1313fdu, 4096, false);
+        q[j] = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x05040100u);
     }
 }
 #ifndef CTAG_DEC_WIDE_WAVES
