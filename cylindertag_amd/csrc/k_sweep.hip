@@ -737,9 +737,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
     if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
     const int bx = idx % xblocks, by = idx / xblocks;
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
-    const int band = by * WAVES + wy;
+    // Odd bands run UPWARD: such a wave works on the vertically mirrored frame (source row r <-> rows - 1 - r, output row y <-> hrows - 1 - y;
+    // the 2x cubic taps, the 5-row tiles and the border rules are symmetric under that mirror) and so walks its band from the bottom.  Bands 2k and
+    // 2k + 1 then end at their common border at the same time, bands 2k + 1 and 2k + 2 start at theirs together: the tile rows a band decimates a
+    // second time for its neighbour's extrema (+7 % source rows) are read by both waves within microseconds of each other -- from the cache, not twice
+    // from HBM (the four waves of a block are the four bands of a frame: same CU).
+#ifndef CTAG_FUSE_MIRROR
+#define CTAG_FUSE_MIRROR 1
+#endif
+    const int band_actual = by * WAVES + wy;
+    if (band_actual * BAND >= g.hrows) return;  // wave-uniform
+    const bool mirror = CTAG_FUSE_MIRROR && (band_actual & 1);
+    const int band = mirror ? g.hrows / BAND - 1 - band_actual : band_actual;  // the band's index in the (mirrored) frame it walks downward
     const int y_begin = band * BAND;
-    if (y_begin >= g.hrows) return;  // wave-uniform
     FuseLds& S = S4[wy];
     const int X0 = bx * kFuseCols;
     const int hx0 = lane < kFuseLanes ? X0 + 16 * lane : lane == 60 ? X0 + kFuseCols : X0 - 16;
@@ -750,7 +760,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
     const int mpitch = g.hcols >> 3;
     uint8_t* __restrict__ mrow0 = mask + (size_t)frame * g.hrows * mpitch + (X0 >> 3) + 2 * lane;
     const int rmax = g.rows - 1;
-    auto rowp = [&](int r) __attribute__((always_inline)) { return src + (ptrdiff_t)min(max(r, 0), rmax) * row_stride; };
+    auto rowp = [&](int r) __attribute__((always_inline)) {
+        const int rr = min(max(r, 0), rmax);
+        return src + (ptrdiff_t)(mirror ? rmax - rr : rr) * row_stride;
+    };
     // the lane's 16 pixels lie in the tiles j0 .. j0 + 3 of the span; sel[k] picks, for pixels 4k .. 4k + 3, their tile's byte of a packed word
     const int j0 = (16 * lane) / 5;
     uint32_t sel[4];
@@ -830,10 +843,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
         wave_sync();
         if (lane < kFuseLanes) {
             const uint32_t T4 = (uint32_t)S.tt[j0] | ((uint32_t)S.tt[j0 + 1] << 8) | ((uint32_t)S.tt[j0 + 2] << 16) | ((uint32_t)S.tt[min(j0 + 3, kFuseTiles - 1)] << 24);
-            uint8_t* mp = mrow0 + (size_t)(5 * e) * mpitch;
+            // (mirrored wave: its row 5 e + r is row hrows - 1 - (5 e + r) of the frame)
+            uint8_t* mp = mrow0 + (size_t)(mirror ? g.hrows - 1 - 5 * e : 5 * e) * mpitch;
+            const ptrdiff_t mstep = mirror ? -(ptrdiff_t)mpitch : (ptrdiff_t)mpitch;
             if (T4 == 0u) {
 #pragma unroll
-                for (int r = 0; r < 5; r++) *reinterpret_cast<uint16_t*>(mp + (size_t)r * mpitch) = (uint16_t)0;
+                for (int r = 0; r < 5; r++) *reinterpret_cast<uint16_t*>(mp + r * mstep) = (uint16_t)0;
             } else {
                 const uint32_t t0 = __builtin_amdgcn_perm(0u, T4, sel[0]), t1 = __builtin_amdgcn_perm(0u, T4, sel[1]), t2 = __builtin_amdgcn_perm(0u, T4, sel[2]),
                                t3 = __builtin_amdgcn_perm(0u, T4, sel[3]);
@@ -842,7 +857,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
                 for (int r = 0; r < 5; r++) {
                     const uint4 px = S.ring[s0 + r][lane];
                     const uint32_t bits = lt4_bytes(px.x, t0) | (lt4_bytes(px.y, t1) << 4) | (lt4_bytes(px.z, t2) << 8) | (lt4_bytes(px.w, t3) << 12);
-                    *reinterpret_cast<uint16_t*>(mp + (size_t)r * mpitch) = (uint16_t)bits;
+                    *reinterpret_cast<uint16_t*>(mp + r * mstep) = (uint16_t)bits;
                 }
             }
         }
