@@ -1322,23 +1322,14 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
         // thread t owns runs t, t + 256, t + 512, ...: consecutive lanes read consecutive words (as eight consecutive runs per
         // thread the lanes' addresses were 8 words apart -- a 16-way LDS bank conflict, the largest share of K2's 27 % conflict rate).
         // Slots are numbered in that (thread, k) order; any numbering is as good as another, later stages use the slot as a name only.
+        // (loops bounded by the tile's run count, not by the capacity: a tile has ~100 runs, one trip instead of eight tested ones)
         int roots_mine = 0;
-        constexpr int per_thread = RUNCAP / kCclThreads;
-        if (!overflow) {
-#pragma unroll
-            for (int k = 0; k < per_thread; k++) {
-                const int i = tid + k * kCclThreads;
-                if (i < nruns && parent_s[i] == (unsigned)i) roots_mine++;
-            }
-        }
+        if (!overflow)
+            for (int i = tid; i < nruns; i += kCclThreads) roots_mine += parent_s[i] == (unsigned)i ? 1 : 0;
         int s = block_excl_scan(roots_mine, misc_s, nslots);
-        if (!overflow) {
-#pragma unroll
-            for (int k = 0; k < per_thread; k++) {
-                const int i = tid + k * kCclThreads;
-                if (i < nruns && parent_s[i] == (unsigned)i) lab_s[i] = (uint16_t)(s++);
-            }
-        }
+        if (!overflow)
+            for (int i = tid; i < nruns; i += kCclThreads)
+                if (parent_s[i] == (unsigned)i) lab_s[i] = (uint16_t)(s++);
     }
     if (nslots > SLOTCAP) overflow = true;
     CCL_SYNC();
