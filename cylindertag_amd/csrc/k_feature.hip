@@ -518,7 +518,15 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     // (the sums kernel reads its rows two doubles at a time -- ds_read_b128 moves 16 bytes per lane at twice the rate of the ds_read2_b64 an
     // 8-byte-aligned row gets -- so its rows are 16-byte aligned: 130 doubles, rows 0-15 then cover the 64 banks exactly once)
     constexpr int kPitch = MODE == 2 ? kRefineSamples + 2 : kRefineSamples + 1;
-    __shared__ __attribute__((aligned(16))) double s_v[MODE == 1 ? 1 : 17][kPitch];
+    // The row of ones sits 16 doubles (32 banks) further than a 17th row would: a row of 130 doubles starts 4 banks after its predecessor, so
+    // rows 0-15 tile the 64 banks and a 17th row would share row 0's; the instructions that read ones (factor A or B of a sum) read x / y rows 0-7
+    // beside it, never the weight rows 8-15 whose banks it now shares (round 4: the sums kernel's 19 % bank conflicts were these two rows)
+#ifndef CTAG_ONES_SHIFT
+#define CTAG_ONES_SHIFT 16
+#endif
+    __shared__ __attribute__((aligned(16))) double s_vall[MODE == 1 ? kPitch : 17 * kPitch + CTAG_ONES_SHIFT];
+    double (*s_v)[kPitch] = reinterpret_cast<double (*)[kPitch]>(s_vall);
+    double* const s_ones = MODE == 1 ? s_vall : s_vall + 16 * kPitch + CTAG_ONES_SHIFT;
     double (*s_bx)[kPitch] = s_v, (*s_by)[kPitch] = s_v + (MODE == 1 ? 0 : 4);
     __shared__ double s_nrm[4][2];                // unit normal of each edge
     __shared__ uint64_t s_step[4][2];             // ctr::fast_step of the normal's components
@@ -545,7 +553,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     double* const accp = MODE == 2 ? acc_out : s_acc;
     if (MODE != 1 && tid < 48) accp[tid] = 0.0;
     if constexpr (MODE != 1) {
-        for (int k = tid; k < kRefineSamples + 1; k += (int)blockDim.x) s_v[16][k] = 1.0;
+        for (int k = tid; k < kRefineSamples + 1; k += (int)blockDim.x) s_ones[k] = 1.0;
     }
     __syncthreads();
     if (tid < 4) {  // :609-615
@@ -730,8 +738,8 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             // edge point has x = y = w = 0 and adds +0.0, which equals the reference skipping it
             const int edge = tid / 12, r = tid - edge * 12;
             const int pass = r / 6, which = r - pass * 6;
-            const double* pa = (which == 0 || which == 2 || which == 3) ? s_bx[edge] : (which == 5 ? s_v[16] : s_by[edge]);
-            const double* pb = which == 2 ? s_bx[edge] : ((which == 3 || which == 4) ? s_by[edge] : s_v[16]);
+            const double* pa = (which == 0 || which == 2 || which == 3) ? s_bx[edge] : (which == 5 ? s_ones : s_by[edge]);
+            const double* pb = which == 2 ? s_bx[edge] : ((which == 3 || which == 4) ? s_by[edge] : s_ones);
             const double* pw = s_v[8 + 4 * pass + edge];
             double acc = accp[tid];
             const int cntS = min(kRefineSamples, s_ns[edge] - sbase);
