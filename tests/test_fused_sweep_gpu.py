@@ -68,3 +68,27 @@ def test_fused_and_two_kernel_sweeps_give_the_same_records(detector, oracle, dic
                 assert_same_record(got[k], want[k], "mode %d frame %d" % (mode, k))
     finally:
         detector.set_option(capi.OPT_FUSED_SWEEP, 1)
+
+
+def test_fused_sweep_padded_rows_and_8k(fused, oracle, dictionary):
+    """Rows padded beyond the frame width (row_stride 2048 for 1920 columns, device memory), and a 7680x4320 frame: four waves per half-size
+    row, the two middle ones with halo lanes on both sides."""
+    import torch
+    state, fs = dictionary
+    frames = np.stack([tk.synth_frame_host(state, 40 + f)[0] for f in range(6)])
+    want, _ = oracle.detect_many(frames, state, fs)
+    dev = torch.device("cuda:0")
+    padded = torch.full((6, 1080, 2048), 77, dtype=torch.uint8, device=dev)
+    padded[:, :, :1920] = torch.from_numpy(frames).to(dev)
+    out = torch.zeros(6 * ca.RESULT_DT.itemsize, dtype=torch.uint8, device=dev)
+    fused.detect_batch_device(padded.data_ptr(), 6, 1080, 1920, 2048, 1080 * 2048, out.data_ptr())
+    fused.sync()
+    got = np.frombuffer(out.cpu().numpy().tobytes(), ca.RESULT_DT)
+    for k in range(6):
+        assert_same_record(got[k], want[k], "padded rows, frame %d" % k)
+    assert (fused.debug(5, tk.DBG_MASK).reshape(540, 960) == (oracle.detect(frames[5], state, fs)["binary"] > 0)).all()
+    big = tk.synth_frame_host(state, 2, 4320, 7680)[0].copy()
+    rng = np.random.RandomState(5)
+    for x0 in (1900, 3820, 5750):  # texture across each of the three seams between the four waves of a row (half-size columns 960, 1920, 2880)
+        big[:, x0:x0 + 60] = np.clip(rng.normal(70, 35, (4320, 60)), 0, 255).astype(np.uint8)
+    _mask_check(fused, oracle, state, fs, big, "8K frame, texture across the wave seams")
