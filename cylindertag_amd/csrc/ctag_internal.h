@@ -133,7 +133,7 @@ struct Workspace {
     uint8_t* half = nullptr;        // [F][hrows][hp]
     uint16_t* labels = nullptr;     // [F][hrows][lp]   tile-local label (0 = background)
     int32_t* tile_base = nullptr;   // [F][tiles]       pool offset of each tile's local components
-    int32_t* tile_dirty = nullptr;  // [F][tiles]       1: the tile's label pixels are not all zero (K2 skips rewriting zeros over zeros)
+    int32_t* tile_dirty = nullptr;  // [F][tiles]       bit b: label block b of the tile (8 rows x 64 columns) is not all zero (K2 skips rewriting zeros over zeros)
     int32_t* frame_ncomp = nullptr; // [F]              pool fill
     int32_t* ovf_count = nullptr;   // [1]              tiles handed to the second CCL pass (k_threshold_ccl_big) ...
     int32_t* ovf_list = nullptr;    // [F * tiles]      ... as frame * tiles + tile

@@ -430,8 +430,8 @@ struct SweepPtrs {
     const uint8_t* mask;   // k_decimate_mask's 1 bit per half-resolution pixel, rows of hcols / 8 bytes (the fused sweep: `half` is not written then)
     uint16_t* labels;
     int32_t* tile_base;
-    int32_t* tile_dirty;   // [F][tiles] 1: the tile's label pixels are not all zero.  The label image starts out zeroed and a tile without foreground
-                           // whose labels are zero already is not written again: background is most of a frame, and its 2 bytes per pixel were most of K2's traffic
+    int32_t* tile_dirty;   // [F][tiles] bit b: label block b of the tile (8 rows x 64 columns) holds label pixels that are not all zero.  The label image
+                           // starts out zeroed and zeros are not written over zeros: background is most of a frame, and its 2 bytes per pixel were most of K2's traffic
     int32_t* frame_ncomp;
     uint32_t* frame_flags;
     uint32_t* parent;
@@ -1261,6 +1261,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
         stamp(3);
   }
     // ---- S5: run starts, run numbering
+    if (tid == 0) misc_s[10] = 0;  // the label blocks S11 finds foreground in (tile_dirty)
     int nruns_mine = 0;
     if (tid < kTileH * kTileWords) {
         const int w = tid % kTileWords;
@@ -1426,14 +1427,22 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
         // whereas a row-major wave crosses a foreground stripe almost every time (8 % foreground groups, 99 % of the waves).
         constexpr int groups = kTileW / 8, gblocks = groups / 8, rblocks = (kTileH + 7) / 8;
         static_assert(groups % 8 == 0, "label blocks are 8 groups wide");
+        // tile_dirty is a bit per such block (20 of them): a block without foreground whose label pixels are zero already -- never written, or
+        // wiped since -- is skipped, stores and address arithmetic alike: within a tile that holds foreground most blocks still hold none
+        static_assert(rblocks * gblocks <= 31, "a bit of tile_dirty per label block");
+        int new_dirty = 0;
         for (int i = tid; i < rblocks * gblocks * 64; i += kCclThreads) {
             const int blk = i >> 6, l = i & 63;
             const int by = blk / gblocks, bx = blk - by * gblocks;
             const int r = by * 8 + (l >> 3), gq = bx * 8 + (l & 7);
-            if (r >= th_eff || gq * 8 >= tw_eff) continue;
-            const int item = r * kTileWords + (gq >> 3);
+            const bool inr = r < th_eff && gq * 8 < tw_eff;
+            const int item = min(r, kTileH - 1) * kTileWords + (gq >> 3);
             const int b0 = (gq & 7) * 8;
-            const unsigned byte = (unsigned)((mask_s[item] >> b0) & 0xff);
+            const unsigned byte = inr ? (unsigned)((mask_s[item] >> b0) & 0xff) : 0u;
+            const bool any = __ballot(byte != 0u) != 0ull;  // wave-uniform: the trip counts are (1280 = 20 x 64 items)
+            if (!any && !((was_dirty >> blk) & 1)) continue;
+            new_dirty |= any ? (1 << blk) : 0;
+            if (!inr) continue;
             uint32_t o[4] = {0, 0, 0, 0};
             if (byte) {
                 // one run-id lookup per run segment of the group (a run's pixels share its label), then a select per pixel
@@ -1454,6 +1463,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
             }
             *reinterpret_cast<uint4*>(limg + (size_t)(ty0 + r) * g.lp + tx0 + gq * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
+        if (lane == 0 && new_dirty) atomicOr(&misc_s[10], new_dirty);
     }
     stamp(8);
     // ---- S10: publish the tile's components in the frame pool
@@ -1466,7 +1476,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     }
     if (tid == 0) {
         P.tile_base[(size_t)frame * g.tiles_x * g.tiles_y + tile] = base;
-        if (!was_dirty) *dirty_p = 1;  // S11 wrote labels
+        if (misc_s[10] != was_dirty) *dirty_p = misc_s[10];  // the label blocks that hold foreground now (S11)
     }
     {
         const size_t pool0 = (size_t)frame * g.pool_cap;
