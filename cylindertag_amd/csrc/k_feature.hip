@@ -80,16 +80,22 @@ __device__ __forceinline__ bool near_ang(float a, float b, float thr) {
     return ctm::fabs32(a - b) < thr || ctm::fabs32(ctm::fabs32(a - b) - 180) < thr || ctm::fabs32(ctm::fabs32(a - b) - 360) < thr;
 }
 
-// featureOrganization (:571-598)
-__device__ void feature_organization(const float* q1, const float* q2, float c1x, float c1y, float c2x, float c2y, float feature_angle, FeatureDev* F) {
+// featureOrganization (:571-598), eight lanes per feature: lane k of the group evaluates ONE of the eight corner angles (an atan2 each, what the
+// function costs), the rest -- a handful of float operations -- every lane repeats and lane 0 stores
+__device__ __forceinline__ void feature_organization(const float* q1, const float* q2, float c1x, float c1y, float c2x, float c2y, float feature_angle, FeatureDev* F, int k, int lane0, bool store) {
+    const int kk = k & 3;
+    const float* q = k < 4 ? q1 : q2;
+    const float ang = (float)angdeg((k < 4 ? c1y : c2y) - q[2 * kk + 1], (k < 4 ? c1x : c2x) - q[2 * kk]);
+    float a1[4], a2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a1[i] = __shfl(ang, lane0 + i);
+        a2[i] = __shfl(ang, lane0 + 4 + i);
+    }
     float angle_max = 0, angle_min = 360;
     int pos1 = -1, pos2 = -1;
-    float a1[4], a2[4];
-    for (int i = 0; i < 4; i++) {
-        a1[i] = (float)angdeg(c1y - q1[2 * i + 1], c1x - q1[2 * i]);
-        a2[i] = (float)angdeg(c2y - q2[2 * i + 1], c2x - q2[2 * i]);
-    }
     auto fold = [&](float a) { return fminf(360 - ctm::fabs32(a - feature_angle), ctm::fabs32(a - feature_angle)); };
+#pragma unroll
     for (int i = 0; i < 4; i++) {
         const float v1 = fold(a1[(i + 2) % 4]) + fold(a1[(i + 3) % 4]);
         if (v1 < angle_min) {
@@ -102,6 +108,7 @@ __device__ void feature_organization(const float* q1, const float* q2, float c1x
             pos2 = i;
         }
     }
+    if (!store) return;
     if (pos1 < 0) pos1 = 0;
     if (pos2 < 0) pos2 = 0;
     for (int i = 0; i < 4; i++) {
@@ -150,9 +157,13 @@ __device__ __forceinline__ bool feature_pair(const QuadDerived& Di, const QuadDe
            ((d1l + d2l) > (d1s + d2s)) && ((d1l + d2l) < 15 * (d1s + d2s)) && (fl - (d1l + d2l) / 2 < 0.3 * (fl + (d1l + d2l) / 2));
 }
 
-__global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int feature_size) {
+// THREADS: 128 for batches (a frame per block, many blocks per CU); 512 for calls of a few frames, where the kernel is as long as one block's
+// chain of phases and every phase is a loop over work items (quads, pairs, features x 8 angles) that more lanes finish in fewer trips
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_features(FeatPtrs P, int nframes, int feature_size) {
+    constexpr int NW = THREADS / 64;
     __shared__ unsigned char s_vis[CTAG_MAX_QUADS];
-    __shared__ int s_scan[4];
+    __shared__ int s_scan[NW];
     __shared__ int s_best;
     __shared__ int s_nf;
     constexpr int kPairCap = 192;  // quads per frame handled by the all-pairs path (a frame has 50-80)
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
     PhaseClock clk(P.stamps);
     // compact accepted quads in candidate (= OpenCV label) order
     int Q = 0;
-    for (int base = 0; base < nc; base += 128) {
+    for (int base = 0; base < nc; base += THREADS) {
         const int i = base + tid;
         const int v = (i < nc && quads[i].valid) ? 1 : 0;
         int inc = v;
@@ -189,9 +200,15 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         }
         if (lane == 63) s_scan[wave] = inc;
         __syncthreads();
-        const int pre = (wave == 1 ? s_scan[0] : 0) + inc - v;
+        int pre = inc - v, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int c = s_scan[w];
+            if (w < wave) pre += c;
+            all += c;
+        }
         if (v && Q + pre < kQuadStride) qidx[Q + pre] = i;
-        Q += s_scan[0] + s_scan[1];
+        Q += all;
         __syncthreads();
     }
     if (tid == 0) {
@@ -215,45 +232,58 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
     }
     __syncthreads();  // qidx visible to the block (global memory, same workgroup)
     clk.mark(0);
-    for (int q = tid; q < Q; q += 128) {
-        const float* c = quads[qidx[q]].c;
-        QuadDerived D;
-        D.cx = (c[0] + c[2] + c[4] + c[6]) / 4;
-        D.cy = (c[1] + c[3] + c[5] + c[7]) / 4;
-        for (int j = 0; j < 4; j++) {
-            const int k = (j + 1) % 4;
-            D.d[j] = ctm::sqrt32((c[2 * j] - c[2 * k]) * (c[2 * j] - c[2 * k]) + (c[2 * j + 1] - c[2 * k + 1]) * (c[2 * j + 1] - c[2 * k + 1]));
+    // per quad: centre, side lengths and the five side directions the pair test asks for (:473-481, :497-539) -- eight lanes per quad, lane k < 5
+    // of the group evaluates ONE atan2 (what the phase costs); lane 0 gathers them
+    for (int q0 = 0; q0 < Q; q0 += THREADS / 8) {  // uniform trip count: the shuffles below need the whole group
+        const int q = q0 + (tid >> 3), k = tid & 7, l0 = lane & ~7;
+        const bool have = q < Q;
+        const float* c = quads[qidx[have ? q : 0]].c;
+        // A = (c1-c3, c0-c2)  B = (c7-c5, c6-c4)  C = (c3-c5, c2-c4)  D = (c1-c7, c0-c6)  E = (c5-c7, c4-c6)
+        const int ya = k == 0 ? 1 : k == 1 ? 7 : k == 2 ? 3 : k == 3 ? 1 : 5, yb = k == 0 ? 3 : k == 1 ? 5 : k == 2 ? 5 : k == 3 ? 7 : 7;
+        const double ang = k < 5 ? angdeg(c[ya] - c[yb], c[ya - 1] - c[yb - 1]) : 0.;
+        double A[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) A[u] = __shfl(ang, l0 + u);
+        if (have && k == 0) {
+            QuadDerived D;
+            D.cx = (c[0] + c[2] + c[4] + c[6]) / 4;
+            D.cy = (c[1] + c[3] + c[5] + c[7]) / 4;
+            for (int j = 0; j < 4; j++) {
+                const int kk = (j + 1) % 4;
+                D.d[j] = ctm::sqrt32((c[2 * j] - c[2 * kk]) * (c[2 * j] - c[2 * kk]) + (c[2 * j + 1] - c[2 * kk + 1]) * (c[2 * j + 1] - c[2 * kk + 1]));
+            }
+            D.a1 = (float)((A[0] + A[1]) / 2);
+            D.a2 = (float)((A[2] + A[3]) / 2);
+            D.e[0] = (float)A[3];
+            D.e[1] = (float)A[2];
+            D.e[2] = (float)A[0];
+            D.e[3] = (float)A[4];
+            der[q] = D;
+            s_vis[q] = 0;
+            if (q < kPairCap) {
+                s_der[q] = D;
+                s_reach[q] = fmaxf((D.d[0] + D.d[2]) / 2, (D.d[1] + D.d[3]) / 2);
+            }
         }
-        D.a1 = (float)((angdeg(c[1] - c[3], c[0] - c[2]) + angdeg(c[7] - c[5], c[6] - c[4])) / 2);
-        D.a2 = (float)((angdeg(c[3] - c[5], c[2] - c[4]) + angdeg(c[1] - c[7], c[0] - c[6])) / 2);
-        D.e[0] = (float)angdeg(c[1] - c[7], c[0] - c[6]);
-        D.e[1] = (float)angdeg(c[3] - c[5], c[2] - c[4]);
-        D.e[2] = (float)angdeg(c[1] - c[3], c[0] - c[2]);
-        D.e[3] = (float)angdeg(c[5] - c[7], c[4] - c[6]);
-        der[q] = D;
-        s_vis[q] = 0;
     }
+    for (int w = tid; w < min(Q, kPairCap) * (kPairCap / 32); w += THREADS) s_pred[w] = 0u;
+    if (tid == 0) s_npair = 0;
     __syncthreads();
     clk.mark(1);
     // ---- greedy pairing (:483-553): quad i takes the first unvisited j > i that passes the pair test.  The test does not
     // depend on the visited flags, so for Q <= kPairCap it is evaluated for all pairs at once (every lane busy, one atan2 per
     // pair) into a bit matrix, one lane replays the greedy order on the bits, and the matches are organised in parallel.
     if (Q <= kPairCap) {
-        for (int q = tid; q < Q; q += 128) {
-            const QuadDerived D = der[q];
-            s_der[q] = D;
-            s_reach[q] = fmaxf((D.d[0] + D.d[2]) / 2, (D.d[1] + D.d[3]) / 2);
-        }
-        for (int w = tid; w < Q * (kPairCap / 32); w += 128) s_pred[w] = 0u;
-        if (tid == 0) s_npair = 0;
-        __syncthreads();
         // The pair test costs an atan2 in double and most pairs are far apart, so a cheap necessary condition goes first: the
         // test ends with  fl - L/2 < 0.3 (fl + L/2)  (fl = centre distance, L = d1l + d2l), and whichever branches are taken
         // d1l <= reach_i = max((d0+d2)/2, (d1+d3)/2) -- the same float expressions -- hence L <= reach_i + reach_j =: S
         // (rounding is monotonic).  With fl >= S the left side is >= fl/2 and the right side <= 0.45 fl: the test fails by a
         // margin no rounding closes.  Pairs that survive are listed and evaluated densely, a pair per lane.
         {
-            const int j0 = tid, j1 = tid + 128;
+            constexpr int JW = THREADS >= 256 ? 256 : 128;  // lanes across j; THREADS / JW interleaved slices of i
+            constexpr int NI = THREADS / JW;
+            const int jl = tid % JW, i0 = tid / JW;
+            const int j0 = jl, j1 = jl + JW;
             const bool h0 = j0 < Q, h1 = j1 < Q;
             const float x0 = h0 ? s_der[j0].cx : 0.f, y0 = h0 ? s_der[j0].cy : 0.f, r0 = h0 ? s_reach[j0] : 0.f;
             const float x1 = h1 ? s_der[j1].cx : 0.f, y1 = h1 ? s_der[j1].cy : 0.f, r1 = h1 ? s_reach[j1] : 0.f;
@@ -262,20 +292,20 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
                 if (at < kPairList) s_plist[at] = (uint16_t)(i | (j << 8));
                 else if (feature_pair(s_der[i], s_der[j], P.threshold_angle)) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));  // list full: in place
             };
-            for (int i = 0; i + 1 < Q; i++) {
+            for (int i = i0; i + 1 < Q; i += NI) {
                 const float xi = s_der[i].cx, yi = s_der[i].cy, ri = s_reach[i];
                 if (h0 && j0 > i) {
                     const float S = ri + r0, dx = xi - x0, dy = yi - y0;
                     if (!(dx * dx + dy * dy > S * S)) consider(i, j0);
                 }
-                if (h1 && j1 > i) {
+                if (JW < kPairCap && h1 && j1 > i) {
                     const float S = ri + r1, dx = xi - x1, dy = yi - y1;
                     if (!(dx * dx + dy * dy > S * S)) consider(i, j1);
                 }
             }
         }
         __syncthreads();
-        for (int t = tid; t < min(s_npair, kPairList); t += 128) {
+        for (int t = tid; t < min(s_npair, kPairList); t += THREADS) {
             const int i = (int)(s_plist[t] & 0xffu), j = (int)(s_plist[t] >> 8);
             if (feature_pair(s_der[i], s_der[j], P.threshold_angle)) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));
         }
@@ -343,11 +373,17 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         }
         __syncthreads();
         clk.mark(3);
-        for (int k = tid; k < min(s_nf, CTAG_MAX_FEATURES); k += 128) {
-            const int i = (int)(s_match[k] & 0xffffu), j = (int)(s_match[k] >> 16);
-            const QuadDerived &Di = s_der[i], &Dj = s_der[j];
-            const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
-            feature_organization(quads[qidx[i]].c, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[k]);
+        {
+            const int nm = min(s_nf, CTAG_MAX_FEATURES);
+            for (int k0 = 0; k0 < nm; k0 += THREADS / 8) {  // eight lanes per feature (uniform trip count: the group shuffles)
+                const int k = k0 + (tid >> 3);
+                const bool have = k < nm;
+                const uint32_t mk = s_match[have ? k : 0];
+                const int i = (int)(mk & 0xffffu), j = (int)(mk >> 16);
+                const QuadDerived &Di = s_der[i], &Dj = s_der[j];
+                const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
+                feature_organization(quads[qidx[i]].c, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[have ? k : 0], tid & 7, lane & ~7, have && (tid & 7) == 0);
+            }
         }
     } else {
         for (int i = 0; i + 1 < Q; i++) {
@@ -356,7 +392,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
             __syncthreads();
             const QuadDerived Di = der[i];
             int mine = 0x7fffffff;
-            for (int j = i + 1 + tid; j < Q && mine == 0x7fffffff; j += 128) {
+            for (int j = i + 1 + tid; j < Q && mine == 0x7fffffff; j += THREADS) {
                 if (s_vis[j]) continue;
                 if (feature_pair(Di, der[j], P.threshold_angle)) mine = j;
             }
@@ -365,16 +401,17 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
             const int j = s_best;
             __syncthreads();
             if (j != 0x7fffffff) {
+                if (tid < 8) {
+                    const int nf = s_nf;
+                    const QuadDerived Dj = der[j];
+                    const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
+                    feature_organization(quads[qidx[i]].c, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[min(nf, CTAG_MAX_FEATURES - 1)], tid, 0, tid == 0 && nf < CTAG_MAX_FEATURES);
+                }
+                __syncthreads();
                 if (tid == 0) {
                     s_vis[i] = 1;
                     s_vis[j] = 1;
-                    const int nf = s_nf;
-                    if (nf < CTAG_MAX_FEATURES) {
-                        const QuadDerived Dj = der[j];
-                        const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
-                        feature_organization(quads[qidx[i]].c, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[nf]);
-                    }
-                    s_nf = nf + 1;
+                    s_nf = s_nf + 1;
                 }
                 __syncthreads();
             }
@@ -396,7 +433,7 @@ __global__ __launch_bounds__(128) void k_features(FeatPtrs P, int nframes, int f
         if (nf > CTAG_MAX_FEATURES) atomicOr(&P.frame_flags[frame], CTAG_FLAG_FEATURE_OVERFLOW);
     }
     // cornerObtain (:561-569): half-res -> full-res coordinates
-    for (int k = tid; k < min(nf, CTAG_MAX_FEATURES); k += 128) {
+    for (int k = tid; k < min(nf, CTAG_MAX_FEATURES); k += THREADS) {
         FeatureDev F = f0[k];
         for (int q = 0; q < 16; q++) F.c[q] = (F.c[q] - 0.5f) * 2 + 0.5f;
         F.center[0] = (F.c[0] + F.c[2] + F.c[8] + F.c[10]) / 4;
@@ -1580,7 +1617,8 @@ static unsigned long long* feat_stamps(hipStream_t s, bool report) {
 
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
     FeatPtrs P{ws.ncand, ws.quads, reinterpret_cast<QuadDerived*>(ws.quad_derived), ws.quad_index, ws.nquads, ws.nfeat, ws.status, ws.frame_flags, ws.feat0, ws.feat1, ws.feat2, feat_stamps(s, false), ws.kp.angle, ws.frame_long, ws.cand_cap};
-    hipLaunchKernelGGL(k_features, dim3(nframes), dim3(128), 0, s, P, nframes, p.feature_size);
+    if (nframes <= kLatencyFrames) hipLaunchKernelGGL(k_features<512>, dim3(nframes), dim3(512), 0, s, P, nframes, p.feature_size);
+    else hipLaunchKernelGGL(k_features<128>, dim3(nframes), dim3(128), 0, s, P, nframes, p.feature_size);
     return hipGetLastError();
 }
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
