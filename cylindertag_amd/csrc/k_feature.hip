@@ -1012,7 +1012,19 @@ __device__ void feature_ids(float* C, int direction, int& ID_left, int& ID_right
     }
 }
 
-__global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int feature_size, int drows, int dcols) {
+// WAVES: 1 for batches (a frame per wave, eight frames per CU); 8 for calls of a few frames: the pair predicate and the per-slot phases spread over
+// all lanes, the union-find stays on wave 0 (its state lives in that wave's registers), and the markers are decoded a wave each -- code
+// positions, dictionary coverage and the choice are independent per marker; only the places of the accepted markers in the record depend on the
+// markers before them, and those are handed out in marker order once a round of WAVES markers is decoded.
+#define WSYNC()                                                \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_markers(MarkerPtrs P, int nframes, int feature_size, int drows, int dcols) {
+    constexpr int NT = 64 * WAVES;
+    constexpr int SL = (CTAG_MAX_FEATURES + NT - 1) / NT;  // feature slots per lane in the per-slot phases
     // the features as K8 left them and, later, the records built from them share one region (records are built from registers):
     // with the coverage table in bytes the block needs 19.6 KB instead of 31.6 KB of LDS -- 8 frames per CU instead of 5
     __shared__ __attribute__((aligned(16))) unsigned char s_fr[CTAG_MAX_FEATURES * sizeof(ctag_feature_rec)];
@@ -1023,24 +1035,25 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     __shared__ int s_group[CTAG_MAX_FEATURES];   // marker index of each feature
     __shared__ int s_order[CTAG_MAX_FEATURES];   // features grouped by marker, in marker order, sorted
     __shared__ int s_mfirst[CTAG_MAX_FEATURES + 1];
-    __shared__ uint8_t s_cov[2 * kMaxDictCells];  // coverage per (dir, row, col): at most CTAG_MAX_CODE_POS
-    __shared__ int s_code[CTAG_MAX_CODE_POS];
-    __shared__ int s_misc[8];
+    __shared__ uint8_t s_cov_w[WAVES][2 * kMaxDictCells];  // coverage per (dir, row, col): at most CTAG_MAX_CODE_POS
+    __shared__ int s_code_w[WAVES][CTAG_MAX_CODE_POS];
+    __shared__ int s_misc_w[WAVES][8];
+    __shared__ int s_cnt;
     __shared__ unsigned long long s_pair[CTAG_MAX_FEATURES][2];
-    __shared__ int s_pos[CTAG_MAX_CODE_POS];
+    __shared__ int s_pos_w[WAVES][CTAG_MAX_CODE_POS];
     __shared__ uint8_t s_dict[kMaxDictCells];  // dictionary entries are 0..63 (checked at load): one byte each
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ctag_frame_result* out = P.out + frame;
     PhaseClock clk(P.stamps);
     // every byte of a result record is defined (unused slots are zero): records are compared / gathered as raw bytes
     {
         uint32_t* w = reinterpret_cast<uint32_t*>(out);
-        for (int i = tid; i < (int)(sizeof(ctag_frame_result) / 4); i += 64) w[i] = 0u;
+        for (int i = tid; i < (int)(sizeof(ctag_frame_result) / 4); i += NT) w[i] = 0u;
         if (P.pre) {
             uint32_t* wp = reinterpret_cast<uint32_t*>(P.pre + frame);
-            for (int i = tid; i < (int)(sizeof(ctag_frame_result) / 4); i += 64) wp[i] = 0u;
+            for (int i = tid; i < (int)(sizeof(ctag_frame_result) / 4); i += NT) wp[i] = 0u;
         }
     }
     __syncthreads();
@@ -1084,8 +1097,8 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         }
         return;
     }
-    for (int i = tid; i < nf; i += 64) s_feat[i] = P.feat[(size_t)frame * CTAG_MAX_FEATURES + i];
-    for (int i = tid; i < drows * dcols; i += 64) s_dict[i] = (uint8_t)P.dict[i];
+    for (int i = tid; i < nf; i += NT) s_feat[i] = P.feat[(size_t)frame * CTAG_MAX_FEATURES + i];
+    for (int i = tid; i < drows * dcols; i += NT) s_dict[i] = (uint8_t)P.dict[i];
     __syncthreads();
     clk.mark(16);
     // ---- markerOrganization (:976-1052).  The O(F^2) pair predicate is evaluated for all pairs i < j at once, a pair per lane
@@ -1093,10 +1106,10 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     // the true pairs are then replayed in the reference's (i, j) order, which is all the union-find state depends on.
     {
         uint32_t* pair32 = reinterpret_cast<uint32_t*>(&s_pair[0][0]);
-        for (int w = tid; w < 4 * nf; w += 64) pair32[w] = 0u;
+        for (int w = tid; w < 4 * nf; w += NT) pair32[w] = 0u;
         __syncthreads();
         const int rows2 = nf / 2;  // ceil((nf - 1) / 2) folded rows
-        for (int idx = tid; idx < rows2 * nf; idx += 64) {
+        for (int idx = tid; idx < rows2 * nf; idx += NT) {
             const int r = idx / nf, c = idx - r * nf;
             int i, j;
             if (c < nf - 1 - r) {
@@ -1122,8 +1135,8 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     clk.mark(17);
     // The union-find runs on the whole wave in lockstep with its state in registers: father[k] lives in lane k & 63 (fa for k < 64,
     // fb above), read with v_readlane (the index is wave-uniform) instead of a chain of dependent LDS round trips.
-    int cnt;
-    {
+    if (wave == 0) {
+        int cnt;
         int fa = tid, fb = 64 + tid;
         auto fget = [&](int x) { return x < 64 ? __builtin_amdgcn_readlane(fa, x) : __builtin_amdgcn_readlane(fb, x - 64); };
         auto fset = [&](int x, int v) {
@@ -1222,21 +1235,25 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             }
             pos += __popcll(ba) + __popcll(bb);
         }
-        if (tid == 0) s_mfirst[cnt] = pos;
+        if (tid == 0) {
+            s_mfirst[cnt] = pos;
+            s_cnt = cnt;
+        }
     }
     __syncthreads();
+    const int cnt = s_cnt;
     clk.mark(18);
     // ---- per marker: orientation (the angles of its features are summed in order, :1021-1031) and the stable sort of its
     // features: angles and ranks are computed a feature slot per lane, only the sum is a lane per marker
     double* s_ang = reinterpret_cast<double*>(&s_pair[0][0]);  // the bit matrix is dead: folded direction of the feature in slot k
-    for (int k = tid; k < nf; k += 64) {
+    for (int k = tid; k < nf; k += NT) {
         const FeatureDev& F = s_feat[s_order[k]];
         double angle_now = ctm::fast_atan2_deg(F.c[1] - F.c[11], F.c[0] - F.c[10]);
         if (angle_now > 180) angle_now -= 180;
         s_ang[k] = angle_now;
     }
     __syncthreads();
-    for (int m = tid; m < cnt; m += 64) {
+    for (int m = tid; m < cnt; m += NT) {
         const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
         float marker_angle = 0;
         for (int k = a; k < b; k++) marker_angle = (float)(marker_angle + s_ang[k]);
@@ -1246,10 +1263,11 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     __syncthreads();
     {
         // rank of slot k among its marker's slots: std::sort on <= 16 elements is an insertion sort, i.e. stable
-        int newv[2] = {0, 0}, newk[2] = {-1, -1}, dirk[2] = {0, 0};
+        int newv[SL], newk[SL], dirk[SL];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int k = tid + 64 * q;
+        for (int q = 0; q < SL; q++) {
+            newv[q] = 0, newk[q] = -1, dirk[q] = 0;
+            const int k = tid + NT * q;
             if (k >= nf) continue;
             const int m = s_father[k], a = s_mfirst[m], b = s_mfirst[m + 1], direc = s_group[m];
             const int v = s_order[k];
@@ -1268,15 +1286,15 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < SL; q++) {
             if (newk[q] < 0) continue;
             s_order[newk[q]] = newv[q];
         }
         __syncthreads();
         // s_group becomes: direction of the marker owning slot k (s_father keeps the marker of slot k; a marker's slots do not move)
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int k = tid + 64 * q;
+        for (int q = 0; q < SL; q++) {
+            const int k = tid + NT * q;
             if (k < nf) s_group[k] = dirk[q];
         }
     }
@@ -1285,17 +1303,17 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
     // ---- featureExtraction (lane per feature slot).  ID_left / ID_right persist from one feature to the next when no
     // cross-ratio band matches, so each lane reports "matched value or carry" and thread 0 replays the carry.
     constexpr int kCarry = -99;
-    static_assert(CTAG_MAX_FEATURES <= 128, "two feature slots per lane");
-    FeatureDev Fk[2];
+    static_assert(CTAG_MAX_FEATURES <= 128, "two feature slots per lane of a one-wave block");
+    FeatureDev Fk[SL];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int k = tid + 64 * q;
+    for (int q = 0; q < SL; q++) {
+        const int k = tid + NT * q;
         if (k < nf) Fk[q] = s_feat[s_order[k]];
     }
     __syncthreads();  // every feature is in registers: the region becomes the records
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int k = tid + 64 * q;
+    for (int q = 0; q < SL; q++) {
+        const int k = tid + NT * q;
         if (k >= nf) continue;
         const FeatureDev& F = Fk[q];
         ctag_feature_rec& R = s_rec[k];
@@ -1337,27 +1355,37 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             pre->n_features = nf;
             pre->flags = flags;
         }
-        for (int m = tid; m < cnt; m += 64) {
+        for (int m = tid; m < cnt; m += NT) {
             pre->markers[m].marker_id = -1;
             pre->markers[m].first_feature = s_mfirst[m];
             pre->markers[m].n_features = s_mfirst[m + 1] - s_mfirst[m];
             pre->markers[m].n_pos = 0;
         }
-        for (int k = tid; k < nf; k += 64) pre->features[k] = s_rec[k];
+        for (int k = tid; k < nf; k += NT) pre->features[k] = s_rec[k];
     }
     clk.mark(21);
     // ---- markerDecoder (:1211-1250) + match_dictionary (:1269-1324)
     int out_markers = 0, out_features = 0;
     uint32_t oflags = flags;
-    for (int m = 0; m < cnt; m++) {
-        const int a = s_mfirst[m], b = s_mfirst[m + 1], n = b - a;
-        if (n < feature_size) continue;  // uniform
-        __syncthreads();
+    for (int m0 = 0; m0 < cnt; m0 += WAVES) {
+        __syncthreads();  // the records are complete / the previous round's markers are stored
+        int* const s_code = s_code_w[wave];
+        uint8_t* const s_cov = s_cov_w[wave];
+        int* const s_misc = s_misc_w[wave];
+        int* const s_pos = s_pos_w[wave];
+        const int m = m0 + wave;
+        const int a = m < cnt ? s_mfirst[m] : 0, b = m < cnt ? s_mfirst[m + 1] : 0, n = b - a;
+        if (lane == 0) {
+            s_misc[3] = 0;  // no code overflow
+            s_misc[5] = 0;  // not accepted
+        }
+        WSYNC();
+        if (m < cnt && n >= feature_size) do {  // (wave-uniform)
         if (n <= 64) {
             // code positions (:1218-1227) a feature per lane: gap_j from features j-1 and j, position = running sum of the gaps;
             // the sequential loop stops at the first bad gap or position, which any lane reports; of several features on one
             // position the last one stays
-            const int j = tid;
+            const int j = lane;
             int gap = 0, bad = 0, idj = -1;
             if (j < n) {
                 const ctag_feature_rec& Rj = s_rec[a + j];
@@ -1374,23 +1402,23 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const int o = __shfl_up(pos, d);
-                if (tid >= d) pos += o;
+                if (lane >= d) pos += o;
             }
             if (j < n && pos >= CTAG_MAX_CODE_POS) bad = 1;
             const int overflow = __ballot(bad != 0) != 0ull;
-            if (tid < CTAG_MAX_CODE_POS) s_code[tid] = -1;
-            __syncthreads();
+            if (lane < CTAG_MAX_CODE_POS) s_code[lane] = -1;
+            WSYNC();
             const int pos_next = __shfl_down(pos, 1);
             if (!overflow && j < n && (j == n - 1 || pos_next != pos)) s_code[pos] = idj;
-            __syncthreads();
-            const unsigned long long lg = __ballot(tid < CTAG_MAX_CODE_POS && s_code[tid < CTAG_MAX_CODE_POS ? tid : 0] > -1);
+            WSYNC();
+            const unsigned long long lg = __ballot(lane < CTAG_MAX_CODE_POS && s_code[lane < CTAG_MAX_CODE_POS ? lane : 0] > -1);
             const int pos_last = __shfl(pos, n - 1);
-            if (tid == 0) {
+            if (lane == 0) {
                 s_misc[2] = pos_last;
                 s_misc[3] = overflow;
                 s_misc[4] = __popcll(lg);
             }
-        } else if (tid == 0) {
+        } else if (lane == 0) {
             for (int k = 0; k < CTAG_MAX_CODE_POS; k++) s_code[k] = -1;
             int pos_now = 0, overflow = 0;
             s_code[0] = s_rec[a].id;
@@ -1416,17 +1444,14 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             s_misc[3] = overflow;
             s_misc[4] = legal;
         }
-        __syncthreads();
+        WSYNC();
         clk.mark(22);
-        if (s_misc[3]) {
-            oflags |= CTAG_FLAG_CODE_OVERFLOW;
-            continue;
-        }
+        if (s_misc[3]) break;  // CTAG_FLAG_CODE_OVERFLOW (set where the round's markers are stored)
         const int length = s_misc[2], legal = s_misc[4];
         // coverage of every hypothesis (dir, row, col), stored in the reference's scan order
         const int hyp = drows * dcols;
         const int per = (2 * hyp + 63) / 64;
-        const int h_lo = min(tid * per, 2 * hyp), h_hi = min(h_lo + per, 2 * hyp);
+        const int h_lo = min(lane * per, 2 * hyp), h_hi = min(h_lo + per, 2 * hyp);
         int lane_max = -1;
         if (P.dict_pos) {
             // Bit-parallel form, a dictionary row per lane: dict_pos[row][v] is the set of columns holding symbol v (built once per
@@ -1435,7 +1460,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             // bit planes.  Reversed direction: the inverted symbol, rotation the other way, and a column that the reference's
             // (j - k + dcols) leaves negative (k > j + dcols) never matches.
             const uint32_t dmask = dcols >= 32 ? 0xffffffffu : ((1u << dcols) - 1u);
-            for (int i = tid; i < drows; i += 64) {
+            for (int i = lane; i < drows; i += 64) {
                 const uint32_t* Ti = P.dict_pos + (size_t)i * 64;
                 uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
                 int sh = 0;  // k % dcols
@@ -1469,7 +1494,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
                         (uint8_t)(((b0 >> j) & 1u) | (((b1 >> j) & 1u) << 1) | (((b2 >> j) & 1u) << 2) | (((b3 >> j) & 1u) << 3) | (((b4 >> j) & 1u) << 4));
                 }
             }
-            __syncthreads();
+            WSYNC();
             for (int h = h_lo; h < h_hi; h++) lane_max = max(lane_max, (int)s_cov[h]);
         } else {
             // more than 32 dictionary columns: a contiguous run of hypotheses per lane, the code and its reversed+inverted form in
@@ -1517,11 +1542,11 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
         int run = lane_max;
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(run, d);
-            if (tid >= d) run = max(run, o);
+            if (lane >= d) run = max(run, o);
         }
         const int gmax = __shfl(run, 63);
         run = __shfl_up(run, 1);
-        if (tid == 0) run = -1;
+        if (lane == 0) run = -1;
         int sec = -1, first_max = 0x7fffffff;
         for (int h = h_lo; h < h_hi; h++) {
             const int cov = s_cov[h];
@@ -1536,7 +1561,7 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             sec = max(sec, __shfl_xor(sec, d));
             first_max = min(first_max, __shfl_xor(first_max, d));
         }
-        if (tid == 0) {
+        if (lane == 0) {
             const int max_cov = gmax, second = sec;
             const int dir = first_max >= hyp, rc = first_max - dir * hyp;
             const int mx = rc / dcols, my = rc - mx * dcols;
@@ -1545,11 +1570,8 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
             const int good = (max_cov >= lim && max_cov > second) ? 1 : 0;
             s_misc[5] = good;
             s_misc[6] = direc;
+            s_misc[1] = mx;
             if (good) {
-                ctag_marker_rec& M = out->markers[out_markers];
-                M.marker_id = mx;
-                M.first_feature = out_features;
-                M.n_features = n;
                 int np = 0;
                 for (int i = 0; i <= length; i++) {
                     if (s_code[i] != -1) {
@@ -1557,15 +1579,28 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
                         np++;
                     }
                 }
-                M.n_pos = np;
                 s_misc[7] = np;
             }
         }
+        } while (0);
+        clk.mark(23);
         __syncthreads();
-        if (s_misc[5]) {
-            const int direc = s_misc[6], np = s_misc[7];
-            for (int k = tid; k < n; k += 64) {
-                ctag_feature_rec R = s_rec[a + k];
+        // the round's markers take their places in the record, in marker order
+        for (int w = 0; w < WAVES && m0 + w < cnt; w++) {
+            const int* const r_misc = s_misc_w[w];
+            if (r_misc[3]) oflags |= CTAG_FLAG_CODE_OVERFLOW;
+            if (!r_misc[5]) continue;
+            const int ra = s_mfirst[m0 + w], rn = s_mfirst[m0 + w + 1] - ra;
+            const int direc = r_misc[6], np = r_misc[7];
+            if (tid == 0) {
+                ctag_marker_rec& M = out->markers[out_markers];
+                M.marker_id = r_misc[1];
+                M.first_feature = out_features;
+                M.n_features = rn;
+                M.n_pos = np;
+            }
+            for (int k = tid; k < rn; k += NT) {
+                ctag_feature_rec R = s_rec[ra + k];
                 if (direc == -1) {
                     for (int q = 0; q < 8; q++) {
                         const float t = R.corners[q];
@@ -1573,13 +1608,11 @@ __global__ __launch_bounds__(64) void k_markers(MarkerPtrs P, int nframes, int f
                         R.corners[8 + q] = t;
                     }
                 }
-                R.pos = k < np ? s_pos[k] : -1;
+                R.pos = k < np ? s_pos_w[w][k] : -1;
                 out->features[out_features + k] = R;
             }
-        }
-        if (s_misc[5]) {
             out_markers++;
-            out_features += n;
+            out_features += rn;
         }
         clk.mark(24);
     }
@@ -1643,7 +1676,8 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
 }
 hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& p, ctag_frame_result* out, const PendingCtx& pend, hipStream_t s) {
     MarkerPtrs P{ws.nfeat, ws.status, ws.frame_flags, ws.feat2, p.dict, ws.premarkers, out, feat_stamps(s, false), p.dict_pos, ws.kp, pend, ws.big ? 1 : 0};
-    hipLaunchKernelGGL(k_markers, dim3(nframes), dim3(64), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
+    if (nframes <= kLatencyFrames) hipLaunchKernelGGL(k_markers<8>, dim3(nframes), dim3(512), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
+    else hipLaunchKernelGGL(k_markers<1>, dim3(nframes), dim3(64), 0, s, P, nframes, p.feature_size, p.dict_rows, p.dict_cols);
     (void)feat_stamps(s, true);
     return hipGetLastError();
 }
