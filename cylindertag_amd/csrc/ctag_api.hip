@@ -106,6 +106,8 @@ struct ctag_handle {
     uint8_t* d_frames = nullptr;
     size_t d_frames_bytes = 0;
     ctag_frame_result* d_results = nullptr;
+    ctag_frame_result* h_res1 = nullptr;       // pinned: the record of a one-frame host call, written by k_markers itself (no download)
+    ctag_frame_result* h_res1_dev = nullptr;   // ... as the device addresses it
     size_t d_results_count = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {}, ev_done[2] = {};
@@ -1025,6 +1027,7 @@ void ctag_destroy(ctag_handle* h) {
     if (h->d_pick_table) (void)hipFree(h->d_pick_table);
     if (h->d_frames) (void)hipFree(h->d_frames);
     if (h->d_results) (void)hipFree(h->d_results);
+    if (h->h_res1) (void)hipHostFree(h->h_res1);
     if (h->d_gray) (void)hipFree(h->d_gray);
     if (h->pose_state && h->pose_state_free) h->pose_state_free(h->pose_state);
     if (h->gather_state && h->gather_state_free) h->gather_state_free(h->gather_state);
@@ -1230,6 +1233,22 @@ static int detect_batch_u8_impl(ctag_handle* h, const uint8_t* frames, int n, in
         HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
         return CTAG_OK;
     };
+    if (n == 1 && ch == 1) {
+        // One frame (main.cpp:52-59: the reference's loop): everything on the compute stream -- a second stream and its event cost the call more than
+        // they could hide -- and the record written by the last kernel straight into pinned host memory instead of fetched by a copy behind it
+        if (!h->h_res1) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_res1), sizeof(ctag_frame_result), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_res1_dev), h->h_res1, 0));
+        }
+        uint8_t* slab = h->d_frames;
+        if (packed) HIP_TRY(hipMemcpyAsync(slab, frames, dframe, hipMemcpyHostToDevice, h->stream));
+        else HIP_TRY(hipMemcpy2DAsync(slab, dstride, frames, row_stride, (size_t)rowbytes, rows, hipMemcpyHostToDevice, h->stream));
+        const int r1 = detect_device_impl(h, slab, 1, rows, cols, dstride, (ptrdiff_t)dframe, adaptive_thresh, corner_subpix, subpix_dist, h->h_res1_dev, nullptr);
+        if (r1 != CTAG_OK) return r1;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::memcpy(out, h->h_res1, sizeof(ctag_frame_result));
+        return rerun_host_frames(h, frames, n, rows, cols, row_stride, frame_stride, ch, adaptive_thresh, corner_subpix, subpix_dist, out);
+    }
     int r = upload(0);
     if (r != CTAG_OK) return r;
     for (int k = 0; k < nsub; k++) {

@@ -1945,8 +1945,7 @@ __device__ __forceinline__ bool welsch_lat_takes(const QuadPtrs& P, int frame, i
 }
 
 // a += src[j] for j = 0 .. n-1 in that order; eight terms are loaded ahead of the additions that wait for one another
-__device__ __forceinline__ double ordered_sum(const float* src, int n) {
-    double a = 0;
+__device__ __forceinline__ double ordered_sum(double a, const float* src, int n) {
     int j = 0;
     for (; j + 8 <= n; j += 8) {
         float v[8];
@@ -1959,29 +1958,39 @@ __device__ __forceinline__ double ordered_sum(const float* src, int n) {
     return a;
 }
 
-// NP: points per edge this build holds in LDS (9 bytes each: 256 points = 9 KB, sixteen waves per CU; the 1024-point build takes the
-// few longer edges -- the first ranks of the frame's list, which is sorted by descending point count)
-template <int NP, int LO>
+// One build for every edge the few-frame path takes (up to kLatPoints points): the edge's points and their weights stay in the lanes' registers
+// (point j in lane j & 63, register j >> 6), the terms go through LDS a chunk of kLatChunk points at a time, and the lanes that add them carry their
+// sums from chunk to chunk -- the additions of one sum are the same, in the same order, whatever the chunking.  (Two builds -- 256 and 1024
+// points of LDS -- ran side by side on two streams before; the fork and the join cost the call more than the second build saved.)
+constexpr int kLatChunk = 256;
+static_assert(kLatPoints % kLatChunk == 0 && kLatChunk % 64 == 0, "k_welsch_lat: register / chunk layout");
 __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, float* rs) {
-    __shared__ uint32_t s_p[NP];
-    __shared__ float s_r[NP], s_w[NP];
-    __shared__ float s_t[6][NP];
+    constexpr int NQ = kLatPoints / 64, CQ = kLatChunk / 64, NC = kLatPoints / kLatChunk;
+    __shared__ float s_r[kLatChunk], s_w[kLatChunk];
+    __shared__ float s_t[6][kLatChunk];
     __shared__ double s_sum[8];
     __shared__ uint16_t s_pk[10];
-    const int frame = blockIdx.z, k = blockIdx.y, lane = threadIdx.x;
+    // blockIdx.x (the fast dispatch index) is the restart: the twenty blocks of the longest edge -- the list is sorted by descending point count -- are
+    // dispatched first, and the grid's thousands of blocks without an edge (ranks beyond the frame's list) last
+    const int frame = blockIdx.z, k = blockIdx.x, lane = threadIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], P.line_cap);
     if (!welsch_lat_takes(P, frame, L)) return;
     const float c = 1 / 2.9846f;
-    for (int rank = blockIdx.x; rank < L; rank += gridDim.x) {
+    for (int rank = blockIdx.y; rank < L; rank += gridDim.y) {
         __syncthreads();  // single wave: the previous edge is done with the arrays
         const int lid = P.line_sorted[(size_t)frame * P.line_cap + rank];
         const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
-        const int n = d.n;
-        if (n <= LO) break;     // block-uniform; the rest of the list is shorter still: the other build's
-        if (n > NP) continue;
+        const int n = d.n;  // <= kLatPoints (welsch_lat_takes)
         const uint32_t* pts = P.cl_pool + (size_t)frame * P.cl_cap + d.off;
-        for (int j = lane; j < n; j += 64) s_p[j] = pts[j];
+        float px[NQ], py[NQ], ww[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t v = pts[min(lane + 64 * q, n - 1)];  // unconditional, from a clamped index: all NQ loads are in flight together
+            px[q] = (float)ux(v);
+            py[q] = (float)uy(v);
+            ww[q] = 0.f;
+        }
         const int npick = min(n, 10);
         if (lane == 0) {  // the restart's initial sample (ascending), as welsch_three builds it
             if (n < kPickN) {
@@ -2013,15 +2022,16 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
         __syncthreads();
         float line[4], prev[4] = {0.f, 0.f, 0.f, 0.f};
         {
+            const uint32_t mine = pts[s_pk[lane < npick ? lane : 0]];  // the sample's points, one per lane
             double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
             for (int i = 0; i < npick; i++) {
-                const uint32_t p = s_p[s_pk[i]];
-                const float px = (float)ux(p), py = (float)uy(p);
-                x += px;
-                y += py;
-                x2 += px * px;
-                y2 += py * py;
-                xy += px * py;
+                const uint32_t p = (uint32_t)__shfl((int)mine, i);
+                const float fx = (float)ux(p), fy = (float)uy(p);
+                x += fx;
+                y += fy;
+                x2 += fx * fx;
+                y2 += fy * fy;
+                xy += fx * fy;
                 w += 1.f;
             }
             moments_to_line(x, y, x2, y2, xy, w, line);
@@ -2039,56 +2049,67 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
                 }
             }
             const float lx = line[2], ly = line[3], nx = line[1], ny = -line[0];
-            for (int j = lane; j < n; j += 64) {
-                const uint32_t p = s_p[j];
-                const float x = (float)ux(p) - lx, y = (float)uy(p) - ly;
-                const float r = ctm::fabs32(nx * x + ny * y);
-                s_r[j] = r;
-                s_w[j] = ctm::exp32_nonpos(-r * r * c * c);
+            double acc = 0;  // lane 0: err += r, lane 1: sum_w += w, in point order
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++) {
+                if (ch * kLatChunk >= n) break;  // uniform
+                if (ch > 0) __syncthreads();     // the adding lanes are done with the previous chunk
+#pragma unroll
+                for (int u = 0; u < CQ; u++) {
+                    const int q = ch * CQ + u;
+                    const float x = px[q] - lx, y = py[q] - ly;
+                    const float r = ctm::fabs32(nx * x + ny * y);
+                    const float wj = ctm::exp32_nonpos(-r * r * c * c);
+                    ww[q] = wj;
+                    s_r[64 * u + lane] = r;
+                    s_w[64 * u + lane] = wj;
+                }
+                __syncthreads();
+                if (lane < 2) acc = ordered_sum(acc, lane == 0 ? s_r : s_w, min(kLatChunk, n - ch * kLatChunk));
             }
-            __syncthreads();
-            if (lane < 2) {  // err += r and sum_w += w, in point order
-                s_sum[lane] = ordered_sum(lane == 0 ? s_r : s_w, n);
-            }
+            if (lane < 2) s_sum[lane] = acc;
             __syncthreads();
             err = s_sum[0];
             const double sum_w = s_sum[1];
             if (err < EPS) break;
-            if (ctm::fabs64(sum_w) > 1.1920928955078125e-07) {
-                const double inv = 1. / sum_w;
-                for (int j = lane; j < n; j += 64) {
-                    const uint32_t p = s_p[j];
-                    const float px = (float)ux(p), py = (float)uy(p);
-                    const float wj = (float)(s_w[j] * inv);
-                    s_t[0][j] = wj * px;
-                    s_t[1][j] = wj * py;
-                    s_t[2][j] = wj * px * px;
-                    s_t[3][j] = wj * py * py;
-                    s_t[4][j] = wj * px * py;
-                    s_t[5][j] = wj;
+            const bool weighted = ctm::fabs64(sum_w) > 1.1920928955078125e-07;
+            const double inv = weighted ? 1. / sum_w : 0.;
+            acc = 0;  // lanes 0..5: x, y, x2, y2, xy, w -- each a column added in point order
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++) {
+                if (ch * kLatChunk >= n) break;  // uniform
+                if (ch > 0) __syncthreads();
+#pragma unroll
+                for (int u = 0; u < CQ; u++) {
+                    const int q = ch * CQ + u, j = 64 * u + lane;
+                    const float fx = px[q], fy = py[q];
+                    if (weighted) {
+                        const float wj = (float)(ww[q] * inv);
+                        s_t[0][j] = wj * fx;
+                        s_t[1][j] = wj * fy;
+                        s_t[2][j] = wj * fx * fx;
+                        s_t[3][j] = wj * fy * fy;
+                        s_t[4][j] = wj * fx * fy;
+                        s_t[5][j] = wj;
+                    } else {
+                        s_t[0][j] = fx;
+                        s_t[1][j] = fy;
+                        s_t[2][j] = fx * fx;
+                        s_t[3][j] = fy * fy;
+                        s_t[4][j] = fx * fy;
+                        s_t[5][j] = 1.f;
+                    }
                 }
-            } else {
-                for (int j = lane; j < n; j += 64) {
-                    const uint32_t p = s_p[j];
-                    const float px = (float)ux(p), py = (float)uy(p);
-                    s_t[0][j] = px;
-                    s_t[1][j] = py;
-                    s_t[2][j] = px * px;
-                    s_t[3][j] = py * py;
-                    s_t[4][j] = px * py;
-                    s_t[5][j] = 1.f;
-                }
+                __syncthreads();
+                if (lane < 6) acc = ordered_sum(acc, s_t[lane], min(kLatChunk, n - ch * kLatChunk));
             }
-            __syncthreads();
-            if (lane < 6) {  // x, y, x2, y2, xy, w: each a column added in point order
-                s_sum[2 + lane] = ordered_sum(s_t[lane], n);
-            }
+            if (lane < 6) s_sum[2 + lane] = acc;
             __syncthreads();
             prev[0] = line[0];
             prev[1] = line[1];
             prev[2] = line[2];
             prev[3] = line[3];
-            moments_to_line(s_sum[2], s_sum[3], s_sum[4], s_sum[5], s_sum[6], s_sum[7], line);
+            moments_to_line(s_sum[2], s_sum[3], s_sum[4], s_sum[5], s_sum[6], s_sum[7], line);  // (the next write of s_sum is behind the next chunk's barrier)
         }
         if (lane == 0) {
             float* o = rs + (((size_t)frame * kLatLines + rank) * 20 + k) * 6;
@@ -2389,8 +2410,9 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
             have[dev] = true;                                                                                                                               \
         }                                                                                                                                                   \
         hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWords, 1, false, REF>), dim3(nframes, bcols), dim3(64), 0, sb, P, ws.g, nframes, 0);                \
-        hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWordsMax, 1, true, REF>), dim3(nframes, latency ? 8 : 2), dim3(64), kWaveWordsMax * 4, sb, P, ws.g, \
-                           nframes, kWaveWords);                                                                                                            \
+        /* few-frame calls: the build for the longest boundaries (rarely any) behind the packs on the main stream, not behind the 32 KB build */          \
+        hipLaunchKernelGGL((k_quad_edges_packed<64, kWaveWordsMax, 1, true, REF>), dim3(nframes, latency ? 8 : 2), dim3(64), kWaveWordsMax * 4,              \
+                           fork ? s : sb, P, ws.g, nframes, kWaveWords);                                                                                    \
     } while (0)
     if (refprm) CTAG_LAUNCH_WAVE(true);
     else CTAG_LAUNCH_WAVE(false);
@@ -2405,16 +2427,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     static const int welsch_gs = getenv("CTAG_WELSCH_GS") ? std::max(1, atoi(getenv("CTAG_WELSCH_GS"))) : 4;   // blocks per frame for the edges of <= 10 points, 64 per wave
     static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? std::max(1, atoi(getenv("CTAG_WELSCH_GX"))) : 72;   // (both at least 1: the grid's two row ranges each own a class of edges)   // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144 -> 72 once the short edges left: fewer empty blocks)
     if (latency && ws.welsch_rs) {  // one wave per (edge, restart); frames it declines (more edges / longer edges than it holds) fall through to k_welsch
-        if (fork) {  // the long edges beside the short ones
-            (void)hipEventRecord(ws.ev_fork, s);
-            (void)hipStreamWaitEvent(ws.aux_stream, ws.ev_fork, 0);
-        }
-        hipLaunchKernelGGL((k_welsch_lat<kLatPoints, 256>), dim3(64, 20, nframes), dim3(64), 0, fork ? ws.aux_stream : s, P, nframes, ws.welsch_rs);
-        hipLaunchKernelGGL((k_welsch_lat<256, 0>), dim3(512, 20, nframes), dim3(64), 0, s, P, nframes, ws.welsch_rs);
-        if (fork) {
-            (void)hipEventRecord(ws.ev_join, ws.aux_stream);
-            (void)hipStreamWaitEvent(s, ws.ev_join, 0);
-        }
+        hipLaunchKernelGGL(k_welsch_lat, dim3(20, 512, nframes), dim3(64), 0, s, P, nframes, ws.welsch_rs);
     }
     hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx + welsch_gs), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr, welsch_gx);
     mark();
