@@ -338,12 +338,15 @@ struct CornerPre {
 // anywhere and were the kernel's tail: a 150-point boundary is ~0.3 ms of dependent LDS round trips).
 // One block per frame; rank sort in LDS like k_candidates.  Oversize components are skipped; the whole-wave builds take them.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words, int scan_words) {
+// Block size: 64 for batches; 1024 for calls of a few frames (the rank sort is nc / threads trips of nc comparisons).  The pack builder -- a
+// sequential scan of the ordered list -- runs on wave 0 with the list in registers, 64 entries at a time, read back with v_readlane.
+__global__ __launch_bounds__(1024) void k_pack(QuadPtrs P, int nframes, int max_per_pack, int big_points, int pack_words, int scan_words) {
     __shared__ int s_key[kLdsCand + 2];
     __shared__ int s_need[kLdsCand];
     __shared__ uint16_t s_ord[kLdsCand];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int nc = min(P.ncand[frame], P.cand_cap);
     const Candidate* cand = P.cand + (size_t)frame * P.cand_cap;
     uint32_t* order = P.pack_order + (size_t)frame * P.cand_cap;
@@ -352,6 +355,32 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
         const int w = c.x_max - c.x_min + 1, h = c.y_max - c.y_min + 1;
         return pack_big(c.x_min, w, h, big_points, pack_words, scan_words) ? -1 : pack_points(w, h);  // -1: not packed, sorts last
     };
+    // the pack builder (wave 0): a pack = consecutive entries [0, npacked) of `order`; need_of(r) = LDS words of entry r
+    auto build_packs = [&](int npacked, auto need_of) {
+        int np = 0, first = -1, cnt = 0, words = 0;  // uniform across the wave
+        for (int r0 = 0; r0 < npacked; r0 += 64) {
+            const int r = r0 + tid;
+            const int need = r < npacked ? need_of(r) : 0;
+            const int m = min(64, npacked - r0);
+            for (int k = 0; k < m; k++) {
+                const int nk = __builtin_amdgcn_readlane(need, k);
+                if (cnt > 0 && (cnt == max_per_pack || words + nk > pack_words)) {
+                    if (tid == 0) packs[np] = (uint32_t)first | ((uint32_t)cnt << 24);
+                    np++;
+                    cnt = 0;
+                    words = 0;
+                }
+                if (cnt == 0) first = r0 + k;
+                cnt++;
+                words += nk;
+            }
+        }
+        if (cnt > 0) {
+            if (tid == 0) packs[np] = (uint32_t)first | ((uint32_t)cnt << 24);
+            np++;
+        }
+        return np;
+    };
     if (nc > kLdsCand) {
         // A frame of thousands of blobs (more candidates than the LDS arrays hold).  The order is scheduling only -- results do not
         // depend on it beyond "oversize components last" -- so a counting sort by boundary capacity (descending, capacities of 2047
@@ -359,11 +388,11 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
         // candidates 64 at a time instead of from LDS.
         constexpr int kB = kLdsCand;  // buckets 0..kB-1: capacity kB-1-b (longest first); bucket kB: oversize
         auto bucket_of = [&](int key) { return key < 0 ? kB : kB - 1 - min(key, kB - 1); };
-        for (int b = threadIdx.x; b <= kB; b += 64) s_key[b] = 0;
+        for (int b = tid; b <= kB; b += nt) s_key[b] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < nc; i += 64) atomicAdd(&s_key[bucket_of(key_of(cand[i]))], 1);
+        for (int i = tid; i < nc; i += nt) atomicAdd(&s_key[bucket_of(key_of(cand[i]))], 1);
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             int run = 0;
             for (int b = 0; b <= kB; b++) {
                 const int v = s_key[b];
@@ -375,48 +404,28 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
         __syncthreads();
         const int first_big = s_key[kB];  // oversize components: entries [first_big, nc) of `order`
         __syncthreads();
-        for (int i = threadIdx.x; i < nc; i += 64) order[atomicAdd(&s_key[bucket_of(key_of(cand[i]))], 1)] = (uint32_t)i;
+        for (int i = tid; i < nc; i += nt) order[atomicAdd(&s_key[bucket_of(key_of(cand[i]))], 1)] = (uint32_t)i;
         __syncthreads();
-        int np = 0, first = -1, cnt = 0, words = 0;  // uniform across the wave
-        for (int r0 = 0; r0 < first_big; r0 += 64) {
-            const int r = r0 + (int)threadIdx.x;
-            int need = 0;
-            if (r < first_big) {
-                const Candidate c = cand[order[r]];
-                need = pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
-            }
-            const int m = min(64, first_big - r0);
-            for (int k = 0; k < m; k++) {
-                const int nk = __shfl(need, k);
-                if (cnt > 0 && (cnt == max_per_pack || words + nk > pack_words)) {
-                    if (threadIdx.x == 0) packs[np] = (uint32_t)first | ((uint32_t)cnt << 24);
-                    np++;
-                    cnt = 0;
-                    words = 0;
-                }
-                if (cnt == 0) first = r0 + k;
-                cnt++;
-                words += nk;
-            }
-        }
-        if (cnt > 0) {
-            if (threadIdx.x == 0) packs[np] = (uint32_t)first | ((uint32_t)cnt << 24);
-            np++;
-        }
-        if (threadIdx.x == 0) {
+        if (tid >= 64) return;
+        const int np = build_packs(first_big, [&](int r) {
+            const Candidate c = cand[order[r]];
+            return pack_need(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1);
+        });
+        if (tid == 0) {
             P.npacks[2 * frame] = np;
             P.npacks[2 * frame + 1] = nc - first_big;
         }
         return;
     }
-    for (int i = threadIdx.x; i < nc; i += 64) {
+    for (int i = tid; i < nc; i += nt) {
         const Candidate c = cand[i];
         const int w = c.x_max - c.x_min + 1, h = c.y_max - c.y_min + 1;
         s_key[i] = key_of(c);
-        s_need[i] = pack_need(w, h);  // for the pack builder below: one lane walks the sorted list, it should not wait for global memory
+        s_need[i] = pack_need(w, h);  // for the pack builder below: it should not wait for global memory
     }
+    if (tid == 0) s_key[kLdsCand] = 0;  // number of oversize components
     __syncthreads();
-    for (int i = threadIdx.x; i < nc; i += 64) {
+    for (int i = tid; i < nc; i += nt) {
         const int ki = s_key[i];
         int rank = 0;
         for (int j = 0; j < nc; j++) {
@@ -424,27 +433,14 @@ __global__ __launch_bounds__(64) void k_pack(QuadPtrs P, int nframes, int max_pe
             rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
         }
         s_ord[rank] = (uint16_t)i;
+        if (ki < 0) atomicAdd(&s_key[kLdsCand], 1);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nc; i += 64) order[i] = s_ord[i];
-    if (threadIdx.x == 0) {
-        int np = 0, first = -1, cnt = 0, words = 0;
-        for (int r = 0; r < nc; r++) {
-            const int i = s_ord[r];
-            if (s_key[i] < 0) break;  // the rest is oversize
-            const int need = s_need[i];
-            if (cnt > 0 && (cnt == max_per_pack || words + need > pack_words)) {  // a pack = consecutive entries of `order`
-                packs[np++] = (uint32_t)first | ((uint32_t)cnt << 24);
-                cnt = 0;
-                words = 0;
-            }
-            if (cnt == 0) first = r;
-            cnt++;
-            words += need;
-        }
-        if (cnt > 0) packs[np++] = (uint32_t)first | ((uint32_t)cnt << 24);
-        int nbig = 0;  // the oversize components sort last: entries [nc - nbig, nc) of `order`, the whole-wave builds walk only those
-        for (int r = nc - 1; r >= 0 && s_key[s_ord[r]] < 0; r--) nbig++;
+    for (int i = tid; i < nc; i += nt) order[i] = s_ord[i];
+    if (tid >= 64) return;
+    const int nbig = s_key[kLdsCand];  // the oversize components sort last: entries [nc - nbig, nc) of `order`, the whole-wave builds walk only those
+    const int np = build_packs(nc - nbig, [&](int r) { return s_need[s_ord[r]]; });
+    if (tid == 0) {
         P.npacks[2 * frame] = np;
         P.npacks[2 * frame + 1] = nbig;
     }
@@ -2349,7 +2345,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     // scan-only kernel with the packs' own 8 x 8 lanes at 4 / 5 / 6 waves per SIMD: 4.09 / 4.11 / 4.14 -- the scan is not what the small build waits for)
     const bool small_frames = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;
     const bool prescan = !latency && (prescan_env == 2 || (prescan_env == 1 && !small_frames));
-    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(64), 0, s, P, nframes, pack_max, big_points, pack_words, prescan ? kScanWords : 0);
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(nframes <= kLatencyFrames ? 1024 : 64), 0, s, P, nframes, pack_max, big_points, pack_words, prescan ? kScanWords : 0);
     mark();
     // A few frames per call (the reference's one detect() per camera frame): the call is as long as its slowest component,
     // so the packs and the whole-wave components run side by side (second stream, fork/join by events)
