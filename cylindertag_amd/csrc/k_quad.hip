@@ -294,7 +294,7 @@ constexpr int kSG = 8;
 constexpr int kUnwind = 8;  // stack frames the whole-wave build tests at once when it unwinds (<= 8: 8 lanes each)
 constexpr int kWaveWords = 8192;      // LDS words of the common whole-wave build (32 KB: five components per CU)
 constexpr int kWaveWordsMax = 36864;  // ... of the build for the longest boundaries (144 KB: one per CU)
-constexpr int kLatencyBigPoints = 96; // calls of <= kLatencyFrames frames: components with a boundary capacity above this get a wave of their own
+constexpr int kLatencyBigPoints = 1;  // calls of <= kLatencyFrames frames: components with a boundary capacity above this get a wave of their own -- all of them (launch_quads)
 __host__ __device__ __forceinline__ int pack_points(int w, int h) { return min(2 * (w + h), w * h) + 1; }
 // LDS words one component needs in the packed kernel: silhouette arrays + boundary list + stack / ping-pong list
 __host__ __device__ __forceinline__ int pack_need(int w, int h) {
@@ -2349,7 +2349,10 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     mark();
     // A few frames per call (the reference's one detect() per camera frame): the call is as long as its slowest component,
     // so the packs and the whole-wave components run side by side (second stream, fork/join by events)
-    const bool fork = latency && ws.aux_stream != nullptr;
+    // ... unless every component is a whole-wave one (the default of such calls: a frame has a few hundred components and the GPU a thousand SIMDs, so
+    // the stage is as long as the longest boundary either way, and without packs there is nothing to fork or join: 0.476 -> 0.46 ms on test.bmp)
+    const bool all_wave = latency && big_points <= 1;
+    const bool fork = latency && !all_wave && ws.aux_stream != nullptr;
     hipStream_t sb = s;
     if (fork) {
         (void)hipEventRecord(ws.ev_fork, s);
@@ -2386,7 +2389,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
                 hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
         }                                                                                                                                                    \
     } while (0)
-    if (refprm) CTAG_LAUNCH_PACKED(true);
+    if (all_wave) {
+    } else if (refprm) CTAG_LAUNCH_PACKED(true);
     else CTAG_LAUNCH_PACKED(false);
 #undef CTAG_LAUNCH_PACKED
     mark();
