@@ -505,13 +505,32 @@ __device__ __forceinline__ ALine approx_line(long long sx, long long sy, long lo
 // is then tested against the line of step t-1 -- by the filtered predicate above, by the reference's own fit where that is not
 // decisive -- exactly as the sequential loop does, and the prefix up to the first event (distance test fails, `left == right`,
 // or every point used) is committed.  Returns nl / nr = points added on the left / right side.  All lanes return the same values.
-template <int SG>
+// lane i <- lane i - D within its row of 16 lanes (v_mov_b32 with DPP row_shr: one vector instruction, no LDS crossbar round trip); lanes without a
+// source get 0.  The 8-lane sub-groups are halves of such rows: the lanes that would read across a sub-group's edge are the ones that ignore the value.
+template <int D>
+__device__ __forceinline__ int dpp_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, false);
+}
+template <int D>
+__device__ __forceinline__ double dpp_shr(double v) {
+    return __hiloint2double(dpp_shr<D>(__double2hiint(v)), dpp_shr<D>(__double2loint(v)));
+}
+template <int D>
+__device__ __forceinline__ float dpp_shr(float v) {
+    return __int_as_float(dpp_shr<D>(__float_as_int(v)));
+}
+// RED / rl: lanes (and this lane's index among them) that add up the moments of the initial span.  The whole-wave build speculates over its first
+// EIGHT lanes only (SG = 8, RED = 64; the other lanes repeat them): an edge rarely grows by more than a few points, and a 64-step round paid six
+// prefix-scan steps, integer divisions for the wrapped indices and a line estimate per lane for steps that were thrown away.
+template <int SG, int RED = SG>
 __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int init, int end, int sl, int lane0, int sgshift, float thr_expand, float kmax, float eps_scale,
-                                               int& nl_out, int& nr_out) {
+                                               int& nl_out, int& nr_out, int rl = -1, unsigned long long* dbg = nullptr) {
+    if (rl < 0) rl = sl;
+    const unsigned long long dbg_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr unsigned long long kSgMask = SG == 64 ? ~0ull : ((1ull << (SG & 63)) - 1ull);
     const double thr = (double)thr_expand, eps = (double)eps_scale * (double)kmax, k2lim = (double)kmax * (double)kmax * 1.4901161193847656e-08;  // K^2 2^-26
     long long Sx = 0, Sy = 0, Sxx = 0, Syy = 0, Sxy = 0;
-    for (int k = init + sl; k <= end; k += SG) {
+    for (int k = init + rl; k <= end; k += RED) {
         const long long x = ux(W[k]), y = uy(W[k]);
         Sx += x;
         Sy += y;
@@ -520,7 +539,7 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
         Sxy += x * y;
     }
 #pragma unroll
-    for (int d = SG / 2; d >= 1; d >>= 1) {
+    for (int d = RED / 2; d >= 1; d >>= 1) {
         Sx += __shfl_xor(Sx, d);
         Sy += __shfl_xor(Sy, d);
         Sxx += __shfl_xor(Sxx, d);
@@ -531,7 +550,9 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
     ALine lineA = approx_line(Sx, Sy, Sxx, Syy, Sxy, m, k2lim);  // of the committed prefix
     bool fl = false, fr = false;
     int left = init - 1, right = end + 1, nl = 0, nr = 0;
+    if (dbg) dbg[0] += __builtin_amdgcn_s_memtime() - dbg_t0;
     while ((!fl || !fr) && (left != right)) {
+        if (dbg) dbg[1] += 1;
         const int mode = (!fl && !fr) ? 0 : (!fl ? 1 : 2);  // 0: L,R alternate; 1: left only; 2: right only
         // The index bookkeeping of steps 0..sl under the "all accepted" assumption, in closed form (a lane per step): before step u the
         // left cursor has moved kl times and the right one kr times; the k-th left step reads index (left - k) mod n and leaves the raw
@@ -575,33 +596,38 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
         // inclusive prefix sums of the five moments over the lanes; 32 bits hold them: coordinates < 2^13 (an 8K frame at
         // half resolution), products < 2^26, 64 of them < 2^32
         uint32_t a0 = (uint32_t)ux(qpt), a1 = (uint32_t)uy(qpt), a2 = a0 * a0, a3 = a1 * a1, a4 = a0 * a1;
-#pragma unroll
-        for (int d = 1; d < SG; d <<= 1) {
-            const uint32_t b0 = (uint32_t)__shfl_up((int)a0, d), b1 = (uint32_t)__shfl_up((int)a1, d), b2 = (uint32_t)__shfl_up((int)a2, d),
-                           b3 = (uint32_t)__shfl_up((int)a3, d), b4 = (uint32_t)__shfl_up((int)a4, d);
-            if (sl >= d) {
-                a0 += b0;
-                a1 += b1;
-                a2 += b2;
-                a3 += b3;
-                a4 += b4;
-            }
+        static_assert(SG == 8, "the prefix sums below are three DPP steps inside half a row of 16 lanes");
+#define CTAG_EXPAND_SCAN(D)                                                                                                          \
+        {                                                                                                                            \
+            const uint32_t b0 = (uint32_t)dpp_shr<D>((int)a0), b1 = (uint32_t)dpp_shr<D>((int)a1), b2 = (uint32_t)dpp_shr<D>((int)a2), \
+                           b3 = (uint32_t)dpp_shr<D>((int)a3), b4 = (uint32_t)dpp_shr<D>((int)a4);                                    \
+            if (sl >= D) {                                                                                                           \
+                a0 += b0;                                                                                                            \
+                a1 += b1;                                                                                                            \
+                a2 += b2;                                                                                                            \
+                a3 += b3;                                                                                                            \
+                a4 += b4;                                                                                                            \
+            }                                                                                                                        \
         }
+        CTAG_EXPAND_SCAN(1)
+        CTAG_EXPAND_SCAN(2)
+        CTAG_EXPAND_SCAN(4)
+#undef CTAG_EXPAND_SCAN
         const long long px = a0, py = a1, pxx = a2, pyy = a3, pxy = a4;
         // ---- the distance test of step sl against the line of step sl - 1: filtered, exact where the filter is not decisive
         const ALine mineA = approx_line(Sx + px, Sy + py, Sxx + pxx, Syy + pyy, Sxy + pxy, m + sl + 1, k2lim);
-        const int prev = lane0 + ((sl + SG - 1) & (SG - 1));
-        ALine lpA;
-        lpA.c = __shfl(mineA.c, prev);
-        lpA.s = __shfl(mineA.s, prev);
-        lpA.x = __shfl(mineA.x, prev);
-        lpA.y = __shfl(mineA.y, prev);
-        lpA.ok = __shfl((int)mineA.ok, prev) != 0;
+        ALine lpA;  // the line of step sl - 1: the lane below (step 0: the committed prefix's)
+        lpA.c = dpp_shr<1>(mineA.c);
+        lpA.s = dpp_shr<1>(mineA.s);
+        lpA.x = dpp_shr<1>(mineA.x);
+        lpA.y = dpp_shr<1>(mineA.y);
+        lpA.ok = dpp_shr<1>((int)mineA.ok) != 0;
         if (sl == 0) lpA = lineA;
         const double D = ctm::fabs64(((double)ux(qpt) - lpA.x) * lpA.s - ((double)uy(qpt) - lpA.y) * lpA.c);
         bool fail = D > thr;
         const bool unsure = !lpA.ok || !(ctm::fabs64(D - thr) > eps);
         if (((unsigned long long)__ballot(unsure) >> sgshift) & kSgMask) {  // uniform within the sub-group
+            if (dbg) dbg[2] += 1;
             float mine[4], base[4];
             moments_to_line((double)(Sx + px), (double)(Sy + py), (double)(Sxx + pxx), (double)(Syy + pyy), (double)(Sxy + pxy),
                             (double)(float)(m + sl + 1), mine);
@@ -609,7 +635,7 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
             float lp[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const float up = __shfl(mine[k], prev);
+                const float up = dpp_shr<1>(mine[k]);
                 lp[k] = sl == 0 ? base[k] : up;
             }
             const float de = ctm::fabs32(ux(qpt) * lp[1] - uy(qpt) * lp[0] + lp[0] * lp[3] - lp[1] * lp[2]);
@@ -635,18 +661,21 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
         }
         if (accepted > 0) {
             const int src = lane0 + accepted - 1;
-            Sx += __shfl(px, src);
-            Sy += __shfl(py, src);
-            Sxx += __shfl(pxx, src);
-            Syy += __shfl(pyy, src);
-            Sxy += __shfl(pxy, src);
-            lineA.c = __shfl(mineA.c, src);
-            lineA.s = __shfl(mineA.s, src);
-            lineA.x = __shfl(mineA.x, src);
-            lineA.y = __shfl(mineA.y, src);
-            lineA.ok = __shfl((int)mineA.ok, src) != 0;
-            left = __shfl(l, src);
-            right = __shfl(r, src);
+            // the whole-wave build's lanes agree on `src`: v_readlane; the packs' sub-groups each have their own: the crossbar (32-bit values)
+            auto pick = [&](int v) { return RED == 64 ? __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)) : __shfl(v, src); };
+            auto pickd = [&](double v) { return __hiloint2double(pick(__double2hiint(v)), pick(__double2loint(v))); };
+            Sx += (long long)(uint32_t)pick((int)a0);
+            Sy += (long long)(uint32_t)pick((int)a1);
+            Sxx += (long long)(uint32_t)pick((int)a2);
+            Syy += (long long)(uint32_t)pick((int)a3);
+            Sxy += (long long)(uint32_t)pick((int)a4);
+            lineA.c = pickd(mineA.c);
+            lineA.s = pickd(mineA.s);
+            lineA.x = pickd(mineA.x);
+            lineA.y = pickd(mineA.y);
+            lineA.ok = pick((int)mineA.ok) != 0;
+            left = pick(l);
+            right = pick(r);
             m += accepted;
             if (mode == 0) {
                 nl += (accepted + 1) >> 1;
@@ -659,7 +688,7 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
         }
         if (failed_step) {
             const bool stepLf = mode == 0 ? ((accepted & 1) == 0) : (mode == 1);
-            const int fidx = __shfl(q_idx, lane0 + accepted);
+            const int fidx = RED == 64 ? __builtin_amdgcn_readlane(q_idx, __builtin_amdgcn_readfirstlane(lane0 + accepted)) : __shfl(q_idx, lane0 + accepted);
             if (stepLf) {
                 fl = true;
                 left = fidx;  // `left` keeps the tested (already wrapped) index
@@ -1616,6 +1645,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         uint32_t* Wn = bufA;
         int cnt_b = 0, init = 0, cl_off[5] = {0, 0, 0, 0, 0};
         bool failed = false;
+        unsigned long long rdp_t = 0, rdp_acc[4] = {0, 0, 0, 0}, exp_dbg[3] = {0, 0, 0};  // developer aid (CTAG_QUAD_STAMPS): where the whole-wave build's RDP spends its ticks
+        auto rdp_mark = [&](int slot) {
+            if (SG == 64 && P.stamps) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (slot >= 0) rdp_acc[slot] += t - rdp_t;
+                rdp_t = t;
+            }
+        };
+        rdp_mark(-1);
         while (n > 0 && !failed && cnt_b < 4) {
             auto tri2 = [&](int a) {
                 const uint32_t q0 = W[a], q2 = W[(a + 2) % n], q1 = W[(a + 1) % n];
@@ -1633,6 +1671,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     c2 = tri2(init);
                 }
             }
+            rdp_mark(0);
             int end = init + n / 2;
             if (end > n - 1) end = n - 1;
             while (true) {  // :303-330
@@ -1675,10 +1714,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     end = bi;  // literal index into dist2line
                     continue;
                 }
+                rdp_mark(1);
                 // ---- expand_line (:125-169), speculative over the sub-group's 8 lanes
                 int nl, nr;
-                sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, k_thr_expand, (float)(g.hcols > g.hrows ? g.hcols : g.hrows), REFPRM ? 3.0e-6f : P.expand_eps, nl,
-                                   nr);
+                if constexpr (SG == 64)
+                    sg_expand_line<8, 64>(W, n, init, end, sl & 7, 0, 0, k_thr_expand, (float)(g.hcols > g.hrows ? g.hcols : g.hrows), REFPRM ? 3.0e-6f : P.expand_eps, nl, nr, sl,
+                                          P.stamps ? exp_dbg : nullptr);
+                else
+                    sg_expand_line<SG>(W, n, init, end, sl, lane0, sgshift, k_thr_expand, (float)(g.hcols > g.hrows ? g.hcols : g.hrows), REFPRM ? 3.0e-6f : P.expand_eps, nl, nr);
+                rdp_mark(2);
                 const int m = end - init + 1 + nl + nr;
                 // the span is a circular arc [a .. b] of m distinct indices
                 const int a = ((init - nl) % n + n) % n;
@@ -1718,8 +1762,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 uint32_t* t = W;
                 W = Wn;
                 Wn = t;
+                rdp_mark(3);
                 break;
             }
+        }
+        if (SG == 64 && P.stamps && lane == 0)
+        {
+            for (int q = 0; q < 4; q++) atomicAdd(&P.stamps[16 + q], rdp_acc[q]);
+            for (int q = 0; q < 3; q++) atomicAdd(&P.stamps[20 + q], exp_dbg[q]);
         }
         stamp(3);
         // ---- export
@@ -2327,8 +2377,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
-        if (!d_stamps) (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), 16 * 8);
-        (void)hipMemsetAsync(d_stamps, 0, 16 * 8, s);
+        if (!d_stamps) (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), 24 * 8);
+        (void)hipMemsetAsync(d_stamps, 0, 24 * 8, s);
         P.stamps = d_stamps;
     }
     static const int pack_max_env = getenv("CTAG_PACK_MAX") ? atoi(getenv("CTAG_PACK_MAX")) : 0;
@@ -2433,9 +2483,12 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     mark();
     hipLaunchKernelGGL(k_quad_final, dim3(std::min(ws.cand_cap, kLdsCand) / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {
-        unsigned long long h[16];
+        unsigned long long h[24];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        if (h[16] | h[17] | h[18] | h[19])
+            fprintf(stderr, "[whole-wave rdp ticks] corner scan %llu split rounds %llu expand_line %llu clusters + erase %llu\n", h[16], h[17], h[18], h[19]),
+            fprintf(stderr, "[whole-wave expand_line] initial sums %llu ticks, %llu rounds, %llu of them through the exact fits\n", h[20], h[21], h[22]);
         for (int b = 0; b < 16; b += 8) {
             unsigned long long tot = 0;
             h[b + 0] += h[b + 7];  // the row scan is stamped separately; it belongs to the silhouette phase
