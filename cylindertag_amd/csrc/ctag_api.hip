@@ -1016,7 +1016,6 @@ void ctag_destroy(ctag_handle* h) {
     if (h->d_big_result) (void)hipFree(h->d_big_result);
     for (auto& A : h->aslot) {
         if (A.d_frame) (void)hipFree(A.d_frame);
-        if (A.d_res) (void)hipFree(A.d_res);
         if (A.h_res) (void)hipHostFree(A.h_res);
         if (A.up) (void)hipEventDestroy(A.up);
         if (A.done) (void)hipEventDestroy(A.done);
@@ -1316,8 +1315,9 @@ int ctag_submit_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrd
     if (!A.up) {
         HIP_TRY(hipEventCreateWithFlags(&A.up, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&A.done, hipEventDisableTiming));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&A.d_res), sizeof(ctag_frame_result)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&A.h_res), sizeof(ctag_frame_result), hipHostMallocDefault));
+        // the record is written by k_markers itself into pinned host memory (d_res = that memory as the device addresses it): no download behind the chain
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&A.h_res), sizeof(ctag_frame_result), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&A.d_res), A.h_res, 0));
     }
     if (A.d_bytes < need) {  // the slot is free: nothing reads its slab
         drop_graphs(h);      // ... but a captured chain may hold its address
@@ -1341,7 +1341,6 @@ int ctag_submit_u8(ctag_handle* h, const uint8_t* gray, int rows, int cols, ptrd
         (void)quiesce(h);
         return r;
     }
-    HIP_TRY(hipMemcpyAsync(A.h_res, A.d_res, sizeof(ctag_frame_result), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(A.done, h->stream));
     h->a_count++;
     return CTAG_OK;

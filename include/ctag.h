@@ -118,8 +118,8 @@ void* ctag_stream(ctag_handle* h);
                                       calls of up to 4 frames only -- one frame per call in a loop gains 0.03-0.04 ms of 0.7; batches gain
                                       nothing, their chain is not launch-bound */
 #define CTAG_OPT_WAVE_POINTS 6     /* components whose boundary can hold more than this many points get a wave of their own instead of 8 lanes of a
-                                      shared one (the longest boundary decides how long a one-frame call takes); 0 = automatic: 96 for calls of
-                                      up to 4 frames, never for batches.  Results do not depend on it. */
+                                      shared one (the longest boundary decides how long a one-frame call takes); 0 = automatic: every component of a call
+                                      of up to 4 frames (no shared waves there, hence no second stream to fork and join), never for batches.  Results do not depend on it. */
 #define CTAG_OPT_STREAMS 8         /* 2 (default): a chunk of >= 256 frames of a device-memory call runs as two halves on two internal streams and workspaces -- the
                                       tail of one half's kernels overlaps the other half's next kernel; the second stream forks from and joins the handle's stream
                                       inside the call, so callers order against ctag_stream() as before.  1: one stream; 3 / 4: thirds / quarters on as many streams (measured on
