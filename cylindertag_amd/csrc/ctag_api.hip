@@ -70,6 +70,7 @@ struct ctag_handle {
     int32_t* d_pending_count = nullptr;
     int pending_cap = 65536;
     bool pending_dirty = false;      // a device-memory call was enqueued since the list was last read
+    uint64_t pending_gen = 0;        // ... and how many such calls there were
     uint8_t* d_big_frame = nullptr;  // private copy of a pending frame (host-memory calls upload it again; BGR frames are converted into d_big_gray)
     size_t d_big_frame_bytes = 0;
     uint8_t* d_big_gray = nullptr;
@@ -558,7 +559,10 @@ static int run_chunk(ctag_handle* h, const uint8_t* frames_dev, int n, ptrdiff_t
                      ctag_frame_result* out_dev, const PendingCtx& pend) {
     const Workspace& W = h->batch.ws;
     h->last_chunk_frames = n;
-    if (pend.list) h->pending_dirty = true;
+    if (pend.list) {
+        h->pending_dirty = true;
+        h->pending_gen++;
+    }
     hipEvent_t* evs = nullptr;
     if (h->timing) {
         const size_t need = (size_t)(h->ev_sets_used + 1) * (CTAG_NUM_STAGES + 1);
@@ -646,6 +650,7 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
                 pc = *pend;
                 pc.src = pend->src + (ptrdiff_t)f0 * pend->frame_stride;
                 h->pending_dirty = true;
+                h->pending_gen++;
             }
             h->last_chunk_frames = m;
             const int r = enqueue_chunk(h, slot[k]->ws, frames_dev + (ptrdiff_t)f0 * frame_stride, m, row_stride, frame_stride, p, out_dev + f0, nullptr, pc,
@@ -797,6 +802,14 @@ static int finish_pending(ctag_handle* h) {
 }
 namespace ctag {
 int handle_finish_pending(ctag_handle* h) { return h ? finish_pending(h) : CTAG_ERR_ARG; }
+bool handle_pending_state(ctag_handle* h, const int32_t** count_dev, uint64_t* gen) {
+    *count_dev = h->d_pending_count;
+    *gen = h->pending_gen;
+    return h->pending_dirty && h->d_pending_count != nullptr;
+}
+void handle_pending_clean(ctag_handle* h, uint64_t gen) {
+    if (h->pending_gen == gen) h->pending_dirty = false;
+}
 }  // namespace ctag
 
 // host-memory calls: the records are on the host already; a CTAG_PENDING one is completed from the caller's own frame

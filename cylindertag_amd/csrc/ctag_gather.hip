@@ -87,6 +87,9 @@ struct GatherState {
     uint64_t* d_sizes = nullptr;     // [world] packed size of every rank
     uint64_t* h_sizes = nullptr;     // pinned copy
     int n_local = 0, n_total = 0;
+    const ctag_frame_result* local_dev = nullptr;  // of the gather in flight (a rank with pending frames packs again in ctag_gather_end)
+    bool tagged = false;             // the sizes in flight carry the ranks' pending-frame counts in their upper bits
+    uint64_t pend_gen = 0;
     bool in_flight = false;
     uint64_t last_local = 0, last_padded = 0;
     char err[256] = {0};
@@ -391,6 +394,17 @@ int gather_unpack_gathered(ctag_handle* h, const void* gathered_dev, int n_total
 }
 }  // namespace ctag
 
+// The size a rank announces carries, above bit 40, how many of its frames still wait for the any-frame pass (CTAG_PENDING records: a cluttered frame
+// that exceeded the batch workspace's pools).  Every rank sees every count with the sizes, so all of them take the same path in ctag_gather_end:
+// none pending (always, on ordinary content) -> the payload exchange as it is; some -> those ranks complete their frames, all pack and announce again.
+// ctag_gather_begin therefore never waits for the detection it is enqueued behind.
+constexpr int kPendShift = 40;
+constexpr uint64_t kSizeMask = (1ull << kPendShift) - 1ull;
+__global__ void k_tag_pending(uint64_t* size, const int32_t* pending_count) {
+    const int c = *pending_count;
+    *size = (*size & kSizeMask) | ((uint64_t)(c < 0 ? 0 : (c > 0xffffff ? 0xffffff : c)) << kPendShift);
+}
+
 extern "C" {
 
 int ctag_shard_range(int n_total, int rank, int world, int* lo, int* hi) {
@@ -551,10 +565,11 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
         return CTAG_ERR_ARG;
     }
     G_HIP(hipSetDevice(g->device));
-    {   // records of frames that wait for the any-frame pass (CTAG_PENDING) are completed before they are packed
-        const int fr = ctag::handle_finish_pending(h);
-        if (fr != CTAG_OK) return fr;
-    }
+    // records of frames that wait for the any-frame pass (CTAG_PENDING) must be completed before they travel; whether there are any is
+    // known only when the detection ahead has run, so the question rides with the sizes (k_tag_pending) and is answered in ctag_gather_end
+    const int32_t* pend_count = nullptr;
+    g->tagged = ctag::handle_pending_state(h, &pend_count, &g->pend_gen);
+    g->local_dev = local_dev;
     hipStream_t main_s = static_cast<hipStream_t>(ctag_stream(h));
     const int n_max = (n_total + g->world - 1) / g->world;
     // the payload all-gather sends the largest packed size ROUNDED UP to 256 bytes from this buffer
@@ -568,6 +583,7 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
     G_HIP(hipStreamWaitEvent(g->gstream, g->ev_main, 0));
     r = enqueue_pack(g, false, local_dev, n_local, g->d_packed, g->d_sizes + g->rank, g->gstream);
     if (r != CTAG_OK) return r;
+    if (g->tagged) hipLaunchKernelGGL(k_tag_pending, dim3(1), dim3(1), 0, g->gstream, g->d_sizes + g->rank, pend_count);
     // local_dev may be overwritten by whatever the caller enqueues next on the main stream: order it behind the pack
     G_HIP(hipEventRecord(g->ev_packed, g->gstream));
     G_HIP(hipStreamWaitEvent(main_s, g->ev_packed, 0));
@@ -594,6 +610,36 @@ int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
     Rccl* R = rccl();
     G_HIP(hipSetDevice(g->device));
     G_HIP(hipEventSynchronize(g->ev_sizes));  // the only host wait of the exchange: world x 8 bytes
+    {
+        uint64_t pending_any = 0;
+        for (int r = 0; r < g->world; r++) {
+            pending_any |= g->h_sizes[r] >> kPendShift;
+            g->h_sizes[r] &= kSizeMask;
+        }
+        if (g->tagged && !pending_any) ctag::handle_pending_clean(h, g->pend_gen);
+        if (pending_any) {
+            // the rare path, taken by EVERY rank (they all read the same counts): complete the pending frames where there are any (a host wait for
+            // this rank's detection and the any-frame passes), then pack and announce again.  local_dev must still hold the records it held at
+            // ctag_gather_begin (include/ctag_gather.h).
+            const int fr = ctag::handle_finish_pending(h);
+            if (fr != CTAG_OK) return fr;
+            hipStream_t main_s = static_cast<hipStream_t>(ctag_stream(h));
+            G_HIP(hipEventRecord(g->ev_main, main_s));
+            G_HIP(hipStreamWaitEvent(g->gstream, g->ev_main, 0));
+            const int pr = enqueue_pack(g, false, g->local_dev, g->n_local, g->d_packed, g->d_sizes + g->rank, g->gstream);
+            if (pr != CTAG_OK) return pr;
+            G_HIP(hipEventRecord(g->ev_packed, g->gstream));
+            G_HIP(hipStreamWaitEvent(main_s, g->ev_packed, 0));
+            if (g->comm) {
+                ncclResult_t nr = ncclSuccess;
+                G_HIP(ordered_collective(g->comm, g->gstream, [&] { return R->AllGather(g->d_sizes + g->rank, g->d_sizes, 1, ncclUint64, g->comm, g->gstream); }, &nr));
+                G_NCCL(nr);
+            }
+            G_HIP(hipMemcpyAsync(g->h_sizes, g->d_sizes, sizeof(uint64_t) * g->world, hipMemcpyDeviceToHost, g->gstream));
+            G_HIP(hipStreamSynchronize(g->gstream));
+            for (int r = 0; r < g->world; r++) g->h_sizes[r] &= kSizeMask;
+        }
+    }
     uint64_t width = 0;
     for (int r = 0; r < g->world; r++) {
         if (g->h_sizes[r] > ctag_packed_capacity((g->n_total + g->world - 1) / g->world)) {

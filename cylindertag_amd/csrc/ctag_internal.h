@@ -237,6 +237,11 @@ bool handle_timing(const struct ::ctag_handle* h);
 // completes the frames of earlier device-memory calls that wait for the any-frame workspace (CTAG_PENDING records); waits for the
 // handle's stream when there may be any.  Every entry point that reads result records on the device calls it first.
 int handle_finish_pending(struct ::ctag_handle* h);
+// the gather layer defers that wait (ctag_gather_begin must not stall the host behind the detection it follows): `may_have` = a device-memory call was
+// enqueued since the list was last read; *count_dev = the list's length on the device (written by k_markers: read it in stream order behind the
+// detection); *gen counts such calls.  handle_pending_clean: the length read behind call number `gen` was 0 -- nothing is pending unless a later call ran.
+bool handle_pending_state(struct ::ctag_handle* h, const int32_t** count_dev, uint64_t* gen);
+void handle_pending_clean(struct ::ctag_handle* h, uint64_t gen);
 int handle_device(const struct ::ctag_handle* h);
 
 // Private window for libctag_testkit.so (include/ctag_testkit.h: parity probes, synthetic frames).  Not declared in any

@@ -78,7 +78,7 @@ void ctag_host_free(void* p);
  * thousands of blobs, fine texture -- is not failed: it is run again, alone, through a workspace whose pools no frame of
  * its size can exhaust, and its record is the reference's like any other.  Host-memory calls (ctag_detect_u8 / _batch_u8 /
  * _bgr8) do that before they return.  Device-memory calls do it at the handle's next synchronisation point: ctag_sync(), a call
- * with CTAG_OPT_TIMING on, ctag_pose_batch_device, ctag_pack_results / ctag_gather_begin; a caller that relies on stream ordering
+ * with CTAG_OPT_TIMING on, ctag_pose_batch_device, ctag_pack_results / ctag_gather_end; a caller that relies on stream ordering
  * alone sees such a frame's record with status CTAG_PENDING until then (the source frames must stay valid that long). */
 int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride,
                              ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,

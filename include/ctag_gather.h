@@ -71,7 +71,11 @@ const char* ctag_comm_last_error(ctag_handle* h);
  * the work already enqueued on the handle's main stream) pack + all-gather of the sizes + their download; the caller
  * may now enqueue the NEXT batch's detection; _end waits for the sizes only, then enqueues the payload all-gather and
  * the unpack and returns; _wait blocks until out_dev is complete.  ctag_gather = the three in a row.
- * One gather may be in flight per handle. */
+ * One gather may be in flight per handle.
+ * Frames that wait for the any-frame workspace (CTAG_PENDING records of a device-memory call, include/ctag.h): _begin does not wait for
+ * the detection ahead of it to find out whether there are any -- every rank's count travels with its size, and _end, on EVERY rank, completes
+ * them and packs again when some rank has one (rare: cluttered frames).  local_dev must therefore hold its records, unchanged, until _end
+ * has returned -- a handle's next batch goes to another buffer (two alternating ones do). */
 int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_local, int n_total);
 int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev);
 int ctag_gather_wait(ctag_handle* h);

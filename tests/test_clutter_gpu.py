@@ -144,3 +144,55 @@ def _write_bmp8(path, img):
         f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 8, 0, len(data), 2835, 2835, 256, 0))
         f.write(pal)
         f.write(data)
+
+
+def test_gather_completes_pending_frames_without_waiting_in_begin(detector, oracle, dictionary):
+    """ctag_gather_begin behind a device-memory batch that holds cluttered frames: it must not wait for the detection (the pipelined N > 1
+    loop of bench.py enqueues the next step behind it), the ranks' pending counts travel with the packed sizes, and ctag_gather_end --
+    on every rank -- completes the frames and packs again: the gathered list is the oracle's, no CTAG_PENDING left (world 1 here)."""
+    import time
+    state, fs = dictionary
+    n = 48
+    frames = np.stack([tk.synth_frame_host(state, 100 + f)[0] for f in range(n)])
+    frames[11] = blob_field(frames[11])[0]
+    frames[30] = chevron_texture(frames[30])[0]
+    want, _ = oracle.detect_many(frames, state, fs)
+    dev = torch.device("cuda:0")
+    fr = torch.from_numpy(frames).to(dev)
+    rec = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    out = torch.full((n, ca.RESULT_DT.itemsize), 0xEE, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    detector.comm_init(capi.comm_unique_id(), 0, 1)
+    try:
+        # ordinary content first: nothing pending, and begin returns while the detection is still running
+        plain = torch.from_numpy(np.ascontiguousarray(np.repeat(frames[:4], 64, axis=0))).to(dev)  # 256 frames: a few ms of GPU work
+        prec = torch.zeros((256, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+        pout = torch.zeros_like(prec)
+        torch.cuda.synchronize()
+        detector.detect_batch_device(plain.data_ptr(), 256, 1080, 1920, 1920, 1920 * 1080, prec.data_ptr())
+        detector.gather(prec.data_ptr(), 256, 256, pout.data_ptr())  # warm: workspaces and the gather's buffers allocated (hipMalloc waits for the device)
+        detector.sync()
+        t0 = time.perf_counter()
+        detector.detect_batch_device(plain.data_ptr(), 256, 1080, 1920, 1920, 1920 * 1080, prec.data_ptr())
+        t1 = time.perf_counter()
+        detector.gather_begin(prec.data_ptr(), 256, 256)
+        t2 = time.perf_counter()
+        detector.sync()
+        t3 = time.perf_counter()
+        detector.gather_end(pout.data_ptr())
+        detector.gather_wait()
+        assert (pout.cpu().numpy() == prec.cpu().numpy()).all()
+        assert (t2 - t1) < 0.5 * (t3 - t0), "gather_begin waited for the detection: %.3f ms of a %.3f ms step" % ((t2 - t1) * 1e3, (t3 - t0) * 1e3)
+        # cluttered frames in the batch
+        before = detector.counters()["reruns"]
+        detector.detect_batch_device(fr.data_ptr(), n, 1080, 1920, 1920, 1920 * 1080, rec.data_ptr())
+        detector.gather_begin(rec.data_ptr(), n, n)
+        detector.gather_end(out.data_ptr())
+        detector.gather_wait()
+        detector.sync()
+        got = np.frombuffer(out.cpu().numpy().tobytes(), ca.RESULT_DT)
+        for k in range(n):
+            assert_same_record(got[k], want[k], "gathered, frame %d" % k)
+        assert detector.counters()["reruns"] == before + 2
+    finally:
+        detector.comm_destroy()
