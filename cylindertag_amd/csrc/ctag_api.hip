@@ -447,13 +447,14 @@ static int enqueue_chunk(ctag_handle* h, const Workspace& ws, const uint8_t* fra
     h->last_frames = frames_dev;
     h->last_row_stride = row_stride;
     h->last_frame_stride = frame_stride;
-    HIP_TRY(launch_zero_counters(n, ws, s));
+    const bool zero_in_k1 = n <= kLatencyFrames;  // a few frames: one launch less at the head of the chain
+    if (!zero_in_k1) HIP_TRY(launch_zero_counters(n, ws, s));
     int st = 0;
     auto mark = [&](int i) -> hipError_t { return evs ? hipEventRecord(evs[i], s) : hipSuccess; };
     HIP_TRY(mark(0));
     const bool fused = sweep_fused(frames_dev, frame_stride, row_stride, n, ws);  // threshold where the pixels are computed: 1 bit per pixel to K2, no `half`
     h->last_fused = fused;
-    HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s, fused));
+    HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s, fused, zero_in_k1));
     HIP_TRY(mark(++st));
     HIP_TRY(launch_threshold_ccl(n, ws, s, fused));
     HIP_TRY(mark(++st));

@@ -212,7 +212,7 @@ struct DetectParams {
 hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s);  // frame_ncomp, frame_flags, line_count, clp_used, ovf_count
 // fused: k_decimate_mask + the mask front end of K2 (1 bit per pixel between them, no `half`) -- sweep_fused says when that form applies
 bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws);
-hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused = false);
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused = false, bool zero_too = false);
 hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s, bool fused = false);
 hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s);

@@ -151,9 +151,27 @@ __device__ __forceinline__ uint32_t vpack4(uint32_t p01, uint32_t p23) { return 
 
 // 5 waves per SIMD (94 VGPRs): measured 4 waves 2.40 ms, 5 waves 2.29, 6 waves (14 spilled registers) 2.34; nontemporal source
 // loads 2.46
+// the per-chunk counters a chain starts by zeroing (k_zero_counters); calls of a few frames pass them to their first kernel instead of launching one for them
+struct ZeroList {
+    int32_t* a;
+    uint32_t* b;
+    int32_t* c;
+    int32_t* d;
+    int32_t* one;
+    int n;  // frames (<= 256); 0: nothing to zero
+};
 template <bool ALIGNED, int BAND, bool HAS_TAIL>  // BAND: compile-time band height (0 = run-time band_rows_rt); HAS_TAIL: hcols % 8 != 0
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_decimate(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
-                                                  uint8_t* __restrict__ half, FrameGeom g, int nframes, int xblocks, int yblocks, int band_rows_rt) {
+                                                  uint8_t* __restrict__ half, FrameGeom g, int nframes, int xblocks, int yblocks, int band_rows_rt, ZeroList Z) {
+    if (BAND == 0 && blockIdx.x == 0) {  // (the kernels behind this one read the counters: nothing in this one does)
+        if ((int)threadIdx.x < Z.n) {
+            Z.a[threadIdx.x] = 0;
+            Z.b[threadIdx.x] = 0u;
+            Z.c[threadIdx.x] = 0;
+            Z.d[threadIdx.x] = 0;
+        }
+        if (threadIdx.x == 0 && Z.n > 0) *Z.one = 0;
+    }
     const int band_rows = BAND ? BAND : band_rows_rt;
     int frame, idx;
     if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
@@ -384,10 +402,23 @@ bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_st
     return bands % 4 == 0;
 }
 
-hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused) {
+hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s);
+// zero_too: the chain's counters have not been zeroed (a call of a few frames): the run-time-band kernel does it, any other form gets k_zero_counters first
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused, bool zero_too) {
     const FrameGeom& g = ws.g;
+    const bool general = (g.rows & 1) || (g.cols & 1) || getenv("CTAG_GENERAL_RESIZE");
+    ZeroList Z{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (zero_too) {
+        if (fused || general || nframes > 256) {
+            const hipError_t e = launch_zero_counters(nframes, ws, s);
+            if (e != hipSuccess) return e;
+            zero_too = false;
+        } else {
+            Z = ZeroList{ws.frame_ncomp, ws.frame_flags, ws.line_count, ws.clp_used, ws.ovf_count, nframes};
+        }
+    }
     if (fused) return launch_decimate_mask(frames, frame_stride, row_stride, nframes, ws, s);
-    if ((g.rows & 1) || (g.cols & 1) || getenv("CTAG_GENERAL_RESIZE")) {  // env: developer aid, runs even sizes through the general kernel
+    if (general) {  // odd sizes (env: developer aid, runs even sizes through the general kernel)
         hipLaunchKernelGGL(k_decimate_general, dim3((g.hcols + 255) / 256, g.hrows, nframes), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g,
                            nframes, ws.rz_xofs, ws.rz_alpha, ws.rz_yofs, ws.rz_beta);
         return hipGetLastError();
@@ -405,9 +436,13 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
     const bool aligned = (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0;
 #define CTAG_DEC_LAUNCH(AL, B, TL)                                                                                                         \
     hipLaunchKernelGGL((k_decimate<AL, B, TL>), dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, \
-                       yblocks, band_rows)
+                       yblocks, band_rows, Z)
     const bool has_tail = (g.hcols & 7) != 0;
     static const int wide_env = getenv("CTAG_DEC_WIDE") ? atoi(getenv("CTAG_DEC_WIDE")) : 1;  // same-box A/B on 4096 1080p frames: 2.276 -> 2.209 ms (5 waves per SIMD: 2.28)
+    if (zero_too && band_rows == 135) {  // (a few frames never get here: their bands are short) the forms below do not zero
+        const hipError_t e = launch_zero_counters(nframes, ws, s);
+        if (e != hipSuccess) return e;
+    }
     if (wide_env && aligned && !has_tail && (g.hcols & 15) == 0 && band_rows == 135) {  // a lane owns 16 output pixels: a wave spans 1024 half-res columns
         const int xb = (g.hcols / 16 + 63) / 64;
         hipLaunchKernelGGL((k_decimate_wide<135>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xb, yblocks,
