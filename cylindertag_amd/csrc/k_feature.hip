@@ -174,6 +174,7 @@ __global__ __launch_bounds__(THREADS) void k_features(FeatPtrs P, int nframes, i
     static_assert(kPairCap <= 256, "a listed pair is two bytes");
     __shared__ uint16_t s_plist[kPairList];
     __shared__ float s_reach[kPairCap];
+    __shared__ float s_qc[kPairCap][8];  // the quads' corners: featureOrganization reads them again (two dependent global loads per feature otherwise)
     __shared__ int s_npair;
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(THREADS) void k_features(FeatPtrs P, int nframes, i
             if (q < kPairCap) {
                 s_der[q] = D;
                 s_reach[q] = fmaxf((D.d[0] + D.d[2]) / 2, (D.d[1] + D.d[3]) / 2);
+#pragma unroll
+                for (int u = 0; u < 8; u++) s_qc[q][u] = c[u];
             }
         }
     }
@@ -280,27 +283,39 @@ __global__ __launch_bounds__(THREADS) void k_features(FeatPtrs P, int nframes, i
         // (rounding is monotonic).  With fl >= S the left side is >= fl/2 and the right side <= 0.45 fl: the test fails by a
         // margin no rounding closes.  Pairs that survive are listed and evaluated densely, a pair per lane.
         {
-            constexpr int JW = THREADS >= 256 ? 256 : 128;  // lanes across j; THREADS / JW interleaved slices of i
-            constexpr int NI = THREADS / JW;
-            const int jl = tid % JW, i0 = tid / JW;
-            const int j0 = jl, j1 = jl + JW;
-            const bool h0 = j0 < Q, h1 = j1 < Q;
-            const float x0 = h0 ? s_der[j0].cx : 0.f, y0 = h0 ? s_der[j0].cy : 0.f, r0 = h0 ? s_reach[j0] : 0.f;
-            const float x1 = h1 ? s_der[j1].cx : 0.f, y1 = h1 ? s_der[j1].cy : 0.f, r1 = h1 ? s_reach[j1] : 0.f;
+            // every wave holds (cx, cy, reach) of all quads in registers -- quad j in lane j & 63, register j >> 6 -- and takes every NW-th row i:
+            // the row's three values come out of those registers with v_readlane (i is wave-uniform), not out of LDS with a round trip per row
+            static_assert(kPairCap <= 192, "three quads per lane");
+            float qx[3], qy[3], qr[3];
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int j = lane + 64 * b;
+                const bool hj = j < Q;
+                qx[b] = hj ? s_der[j].cx : 0.f;
+                qy[b] = hj ? s_der[j].cy : 0.f;
+                qr[b] = hj ? s_reach[j] : 0.f;
+            }
             auto consider = [&](int i, int j) {
                 const int at = atomicAdd(&s_npair, 1);
                 if (at < kPairList) s_plist[at] = (uint16_t)(i | (j << 8));
                 else if (feature_pair(s_der[i], s_der[j], P.threshold_angle)) atomicOr(&s_pred[i * (kPairCap / 32) + (j >> 5)], 1u << (j & 31));  // list full: in place
             };
-            for (int i = i0; i + 1 < Q; i += NI) {
-                const float xi = s_der[i].cx, yi = s_der[i].cy, ri = s_reach[i];
-                if (h0 && j0 > i) {
-                    const float S = ri + r0, dx = xi - x0, dy = yi - y0;
-                    if (!(dx * dx + dy * dy > S * S)) consider(i, j0);
-                }
-                if (JW < kPairCap && h1 && j1 > i) {
-                    const float S = ri + r1, dx = xi - x1, dy = yi - y1;
-                    if (!(dx * dx + dy * dy > S * S)) consider(i, j1);
+            auto bcast = [&](const float (&v)[3], int i) {  // v of quad i (uniform)
+                const int l = i & 63;
+                const int b = i >> 6;
+                const int r0 = __builtin_amdgcn_readlane(__float_as_int(v[0]), l), r1 = __builtin_amdgcn_readlane(__float_as_int(v[1]), l),
+                          r2 = __builtin_amdgcn_readlane(__float_as_int(v[2]), l);
+                return __int_as_float(b == 0 ? r0 : (b == 1 ? r1 : r2));
+            };
+            for (int i = wave; i + 1 < Q; i += NW) {
+                const float xi = bcast(qx, i), yi = bcast(qy, i), ri = bcast(qr, i);
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const int j = lane + 64 * b;
+                    if (j < Q && j > i) {
+                        const float S = ri + qr[b], dx = xi - qx[b], dy = yi - qy[b];
+                        if (!(dx * dx + dy * dy > S * S)) consider(i, j);
+                    }
                 }
             }
         }
@@ -312,62 +327,53 @@ __global__ __launch_bounds__(THREADS) void k_features(FeatPtrs P, int nframes, i
         __syncthreads();
         clk.mark(2);
         if (wave == 0) {
-            // the greedy replay (first unvisited j of every unvisited i, ascending i) on wave 0 in lockstep: the visited bits live
-            // in lanes 0..5 (a 32-bit word each), a row of the bit matrix is read by those lanes at once, rows without a
-            // candidate are skipped from a bitmap built in parallel, and the next row is in flight while this one is decided
+            // the greedy replay (first unvisited j of every unvisited i, ascending i) on wave 0: row q of the bit matrix sits in lane q & 63 (three rows
+            // per lane, three 64-bit words per row), the visited set and the rows still to look at are wave-uniform 64-bit words, so a step is a
+            // v_readlane of the row's words and a handful of scalar bit operations -- no LDS round trip, no vector compare, no ballot
             constexpr int kW = kPairCap / 32;
-            static_assert(kPairCap <= 192, "three 64-row bitmap words");
-            unsigned long long rows0, rows1, rows2;
-            {
-                bool any[3];
+            static_assert(kPairCap == 192, "three 64-bit words per row, three rows per lane");
+            unsigned long long row[3][3];  // [row block a: row = lane + 64 a][word b: columns 64 b .. 64 b + 63]
 #pragma unroll
-                for (int b3 = 0; b3 < 3; b3++) {
-                    const int q = b3 * 64 + lane;
-                    any[b3] = false;
-                    if (q < Q)
-                        for (int w = 0; w < kW; w++) any[b3] = any[b3] || s_pred[q * kW + w] != 0u;
-                }
-                rows0 = __ballot(any[0]);
-                rows1 = __ballot(any[1]);
-                rows2 = __ballot(any[2]);
+            for (int a3 = 0; a3 < 3; a3++) {
+                const int q = a3 * 64 + lane;
+#pragma unroll
+                for (int b3 = 0; b3 < 3; b3++)
+                    row[a3][b3] = q < Q ? ((unsigned long long)s_pred[q * kW + 2 * b3] | ((unsigned long long)s_pred[q * kW + 2 * b3 + 1] << 32)) : 0ull;
             }
-            auto next_row = [&]() {
-                int r = -1;
-                if (rows0) {
-                    r = __builtin_ctzll(rows0);
-                    rows0 &= rows0 - 1;
-                } else if (rows1) {
-                    r = 64 + __builtin_ctzll(rows1);
-                    rows1 &= rows1 - 1;
-                } else if (rows2) {
-                    r = 128 + __builtin_ctzll(rows2);
-                    rows2 &= rows2 - 1;
-                }
-                return r;
+            unsigned long long todo[3], vis[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+            for (int a3 = 0; a3 < 3; a3++) todo[a3] = __ballot((row[a3][0] | row[a3][1] | row[a3][2]) != 0ull);  // rows with a candidate at all
+            auto rd = [&](unsigned long long v, int l) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+                return (unsigned long long)lo | ((unsigned long long)hi << 32);
             };
-            uint32_t visw = 0u;  // lane w < kW: visited bits of quads 32 w .. 32 w + 31
             int nm = 0;
-            int i = next_row();
-            uint32_t cur = (i >= 0 && lane < kW) ? s_pred[i * kW + lane] : 0u;
-            while (i >= 0) {
-                const int inext = next_row();
-                const uint32_t nxt = (inext >= 0 && lane < kW) ? s_pred[inext * kW + lane] : 0u;
-                const uint32_t vi = (uint32_t)__builtin_amdgcn_readlane((int)visw, i >> 5);
-                if (!((vi >> (i & 31)) & 1u)) {
-                    const uint32_t m = cur & ~visw;  // a row holds bits j > i only
-                    const unsigned long long bal = __ballot(m != 0u);
-                    if (bal) {
-                        const int w0 = __builtin_ctzll(bal);
-                        const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)m, w0);
-                        const int j = w0 * 32 + __ffs(mw) - 1;
-                        if (lane == (i >> 5)) visw |= 1u << (i & 31);
-                        if (lane == (j >> 5)) visw |= 1u << (j & 31);
-                        if (lane == 0 && nm < CTAG_MAX_FEATURES) s_match[nm] = (uint32_t)i | ((uint32_t)j << 16);
-                        nm++;
-                    }
+#pragma unroll
+            for (int a3 = 0; a3 < 3; a3++) {
+                unsigned long long t = todo[a3];
+                while (t) {  // uniform
+                    const int l = __builtin_ctzll(t);
+                    t &= t - 1;
+                    if ((vis[a3] >> l) & 1ull) continue;
+                    // a row holds bits j > i only: the words below the row's own are empty
+                    unsigned long long m[3];
+#pragma unroll
+                    for (int b3 = 0; b3 < 3; b3++) m[b3] = b3 >= a3 ? (rd(row[a3][b3], l) & ~vis[b3]) : 0ull;
+                    int jb = -1;
+#pragma unroll
+                    for (int b3 = 2; b3 >= 0; b3--)
+                        if (m[b3]) jb = b3;
+                    if (jb < 0) continue;
+                    const unsigned long long mj = jb == 0 ? m[0] : (jb == 1 ? m[1] : m[2]);
+                    const int jl = __builtin_ctzll(mj);
+                    const int i = a3 * 64 + l, j = jb * 64 + jl;
+                    vis[a3] |= 1ull << l;
+#pragma unroll
+                    for (int b3 = 0; b3 < 3; b3++)
+                        if (b3 == jb) vis[b3] |= 1ull << jl;
+                    if (lane == 0 && nm < CTAG_MAX_FEATURES) s_match[nm] = (uint32_t)i | ((uint32_t)j << 16);
+                    nm++;
                 }
-                i = inext;
-                cur = nxt;
             }
             if (lane == 0) s_nf = nm;
         }
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(THREADS) void k_features(FeatPtrs P, int nframes, i
                 const int i = (int)(mk & 0xffffu), j = (int)(mk >> 16);
                 const QuadDerived &Di = s_der[i], &Dj = s_der[j];
                 const float fa = (float)angdeg(Di.cy - Dj.cy, Di.cx - Dj.cx);
-                feature_organization(quads[qidx[i]].c, quads[qidx[j]].c, Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[have ? k : 0], tid & 7, lane & ~7, have && (tid & 7) == 0);
+                feature_organization(s_qc[i], s_qc[j], Di.cx, Di.cy, Dj.cx, Dj.cy, fa, &f0[have ? k : 0], tid & 7, lane & ~7, have && (tid & 7) == 0);
             }
         }
     } else {

@@ -2226,20 +2226,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_
 // K6c: per candidate, the six pairwise intersections of its four fitted edges, angular sort and the best
 // 4-subset by RAC (corner_detector.cpp:362-403, :420-463).  One thread per candidate.
 // =====================================================================================================
-__device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeom& g, int frame, int ci);
+// LANES: 1 for batches (a thread per candidate); 8 for calls of a few frames: lane q < 6 of a candidate's group computes intersection q -- its atan2 is
+// what a candidate costs -- and hands it to the others; the rest (a rank sort of six, fifteen subsets) every lane repeats, lane 0 stores
+template <int LANES>
+__device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeom& g, int frame, int ci, int sub);
+template <int LANES>
 __global__ __launch_bounds__(64) void k_quad_final(QuadPtrs P, FrameGeom g, int nframes) {
     const int frame = blockIdx.y;
     if (frame >= nframes) return;
     const int nc = min(P.ncand[frame], P.cand_cap);
+    constexpr int PER = 64 / LANES;  // candidates per block
     // column rotated by frame: spreads the few busy blocks over the XCDs; a block loops when a frame has more candidates than the grid has threads
-    for (int ci = (int)((blockIdx.x + frame) % gridDim.x) * 64 + threadIdx.x; ci < nc; ci += (int)gridDim.x * 64) quad_final_one(P, g, frame, ci);
+    // (uniform trip count per group of LANES lanes: the group's shuffles need all of them)
+    for (int ci = (int)((blockIdx.x + frame) % gridDim.x) * PER + (int)threadIdx.x / LANES; ci < nc; ci += (int)gridDim.x * PER)
+        quad_final_one<LANES>(P, g, frame, ci, (int)threadIdx.x % LANES);
 }
-__device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeom& g, int frame, int ci) {
+template <int LANES>
+__device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeom& g, int frame, int ci, int sub) {
     const CandAux aux = P.cand_aux[(size_t)frame * P.cand_cap + ci];
     QuadOut* out = P.quads + (size_t)frame * P.cand_cap + ci;
-    out->n_boundary = aux.n_boundary;
-    if (aux.line0 < 0) {
-        out->valid = 0;
+    if (sub == 0) out->n_boundary = aux.n_boundary;
+    if (aux.line0 < 0) {  // (uniform within the candidate's group)
+        if (sub == 0) out->valid = 0;
         return;
     }
     const int areaPx = P.cand[(size_t)frame * P.cand_cap + ci].area;
@@ -2266,16 +2274,30 @@ __device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeo
                 const float b0 = lf[j][1] * lf[j][2] - lf[j][0] * lf[j][3];
                 const float b1 = lf[k][1] * lf[k][2] - lf[k][0] * lf[k][3];
                 CornerPre c{0.f, 0.f, 0.f, 0.f};
-                bool ok = solve2x2(a00, a01, a10, a11, b0, b1, c.x, c.y);
-                if (ok) {
-                    c.dis = ctm::sqrt32((c.x - acx) * (c.x - acx) + (c.y - acy) * (c.y - acy));
-                    c.ang = (float)(ctm::atan2_32(c.y - acy, c.x - acx) * 180 / 3.1415926535897932384626433832795);
-                    ok = c.dis < g.hcols && c.dis < g.hrows;
+                bool ok = false;
+                if (LANES == 1 || sub == q) {
+                    ok = solve2x2(a00, a01, a10, a11, b0, b1, c.x, c.y);
+                    if (ok) {
+                        c.dis = ctm::sqrt32((c.x - acx) * (c.x - acx) + (c.y - acy) * (c.y - acy));
+                        c.ang = (float)(ctm::atan2_32(c.y - acy, c.x - acx) * 180 / 3.1415926535897932384626433832795);
+                        ok = c.dis < g.hcols && c.dis < g.hrows;
+                    }
                 }
                 raw[q] = c;
                 ok6[q] = ok;
                 q++;
             }
+        if constexpr (LANES > 1) {  // intersection q from lane q of the group
+            const int l0 = (int)threadIdx.x & ~(LANES - 1);
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                raw[u].x = __shfl(raw[u].x, l0 + u);
+                raw[u].y = __shfl(raw[u].y, l0 + u);
+                raw[u].dis = __shfl(raw[u].dis, l0 + u);
+                raw[u].ang = __shfl(raw[u].ang, l0 + u);
+                ok6[u] = __shfl((int)ok6[u], l0 + u) != 0;
+            }
+        }
     }
     int ncp = 0;
     int rank6[6];
@@ -2358,6 +2380,7 @@ __device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeo
             if (c.x < 0 || c.y < 0 || c.x > g.hcols || c.y > g.hrows) valid = 0;
         }
     }
+    if (sub != 0) return;
     out->valid = valid;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -2481,7 +2504,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     }
     hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx + welsch_gs), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr, welsch_gx);
     mark();
-    hipLaunchKernelGGL(k_quad_final, dim3(std::min(ws.cand_cap, kLdsCand) / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    if (latency) hipLaunchKernelGGL(k_quad_final<8>, dim3(std::min(ws.cand_cap, kLdsCand) / 8, nframes), dim3(64), 0, s, P, ws.g, nframes);
+    else hipLaunchKernelGGL(k_quad_final<1>, dim3(std::min(ws.cand_cap, kLdsCand) / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {
         unsigned long long h[24];
         (void)hipStreamSynchronize(s);
