@@ -265,6 +265,7 @@ static int ensure_workspace(ctag_handle* h, ctag_handle::WsSlot& S, int rows, in
         W.g.pool_cap = c.pool_cap;
         W.kp = h->kp;
         W.pick_table = h->d_pick_table;
+        W.pick_table16 = reinterpret_cast<const uint16_t*>(h->d_pick_table + (size_t)kPickN * 200);
         W.aux_stream = h->aux_stream;
         W.wave_points = h->wave_points;
         W.fuse_mode = h->fuse_mode;
@@ -986,10 +987,15 @@ int ctag_create_ex(const int32_t* state, int dict_rows, int dict_cols, int featu
              hipMemcpy(h->d_dict_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok) {
-        std::vector<uint8_t> tab((size_t)kPickN * 200);
-        build_pick_table(tab.data());
-        ok = hipMalloc(reinterpret_cast<void**>(&h->d_pick_table), tab.size()) == hipSuccess &&
-             hipMemcpy(h->d_pick_table, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
+        // fitLine2D's initial samples: cv::RNG is seeded the same way for every fit, so the ten points a restart starts from depend on the edge's
+        // point count alone -- tabulated for every count below kPickN2 (bytes below kPickN, halfwords above, one allocation)
+        const size_t nb = (size_t)kPickN * 200, nh = (size_t)(kPickN2 - kPickN) * 200;
+        std::vector<uint8_t> tab(nb);
+        std::vector<uint16_t> tab16(nh);
+        build_pick_table(tab.data(), tab16.data());
+        ok = hipMalloc(reinterpret_cast<void**>(&h->d_pick_table), nb + nh * 2) == hipSuccess &&
+             hipMemcpy(h->d_pick_table, tab.data(), nb, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(h->d_pick_table + nb, tab16.data(), nh * 2, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok) {
         const size_t tb = (size_t)kp.thr_dim * kp.thr_dim;

@@ -46,9 +46,10 @@ constexpr int kMaxThreshWin = 32;       // supported adaptiveThresh window range
 // ---- K6 limits ----------------------------------------------------------------------------------------------
 constexpr int kLatencyFrames = 4;           // calls with at most this many frames are tuned for the latency of the call (launch_quads, hipGraph replay)
 constexpr int kLatLines = 2048;             // edges per frame / points per edge the one-wave-per-restart Welsch kernel of such calls holds;
-constexpr int kLatPoints = 1024;            // a frame beyond either takes the batch kernel
+constexpr int kLatPoints = 512;             // a frame beyond either takes the batch kernel
 constexpr int kClPoolMin = 262144;        // edge-cluster points per frame the batch workspace holds at least (a candidate reserves its boundary capacity + 64)
-constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table
+constexpr int kPickN = 256;               // point counts covered by the precomputed cv::RNG pick table (bytes)
+constexpr int kPickN2 = 4096;             // ... and by its 16-bit continuation [kPickN, kPickN2); longer edges replay cv::RNG on the device
 constexpr int kMaxDictCells = 2048;       // dictionary rows*cols supported by K9 (reference dictionary: 41*12)
 
 struct Candidate {  // one area-filtered connected component, in OpenCV label order
@@ -172,6 +173,7 @@ struct Workspace {
     uint32_t* pack_order = nullptr; // [F][cand_cap]
     float* welsch_rs = nullptr;     // [min(F, kLatencyFrames)][kLatLines][20][6]: line + err (as a double) of every restart, few-frame calls only
     const uint8_t* pick_table = nullptr;  // [kPickN][20][10], owned by the handle
+    const uint16_t* pick_table16 = nullptr;  // [kPickN2 - kPickN][20][10]
     hipStream_t aux_stream = nullptr;     // owned by the handle: side branch for few-frame calls (launch_quads)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int wave_points = 0;                  // CTAG_OPT_WAVE_POINTS (0 = automatic)
@@ -226,7 +228,7 @@ hipError_t launch_markers(int nframes, const Workspace& ws, const DetectParams& 
 size_t threshold_ccl_lds_bytes(int tw);
 // adaptive-threshold bound table for a dark cap (host): returns false when the cap is outside what K2's packed compares hold
 bool build_threshold_table(float dark_cap, uint8_t* table /* 256*256 */, int* dim, int* tcap);
-void build_pick_table(uint8_t* table);  // kPickN*20*10 bytes
+void build_pick_table(uint8_t* table, uint16_t* table16);  // kPickN*20*10 bytes, (kPickN2 - kPickN)*20*10 halfwords
 
 
 // accessors of the opaque handle for the pose back end (k_pose.hip)

@@ -38,6 +38,7 @@ struct QuadPtrs {
     float* line_fit;       // [F][line_cap][4]
     CandAux* cand_aux;     // [F][cand_cap]
     const uint8_t* pick_table;  // [kPickN][20][10] cv::RNG initial samples of fitLine2D for every point count < kPickN
+    const uint16_t* pick_table16;  // [kPickN2 - kPickN][20][10] the same for point counts in [kPickN, kPickN2)
     const int32_t* pool_tile;    // [F][pool_cap]
     const int32_t* member_head;  // [F][pool_cap]
     const int32_t* member_next;  // [F][pool_cap]
@@ -1936,6 +1937,8 @@ __device__ __forceinline__ void welsch_three(const QuadPtrs& P, WelschLds& S, in
     } else if (active) {
         if (n < kPickN) {
             welsch_restart(GlobalPts{pts}, n, TablePicks{P.pick_table + ((size_t)n * 20 + k) * 10}, 10, EPS, S.wc + lane, 64, S.wc + lane);
+        } else if (n < kPickN2) {
+            welsch_restart(GlobalPts{pts}, n, ListPicks{P.pick_table16 + ((size_t)(n - kPickN) * 20 + k) * 10}, 10, EPS, S.wc + lane, 64, S.wc + lane);
         } else {  // replay cv::RNG up to this restart
             uint16_t* pk = reinterpret_cast<uint16_t*>(&S.pt[0][0]) + lane * 10;
             CvRng rng;
@@ -2008,9 +2011,12 @@ __device__ __forceinline__ double ordered_sum(double a, const float* src, int n)
 // (point j in lane j & 63, register j >> 6), the terms go through LDS a chunk of kLatChunk points at a time, and the lanes that add them carry their
 // sums from chunk to chunk -- the additions of one sum are the same, in the same order, whatever the chunking.  (Two builds -- 256 and 1024
 // points of LDS -- ran side by side on two streams before; the fork and the join cost the call more than the second build saved.)
-constexpr int kLatChunk = 256;
+constexpr int kLatChunk = 128;  // (256: 9.3 KB of LDS per restart, 17 per CU -- a frame's ~5000-7700 restarts took two rounds of residency; 128: one)
 static_assert(kLatPoints % kLatChunk == 0 && kLatChunk % 64 == 0, "k_welsch_lat: register / chunk layout");
-__global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, float* rs) {
+#ifndef CTAG_WLAT_WAVES
+#define CTAG_WLAT_WAVES 5
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WLAT_WAVES))) void k_welsch_lat(QuadPtrs P, int nframes, float* rs) {
     constexpr int NQ = kLatPoints / 64, CQ = kLatChunk / 64, NC = kLatPoints / kLatChunk;
     __shared__ float s_r[kLatChunk], s_w[kLatChunk];
     __shared__ float s_t[6][kLatChunk];
@@ -2024,23 +2030,26 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
     if (!welsch_lat_takes(P, frame, L)) return;
     const float c = 1 / 2.9846f;
     for (int rank = blockIdx.y; rank < L; rank += gridDim.y) {
+        const unsigned long long dbg_t0 = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
         __syncthreads();  // single wave: the previous edge is done with the arrays
         const int lid = P.line_sorted[(size_t)frame * P.line_cap + rank];
         const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
         const int n = d.n;  // <= kLatPoints (welsch_lat_takes)
         const uint32_t* pts = P.cl_pool + (size_t)frame * P.cl_cap + d.off;
-        float px[NQ], py[NQ], ww[NQ];
+        uint32_t pp[NQ];  // packed (x | y << 16): a register per point, unpacked where it is used (two conversions), not two
+        float ww[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            const uint32_t v = pts[min(lane + 64 * q, n - 1)];  // unconditional, from a clamped index: all NQ loads are in flight together
-            px[q] = (float)ux(v);
-            py[q] = (float)uy(v);
+            pp[q] = pts[min(lane + 64 * q, n - 1)];  // unconditional, from a clamped index: all NQ loads are in flight together
             ww[q] = 0.f;
         }
         const int npick = min(n, 10);
         if (lane == 0) {  // the restart's initial sample (ascending), as welsch_three builds it
             if (n < kPickN) {
                 const uint8_t* t = P.pick_table + ((size_t)n * 20 + k) * 10;
+                for (int q = 0; q < npick; q++) s_pk[q] = t[q];
+            } else if (n < kPickN2) {  // (replayed on the spot the twentieth restart of a 450-point edge spent 27 us here: 200 draws, a division each)
+                const uint16_t* t = P.pick_table16 + ((size_t)(n - kPickN) * 20 + k) * 10;
                 for (int q = 0; q < npick; q++) s_pk[q] = t[q];
             } else {
                 CvRng rng;
@@ -2103,7 +2112,7 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
 #pragma unroll
                 for (int u = 0; u < CQ; u++) {
                     const int q = ch * CQ + u;
-                    const float x = px[q] - lx, y = py[q] - ly;
+                    const float x = (float)ux(pp[q]) - lx, y = (float)uy(pp[q]) - ly;
                     const float r = ctm::fabs32(nx * x + ny * y);
                     const float wj = ctm::exp32_nonpos(-r * r * c * c);
                     ww[q] = wj;
@@ -2128,7 +2137,7 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
 #pragma unroll
                 for (int u = 0; u < CQ; u++) {
                     const int q = ch * CQ + u, j = 64 * u + lane;
-                    const float fx = px[q], fy = py[q];
+                    const float fx = (float)ux(pp[q]), fy = (float)uy(pp[q]);
                     if (weighted) {
                         const float wj = (float)(ww[q] * inv);
                         s_t[0][j] = wj * fx;
@@ -2164,6 +2173,7 @@ __global__ __launch_bounds__(64) void k_welsch_lat(QuadPtrs P, int nframes, floa
             o[2] = line[2];
             o[3] = line[3];
             *reinterpret_cast<double*>(o + 4) = err;
+            if (P.stamps && rank < 8 && (k == 0 || k == 19)) P.stamps[16 + 8 + (k ? 1 : 0) * 4 + (rank >> 1)] = __builtin_amdgcn_s_memtime() - dbg_t0;  // developer aid: restarts 0 / 19 of ranks 0, 2, 4, 6
         }
     }
 }
@@ -2395,13 +2405,13 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         if (ev5) (void)hipEventRecord(ev5[evi++], s);
     };
     QuadPtrs P{ws.labels, ws.tile_base, ws.root_of, ws.ncand, ws.cand, ws.quads, ws.frame_flags,
-               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr, ws.kp.thr_line, ws.kp.thr_expand, ws.kp.rac, ws.kp.c2_far, ws.kp.c2_near,
+               ws.line_count, ws.clp_used, ws.cl_pool, ws.line_desc, ws.line_sorted, ws.line_long, ws.line_fit, ws.cand_aux, ws.pick_table, ws.pick_table16, ws.pool_tile, ws.member_head, ws.member_next, ws.npacks, ws.packs, ws.pack_order, nullptr, ws.kp.thr_line, ws.kp.thr_expand, ws.kp.rac, ws.kp.c2_far, ws.kp.c2_near,
                ws.cand_cap, ws.line_cap, ws.cl_cap, ws.kp.expand_eps};
     static unsigned long long* d_stamps = nullptr;
     const bool want_stamps = getenv("CTAG_QUAD_STAMPS") != nullptr;
     if (want_stamps) {
-        if (!d_stamps) (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), 24 * 8);
-        (void)hipMemsetAsync(d_stamps, 0, 24 * 8, s);
+        if (!d_stamps) (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), 32 * 8);
+        (void)hipMemsetAsync(d_stamps, 0, 32 * 8, s);
         P.stamps = d_stamps;
     }
     static const int pack_max_env = getenv("CTAG_PACK_MAX") ? atoi(getenv("CTAG_PACK_MAX")) : 0;
@@ -2507,12 +2517,13 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     if (latency) hipLaunchKernelGGL(k_quad_final<8>, dim3(std::min(ws.cand_cap, kLdsCand) / 8, nframes), dim3(64), 0, s, P, ws.g, nframes);
     else hipLaunchKernelGGL(k_quad_final<1>, dim3(std::min(ws.cand_cap, kLdsCand) / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
     if (want_stamps) {
-        unsigned long long h[24];
+        unsigned long long h[32];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
         if (h[16] | h[17] | h[18] | h[19])
             fprintf(stderr, "[whole-wave rdp ticks] corner scan %llu split rounds %llu expand_line %llu clusters + erase %llu\n", h[16], h[17], h[18], h[19]),
             fprintf(stderr, "[whole-wave expand_line] initial sums %llu ticks, %llu rounds, %llu of them through the exact fits\n", h[20], h[21], h[22]);
+        if (h[24]) fprintf(stderr, "[k_welsch_lat ticks] restart 0 of the edges of rank 0 / 2 / 4 / 6: %llu %llu %llu %llu; restart 19: %llu %llu %llu %llu\n", h[24], h[25], h[26], h[27], h[28], h[29], h[30], h[31]);
         for (int b = 0; b < 16; b += 8) {
             unsigned long long tot = 0;
             h[b + 0] += h[b + 7];  // the row scan is stamped separately; it belongs to the silhouette phase
@@ -2527,31 +2538,35 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     return hipGetLastError();
 }
 
-// cv::RNG replay on the host: initial samples of fitLine2D for every point count below kPickN (ascending per restart)
-void build_pick_table(uint8_t* table) {
-    for (int n = 0; n < kPickN; n++) {
+// cv::RNG replay on the host: initial samples of fitLine2D for every point count below kPickN2 (ascending per restart)
+void build_pick_table(uint8_t* table, uint16_t* table16) {
+    for (int n = 0; n < kPickN2; n++) {
         uint64_t state = 0xffffffffffffffffULL;
         for (int k = 0; k < 20; k++) {
-            uint8_t* pk = table + ((size_t)n * 20 + k) * 10;
-            for (int q = 0; q < 10; q++) pk[q] = 0;
-            if (n < 2) continue;
-            const int npick = n < 10 ? n : 10;
-            int got = 0;
-            while (got < npick) {
-                state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
-                const int j = (int)((unsigned)state % (unsigned)n);
-                bool dup = false;
-                for (int q = 0; q < got; q++) dup |= (pk[q] == j);
-                if (!dup) pk[got++] = (uint8_t)j;
-            }
-            for (int a = 1; a < npick; a++) {
-                const uint8_t v = pk[a];
-                int b = a - 1;
-                while (b >= 0 && pk[b] > v) {
-                    pk[b + 1] = pk[b];
-                    b--;
+            uint16_t pk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (n >= 2) {
+                const int npick = n < 10 ? n : 10;
+                int got = 0;
+                while (got < npick) {
+                    state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+                    const int j = (int)((unsigned)state % (unsigned)n);
+                    bool dup = false;
+                    for (int q = 0; q < got; q++) dup |= (pk[q] == j);
+                    if (!dup) pk[got++] = (uint16_t)j;
                 }
-                pk[b + 1] = v;
+                for (int a = 1; a < npick; a++) {
+                    const uint16_t v = pk[a];
+                    int b = a - 1;
+                    while (b >= 0 && pk[b] > v) {
+                        pk[b + 1] = pk[b];
+                        b--;
+                    }
+                    pk[b + 1] = v;
+                }
+            }
+            for (int q = 0; q < 10; q++) {
+                if (n < kPickN) table[((size_t)n * 20 + k) * 10 + q] = (uint8_t)pk[q];
+                else table16[((size_t)(n - kPickN) * 20 + k) * 10 + q] = pk[q];
             }
         }
     }
