@@ -2480,7 +2480,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     // oversize components, a wave each: working sets up to kWaveWords in a 32 KB build (5 per CU), the rest (up to the 144 KB a
     // 4K frame's longest possible boundary needs three times over) in a build that owns a CU's LDS
     static const int bcols_env = getenv("CTAG_BIG_COLS") ? atoi(getenv("CTAG_BIG_COLS")) : 0;
-    const int bcols = bcols_env > 0 ? bcols_env : (latency ? 128 : 4);
+    const int bcols = bcols_env > 0 ? bcols_env : (latency ? 512 : 4);  // (few frames: every component a block of its own up to 512 per frame; a 2666-blob frame 3.0 -> 2.5 ms against 128)
 #define CTAG_LAUNCH_WAVE(REF)                                                                                                                               \
     do {                                                                                                                                                    \
         int dev = 0;                                                                                                                                        \
