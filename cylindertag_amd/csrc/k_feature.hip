@@ -494,15 +494,26 @@ constexpr int kRefineTails = CTAG_REFINE_TAILS;  // quads whose tails k_edge_ref
 #endif
 // what k_edge_refine<2> needs from global memory for one quad, requested ahead of its use (a looping block asks for the next quad's
 // while it works on the current one's): the search kernel's n0 of the lane's eight samples and, lanes 0-3, a corner
+#ifndef CTAG_REFINE_SEG
+#define CTAG_REFINE_SEG 32
+#endif
+constexpr int kRefineSeg = CTAG_REFINE_SEG;  // samples of an edge the sums kernel holds in LDS at a time (a divisor of 64)
+static_assert(kRefineSeg == 32 || kRefineSeg == 64, "k_edge_refine<2>: items per lane and segment");
+// the sums kernel's lane <-> sample map: in segment g a lane builds items i = 0 .. 4 kRefineSeg / 64 - 1: with idx = 64 i + tid, the sample
+// kRefineSeg g + idx % kRefineSeg of edge idx / kRefineSeg
 struct RefinePrefetch {
-    double n0[(4 * kRefineSamples) / 64];
+    double n0[(4 * kRefineSamples) / 64];  // [segment][item]
     float cx, cy;
 };
 __device__ __forceinline__ void refine_prefetch(const RefinePtrs& P, int frame, int qidx, RefinePrefetch& R) {
     const int tid = threadIdx.x;
     const double* src = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples);
+    constexpr int kIps = 4 * kRefineSeg / 64;
 #pragma unroll
-    for (int u = 0; u < (4 * kRefineSamples) / 64; u++) R.n0[u] = src[u * 64 + tid];
+    for (int u = 0; u < (4 * kRefineSamples) / 64; u++) {
+        const int g = u / kIps, idx = (u % kIps) * 64 + tid;
+        R.n0[u] = src[(idx / kRefineSeg) * kRefineSamples + g * kRefineSeg + idx % kRefineSeg];
+    }
     const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + (qidx >> 1);
     const int c = (qidx & 1) * 4 + (tid & 3);
     R.cx = F->c[2 * c];
@@ -560,16 +571,21 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     // every lane of the accumulation walks three unit-stride columns (immediate offsets, no address arithmetic in the loop)
     // (the sums kernel reads its rows two doubles at a time -- ds_read_b128 moves 16 bytes per lane at twice the rate of the ds_read2_b64 an
     // 8-byte-aligned row gets -- so its rows are 16-byte aligned: 130 doubles, rows 0-15 then cover the 64 banks exactly once)
-    constexpr int kPitch = MODE == 2 ? kRefineSamples + 2 : kRefineSamples + 1;
+    // MODE 2 (the sums kernel) works on an edge's 128 samples in segments of kRefineSeg = 32: short rows, so that the PRODUCTS x x, x y, y y of every
+    // sample (rows 16-27, written once where the sample is built) fit as well -- a sum then reads two rows per term, (A B) and w, instead of three
+    // (A, B, w): the same two roundings, (A B) first, then times w -- in 9.8 KB instead of 17.8.  The kernel lives on its occupancy: with full-length
+    // rows the products cost 32 KB and it went from 1.25 to 2.0 ms per 4096 frames; 64-sample rows 1.10; 32-sample rows at three waves per SIMD 1.03.
+    constexpr int kPitch = MODE == 2 ? kRefineSeg + 2 : kRefineSamples + 1;
+    constexpr int kRows = MODE == 2 ? 28 : 16;
     // The row of ones sits 16 doubles (32 banks) further than a 17th row would: a row of 130 doubles starts 4 banks after its predecessor, so
     // rows 0-15 tile the 64 banks and a 17th row would share row 0's; the instructions that read ones (factor A or B of a sum) read x / y rows 0-7
     // beside it, never the weight rows 8-15 whose banks it now shares (round 4: the sums kernel's 19 % bank conflicts were these two rows)
 #ifndef CTAG_ONES_SHIFT
 #define CTAG_ONES_SHIFT 16
 #endif
-    __shared__ __attribute__((aligned(16))) double s_vall[MODE == 1 ? kPitch : 17 * kPitch + CTAG_ONES_SHIFT];
+    __shared__ __attribute__((aligned(16))) double s_vall[MODE == 1 ? kPitch : (kRows + 1) * kPitch + CTAG_ONES_SHIFT];
     double (*s_v)[kPitch] = reinterpret_cast<double (*)[kPitch]>(s_vall);
-    double* const s_ones = MODE == 1 ? s_vall : s_vall + 16 * kPitch + CTAG_ONES_SHIFT;
+    double* const s_ones = MODE == 1 ? s_vall : s_vall + kRows * kPitch + CTAG_ONES_SHIFT;
     double (*s_bx)[kPitch] = s_v, (*s_by)[kPitch] = s_v + (MODE == 1 ? 0 : 4);
     __shared__ double s_nrm[4][2];                // unit normal of each edge
     __shared__ uint64_t s_step[4][2];             // ctr::fast_step of the normal's components
@@ -596,7 +612,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     double* const accp = MODE == 2 ? acc_out : s_acc;
     if (MODE != 1 && tid < 48) accp[tid] = 0.0;
     if constexpr (MODE != 1) {
-        for (int k = tid; k < kRefineSamples + 1; k += (int)blockDim.x) s_ones[k] = 1.0;
+        for (int k = tid; k < kPitch; k += (int)blockDim.x) s_ones[k] = 1.0;
     }
     __syncthreads();
     if (tid < 4) {  // :609-615
@@ -693,32 +709,81 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
         }
         __syncthreads();
     }
+    if constexpr (MODE == 2) {
+        // the samples' points from the search kernel's n0, with the search's own expressions: x0 = alpha ax + (1 - alpha) bx, best = x0 + n0 nx.  A lane's
+        // sample of a half is sm = 64 h + tid of each of the four edges: two position parameters in all, not eight divisions.
+        constexpr int kIps = 4 * kRefineSeg / 64, kSegs = kRefineSamples / kRefineSeg;
+        const int edge_s = tid / 12, r_s = tid - edge_s * 12, pass_s = r_s / 6, which_s = r_s - pass_s * 6;  // this lane's sum (tid < 48)
+        const int es = tid < 48 ? edge_s : 0;
+        // the row of (A B): x 1 = x and y 1 = y exactly, the products from their rows, 1 1 = 1
+        const double* pp = which_s == 0 ? s_bx[es] : which_s == 1 ? s_by[es] : which_s == 2 ? s_v[16 + es] : which_s == 3 ? s_v[20 + es] : which_s == 4 ? s_v[24 + es] : s_ones;
+        const double* pw = s_v[8 + 4 * (tid < 48 ? pass_s : 0) + es];
+        const double2 *pp2 = reinterpret_cast<const double2*>(pp), *pw2 = reinterpret_cast<const double2*>(pw);
+        double acc = 0.0;
+#pragma unroll
+        for (int g = 0; g < kSegs; g++) {
+            const int loc = tid % kRefineSeg;
+            const double alpha = (15.0 + (kRefineSeg * g + loc)) / (kRefineSamples + 30);  // == (15.0 + sm) / (s_ns[edge] + 30): s_ns[edge] == kRefineSamples for every edge of this quad
+            if (g) __syncthreads();  // the sums of the segment before are done with the rows
+#pragma unroll
+            for (int i = 0; i < kIps; i++) {
+                const int edge = (i * 64 + tid) / kRefineSeg;
+                const int a = edge, b = (edge + 1) & 3;
+                const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
+                const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
+                const double x0 = alpha * ax + (1 - alpha) * bx;
+                const double y0 = alpha * ay + (1 - alpha) * by;
+                const double n0 = pre->n0[g * kIps + i];
+                const bool ok = n0 == n0;
+                const double bxv = ok ? x0 + n0 * nx : 0.0, byv = ok ? y0 + n0 * ny : 0.0;
+                s_bx[edge][loc] = bxv;
+                s_by[edge][loc] = byv;
+                s_v[8 + edge][loc] = ok ? 1 - alpha : 0.0;
+                s_v[12 + edge][loc] = ok ? alpha : 0.0;
+                s_v[16 + edge][loc] = bxv * bxv;
+                s_v[20 + edge][loc] = bxv * byv;
+                s_v[24 + edge][loc] = byv * byv;
+            }
+            __syncthreads();
+            if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
+                // the operands of the next eight terms are requested before the current eight are folded in (left to itself the compiler loads a
+                // pair of terms into the same registers every time and waits for the LDS before each pair)
+                double cp[8], cw[8], np[8], nw[8];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double2 p2 = pp2[u], w2 = pw2[u];
+                    cp[2 * u] = p2.x, cp[2 * u + 1] = p2.y;
+                    cw[2 * u] = w2.x, cw[2 * u + 1] = w2.y;
+                }
+#pragma unroll 1
+                for (int k = 0; k + 16 <= kRefineSeg; k += 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const double2 p2 = pp2[(k >> 1) + 4 + u], w2 = pw2[(k >> 1) + 4 + u];
+                        np[2 * u] = p2.x, np[2 * u + 1] = p2.y;
+                        nw[2 * u] = w2.x, nw[2 * u + 1] = w2.y;
+                    }
+                    asm volatile("" ::: "memory");  // the requests above stay above the additions below
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc += cp[u] * cw[u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        cp[u] = np[u];
+                        cw[u] = nw[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += cp[u] * cw[u];  // the last group, already in registers
+            }
+        }
+        if (tid < 48) accp[tid] = acc;
+        __syncthreads();
+        return true;
+    }
     const int half = tid >> 7, st = tid & (kRefineSamples - 1);
     double* const n0_quad = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples);
     for (int sbase = 0; sbase < max_ns; sbase += kRefineSamples) {
         const int s = sbase + st;
-        if constexpr (MODE == 2) {
-            // the samples' points from the search kernel's n0, with the search's own expressions (below): x0 = alpha ax + (1 - alpha) bx, best = x0 + n0 nx
-            // (a lane's eight samples are sm = tid and sm = 64 + tid of the four edges: two position parameters, not eight divisions)
-            const double alpha_lo = (15.0 + tid) / (kRefineSamples + 30), alpha_hi = (15.0 + (64 + tid)) / (kRefineSamples + 30);
-#pragma unroll
-            for (int u = 0; u < (4 * kRefineSamples) / 64; u++) {
-                const int idx = u * 64 + tid;
-                const int edge = idx >> 7, sm = idx & (kRefineSamples - 1);
-                const int a = edge, b = (edge + 1) & 3;
-                const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
-                const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
-                const double alpha = (u & 1) ? alpha_hi : alpha_lo;  // == (15.0 + sm) / (s_ns[edge] + 30): s_ns[edge] == kRefineSamples for every edge of this quad
-                const double x0 = alpha * ax + (1 - alpha) * bx;
-                const double y0 = alpha * ay + (1 - alpha) * by;
-                const double n0 = pre->n0[u];
-                const bool ok = n0 == n0;
-                s_bx[edge][sm] = ok ? x0 + n0 * nx : 0.0;
-                s_by[edge][sm] = ok ? y0 + n0 * ny : 0.0;
-                s_v[8 + edge][sm] = ok ? 1 - alpha : 0.0;
-                s_v[12 + edge][sm] = ok ? alpha : 0.0;
-            }
-        } else
 #pragma nounroll
         for (int epair = 0; epair < 2; epair++) {  // rolled on purpose: one copy of the search loops
             const int edge = 2 * epair + half;
@@ -787,45 +852,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             double acc = accp[tid];
             const int cntS = min(kRefineSamples, s_ns[edge] - sbase);
             int k = 0;
-            if constexpr (MODE == 2) {
-                // the sums kernel has registers to spare: the operands of the next eight terms are requested before the current eight
-                // are folded in (left to itself the compiler loads a pair of terms into the same registers every time and waits for the
-                // LDS before each pair: 64 exposed round trips per sum)
-                // (measured and not kept, round 4: lanes whose factor is the constant 1 -- 24 of the 48 lanes' B, 8 lanes' A -- sitting out that
-                // ds_read_b128: the exec-masked reads cost more than the bank cycles they save, edge_refine 5.03 -> 5.54 ms per 4096 frames)
-                double ca[8], cb[8], cw[8], na[8], nb[8], nw[8];
-                const double2 *pa2 = reinterpret_cast<const double2*>(pa), *pb2 = reinterpret_cast<const double2*>(pb), *pw2 = reinterpret_cast<const double2*>(pw);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const double2 a = pa2[u], b = pb2[u], w = pw2[u];
-                    ca[2 * u] = a.x, ca[2 * u + 1] = a.y;
-                    cb[2 * u] = b.x, cb[2 * u + 1] = b.y;
-                    cw[2 * u] = w.x, cw[2 * u + 1] = w.y;
-                }
-                for (; k + 16 <= cntS; k += 8) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const double2 a = pa2[(k >> 1) + 4 + u], b = pb2[(k >> 1) + 4 + u], w = pw2[(k >> 1) + 4 + u];
-                        na[2 * u] = a.x, na[2 * u + 1] = a.y;
-                        nb[2 * u] = b.x, nb[2 * u + 1] = b.y;
-                        nw[2 * u] = w.x, nw[2 * u + 1] = w.y;
-                    }
-                    asm volatile("" ::: "memory");  // the requests above stay above the additions below
-#pragma unroll
-                    for (int u = 0; u < 8; u++) acc += (ca[u] * cb[u]) * cw[u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        ca[u] = na[u];
-                        cb[u] = nb[u];
-                        cw[u] = nw[u];
-                    }
-                }
-                if (k + 8 <= cntS) {  // the group already in registers
-#pragma unroll
-                    for (int u = 0; u < 8; u++) acc += (ca[u] * cb[u]) * cw[u];
-                    k += 8;
-                }
-            } else {
+            {
                 for (; k + 16 <= cntS; k += 16) {
 #pragma unroll
                     for (int u = 0; u < 16; u++) acc += (pa[k + u] * pb[k + u]) * pw[k + u];
@@ -836,7 +863,6 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
         }
         __syncthreads();
     }
-    if constexpr (MODE == 2) return true;
     if (tid < 8) {  // line of (edge, pass)
         const int edge = tid >> 1, pass = tid & 1;
         refine_line(s_acc + edge * 12 + pass * 6, s_acc + edge * 12 + pass * 6);
@@ -847,7 +873,10 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
 }
 
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 64 : kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
+#ifndef CTAG_REFINE_SUMS_WAVES
+#define CTAG_REFINE_SUMS_WAVES 3  // three waves per SIMD (168 registers, 4 spilled); 1: 194 registers, two waves; 4: 128 registers, 32 spilled -- 4.78 / 4.85 / 5.15 ms edge_refine per 4096 frames
+#endif
+__global__ __launch_bounds__(MODE == 2 ? 64 : kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : (MODE == 2 ? CTAG_REFINE_SUMS_WAVES : 1), MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
 void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, int per_frame) {
     // per_frame > 0: a 1-D grid of per_frame blocks per frame in which blocks b and b + 8 -- one XCD -- belong to the same frame: the
     // boxes of a frame's quads overlap, and on one XCD the shared pixels come out of its L2 instead of HBM
