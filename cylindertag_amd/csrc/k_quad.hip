@@ -290,7 +290,10 @@ constexpr int kPackWords = CTAG_PACK_WORDS;  // LDS words shared by the up to 8 
 // SIMD), so for frames of 1080p class -- boundaries of ~150 points, a pack of 5 components in 10 KB -- the small configuration
 // runs 4 waves per SIMD (128 VGPRs, 61 of them spilled to scratch: still 6.8 -> 6.2 ms per 4096 frames); 4K frames have
 // components four times the size and keep the large one (same-box A/B: 8.4 vs 7.9 ms per 1024 frames with the small one).
-constexpr int kPackWordsSmall = 2560, kPackWavesSmall = 4;
+#ifndef CTAG_PACK_WAVES_P2
+#define CTAG_PACK_WAVES_P2 4
+#endif
+constexpr int kPackWordsSmall = 2560, kPackWavesSmall = 4, kPackWavesSmallP2 = CTAG_PACK_WAVES_P2;  // (the second kernel's own waves per SIMD: see launch_quads)
 constexpr int kSG = 8;
 constexpr int kUnwind = 8;  // stack frames the whole-wave build tests at once when it unwinds (<= 8: 8 lanes each)
 constexpr int kWaveWords = 8192;      // LDS words of the common whole-wave build (32 KB: five components per CU)
@@ -2455,7 +2458,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
             hipLaunchKernelGGL((k_quad_edges_packed<64, kScanWords, CTAG_SCAN_WAVES, false, true, 3>), dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (small_cfg) {                                                                                                                                 \
                 hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 1, true>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
-                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmallP2, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             } else {                                                                                                                                         \
                 hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF, CTAG_PACK_SPLIT_LARGE ? 1 : 0, true>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
                 if (CTAG_PACK_SPLIT_LARGE)                                                                                                                   \
@@ -2465,7 +2468,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         {                                                                                                                                                    \
             hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, CTAG_PACK_SPLIT ? 1 : 0>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (CTAG_PACK_SPLIT)                                                                                                                             \
-                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+                hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmallP2, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
         } else {                                                                                                                                             \
             hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWords, CTAG_PACK_WAVES, false, REF, CTAG_PACK_SPLIT_LARGE ? 1 : 0>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (CTAG_PACK_SPLIT_LARGE)                                                                                                                       \
