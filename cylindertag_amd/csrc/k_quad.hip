@@ -523,6 +523,68 @@ template <int D>
 __device__ __forceinline__ float dpp_shr(float v) {
     return __int_as_float(dpp_shr<D>(__float_as_int(v)));
 }
+// All-reduce over a sub-group of 8 lanes or over the wave, without the LDS crossbar: lane ^ 1 and lane ^ 2 by DPP quad permutes, the other quad of
+// the 8 lanes by row_half_mirror (lane i <- 7 - i), the other half of a row of 16 by row_mirror, and the wave's four rows by four v_readlane.  The
+// operations are exact (integer sums) or a total order (best distance, ties by index), so the order of combination does not matter.  (A
+// __shfl_xor is a ds_bpermute_b32: address arithmetic, the instruction and ~100 cycles before the value can be used -- per step, and a wave's
+// reduction has six; the split loop of the RDP runs one per round.)
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(dpp_mov<CTRL>(__float_as_int(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ long long dpp_mov(long long v) {
+    const unsigned lo = (unsigned)dpp_mov<CTRL>((int)(unsigned)((unsigned long long)v & 0xffffffffull)), hi = (unsigned)dpp_mov<CTRL>((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ long long readlane_ll(long long v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v & 0xffffffffull), l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+    return (long long)((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRowMirror = 0x140;
+template <int SG, class T>
+__device__ __forceinline__ T sg_sum(T v) {  // T: int, long long
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppHalfMirror>(v);
+    if constexpr (SG == 64) {
+        v += dpp_mov<kDppRowMirror>(v);
+        if constexpr (sizeof(T) == 8) v = (T)(readlane_ll((long long)v, 0) + readlane_ll((long long)v, 16) + readlane_ll((long long)v, 32) + readlane_ll((long long)v, 48));
+        else v = (T)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+    }
+    return v;
+}
+// the best (d, i) pair of the sub-group under `better(od, oi, d, i)` ("the other pair beats mine"): every lane ends with the same pair
+template <int SG, class Better>
+__device__ __forceinline__ void sg_best(float& bd, int& bi, Better better) {
+    auto step = [&](float od, int oi) {
+        if (better(od, oi, bd, bi)) {
+            bd = od;
+            bi = oi;
+        }
+    };
+    step(dpp_mov<kDppXor1>(bd), dpp_mov<kDppXor1>(bi));
+    step(dpp_mov<kDppXor2>(bd), dpp_mov<kDppXor2>(bi));
+    step(dpp_mov<kDppHalfMirror>(bd), dpp_mov<kDppHalfMirror>(bi));
+    if constexpr (SG == 64) {
+        step(dpp_mov<kDppRowMirror>(bd), dpp_mov<kDppRowMirror>(bi));
+        float rd[4];
+        int ri[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            rd[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), 16 * r));
+            ri[r] = __builtin_amdgcn_readlane(bi, 16 * r);
+        }
+        bd = rd[0];
+        bi = ri[0];
+#pragma unroll
+        for (int r = 1; r < 4; r++) step(rd[r], ri[r]);
+    }
+}
 // RED / rl: lanes (and this lane's index among them) that add up the moments of the initial span.  The whole-wave build speculates over its first
 // EIGHT lanes only (SG = 8, RED = 64; the other lanes repeat them): an edge rarely grows by more than a few points, and a 64-step round paid six
 // prefix-scan steps, integer divisions for the wrapped indices and a line estimate per lane for steps that were thrown away.
@@ -542,14 +604,11 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
         Syy += y * y;
         Sxy += x * y;
     }
-#pragma unroll
-    for (int d = RED / 2; d >= 1; d >>= 1) {
-        Sx += __shfl_xor(Sx, d);
-        Sy += __shfl_xor(Sy, d);
-        Sxx += __shfl_xor(Sxx, d);
-        Syy += __shfl_xor(Syy, d);
-        Sxy += __shfl_xor(Sxy, d);
-    }
+    Sx = sg_sum<RED>(Sx);
+    Sy = sg_sum<RED>(Sy);
+    Sxx = sg_sum<RED>(Sxx);
+    Syy = sg_sum<RED>(Syy);
+    Sxy = sg_sum<RED>(Sxy);
     int m = end - init + 1;
     ALine lineA = approx_line(Sx, Sy, Sxx, Syy, Sxy, m, k2lim);  // of the committed prefix
     bool fl = false, fr = false;
@@ -1403,8 +1462,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 if (xr != xl && (tr & 0xffffu) != ky && (tr >> 16) != ky) ntotal++;
             }
         }
-#pragma unroll
-        for (int d = SG / 2; d >= 1; d >>= 1) ntotal += __shfl_xor(ntotal, d);
+        ntotal = sg_sum<SG>(ntotal);
         stamp(0);
         // ---- P2: ordered traversal (corner_detector.cpp:235-247, :407-418): lanes 0..7 of the sub-group test the
         // 8 neighbours (N,NE,E,SE,S,SW,W,NW); the first hit at or after the frame's resume index wins (B7)
@@ -1571,11 +1629,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 sx += (unsigned)ux(bufA[k]);
                 sy += (unsigned)uy(bufA[k]);
             }
-#pragma unroll
-            for (int d = SG / 2; d >= 1; d >>= 1) {
-                sx += __shfl_xor(sx, d);
-                sy += __shfl_xor(sy, d);
-            }
+            sx = (unsigned long long)sg_sum<SG>((long long)sx);
+            sy = (unsigned long long)sg_sum<SG>((long long)sy);
             acx = (float)(1.0 * (long long)sx / (double)(unsigned long long)n);
             acy = (float)(1.0 * (long long)sy / (double)(unsigned long long)n);
             float bd = 3.0e38f;
@@ -1588,15 +1643,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     bi = k;
                 }
             }
-#pragma unroll
-            for (int d = SG / 2; d >= 1; d >>= 1) {
-                const float od = __shfl_xor(bd, d);
-                const int oi = __shfl_xor(bi, d);
-                if (od < bd || (od == bd && oi < bi)) {
-                    bd = od;
-                    bi = oi;
-                }
-            }
+            sg_best<SG>(bd, bi, [](float od, int oi, float d, int i) { return od < d || (od == d && oi < i); });  // the nearest, ties: the first
             for (int k = sl; k < n; k += SG) {
                 int src = k + bi;
                 if (src >= n) src -= n;
@@ -1704,15 +1751,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         bi = rel;
                     }
                 }
-#pragma unroll
-                for (int d = SG / 2; d >= 1; d >>= 1) {
-                    const float od = __shfl_xor(bd, d);
-                    const int oi = __shfl_xor(bi, d);
-                    if (od > bd || (od == bd && oi > bi)) {
-                        bd = od;
-                        bi = oi;
-                    }
-                }
+                sg_best<SG>(bd, bi, [](float od, int oi, float d, int i) { return od > d || (od == d && oi > i); });  // the farthest, ties: the last
                 const int count = end - init - 1;
                 if (bd > k_thr_line && count > 1) {
                     end = bi;  // literal index into dist2line
