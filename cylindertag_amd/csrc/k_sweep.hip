@@ -571,12 +571,15 @@ constexpr int kCclThreads = 256;  // threads per 320x30 tile: the phases are sho
                                   // shorten every barrier-to-barrier critical path and fill the CU at the same LDS footprint
 __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int& total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // inclusive scan of the wave by DPP: shifts by 1, 2, 4, 8 inside the rows of 16 lanes (a lane without a source adds 0), then lane 15 of every even
+    // row into the odd row behind it and lane 31 into rows 2 and 3 -- six vector instructions instead of six ds_bpermute round trips
     int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int n = __shfl_up(inc, d);
-        if (lane >= d) inc += n;
-    }
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);   // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);   // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);   // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);   // row_shr:8
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     if (lane == 63) scratch[w] = inc;
     CCL_SYNC();
     int base = 0;
