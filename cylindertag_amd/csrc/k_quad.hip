@@ -1112,10 +1112,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
                     // row extents: first / last foreground column over the row's G lanes
                     unsigned lo = bits ? (unsigned)(xl0 + __ffs(bits) - 1) : 0xffffffffu, hi = bits ? (unsigned)(xl0 + 32 - __clz(bits)) : 0u;
-#pragma unroll
-                    for (int dd = 1; dd < G; dd <<= 1) {
-                        lo = min(lo, (unsigned)__shfl_xor((int)lo, dd));
-                        hi = max(hi, (unsigned)__shfl_xor((int)hi, dd));
+                    {   // over the row's G consecutive lanes (G >= 8): DPP permutes inside a row of 16 lanes, the crossbar only across rows
+                        auto mm = [&](int olo, int ohi) {
+                            lo = min(lo, (unsigned)olo);
+                            hi = max(hi, (unsigned)ohi);
+                        };
+                        mm(dpp_mov<kDppXor1>((int)lo), dpp_mov<kDppXor1>((int)hi));
+                        mm(dpp_mov<kDppXor2>((int)lo), dpp_mov<kDppXor2>((int)hi));
+                        mm(dpp_mov<kDppHalfMirror>((int)lo), dpp_mov<kDppHalfMirror>((int)hi));
+                        if constexpr (G >= 16) mm(dpp_mov<kDppRowMirror>((int)lo), dpp_mov<kDppRowMirror>((int)hi));
+                        if constexpr (G >= 32) mm(__shfl_xor((int)lo, 16), __shfl_xor((int)hi, 16));
                     }
                     if (cg == 0 && y < h) {
                         lef[y] = lo;

@@ -78,8 +78,9 @@ __device__ __forceinline__ Raw18 load_row(const uint8_t* __restrict__ rowp, int 
             r.w3 = w[3];
         }
     }
-    uint32_t left = __shfl_up(r.w3 >> 24, 1);
-    uint32_t right2 = __shfl_down(r.w0 & 0xffffu, 1);
+    // the neighbour lanes' edge pixels by DPP wave shifts (lane 0 / lane 63 get 0 and are replaced below), not by the LDS crossbar
+    uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(r.w3 >> 24), 0x138, 0xf, 0xf, false);       // wave_shr:1
+    uint32_t right2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(r.w0 & 0xffffu), 0x130, 0xf, 0xf, false);  // wave_shl:1
     if (active) {
         if (lane == 0) left = rowp[max(x0 - 1, 0)];
         if (lane == 63 || !full || x0 + 32 > cols) {
@@ -248,8 +249,8 @@ __device__ __forceinline__ Raw34 load_row_wide(const uint8_t* __restrict__ rowp,
         r.w[0] = a.x, r.w[1] = a.y, r.w[2] = a.z, r.w[3] = a.w;
         r.w[4] = b.x, r.w[5] = b.y, r.w[6] = b.z, r.w[7] = b.w;
     }
-    uint32_t left = __shfl_up(r.w[7] >> 24, 1);
-    uint32_t right2 = __shfl_down(r.w[0] & 0xffffu, 1);
+    uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(r.w[7] >> 24), 0x138, 0xf, 0xf, false);       // wave_shr:1
+    uint32_t right2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(r.w[0] & 0xffffu), 0x130, 0xf, 0xf, false);  // wave_shl:1
     if (active) {
         if (lane == 0) left = x0 > 0 ? (uint32_t)rowp[x0 - 1] : (r.w[0] & 0xffu);  // index clamp at the image border
         if (lane == 63 || x0 + 32 >= cols)
