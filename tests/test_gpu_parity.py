@@ -652,16 +652,20 @@ def test_full_size_batch_properties(detector, oracle, dictionary):
     # the only flag a clean frame may carry is CODE_OVERFLOW (a marker whose code position ran past code[20] is
     # dropped); flagged frames are compared with the oracle below
     assert (a["status"] == 0).all() and ((a["flags"] & ~np.uint32(4)) == 0).all()
-    exact = 0
+    exact, inexact = 0, []
     for f in range(n):
         truth = tk.synth_truth(state, f)
         planted = sorted(int(x) for x in truth["dict_row"][:truth["n_markers"]])
         found = sorted(int(x) for x in a[f]["markers"]["marker_id"][:a[f]["n_markers"]])
         exact += planted == found
+        if planted != found:
+            inexact.append(f)
         assert set(found) <= set(planted), f  # never a wrong id
-    assert exact >= int(0.9 * n)  # cylinder-compressed end columns are occasionally too narrow to decode
+    # a planted marker that does not come out (cylinder-compressed end columns are occasionally too narrow to decode) is the ALGORITHM's miss, not
+    # this implementation's: every such frame must be the oracle's record byte for byte, like the sampled ones
+    assert exact >= int(0.9 * n)
     flagged = [int(f) for f in np.nonzero(a["flags"])[0][:4]]
-    for f in sorted(set(list(range(0, n, 16)) + [17, 255, 511] + flagged)):
+    for f in sorted(set(list(range(0, n, 16)) + [17, 255, 511] + flagged + inexact)):
         assert_same_record(a[f], oracle.detect_fast(frames[f].cpu().numpy(), state, fs), "synthetic frame %d" % f)
 
 
