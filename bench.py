@@ -3,7 +3,8 @@
 a synthetic batch of 1920x1080 random-stripe frames, resident in HBM, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or plainly as
+    above -- bench.py then starts that launcher itself as a child process, before anything touches a GPU: launch_ranks)
 
 A "step" is one pass of the whole detect() path (resize -> threshold -> label -> quads -> features -> sub-pixel
 refine -> decode) over the job's batch of frames.  Frames are independent, so with N GPUs every rank owns a contiguous
@@ -469,12 +470,48 @@ def latency_side(det, state, fs, calls=200):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N bench.py <the same arguments>`, one process per GPU -- as a CHILD of this process, which has not imported
+    torch and never touches a GPU (a process that has initialised one must not exec another program on this pool).  Rank 0's JSON
+    line goes to the inherited stdout; the launcher's exit code (non-zero as soon as one rank fails, and the launcher then ends the
+    other ranks) is this process's."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)  # its own process group: a signal to us ends exactly our ranks
+    def forward(sig, _frame):
+        try:
+            os.killpg(child.pid, sig)
+        except ProcessLookupError:
+            pass
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, forward)
+    rc = child.wait()
+    try:
+        os.killpg(child.pid, signal.SIGKILL)  # ranks the launcher left behind (it does not, normally)
+    except (ProcessLookupError, PermissionError):
+        pass
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     global ROWS, COLS, ALGO_BYTES_PER_FRAME
     args = parse_args()
     COLS, ROWS = (int(v) for v in args.size.lower().split("x"))
     ALGO_BYTES_PER_FRAME = 2 * ROWS * COLS
     import hashlib
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)  # before torch is imported: this process never touches a GPU
     import torch
     import cylindertag_amd as ca
     import testkit as tk
@@ -485,9 +522,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d inside a job of WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the detection path has no CPU fallback")
     dev_index = local_rank % max(1, torch.cuda.device_count())  # identity on a node with one GPU per rank
@@ -622,6 +657,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if os.environ.get("CTAG_BENCH_FAULT") == "rank1_exit" and rank == 1:  # test hook (tests/test_bench_gpu.py): a rank that dies mid-job
+        os._exit(17)
     # The timed steps run as the library runs any device-memory batch: every chunk as two halves on two internal streams
     # (CTAG_OPT_STREAMS, default 2), no events.  Per-kernel device time comes from the SAME number of extra steps behind the timed
     # region with CTAG_OPT_TIMING on -- HIP events recorded by the library on ITS stream around every kernel (torch.cuda.Event would

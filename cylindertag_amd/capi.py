@@ -31,7 +31,7 @@ POSE_EXPORTS = ["ctag_model_load", "ctag_model_create", "ctag_model_free", "ctag
 # ... and include/ctag_gather.h
 GATHER_EXPORTS = ["ctag_shard_range", "ctag_packed_capacity", "ctag_pack_results", "ctag_unpack_results", "ctag_comm_unique_id",
                   "ctag_comm_init", "ctag_comm_attach", "ctag_comm_destroy", "ctag_comm_native", "ctag_comm_last_error", "ctag_gather_begin",
-                  "ctag_gather_end", "ctag_gather_wait", "ctag_gather", "ctag_gather_last_bytes"]
+                  "ctag_gather_end", "ctag_gather_wait", "ctag_gather", "ctag_gather_set_timeout", "ctag_gather_last_bytes"]
 EXPORTS = EXPORTS + POSE_EXPORTS + GATHER_EXPORTS
 COMM_ID_BYTES = 128
 
@@ -57,6 +57,7 @@ def default_params():
 
 COUNTER_NAMES = ["components", "candidates", "quads", "features", "markers"]
 PENDING = -5  # CTAG_PENDING
+ERR_ARG, ERR_HIP, ERR_LIMIT, ERR_UNSUPPORTED = -1, -2, -3, -4  # include/ctag_types.h
 
 
 class CountersC(C.Structure):  # ctag_counters (include/ctag_types.h)
@@ -200,6 +201,8 @@ def load_library():
     L.ctag_gather.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.ctag_gather_last_bytes.restype = C.c_int
     L.ctag_gather_last_bytes.argtypes = [vp, u64p, u64p]
+    L.ctag_gather_set_timeout.restype = C.c_int
+    L.ctag_gather_set_timeout.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -507,6 +510,10 @@ class Detector:
 
     def gather(self, local_ptr, n_local, n_total, out_ptr):
         self._gcheck(self.L.ctag_gather(self.h, local_ptr, n_local, n_total, out_ptr), "ctag_gather")
+
+    def gather_set_timeout(self, timeout_ms):
+        """Deadline of the gather's host waits (ms; 0 none; < 0 the default: CTAG_GATHER_TIMEOUT_MS, else 60 s)."""
+        self._gcheck(self.L.ctag_gather_set_timeout(self.h, int(timeout_ms)), "ctag_gather_set_timeout")
 
     def gather_last_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

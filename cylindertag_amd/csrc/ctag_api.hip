@@ -789,15 +789,24 @@ static int finish_pending(ctag_handle* h) {
     std::vector<PendingRec> recs((size_t)take);
     HIP_TRY(hipMemcpy(recs.data(), h->d_pending, sizeof(PendingRec) * (size_t)take, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(h->d_pending_count, 0, 4));
+    // "the last chunk" (ctag_get_counters, the parity probes) stays the caller's chunk, not the one-frame passes below (round-4 ADVICE)
+    const Workspace* const keep_ws = h->last_ws;
+    const ctag_frame_result* const keep_out = h->last_out;
+    const int keep_frames = h->last_chunk_frames;
+    int rc = CTAG_OK;
     for (const PendingRec& r : recs) {
-        const int rc = rerun_frame(h, r.src, r.ch, r.rows, r.cols, (ptrdiff_t)r.row_stride, r.tw, r.subpix, r.dist, r.out);
-        if (rc != CTAG_OK) return rc;
+        rc = rerun_frame(h, r.src, r.ch, r.rows, r.cols, (ptrdiff_t)r.row_stride, r.tw, r.subpix, r.dist, r.out);
+        if (rc != CTAG_OK) break;
     }
+    h->last_ws = keep_ws;
+    h->last_out = keep_out;
+    h->last_chunk_frames = keep_frames;
+    if (rc != CTAG_OK) return rc;
     if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (count > h->pending_cap) {  // more than the list holds between two synchronisation points: the surplus keeps CTAG_PENDING
-        std::snprintf(h->last_error, sizeof(h->last_error), "%d frames waited for the any-frame pass, the list holds %d: synchronise more often", count,
-                      h->pending_cap);
+    if (count > h->pending_cap) {  // more than the list holds between two synchronisation points: k_markers gave the surplus the terminal status CTAG_ERR_LIMIT
+        std::snprintf(h->last_error, sizeof(h->last_error), "%d frames waited for the any-frame pass, the list holds %d: the surplus carries CTAG_ERR_LIMIT; synchronise more often",
+                      count, h->pending_cap);
         return CTAG_ERR_LIMIT;
     }
     return CTAG_OK;

@@ -10,7 +10,9 @@
 #include <rccl/rccl.h>  // types only; every entry point is resolved at run time
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -36,6 +38,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional: a bounded wait that expires aborts the communicator
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional: polled while the host waits
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     char err[256] = {0};
@@ -61,6 +65,8 @@ Rccl* rccl_bind() {
     R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.lib, "ncclCommInitRank"));
     R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));
     R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.lib, "ncclAllGather"));
+    R.CommAbort = reinterpret_cast<decltype(R.CommAbort)>(dlsym(R.lib, "ncclCommAbort"));
+    R.CommGetAsyncError = reinterpret_cast<decltype(R.CommGetAsyncError)>(dlsym(R.lib, "ncclCommGetAsyncError"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
     if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) {
         std::snprintf(R.err, sizeof(R.err), "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather");
@@ -92,17 +98,19 @@ struct GatherState {
     uint64_t pend_gen = 0;
     bool in_flight = false;
     uint64_t last_local = 0, last_padded = 0;
+    int timeout_ms = -1;             // deadline of every host wait of the exchange; -1: CTAG_GATHER_TIMEOUT_MS, else 60 s; 0: none
     char err[256] = {0};
 };
 
-void order_unref(ncclComm_t c, bool wait_for_last);  // below
+bool order_unref(ncclComm_t c, bool wait_for_last);  // below
+bool order_dead(ncclComm_t c);
+void release_comm(GatherState* g);
 
 void gather_state_free(void* p) {
     GatherState* g = static_cast<GatherState*>(p);
     (void)hipSetDevice(g->device);
+    release_comm(g);
     if (g->gstream) (void)hipStreamSynchronize(g->gstream);
-    if (g->comm) order_unref(g->comm, g->own_comm);
-    if (g->comm && g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
     if (g->d_packed) (void)hipFree(g->d_packed);
     if (g->d_gathered) (void)hipFree(g->d_gathered);
     if (g->d_off) (void)hipFree(g->d_off);
@@ -139,20 +147,29 @@ GatherState* gather_state(ctag_handle* h) {
 // Collectives of ONE communicator issued from several streams (two handles sharing it: ctag_comm_attach(b, ctag_comm_native(a), ..))
 // are ordered here explicitly, not left to the library: every collective waits for the event recorded behind the previous
 // collective of the same communicator, whatever stream that one went to.  Per process; a communicator has one entry, counted by the
-// handles that use it (its owner + the attached ones).  The lock is held from the wait to the record: two threads driving two handles
-// on one communicator cannot both wait for the same predecessor and then issue in either order (round-3 ADVICE).
+// handles that use it (its owner + the attached ones).  The ENTRY's lock is held from the wait to the record: two threads driving two
+// handles on one communicator cannot both wait for the same predecessor and then issue in either order (round-3 ADVICE); the table's
+// lock covers look-ups only, so an RCCL call that blocks on its peers stalls the users of that communicator and nobody else (round-4
+// ADVICE).  `dead`: a bounded wait expired (or RCCL reported an asynchronous error) and the communicator was aborted -- by whichever
+// handle noticed; every handle that shares it then fails its calls instead of enqueuing behind a collective that will never run.
 struct CommOrder {
-    ncclComm_t comm;
-    hipEvent_t last;   // created when the entry is taken (on the device that is current then: a communicator lives on one device), destroyed with it
-    bool has;
-    int refs;
+    ncclComm_t comm = nullptr;
+    hipEvent_t last = nullptr;   // created when the entry is taken (on the device that is current then: a communicator lives on one device), destroyed with it
+    bool has = false;
+    bool dead = false;
+    int refs = 0;
+    std::mutex mu;     // wait -> issue -> record of one collective; also the abort
 };
 CommOrder g_order[16];
-std::mutex g_order_mu;
+std::mutex g_order_mu;  // the table: comm / refs of every entry
 CommOrder* order_find(ncclComm_t c) {  // caller holds g_order_mu
     for (CommOrder& o : g_order)
         if (o.comm == c) return &o;
     return nullptr;
+}
+CommOrder* order_lookup(ncclComm_t c) {  // an entry stays put while a handle holds a reference to it
+    std::lock_guard<std::mutex> lk(g_order_mu);
+    return order_find(c);
 }
 // a handle starts / stops using communicator c; false: the table is full (16 communicators per process)
 bool order_ref(ncclComm_t c) {
@@ -166,27 +183,39 @@ bool order_ref(ncclComm_t c) {
             if (hipEventCreateWithFlags(&o.last, hipEventDisableTiming) != hipSuccess) return false;
             o.comm = c;
             o.has = false;
+            o.dead = false;
             o.refs = 1;
             return true;
         }
     return false;
 }
-void order_unref(ncclComm_t c, bool wait_for_last) {
-    std::lock_guard<std::mutex> lk(g_order_mu);
-    CommOrder* o = order_find(c);
-    if (!o) return;
-    if (wait_for_last && o->has) (void)hipEventSynchronize(o->last);  // the owner is about to destroy the communicator: nothing issued on it may still run
-    if (--o->refs <= 0) {
-        if (o->last) (void)hipEventDestroy(o->last);
-        *o = CommOrder{};
-    }
+bool order_dead(ncclComm_t c) {
+    CommOrder* o = order_lookup(c);
+    if (!o) return false;
+    std::lock_guard<std::mutex> lk(o->mu);
+    return o->dead;
 }
-// one collective on `s`, ordered behind the previous one of this communicator and published for the next, under ONE lock
+// ncclCommAbort, once per communicator, whichever handle asks first: the collectives in flight end (their kernels leave), the
+// communicator's memory is released by RCCL; nothing may be issued on it afterwards (dead) and its owner must not destroy it again
+void order_abort(ncclComm_t c) {
+    CommOrder* o = order_lookup(c);
+    if (!o) return;
+    std::lock_guard<std::mutex> lk(o->mu);
+    if (o->dead) return;
+    o->dead = true;
+    if (rccl()->CommAbort) (void)rccl()->CommAbort(c);
+}
+bool order_unref(ncclComm_t c, bool wait_for_last);  // below: needs the bounded wait
+// one collective on `s`, ordered behind the previous one of this communicator and published for the next, under the entry's lock
 template <class F>
 hipError_t ordered_collective(ncclComm_t c, hipStream_t s, F issue, ncclResult_t* nr) {
-    std::lock_guard<std::mutex> lk(g_order_mu);
-    CommOrder* o = order_find(c);
+    CommOrder* o = order_lookup(c);
     if (!o) return hipErrorInvalidValue;  // ctag_comm_init / _attach registers every communicator
+    std::lock_guard<std::mutex> lk(o->mu);
+    if (o->dead) {
+        *nr = ncclInvalidUsage;  // aborted earlier
+        return hipSuccess;
+    }
     if (o->has) {
         const hipError_t e = hipStreamWaitEvent(s, o->last, 0);
         if (e != hipSuccess) return e;
@@ -195,6 +224,79 @@ hipError_t ordered_collective(ncclComm_t c, hipStream_t s, F issue, ncclResult_t
     if (*nr != ncclSuccess) return hipSuccess;
     o->has = true;
     return hipEventRecord(o->last, s);
+}
+
+// ---- bounded host waits ---------------------------------------------------------------------------------------
+// Every host wait of the exchange polls instead of blocking: a peer that died or never reaches its collective would otherwise
+// hold this rank in hipEventSynchronize / hipStreamSynchronize for ever.  While it polls it asks RCCL for
+// asynchronous errors of the communicator (a peer's process that ends closes its sockets / IPC handles: RCCL notices); at the
+// deadline -- CTAG_GATHER_TIMEOUT_MS, default 60 s, 0 = none; ctag_gather_set_timeout overrides it per handle -- the
+// communicator is aborted, the call returns CTAG_ERR_HIP with the reason in ctag_comm_last_error and the caller exits.
+int env_timeout_ms() {
+    static const int v = [] {
+        const char* e = std::getenv("CTAG_GATHER_TIMEOUT_MS");
+        if (!e || !*e) return 60000;
+        const long t = std::strtol(e, nullptr, 10);
+        return t < 0 ? 0 : (t > 86400000 ? 86400000 : (int)t);
+    }();
+    return v;
+}
+enum WaitResult { kWaitOk = 0, kWaitHipError, kWaitTimeout, kWaitCommError };
+// polls `ready()` (hipEventQuery / hipStreamQuery: hipSuccess, hipErrorNotReady or a failure) until it succeeds, the communicator
+// reports an asynchronous error, or the deadline passes; *detail receives the hip / RCCL code
+template <class Q>
+WaitResult poll_until(Q ready, ncclComm_t comm, int timeout_ms, int* detail) {
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t0 = clock::now();
+    Rccl* R = rccl();
+    for (unsigned spin = 0;; spin++) {
+        const hipError_t e = ready();
+        if (e == hipSuccess) return kWaitOk;
+        if (e != hipErrorNotReady) {
+            *detail = (int)e;
+            return kWaitHipError;
+        }
+        (void)hipGetLastError();  // hipErrorNotReady is sticky in the last-error slot
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
+        if (comm && R->CommGetAsyncError && (spin & 63) == 63 && !order_dead(comm)) {
+            ncclResult_t ar = ncclSuccess;
+            if (R->CommGetAsyncError(comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                *detail = (int)ar;
+                return kWaitCommError;
+            }
+        }
+        if (timeout_ms > 0 && us > (long long)timeout_ms * 1000) return kWaitTimeout;
+        if (us > 200) std::this_thread::sleep_for(std::chrono::microseconds(us > 20000 ? 200 : 20));  // the sizes arrive within microseconds normally
+    }
+}
+
+// returns whether the communicator is dead (aborted): its owner must not destroy it a second time
+bool order_unref(ncclComm_t c, bool wait_for_last) {
+    CommOrder* o = order_lookup(c);
+    if (!o) return false;
+    bool has, dead;
+    {
+        std::lock_guard<std::mutex> lk(o->mu);
+        has = o->has;
+        dead = o->dead;
+    }
+    if (wait_for_last && has && !dead) {  // the owner is about to destroy the communicator: nothing issued on it may still run
+        int detail = 0;
+        hipEvent_t ev = o->last;
+        if (poll_until([&] { return hipEventQuery(ev); }, c, env_timeout_ms(), &detail) != kWaitOk) {
+            order_abort(c);
+            dead = true;
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_order_mu);
+    if (--o->refs <= 0) {
+        if (o->last) (void)hipEventDestroy(o->last);
+        o->comm = nullptr;
+        o->last = nullptr;
+        o->has = o->dead = false;
+        o->refs = 0;
+    }
+    return dead;
 }
 
 #define G_HIP(expr)                                                                              \
@@ -213,6 +315,45 @@ hipError_t ordered_collective(ncclComm_t c, hipStream_t s, F issue, ncclResult_t
             return CTAG_ERR_HIP;                                                                                        \
         }                                                                                                               \
     } while (0)
+
+int timeout_of(const GatherState* g) { return g->comm ? (g->timeout_ms >= 0 ? g->timeout_ms : env_timeout_ms()) : 0; }  // no communicator, no peer to wait for
+// the bounded form of hipEventSynchronize / hipStreamSynchronize for the waits of the exchange (poll_until above)
+template <class Q>
+int bounded_wait(GatherState* g, Q ready, const char* what) {
+    int detail = 0;
+    const int ms = timeout_of(g);
+    const WaitResult w = poll_until(ready, g->comm, ms, &detail);
+    if (w == kWaitOk) return CTAG_OK;
+    if (w == kWaitHipError) {
+        std::snprintf(g->err, sizeof(g->err), "%s: %s", what, hipGetErrorString((hipError_t)detail));
+        return CTAG_ERR_HIP;
+    }
+    Rccl* R = rccl();
+    if (w == kWaitTimeout)
+        std::snprintf(g->err, sizeof(g->err), "%s: not complete after %d ms (CTAG_GATHER_TIMEOUT_MS / ctag_gather_set_timeout): a peer is late or gone; communicator aborted", what, ms);
+    else
+        std::snprintf(g->err, sizeof(g->err), "%s: RCCL reports an asynchronous error (%s); communicator aborted", what,
+                      R->GetErrorString ? R->GetErrorString((ncclResult_t)detail) : "?");
+    if (g->comm) order_abort(g->comm);
+    g->in_flight = false;
+    return CTAG_ERR_HIP;
+}
+int bounded_event(GatherState* g, hipEvent_t ev, const char* what) {
+    return bounded_wait(g, [&] { return hipEventQuery(ev); }, what);
+}
+int bounded_stream(GatherState* g, hipStream_t s, const char* what) {
+    return bounded_wait(g, [&] { return hipStreamQuery(s); }, what);
+}
+// the handle lets go of its communicator: what it enqueued must have run (bounded: a dead peer ends in an abort, not in a hang); the
+// owner then waits for the communicator's last collective, whichever handle issued it, and destroys it -- unless it was aborted
+void release_comm(GatherState* g) {
+    if (!g->comm) return;
+    if (g->gstream) (void)bounded_stream(g, g->gstream, "gather stream at communicator release");
+    const bool dead = order_unref(g->comm, g->own_comm);
+    if (g->own_comm && !dead && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
+    g->comm = nullptr;
+    g->own_comm = false;
+}
 
 int grow(GatherState* g, unsigned char** p, size_t* cap, size_t need) {
     if (*cap >= need) return CTAG_OK;
@@ -471,15 +612,22 @@ int ctag_comm_destroy(ctag_handle* h) {
     g->err[0] = 0;
     if (g->comm) {
         (void)hipSetDevice(g->device);
-        (void)hipStreamSynchronize(g->gstream);
-        order_unref(g->comm, g->own_comm);  // the owner waits for the communicator's last collective, whichever handle issued it
-        if (g->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
+        release_comm(g);
     }
     g->comm = nullptr;
     g->own_comm = false;
     g->rank = 0;
     g->world = 1;
     g->in_flight = false;
+    return CTAG_OK;
+}
+
+int ctag_gather_set_timeout(ctag_handle* h, int timeout_ms) {
+    if (!h) return CTAG_ERR_ARG;
+    GatherState* g = gather_state(h);
+    if (!g) return CTAG_ERR_HIP;
+    g->err[0] = 0;
+    g->timeout_ms = timeout_ms < 0 ? -1 : timeout_ms;
     return CTAG_OK;
 }
 
@@ -564,6 +712,10 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
         std::snprintf(g->err, sizeof(g->err), "no communicator: call ctag_comm_init / ctag_comm_attach first");
         return CTAG_ERR_ARG;
     }
+    if (g->comm && order_dead(g->comm)) {
+        std::snprintf(g->err, sizeof(g->err), "the communicator was aborted by an earlier gather (deadline or RCCL error): nothing can be gathered through it");
+        return CTAG_ERR_HIP;
+    }
     G_HIP(hipSetDevice(g->device));
     // records of frames that wait for the any-frame pass (CTAG_PENDING) must be completed before they travel; whether there are any is
     // known only when the detection ahead has run, so the question rides with the sizes (k_tag_pending) and is answered in ctag_gather_end
@@ -609,7 +761,10 @@ int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
     g->in_flight = false;
     Rccl* R = rccl();
     G_HIP(hipSetDevice(g->device));
-    G_HIP(hipEventSynchronize(g->ev_sizes));  // the only host wait of the exchange: world x 8 bytes
+    {   // the only host wait of the exchange: world x 8 bytes -- bounded (a dead or late peer must not hold this rank for ever)
+        const int wr = bounded_event(g, g->ev_sizes, "all-gather of the packed sizes");
+        if (wr != CTAG_OK) return wr;
+    }
     {
         uint64_t pending_any = 0;
         for (int r = 0; r < g->world; r++) {
@@ -636,7 +791,8 @@ int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev) {
                 G_NCCL(nr);
             }
             G_HIP(hipMemcpyAsync(g->h_sizes, g->d_sizes, sizeof(uint64_t) * g->world, hipMemcpyDeviceToHost, g->gstream));
-            G_HIP(hipStreamSynchronize(g->gstream));
+            const int wr = bounded_stream(g, g->gstream, "second all-gather of the packed sizes");
+            if (wr != CTAG_OK) return wr;
             for (int r = 0; r < g->world; r++) g->h_sizes[r] &= kSizeMask;
         }
     }
@@ -673,8 +829,7 @@ int ctag_gather_wait(ctag_handle* h) {
     if (!g) return CTAG_ERR_HIP;
     g->err[0] = 0;
     G_HIP(hipSetDevice(g->device));
-    G_HIP(hipStreamSynchronize(g->gstream));
-    return CTAG_OK;
+    return bounded_stream(g, g->gstream, "payload all-gather + unpack");
 }
 
 int ctag_gather(ctag_handle* h, const ctag_frame_result* local_dev, int n_local, int n_total, ctag_frame_result* out_dev) {

@@ -1116,6 +1116,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_markers(MarkerPtrs P, int nframe
                         r.subpix = P.pend.subpix;
                         r.dist = P.pend.dist;
                         P.pend.list[at] = r;
+                    } else {
+                        st = CTAG_ERR_LIMIT;  // the list is full (65 536 frames between two synchronisation points): a terminal status, the flag says why
                     }
                 }
             }

@@ -1510,6 +1510,9 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     CCL_SYNC();  // also orders the S9 LDS atomics before the reads below
     const int base = misc_s[9];
     if (base < 0) {  // second pass only: the frame's pool is exhausted
+        // S11 has stored this tile's labels: the dirty bits must say so although the tile publishes nothing (the frame is rerun through the
+        // any-frame workspace) -- or the next frame in this workspace slot skips label blocks that still hold THIS frame's labels (round-4 ADVICE)
+        if (tid == 0 && misc_s[10] != was_dirty) *dirty_p = misc_s[10];
         hand_over();
         return;
     }

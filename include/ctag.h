@@ -79,7 +79,9 @@ void ctag_host_free(void* p);
  * its size can exhaust, and its record is the reference's like any other.  Host-memory calls (ctag_detect_u8 / _batch_u8 /
  * _bgr8) do that before they return.  Device-memory calls do it at the handle's next synchronisation point: ctag_sync(), a call
  * with CTAG_OPT_TIMING on, ctag_pose_batch_device, ctag_pack_results / ctag_gather_end; a caller that relies on stream ordering
- * alone sees such a frame's record with status CTAG_PENDING until then (the source frames must stay valid that long). */
+ * alone sees such a frame's record with status CTAG_PENDING until then (the source frames must stay valid that long).  The list of
+ * waiting frames holds 65 536 entries between two synchronisation points; a frame beyond that gets the terminal status CTAG_ERR_LIMIT
+ * with CTAG_FLAG_POOL_OVERFLOW set (and the synchronisation point returns CTAG_ERR_LIMIT): it is never left pending. */
 int ctag_detect_batch_device(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride,
                              ptrdiff_t frame_stride, int adaptive_thresh, int corner_subpix, int subpix_dist,
                              ctag_frame_result* out_dev);
@@ -142,8 +144,9 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value);
 #define CTAG_NUM_STAGES 14
 int ctag_get_timings(ctag_handle* h, float* ms, int capacity);
 const char* ctag_stage_name(int stage);
-/* Per-frame counts of the LAST chunk the handle processed (at most CTAG_OPT_MAX_CHUNK frames; one small kernel, waits for the
- * stream): sums and maxima of components / candidates / quads / features / markers -- the numbers behind the reference's two
+/* Per-frame counts of the LAST chunk the handle processed (at most CTAG_OPT_MAX_CHUNK frames -- with CTAG_OPT_STREAMS >= 2, the default, the
+ * last PIECE of that chunk: the part its last stream ran; frames completed through the any-frame workspace do not count as a chunk;
+ * one small kernel, waits for the stream): sums and maxima of components / candidates / quads / features / markers -- the numbers behind the reference's two
  * log lines (CylinderTag.cpp:88,94) -- and how many frames have needed the any-frame workspace so far. */
 int ctag_get_counters(ctag_handle* h, ctag_counters* out);
 const char* ctag_strerror(int status);

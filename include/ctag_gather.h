@@ -80,6 +80,15 @@ int ctag_gather_begin(ctag_handle* h, const ctag_frame_result* local_dev, int n_
 int ctag_gather_end(ctag_handle* h, ctag_frame_result* out_dev);
 int ctag_gather_wait(ctag_handle* h);
 int ctag_gather(ctag_handle* h, const ctag_frame_result* local_dev, int n_local, int n_total, ctag_frame_result* out_dev);
+/* Deadline of the exchange's host waits.  A peer that died, or never reaches its collective, must not hold the other ranks for
+ * ever: every host wait of the gather (_end's wait for the sizes, _wait, ctag_comm_destroy / ctag_destroy behind a collective in
+ * flight) polls with a deadline and asks RCCL for asynchronous errors of the communicator (ncclCommGetAsyncError) while it
+ * does.  At the deadline, or on such an error, the communicator is aborted (ncclCommAbort: the collectives in flight end), the call
+ * returns CTAG_ERR_HIP and ctag_comm_last_error says why; every handle that shares the communicator fails its later gather calls the
+ * same way and the process is expected to exit non-zero.  timeout_ms > 0: that many milliseconds; 0: no deadline; < 0: back to the
+ * default = the environment variable CTAG_GATHER_TIMEOUT_MS, else 60 000 ms.  Without a communicator (one rank) nothing is bounded:
+ * there is no peer to wait for. */
+int ctag_gather_set_timeout(ctag_handle* h, int timeout_ms);
 /* bytes this rank contributed / the padded per-rank width of the last payload all-gather (introspection for the bench) */
 int ctag_gather_last_bytes(ctag_handle* h, uint64_t* local_bytes, uint64_t* padded_bytes);
 

@@ -48,6 +48,11 @@ int ctag_math_probe(ctag_handle* h, int op, int n, const double* a, const double
 int ctag_testkit_unpack_gathered(ctag_handle* h, const void* gathered_dev, int n_total, int world, uint64_t width,
                                  ctag_frame_result* out_dev);
 
+/* Occupies the handle's stream (ctag_stream) with a kernel that spins for about `milliseconds` (<= 10 000): what a late peer looks
+ * like to the gather's bounded waits (include/ctag_gather.h: ctag_gather_set_timeout) -- work enqueued behind it, the gather stream
+ * included, does not complete until it ends.  Returns at once. */
+int ctag_testkit_stall_stream(ctag_handle* h, int milliseconds);
+
 /* ---- synthetic frames -------------------------------------------------------------
  * Frame f is a pure function of (seed + f): gray background with a ramp and noise plus `markers` planted
  * CylinderTag strips of the handle's dictionary.  The same code renders on the device and on the host. */

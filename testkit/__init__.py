@@ -22,7 +22,7 @@ DBG_HALF, DBG_LABELS, DBG_CANDIDATES, DBG_CAND_QUADS, DBG_FEATURES0, DBG_FEATURE
 SYNTH_SEED = 0x4354616753594E00  # "CTagSYN\0", SURVEY.md 8(d)
 
 # every symbol include/ctag_testkit.h declares (tests check the library exports all of them)
-EXPORTS = ["ctag_debug_fetch", "ctag_math_probe", "ctag_testkit_unpack_gathered", "ctag_synth_frames_device", "ctag_synth_frame_host",
+EXPORTS = ["ctag_debug_fetch", "ctag_math_probe", "ctag_testkit_unpack_gathered", "ctag_testkit_stall_stream", "ctag_synth_frames_device", "ctag_synth_frame_host",
            "ctag_synth_layout_truth", "ctag_synth3d_frames_device", "ctag_synth3d_frame_host", "ctag_synth3d_model"]
 
 
@@ -54,6 +54,8 @@ def load_library():
     L.ctag_math_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.ctag_testkit_unpack_gathered.restype = C.c_int
     L.ctag_testkit_unpack_gathered.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint64, vp]
+    L.ctag_testkit_stall_stream.restype = C.c_int
+    L.ctag_testkit_stall_stream.argtypes = [vp, C.c_int]
     L.ctag_synth_frames_device.restype = C.c_int
     L.ctag_synth_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t,
                                            C.c_uint64, C.c_int]
@@ -143,6 +145,12 @@ class Detector(ca.Detector):
                                                K[0, 0], K[1, 1], K[0, 2], K[1, 2])
         if st != 0:
             raise CtagError(st, "ctag_synth3d_frames_device")
+
+    def stall_stream(self, milliseconds):
+        """A kernel that spins for `milliseconds` on the handle's stream: a late peer, as the gather's bounded waits see one."""
+        st = self.T.ctag_testkit_stall_stream(self.h, int(milliseconds))
+        if st != 0:
+            raise CtagError(st, "ctag_testkit_stall_stream")
 
     def unpack_gathered(self, gathered_ptr, n_total, world, width, out_ptr):
         """ctag_gather_end's segment table + unpack kernels for a `world`-rank job on a caller-built gathered buffer."""

@@ -295,6 +295,16 @@ int ctag_testkit_unpack_gathered(ctag_handle* h, const void* gathered_dev, int n
     return gather_unpack_gathered(h, gathered_dev, n_total, world, width, out_dev);
 }
 
+__global__ void k_stall(long long ticks) {  // s_memrealtime counts at 100 MHz
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int ctag_testkit_stall_stream(ctag_handle* h, int milliseconds) {
+    if (!h || milliseconds < 0 || milliseconds > 10000) return CTAG_ERR_ARG;
+    hipLaunchKernelGGL(k_stall, dim3(1), dim3(1), 0, static_cast<hipStream_t>(ctag_stream(h)), (long long)milliseconds * 100000ll);
+    return hipGetLastError() == hipSuccess ? CTAG_OK : CTAG_ERR_HIP;
+}
+
 int ctag_synth_frames_device(ctag_handle* h, uint8_t* frames_dev, int first_frame, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
                              uint64_t seed, int markers_per_frame) {
     return synth_frames_device(h, frames_dev, first_frame, n, rows, cols, row_stride, frame_stride, seed, markers_per_frame, false, 1, 1, 0, 0);

@@ -70,3 +70,27 @@ def long_diagonal(rows=2160, cols=3840, width=7, level=200, ink=20):
         x = 40 + (y - 40) * (cols - 80 - width) // (rows - 80)
         img[y, x:x + width] = ink
     return img
+
+
+def tile_border_specks(base, tile_w=320, tile_h=30, ink=0, margin=4):
+    """Isolated dark specks -- one half-size pixel each, every other pixel -- along all four borders of every 320 x 30 label tile of the
+    half-size image, wherever `base` is bright: the second labelling pass publishes a component that touches its tile's border, so a
+    1080p frame asks for ~350 pool entries per tile, 54 tiles of them more than its component pool (13 824) holds.  The reference
+    labels such a frame like any other (every speck is a 1..2-pixel component below the area filter)."""
+    img = base.copy()
+    rows, cols = img.shape
+    hy, hx = np.mgrid[0:rows // 2, 0:cols // 2]
+    on_row = ((hy % tile_h == 0) | (hy % tile_h == tile_h - 1)) & (hx % 2 == 0)
+    on_col = ((hx % tile_w == 0) | (hx % tile_w == tile_w - 1)) & (hy % 2 == 0)
+    speck = on_row | on_col
+    bright = base >= 140
+    k = 2 * margin + 1
+    # a speck only where its whole neighbourhood is bright (keeps clear of the markers)
+    from numpy.lib.stride_tricks import sliding_window_view
+    pad = np.pad(bright, margin, mode="edge")
+    ok = sliding_window_view(pad, (k, k)).all(axis=(2, 3))
+    ok_half = ok[0::2, 0::2] & ok[1::2, 1::2]
+    speck &= ok_half[:rows // 2, :cols // 2]
+    full = np.repeat(np.repeat(speck, 2, axis=0), 2, axis=1)
+    img[:full.shape[0], :full.shape[1]][full] = ink
+    return img

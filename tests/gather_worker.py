@@ -34,6 +34,23 @@ def main():
     det.sync()
     want = full.cpu().numpy()
     comm = CommGather(det, dist)
+    if "--dead-peer" in sys.argv:
+        # rank 1 leaves without entering the collective (os._exit: no teardown, as a crashed process); rank 0's gather must come back
+        # with CTAG_ERR_HIP within CTAG_GATHER_TIMEOUT_MS instead of hanging, and the process exits non-zero
+        import time
+        dist.barrier()
+        if rank == 1:
+            os._exit(17)
+        lo, hi = shard_range(n_all, rank, world)
+        out = torch.zeros((n_all, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+        t0 = time.perf_counter()
+        try:
+            det.gather(full[lo:hi].contiguous().data_ptr(), hi - lo, n_all, out.data_ptr())
+        except Exception as e:  # noqa: BLE001
+            print("DEAD_PEER_DETECTED after %.1f s: %s" % (time.perf_counter() - t0, e), flush=True)
+            os._exit(3)
+        print("gather returned although rank 1 is gone", flush=True)
+        os._exit(0)
     comm2 = CommGather(det2, dist, share=comm)  # the second handle gathers through the first one's communicator
     for n_total in (37, 1, 0, 36):
         lo, hi = shard_range(n_total, rank, world)

@@ -38,12 +38,30 @@ def test_one_gpu_line_and_two_rank_hash():
     assert one["roofline"]["bound"] == "hbm" and 0.0 < one["roofline"]["frac"] < 1.0 and one["roofline"]["traffic_source"]
     assert one["cpu_baseline"]["kind"] == "port" and one["cpu_baseline"]["cores"] == 1 and one["cpu_baseline"]["value"] > 0
     assert set(one["issue_roofline"]["kernels"]) >= {"k_edge_refine", "k_welsch", "k_quad_edges_packed"}
+    # N = 2 the way the driver starts it: `python bench.py --gpus 2 ...`, no launcher around it -- bench.py starts torch.distributed.run
+    # itself as a child process before anything touches the GPU (launch_ranks) and hands back the launcher's exit code
     env = dict(os.environ, CTAG_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port())] + base[1:] + ["--gpus", "2", "--cpu-frames", "0"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    p = subprocess.run(base + ["--gpus", "2", "--cpu-frames", "0"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     two = _line(p.stdout)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["frames_per_gpu"] == 96 and two["frames_ok"] == 192
     assert two["results_sha256"] == one["results_sha256"]  # the gathered list equals the one-GPU list
     assert two["config"]["pipelining"].startswith("steps alternate between 2 handles")
+    # ... and under an explicit launcher (the other command shape of the contract)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + base[1:] + ["--gpus", "2", "--cpu-frames", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert _line(p.stdout)["results_sha256"] == one["results_sha256"]
+
+
+def test_a_rank_that_dies_ends_the_job_non_zero():
+    """A rank that fails must end the whole job with a non-zero exit code, promptly: rank 1 is made to leave after the warm-up
+    (CTAG_BENCH_FAULT=rank1_exit, a test hook), the launcher ends rank 0 and `python bench.py --gpus 2` returns non-zero."""
+    import time
+    env = dict(os.environ, CTAG_BENCH_BACKEND="gloo", CTAG_BENCH_FAULT="rank1_exit")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "64", "--cpu-frames", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and time.perf_counter() - t0 < 300
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]  # no line from a job that lost a rank

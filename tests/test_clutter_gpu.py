@@ -11,7 +11,7 @@ import torch
 import cylindertag_amd as ca
 import testkit as tk
 from cylindertag_amd import capi
-from clutter import blob_field, chevron_texture, long_diagonal
+from clutter import blob_field, chevron_texture, long_diagonal, tile_border_specks
 from test_gpu_parity import _stage_check, assert_same_record
 
 pytestmark = pytest.mark.gpu
@@ -113,6 +113,46 @@ def test_cluttered_frames_inside_batches(detector, oracle, dictionary):
     got3 = np.frombuffer(out3.cpu().numpy().tobytes(), ca.RESULT_DT)
     for k in range(3):
         assert_same_record(got3[k], want[16 + k], "BGR device batch, frame %d" % (16 + k))
+
+
+def test_ordinary_frames_after_a_frame_that_exhausted_the_component_pool(detector, oracle, dictionary):
+    """Round-4 ADVICE (high): a frame whose second labelling pass runs out of component-pool entries (specks along every label tile's
+    border: ~17 000 entries asked of 13 824) is rerun through the any-frame workspace -- but its tiles' labels stay in the BATCH workspace's
+    slot, and the slot's tile_dirty bits must say so, or the next frames in that slot skip label blocks that still hold the texture's
+    labels.  Batch 1 holds the texture in slot 3 (and a second one in slot 6), batch 2 ordinary marker frames in every slot: every
+    record of both batches equals the oracle's, and slot 3's label image of batch 2 is the oracle's partition."""
+    state, fs = dictionary
+    dev = torch.device("cuda:0")
+    specks = tile_border_specks(np.full((1080, 1920), 200, np.uint8))
+    first = np.stack([tk.synth_frame_host(state, f)[0] for f in range(8)])
+    first[3] = specks
+    first[6] = tile_border_specks(np.full((1080, 1920), 170, np.uint8), ink=8)
+    second = np.stack([tk.synth_frame_host(state, 20 + f)[0] for f in range(8)])
+    want1, _ = oracle.detect_many(first, state, fs)
+    want2, _ = oracle.detect_many(second, state, fs)
+    assert want1["status"][3] == 1 and (want2["status"] == 0).all() and (want1["flags"] == 0).all()
+    out = torch.zeros(8 * ca.RESULT_DT.itemsize, dtype=torch.uint8, device=dev)
+    before = detector.counters()["reruns"]
+    for rep in range(2):  # twice: the second round's texture lands on slots that held ordinary frames
+        fr = torch.from_numpy(first).to(dev)
+        detector.detect_batch_device(fr.data_ptr(), 8, 1080, 1920, 1920, 1920 * 1080, out.data_ptr())
+        detector.sync()
+        got = np.frombuffer(out.cpu().numpy().tobytes(), ca.RESULT_DT)
+        for k in range(8):
+            assert_same_record(got[k], want1[k], "round %d, batch with the speck textures, frame %d" % (rep, k))
+        fr = torch.from_numpy(second).to(dev)
+        detector.detect_batch_device(fr.data_ptr(), 8, 1080, 1920, 1920, 1920 * 1080, out.data_ptr())
+        detector.sync()
+        got = np.frombuffer(out.cpu().numpy().tobytes(), ca.RESULT_DT)
+        for k in range(8):
+            assert_same_record(got[k], want2[k], "round %d, ordinary batch behind the textures, frame %d" % (rep, k))
+        for slot in (3, 6):
+            o = oracle.detect(second[slot], state, fs)
+            lab = detector.debug(slot, tk.DBG_LABELS).reshape(o["labels"].shape)
+            assert ((lab != 0) == (o["binary"] > 0)).all(), "stale labels in slot %d" % slot
+            pairs = np.unique(np.stack([o["labels"].ravel(), lab.ravel()], 1), axis=0)
+            assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
+    assert detector.counters()["reruns"] >= before + 4  # the textures really took the any-frame pass (pool exhausted in the batch workspace)
 
 
 def test_cpp_class_does_not_throw_on_a_cluttered_frame(detector, oracle, dictionary, tmp_path):

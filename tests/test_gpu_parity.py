@@ -776,6 +776,75 @@ def test_packed_shards_and_rccl_gather_single_rank(detector, dictionary):
         detector.comm_destroy()
 
 
+def test_gather_deadline_aborts_instead_of_hanging(dictionary):
+    """a dead or late peer must make the gather FAIL, not hang.  On one GPU a late peer is a stream that does not
+    advance: a stall kernel (testkit) holds the handle's stream, the gather stream behind it and so the all-gather of the sizes for
+    3 s; with a 300 ms deadline ctag_gather_end returns CTAG_ERR_HIP well before that, names the deadline, the communicator is
+    aborted (ncclCommAbort), the handle that shares it fails its next gather at once, and everything tears down without a hang.
+    Without a deadline (0) the same stall only delays the result."""
+    import time
+    import torch
+    state, fs = dictionary
+    n, rows, cols = 8, 1080, 1920
+    det, det2 = tk.Detector(state, fs), tk.Detector(state, fs)
+    try:
+        frames = torch.empty((n, rows, cols), dtype=torch.uint8, device="cuda")
+        det.synth_frames_device(frames.data_ptr(), 3, n, rows, cols, cols, rows * cols)
+        rec = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+        out = torch.zeros_like(rec)
+        det.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, rec.data_ptr())
+        det.sync()
+        host = rec.cpu().numpy()
+        det.comm_init(capi.comm_unique_id(), 0, 1)
+        det2.comm_attach(det.comm_native(), 0, 1)
+        # no deadline: a 400 ms stall delays the gather, nothing else
+        det.gather_set_timeout(0)
+        det.stall_stream(400)
+        t0 = time.perf_counter()
+        det.gather(rec.data_ptr(), n, n, out.data_ptr())
+        assert time.perf_counter() - t0 > 0.3 and (out.cpu().numpy() == host).all()
+        # a deadline longer than the stall: same
+        det.gather_set_timeout(5000)
+        det.stall_stream(400)
+        det.gather(rec.data_ptr(), n, n, out.data_ptr())
+        assert (out.cpu().numpy() == host).all()
+        # a deadline shorter than the stall: the call fails within the deadline (plus scheduling slack), long before the stall ends
+        det.gather_set_timeout(300)
+        det.stall_stream(3000)
+        det.gather_begin(rec.data_ptr(), n, n)
+        t0 = time.perf_counter()
+        with pytest.raises(capi.CtagError) as ei:
+            det.gather_end(out.data_ptr())
+        dt = time.perf_counter() - t0
+        assert ei.value.status == capi.ERR_HIP and 0.25 < dt < 1.5, (ei.value, dt)
+        assert "300 ms" in str(ei.value) and "aborted" in str(ei.value)
+        # the communicator is dead for every handle that shares it
+        for d in (det, det2):
+            with pytest.raises(capi.CtagError) as e2:
+                d.gather_begin(rec.data_ptr(), n, n)
+            assert "aborted" in str(e2.value)
+        # the detector itself is unharmed
+        det.sync()
+        det.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr())
+        det.sync()
+        assert (out.cpu().numpy() == host).all()
+        # a fresh communicator works again
+        det2.comm_destroy()
+        det.comm_destroy()
+        det.comm_init(capi.comm_unique_id(), 0, 1)
+        det.gather_set_timeout(-1)
+        out.zero_()
+        det.gather(rec.data_ptr(), n, n, out.data_ptr())
+        assert (out.cpu().numpy() == host).all()
+    finally:
+        t0 = time.perf_counter()
+        det2.comm_destroy()
+        det.comm_destroy()
+        det2.close()
+        det.close()
+        assert time.perf_counter() - t0 < 10
+
+
 def _gathered_buffer(records, world, width=None):
     """What the payload all-gather of a `world`-rank job delivers for `records` (uint8 [n_total, 11616]): every rank's packed shard
     (cylindertag_amd/dist.pack_records, the host restatement of the format) at r * width, padding filled with 0xA5."""
@@ -858,6 +927,14 @@ def test_two_rank_rccl_gather_when_two_gpus_are_present(dictionary):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     assert "GATHER_WORKER_OK" in p.stdout
+    # a peer that dies before its collective: the survivor's ctag_gather returns CTAG_ERR_HIP within the deadline and exits non-zero
+    import time
+    cmd[-1:] = [os.path.join(ROOT, "tests", "gather_worker.py"), "--dead-peer"]
+    cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, CTAG_GATHER_TIMEOUT_MS="3000"))
+    assert p.returncode != 0 and "DEAD_PEER_DETECTED" in p.stdout + p.stderr, (p.stdout[-2000:], p.stderr[-3000:])
+    assert time.perf_counter() - t0 < 120
 
 
 def _colourise(gray, seed):

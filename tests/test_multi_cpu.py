@@ -97,3 +97,56 @@ def test_shard_ranges_cover_all_frames():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
             assert spans == [capi.shard_range(n, r, world) for r in range(world)]  # the C ABI's rule (ctag_shard_range)
+
+
+def _dying_worker(rank, world, port, n_total, ret):
+    import datetime
+    import time
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from cylindertag_amd.dist import gather_records, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=5))
+    dist.barrier()
+    if rank == 1:
+        os._exit(17)  # a crashed peer: no teardown, never enters the exchange
+    lo, hi = shard_range(n_total, rank, world)
+    t0 = time.perf_counter()
+    try:
+        gather_records(_golden_records(n_total)[lo:hi], n_total, dist)
+        ret[rank] = ("returned", time.perf_counter() - t0)
+    except Exception as e:  # noqa: BLE001
+        ret[rank] = ("raised %s" % type(e).__name__, time.perf_counter() - t0)
+    os._exit(3)
+
+
+def test_gather_with_a_dead_peer_fails_within_the_deadline():
+    """a rank that dies must make the others fail, not hang.  Host form of the protocol (gloo): rank 1 exits before the
+    exchange, rank 0's gather raises within the group's deadline and its process exits non-zero.  (The device form's deadline --
+    ctag_gather_set_timeout / CTAG_GATHER_TIMEOUT_MS, ncclCommAbort -- is covered under -m gpu: test_gather_deadline_aborts_instead_of_hanging.)"""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [mp.Process(target=_dying_worker, args=(r, 2, port, 64, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode is not None, "a rank hangs behind a dead peer"
+    assert procs[1].exitcode == 17 and procs[0].exitcode == 3
+    what, dt = ret[0]
+    assert what.startswith("raised") and dt < 30, ret[0]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher around it (the driver's command shape): bench.py starts torch.distributed.run
+    itself, as a child, before anything touches a GPU.  On this GPU-less machine the RANKS then refuse ("needs a GPU": the path has no
+    CPU fallback) and the launcher's non-zero exit code comes back -- the failure is the ranks', not a launcher check."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "8"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs a GPU") == 2, p.stderr[-3000:]
+    assert "needs `python -m torch.distributed.run" not in p.stderr  # round 4's launcher check is gone
