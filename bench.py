@@ -740,9 +740,11 @@ def main():
         achieved = ALGO_BYTES_PER_FRAME * n / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic, traffic_source = None, None
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))  # per-round PMC passes; latest round wins
+        # per-round PMC passes, one file per frame size they were collected on (r05_pmc_traffic.json: 1080p; r05_4k_pmc_traffic.json: 3840x2160); latest round wins
+        pat = {(1080, 1920): "r[0-9][0-9]_pmc_traffic.json", (2160, 3840): "r[0-9][0-9]_4k_pmc_traffic.json"}.get((ROWS, COLS))
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
         tpath = cands[-1] if cands else ""
-        if os.path.exists(tpath) and (ROWS, COLS) == (1080, 1920):  # the PMC passes were collected on the 1080p workload
+        if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("sweep_bytes_per_frame") * min(n, chunk)  # measured per frame
                 traffic_source = "replayed from %s (separate rocprofv3 --pmc passes; not collected in this run)" % os.path.relpath(tpath, ROOT)

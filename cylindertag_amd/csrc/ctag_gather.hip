@@ -10,7 +10,9 @@
 #include <rccl/rccl.h>  // types only; every entry point is resolved at run time
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cstdio>
@@ -203,7 +205,20 @@ void order_abort(ncclComm_t c) {
     std::lock_guard<std::mutex> lk(o->mu);
     if (o->dead) return;
     o->dead = true;
-    if (rccl()->CommAbort) (void)rccl()->CommAbort(c);
+    if (!rccl()->CommAbort) return;
+    // ncclCommAbort returns when the communicator's kernels have left -- at once when they are spinning on a peer that is gone, but it
+    // waits as long as whatever holds the stream AHEAD of a collective that has not started.  The caller has a deadline to keep: the abort
+    // runs on a thread of its own and is given half a second; if it is still busy then it finishes (or not) without us.
+    auto done = std::make_shared<std::atomic<bool>>(false);
+    ncclResult_t (*abort_fn)(ncclComm_t) = rccl()->CommAbort;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::thread([=] {
+        (void)hipSetDevice(dev);
+        (void)abort_fn(c);
+        done->store(true);
+    }).detach();
+    for (int i = 0; i < 500 && !done->load(); i++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
 }
 bool order_unref(ncclComm_t c, bool wait_for_last);  // below: needs the bounded wait
 // one collective on `s`, ordered behind the previous one of this communicator and published for the next, under the entry's lock

@@ -1703,6 +1703,8 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
     } else {
         static const int xcd = getenv("CTAG_REFINE_XCD") ? atoi(getenv("CTAG_REFINE_XCD")) : 3;
         const int f8 = ((nframes + 7) / 8) * 8;
+        // (round 5: searches and sums alternating over slices of 256 / 512 / 1024 frames, so that a slice's n0 is read back while the memory-side cache
+        // still holds it, lost -- 5.13 / 4.95 / 4.84 against 4.71-4.76 ms per 4096 frames: the round trip through HBM is not what the sums kernel waits for)
         if (xcd & 1) hipLaunchKernelGGL(k_edge_refine<1>, dim3(f8 * refine_gx), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_gx);
         else hipLaunchKernelGGL(k_edge_refine<1>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
         if (xcd & 2) hipLaunchKernelGGL(k_edge_refine<2>, dim3(f8 * refine_sums_gx), dim3(64), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_sums_gx);

@@ -123,6 +123,13 @@ struct LdsPts {
     const float2* p;
     __device__ __forceinline__ float2 operator()(int j) const { return p[j]; }
 };
+struct LdsPackedPts {  // the packed words themselves in LDS: half the bytes of float pairs (longer edges fit), the unpacking of GlobalPts, no trip through the texture path
+    const uint32_t* p;
+    __device__ __forceinline__ float2 operator()(int j) const {
+        const uint32_t v = p[j];
+        return make_float2((float)ux(v), (float)uy(v));
+    }
+};
 // Initial samples: the precomputed cv::RNG table (bytes, point counts below kPickN), a replayed list (16-bit), or -- short edges --
 // every point of the edge.
 struct TablePicks {
@@ -150,28 +157,33 @@ __device__ __forceinline__ RestartResult restart_result(const float* res, int rs
     r.err = ctm::bits_to_f64(lo | (hi << 32));
     return r;
 }
+// the initial fit of a restart: fitLine2D's weights are 1 on the restart's sample and 0 elsewhere (zero-weight points add +0.0: skipping them is exact)
 template <class Pts, class Picks>
-__device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npick, double EPS, float* res, int rstride, float* wc = nullptr) {
-    const int ncache = wc ? min(n, kWCap) : 0;
-    float line[4], prev[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-        double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
-        for (int i = 0; i < npick; i++) {  // zero-weight points add +0.0: skipping them is exact
-            const float2 p = pts(picks(i));
-            const float px = p.x, py = p.y;
-            x += px;
-            y += py;
-            x2 += px * px;
-            y2 += py * py;
-            xy += px * py;
-            w += 1.f;
-        }
-        moments_to_line(x, y, x2, y2, xy, w, line);
+__device__ __forceinline__ void welsch_first_fit(const Pts pts, const Picks picks, int npick, float* line) {
+    double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
+    for (int i = 0; i < npick; i++) {
+        const float2 p = pts(picks(i));
+        const float px = p.x, py = p.y;
+        x += px;
+        y += py;
+        x2 += px * px;
+        y2 += py * py;
+        xy += px * py;
+        w += 1.f;
     }
+    moments_to_line(x, y, x2, y2, xy, w, line);
+}
+// IRLS iterations it0, it0 + 1, ... of one restart from `line` (the body of fitLine2D's inner loop).  Returns true when the restart has ENDED -- converged,
+// err < EPS, or 30 iterations -- with (line, err) as the reference leaves them; returns false at iteration it_stop, AFTER that iteration's convergence test
+// has failed: the caller goes on later (on any lane) with welsch_rounds(.., it0 = it_stop, resume = true), which skips the test it already knows the
+// outcome of -- so neither the previous line nor err has to travel.  it_stop = 30: to the end.
+// wc: this lane's column of a [rows][WS] float array in LDS (element j at wc[j * WS]) for the weights of the first `ncache` points between the two passes.
+template <int WS, class Pts>
+__device__ __forceinline__ bool welsch_rounds(const Pts pts, int n, double EPS, float* line, double& err, int it0, int it_stop, bool resume, float* wc, int ncache) {
+    float prev[4] = {0.f, 0.f, 0.f, 0.f};
     const float c = 1 / 2.9846f;
-    double err = 0;
-    for (int it = 0; it < 30; it++) {
-        if (it > 0) {
+    for (int it = it0; it < 30; it++) {
+        if (it > 0 && !(resume && it == it0)) {
             // reference: fabs(acos(clamp(t))) < 0.01f with t a float-valued dot product.  acos64 is decreasing, so the
             // test is a threshold on t: kAcosBelowTenMilli is the smallest float with acos64(t) < 0.01f (checked over every
             // float by tests/test_oracle_cpu.py), which keeps ~100 FP64 operations out of every iteration.
@@ -180,9 +192,10 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
                 const float dx = ctm::fabs32(line[2] - prev[2]);
                 const float dy = ctm::fabs32(line[3] - prev[3]);
                 const float d = dx > dy ? dx : dy;
-                if (d < 0.01f) break;
+                if (d < 0.01f) return true;
             }
         }
+        if (it == it_stop) return false;
         const float lx = line[2], ly = line[3], nx = line[1], ny = -line[0];
         double sum_w = 0;
         err = 0;
@@ -197,7 +210,7 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
             const float r = ctm::fabs32(nx * x + ny * y);
             err += r;
             const float wj = ctm::exp32_nonpos(-r * r * c * c);
-            wc[j * 64] = wj;
+            wc[j * WS] = wj;
             sum_w += wj;
         }
         float2 pn1 = pts(min(ncache, n - 1));  // next point, loaded one trip ahead
@@ -210,17 +223,17 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
             err += r;
             sum_w += ctm::exp32_nonpos(-r * r * c * c);
         }
-        if (err < EPS) break;
+        if (err < EPS) return true;
         double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
         if (ctm::fabs64(sum_w) > 1.1920928955078125e-07) {
             const double inv = 1. / sum_w;
-        float2 pn2 = pts(min(0, n - 1));  // next point, loaded one trip ahead
+            float2 pn2 = pts(min(0, n - 1));  // next point, loaded one trip ahead
             CTAG_PRAGMA(unroll CTAG_WUNROLL)
-        for (int j = 0; j < ncache; j++) {
+            for (int j = 0; j < ncache; j++) {
                 const float2 p = pn2;
                 pn2 = pts(j + 1);
                 const float px = p.x, py = p.y;
-                const float wj = (float)(wc[j * 64] * inv);
+                const float wj = (float)(wc[j * WS] * inv);
                 x += wj * px;
                 y += wj * py;
                 x2 += wj * px * px;
@@ -228,9 +241,9 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
                 xy += wj * px * py;
                 w += wj;
             }
-        float2 pn3 = pts(min(ncache, n - 1));  // next point, loaded one trip ahead
+            float2 pn3 = pts(min(ncache, n - 1));  // next point, loaded one trip ahead
             CTAG_PRAGMA(unroll CTAG_WUNROLL)
-        for (int j = ncache; j < n; j++) {
+            for (int j = ncache; j < n; j++) {
                 const float2 p = pn3;
                 pn3 = pts(j + 1);
                 const float px = p.x, py = p.y;
@@ -263,10 +276,24 @@ __device__ void welsch_restart(const Pts pts, int n, const Picks picks, int npic
         prev[3] = line[3];
         moments_to_line(x, y, x2, y2, xy, w, line);
     }
+    return true;
+}
+// a restart's result where the selection reads it: the line in res[q * rstride], q = 0..3, the two halves of the error (a double) in q = 4, 5
+__device__ __forceinline__ void restart_store(float* res, int rstride, const float* line, double err) {
     for (int q = 0; q < 4; q++) res[q * rstride] = line[q];
     const uint64_t eb = ctm::f64_to_bits(err);
     res[4 * rstride] = ctm::bits_to_f32((uint32_t)eb);
     res[5 * rstride] = ctm::bits_to_f32((uint32_t)(eb >> 32));
+}
+// One whole Welsch restart (the body of fitLine2D's `for k` loop) on one lane; with res = wc and rstride = WS the result lands in the lane's own
+// weight column, which is dead by then (needs kWCap >= 6).
+template <int WS, class Pts, class Picks>
+__device__ __forceinline__ void welsch_restart(const Pts pts, int n, const Picks picks, int npick, double EPS, float* res, int rstride, float* wc) {
+    float line[4];
+    double err = 0;
+    welsch_first_fit(pts, picks, npick, line);
+    (void)welsch_rounds<WS>(pts, n, EPS, line, err, 0, 30, false, wc, min(n, kWCap));
+    restart_store(res, rstride, line, err);
 }
 
 // ---- sub-wave packing: 8 components per wave, 8 lanes each (k_quad_edges_packed) -------------------------
@@ -1947,84 +1974,199 @@ __device__ __forceinline__ void welsch_select(const QuadPtrs& P, int frame, int 
     for (int q = 0; q < 4; q++) o[q] = best[q];
 }
 
-// LDS of a k_welsch wave: the weight columns (which also receive the restarts' results) and the staged points of its three edges;
-// the replayed pick lists of edges of kPickN points and more (never staged: kPickN > kWPts) live in the point area
-constexpr int kWPts = 128;  // points of an edge staged in LDS as float pairs; a triple with a longer edge reads global memory
-static_assert(kWCap >= 10 && kWPts < kPickN && 3 * kWPts * 8 >= 64 * 10 * 2, "k_welsch LDS layout");
+// ---- k_welsch's block: kWB = 4 waves = kWE = 12 edges x 20 restarts, one restart per lane.  A restart runs two or three IRLS iterations (45.0 % of the
+// synthetic batch's restarts go on after the second, 0.1 % after the third: CTAG_QUAD_STAMPS counts them); a wave used to run three while more than half of
+// its lanes had ended after two.  Here the block REGROUPS after the second: the restarts whose convergence test failed are compacted onto the first lanes of
+// the block (their state is the line: 16 bytes), waves without work wait at the next barrier and cost no instruction issue, and the rest goes on -- 2 x 4 + 2
+// wave-rounds per 12 edges instead of 12.
+// Measured (round 5, per 4096 frames, builds side by side on one box): the per-wave kernel of round 4 (3 edges per wave, no barriers) 4.87-4.93 ms; this
+// block without the regroup 5.06; with it 4.81-4.86 -- the barriers of a block cost what the regroup saves, bar 1 %.  Five-wave blocks (16 edges fill
+// 320 lanes exactly) ran 5.9-6.1 ms: a CU then holds three of them (15 waves), and the kernel needs its five waves per SIMD; idle waves leaving instead of
+// waiting, at six blocks per CU: 5.05; a larger weight cache at four waves per SIMD (CTAG_WCAP 20 / 24): 5.18 / 5.06.
+// LDS: the weight columns [kWCap][kWT] -- which at the regroup carry the states (rows 0-4 of column r: line, item) and from then on the results (rows
+// kWRes .. kWRes + 5 of column 20 e + k; the second phase's weight cache keeps to rows below kWRes) --, the staged points of the block's edges, a table of
+// the edges.  The replayed pick lists of edges of kPickN2 points and more (never staged) live in the point area.
+#ifndef CTAG_WELSCH_BLOCK_WAVES
+#define CTAG_WELSCH_BLOCK_WAVES 4
+#endif
+constexpr int kWB = CTAG_WELSCH_BLOCK_WAVES;
+constexpr int kWT = kWB * 64;   // 256 threads
+constexpr int kWE = kWT / 20;   // 12 edges (16 lanes of the block idle)
+constexpr int kWRes = 10;       // first result row
+#ifndef CTAG_WELSCH_REGROUP_AT
+#define CTAG_WELSCH_REGROUP_AT 2  // iterations before the regroup (30: never)
+#endif
+constexpr int kWRegroupAt = CTAG_WELSCH_REGROUP_AT;
+#ifndef CTAG_WPTS
+#define CTAG_WPTS 128
+#endif
+constexpr int kWPts = CTAG_WPTS;  // points of an edge staged in LDS as float pairs; a block with a longer edge stages packed words, or reads global memory
+#ifndef CTAG_WPTSU
+#define CTAG_WPTSU 240
+#endif
+constexpr int kWPtsU = CTAG_WPTSU;  // points of an edge staged in LDS as packed words
+static_assert(kWPtsU % 2 == 0 && kWPtsU < kPickN, "packed rows: an odd number of words, picks from the byte table");
+static_assert(kWE * 20 <= kWT && kWCap >= kWRes + 6 && kWRes >= 5 && kWRes >= kWShort && kWPts < kPickN && kWE * kWPts * 8 >= kWT * 10 * 2 && (kWPts + 1) % 32 == 1, "k_welsch LDS layout");
 struct WelschLds {
-    float wc[kWCap * 64];
-    float2 pt[3][kWPts];
-    float2 pad;  // pt[2][kWPts]: welsch_restart requests one point past an edge's last
+    float wc[kWCap * kWT];
+    union {
+    uint32_t ptu[kWE][kWPtsU + 1];  // ... or, when the block's longest edge has more than kWPts points, as the packed words (rows of an odd number of words: one bank apart)
+    float2 pt[kWE][kWPts + 1];  // rows one point longer than they need to be: welsch_rounds requests one point past an edge's last -- and the lanes of a wave read the
+                                // same point index of up to five (after the regroup: sixteen) edges at once, which rows of a multiple of 256 bytes would put on ONE bank pair
+    };
+    const uint32_t* gpts[kWE];
+    int n[kWE];
+    int lid[kWE];
+    int cnt[kWB];
 };
 
-__device__ __forceinline__ void welsch_three(const QuadPtrs& P, WelschLds& S, int frame, int first, int L) {
-    const int lane = threadIdx.x;
-    const int grp = lane / 20, k = lane - grp * 20;
-    const bool active = lane < 60 && first + grp < L;
-    int lid = 0, n = 0;
-    const uint32_t* pts = nullptr;
-    if (active) {
-        lid = P.line_sorted[(size_t)frame * P.line_cap + first + grp];
-        const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
-        n = d.n;
-        pts = P.cl_pool + (size_t)frame * P.cl_cap + d.off;
-    }
-    // the triple's edges are sorted by descending length: the first one decides whether all three fit the staged form
-    const int n_first = __shfl(n, 0, 64);
-    const double EPS = n * 1.1920928955078125e-07;
-    if (n_first <= kWPts) {
-        if (active) {
-            for (int j = k; j < n; j += 20) {
-                const uint32_t v = pts[j];
-                S.pt[grp][j] = make_float2((float)ux(v), (float)uy(v));
+template <int MODE>  // 0: float pairs in LDS, 1: packed words in LDS, 2: global memory
+__device__ __forceinline__ void welsch_block_run(const QuadPtrs& P, WelschLds& S, int frame) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool STAGED = MODE != 2;
+    using PtsT = typename std::conditional<MODE == 0, LdsPts, typename std::conditional<MODE == 1, LdsPackedPts, GlobalPts>::type>::type;
+    auto pts_of = [&](int e) -> PtsT {
+        if constexpr (MODE == 0) return LdsPts{S.pt[e]};
+        else if constexpr (MODE == 1) return LdsPackedPts{S.ptu[e]};
+        else return GlobalPts{S.gpts[e]};
+    };
+    float line[4] = {0.f, 0.f, 0.f, 0.f};
+    double err = 0;
+    bool fin = true;
+    int item = tid;
+    for (int phase = 0; phase < 2; phase++) {
+        bool run;
+        if (phase == 0) {
+            run = tid < kWE * 20 && S.n[min(tid / 20, kWE - 1)] > 0;
+            if (P.stamps) {
+                const unsigned long long act = __ballot(run);
+                if (lane == 0) atomicAdd(&P.stamps[24], (unsigned long long)__popcll(act));
+            }
+        } else {
+            // ---- regroup: restarts that have not ended move to the block's first lanes
+            const unsigned long long bal = __ballot(!fin);
+            if (lane == 0) S.cnt[wave] = __popcll(bal);
+            __syncthreads();  // every lane is done with its weight column
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kWB; w++) {
+                const int c = S.cnt[w];
+                base += w < wave ? c : 0;
+                total += c;
+            }
+            if (!fin) {
+                const int r = base + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int q = 0; q < 4; q++) S.wc[q * kWT + r] = line[q];
+                S.wc[4 * kWT + r] = __int_as_float(tid);
+            }
+            __syncthreads();
+            if (P.stamps && tid == 0) {  // developer aid (CTAG_QUAD_STAMPS): restarts that went past the regroup, blocks
+                atomicAdd(&P.stamps[25], (unsigned long long)total);
+                atomicAdd(&P.stamps[26], 1ull);
+            }
+            run = tid < total;
+            if (run) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) line[q] = S.wc[q * kWT + tid];
+                item = __float_as_int(S.wc[4 * kWT + tid]);
             }
         }
-        __syncthreads();
-        if (active)
-            welsch_restart(LdsPts{S.pt[grp]}, n, TablePicks{P.pick_table + ((size_t)n * 20 + k) * 10}, min(n, 10), EPS, S.wc + lane, 64, S.wc + lane);
-    } else if (active) {
-        if (n < kPickN) {
-            welsch_restart(GlobalPts{pts}, n, TablePicks{P.pick_table + ((size_t)n * 20 + k) * 10}, 10, EPS, S.wc + lane, 64, S.wc + lane);
-        } else if (n < kPickN2) {
-            welsch_restart(GlobalPts{pts}, n, ListPicks{P.pick_table16 + ((size_t)(n - kPickN) * 20 + k) * 10}, 10, EPS, S.wc + lane, 64, S.wc + lane);
-        } else {  // replay cv::RNG up to this restart
-            uint16_t* pk = reinterpret_cast<uint16_t*>(&S.pt[0][0]) + lane * 10;
-            CvRng rng;
-            rng.state = 0xffffffffffffffffULL;
-            for (int kk = 0; kk <= k; kk++) {
-                int got = 0;
-                while (got < 10) {
-                    const int j = (int)(rng.next() % (unsigned)n);
-                    bool dup = false;
-                    for (int q = 0; q < got; q++) dup |= (pk[q] == j);
-                    if (!dup) pk[got++] = (uint16_t)j;
+        if (run) {
+            const int e = item / 20, k = item - e * 20;
+            const int n = S.n[e];
+            const double EPS = n * 1.1920928955078125e-07;
+            const PtsT pts = pts_of(e);
+            if (phase == 0) {
+                if (STAGED || n < kPickN) {
+                    welsch_first_fit(pts, TablePicks{P.pick_table + ((size_t)n * 20 + k) * 10}, min(n, 10), line);
+                } else if (n < kPickN2) {
+                    welsch_first_fit(pts, ListPicks{P.pick_table16 + ((size_t)(n - kPickN) * 20 + k) * 10}, 10, line);
+                } else {  // replay cv::RNG up to this restart
+                    uint16_t* pk = reinterpret_cast<uint16_t*>(&S.pt[0][0]) + tid * 10;
+                    CvRng rng;
+                    rng.state = 0xffffffffffffffffULL;
+                    for (int kk = 0; kk <= k; kk++) {
+                        int got = 0;
+                        while (got < 10) {
+                            const int j = (int)(rng.next() % (unsigned)n);
+                            bool dup = false;
+                            for (int q = 0; q < got; q++) dup |= (pk[q] == j);
+                            if (!dup) pk[got++] = (uint16_t)j;
+                        }
+                    }
+                    for (int a = 1; a < 10; a++) {
+                        const uint16_t v = pk[a];
+                        int b = a - 1;
+                        while (b >= 0 && pk[b] > v) {
+                            pk[b + 1] = pk[b];
+                            b--;
+                        }
+                        pk[b + 1] = v;
+                    }
+                    welsch_first_fit(pts, ListPicks{pk}, 10, line);
                 }
             }
-            for (int a = 1; a < 10; a++) {
-                const uint16_t v = pk[a];
-                int b = a - 1;
-                while (b >= 0 && pk[b] > v) {
-                    pk[b + 1] = pk[b];
-                    b--;
-                }
-                pk[b + 1] = v;
-            }
-            welsch_restart(GlobalPts{pts}, n, ListPicks{pk}, 10, EPS, S.wc + lane, 64, S.wc + lane);
+            fin = welsch_rounds<kWT>(pts, n, EPS, line, err, phase == 0 ? 0 : kWRegroupAt, phase == 0 ? kWRegroupAt : 30, phase != 0, S.wc + tid, min(n, phase == 0 ? kWCap : kWRes));
+            if (fin) restart_store(S.wc + kWRes * kWT + item, kWT, line, err);
+        } else {
+            fin = true;
         }
     }
     __syncthreads();
-    if (active && k == 0) welsch_select(P, frame, lid, n, S.wc + lane, 1, 64, 20);
+    if (tid < kWE && S.n[tid] > 0) welsch_select(P, frame, S.lid[tid], S.n[tid], S.wc + kWRes * kWT + tid * 20, 1, kWT, 20);
+}
+
+// the edges of sorted ranks [first, first + kWE) of the frame (ranks below L: the edges of more than kWShort points)
+__device__ __forceinline__ void welsch_block(const QuadPtrs& P, WelschLds& S, int frame, int first, int L) {
+    const int tid = threadIdx.x;
+    if (tid < kWE) {
+        int n = 0, lid = 0;
+        const uint32_t* p = nullptr;
+        if (first + tid < L) {
+            lid = P.line_sorted[(size_t)frame * P.line_cap + first + tid];
+            const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
+            n = d.n;
+            p = P.cl_pool + (size_t)frame * P.cl_cap + d.off;
+        }
+        S.n[tid] = n;
+        S.lid[tid] = lid;
+        S.gpts[tid] = p;
+    }
+    __syncthreads();
+    // the block's edges are sorted by descending length: the first one decides which form all of them take
+    const int n0 = S.n[0];
+    if (n0 <= kWPts) {
+        for (int idx = tid; idx < kWE * kWPts; idx += kWT) {
+            const int e = idx / kWPts, j = idx - e * kWPts;
+            if (j < S.n[e]) {
+                const uint32_t v = S.gpts[e][j];
+                S.pt[e][j] = make_float2((float)ux(v), (float)uy(v));
+            }
+        }
+        __syncthreads();
+        welsch_block_run<0>(P, S, frame);
+    } else if (n0 <= kWPtsU) {
+        for (int idx = tid; idx < kWE * kWPtsU; idx += kWT) {
+            const int e = idx / kWPtsU, j = idx - e * kWPtsU;
+            if (j < S.n[e]) S.ptu[e][j] = S.gpts[e][j];
+        }
+        __syncthreads();
+        welsch_block_run<1>(P, S, frame);
+    } else {
+        welsch_block_run<2>(P, S, frame);
+    }
 }
 
 // Edges of at most kWShort points, a lane each: ONE restart on all of the edge's points (see kWShort)
 __device__ __forceinline__ void welsch_short(const QuadPtrs& P, WelschLds& S, int frame, int first, int L) {
-    const int lane = threadIdx.x;
-    if (first + lane >= L) return;
-    const int lid = P.line_sorted[(size_t)frame * P.line_cap + first + lane];
+    const int tid = threadIdx.x;
+    if (first + tid >= L) return;
+    const int lid = P.line_sorted[(size_t)frame * P.line_cap + first + tid];
     const LineDesc d = P.line_desc[(size_t)frame * P.line_cap + lid];
     const int n = d.n;  // 2 <= n <= kWShort <= kWCap: every weight stays in LDS
-    welsch_restart(GlobalPts{P.cl_pool + (size_t)frame * P.cl_cap + d.off}, n, AllPicks{}, n, n * 1.1920928955078125e-07, S.wc + lane, 64, S.wc + lane);
-    welsch_select(P, frame, lid, n, S.wc + lane, 0, 64, 1);
+    welsch_restart<kWT>(GlobalPts{P.cl_pool + (size_t)frame * P.cl_cap + d.off}, n, AllPicks{}, n, n * 1.1920928955078125e-07, S.wc + tid, kWT, S.wc + tid);
+    welsch_select(P, frame, lid, n, S.wc + tid, 0, kWT, 1);
 }
 
 // ---- few-frame calls: one wave per (edge, restart) ------------------------------------------------------------------
@@ -2247,36 +2389,36 @@ __device__ __forceinline__ void welsch_pick(const QuadPtrs& P, int frame, int ra
 }
 
 #ifndef CTAG_WELSCH_PRIO_RANKS
-#define CTAG_WELSCH_PRIO_RANKS 16
+#define CTAG_WELSCH_PRIO_RANKS 3  // blocks of kWE edges
 #endif
 #ifndef CTAG_WELSCH_WAVES
 #define CTAG_WELSCH_WAVES 5
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes, const float* lat_rs, int gy_long) {
+__global__ __launch_bounds__(kWT) __attribute__((amdgpu_waves_per_eu(CTAG_WELSCH_WAVES, CTAG_WELSCH_WAVES))) void k_welsch(QuadPtrs P, int nframes, const float* lat_rs, int gy_long) {
     // Longest first across the WHOLE batch: blockIdx.x (the fast dispatch index) is the frame, blockIdx.y the rank of the
-    // edge triple in the frame's list sorted by descending point count.  The longest triples of all frames are dispatched
-    // first and the kernel drains on the short ones: a long triple runs ~0.3 ms as a lone wave, and with the triple rank on
+    // group of kWE edges in the frame's list sorted by descending point count.  The longest groups of all frames are dispatched
+    // first and the kernel drains on the short ones: a long edge runs ~0.3 ms, and with the rank on
     // the fast index some of them started last and WERE the kernel's tail.  Consecutive frames fall on consecutive XCDs, so
     // the load stays balanced without the column rotation the other layout needed.
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int L = min(P.line_count[frame], P.line_cap);
     if (lat_rs && welsch_lat_takes(P, frame, L)) {  // few-frame call: k_welsch_lat has run the restarts of this frame's edges; pick per edge
-        for (int rank = (int)blockIdx.y * 64 + (int)threadIdx.x; rank < L; rank += (int)gridDim.y * 64) welsch_pick(P, frame, rank, lat_rs);
+        for (int rank = (int)blockIdx.y * kWT + (int)threadIdx.x; rank < L; rank += (int)gridDim.y * kWT) welsch_pick(P, frame, rank, lat_rs);
         return;
     }
     // the first ranks are the long edges: their waves are the kernel's critical path, so they get issue priority over the short
     // ones they share a SIMD with (s_setprio; the bulk fills the slots they leave)
     if (blockIdx.y < (unsigned)CTAG_WELSCH_PRIO_RANKS) __builtin_amdgcn_s_setprio(3);
     __shared__ WelschLds S;
-    const int nlong = min(P.line_long[frame], L);  // ranks [0, nlong): edges of more than kWShort points, three per wave x 20 restarts
+    const int nlong = min(P.line_long[frame], L);  // ranks [0, nlong): edges of more than kWShort points, kWE per block x 20 restarts
     if ((int)blockIdx.y < gy_long) {
-        for (int first = (int)blockIdx.y * 3; first < nlong; first += gy_long * 3) {
-            welsch_three(P, S, frame, first, nlong);
+        for (int first = (int)blockIdx.y * kWE; first < nlong; first += gy_long * kWE) {
+            welsch_block(P, S, frame, first, nlong);
             __syncthreads();
         }
-    } else {  // ranks [nlong, L): 64 short edges per wave, one restart each
-        for (int first = nlong + ((int)blockIdx.y - gy_long) * 64; first < L; first += ((int)gridDim.y - gy_long) * 64) welsch_short(P, S, frame, first, L);
+    } else {  // ranks [nlong, L): kWT short edges per block, one restart each
+        for (int first = nlong + ((int)blockIdx.y - gy_long) * kWT; first < L; first += ((int)gridDim.y - gy_long) * kWT) welsch_short(P, S, frame, first, L);
     }
 }
 
@@ -2555,12 +2697,12 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     mark();
     hipLaunchKernelGGL(k_line_sort, dim3(nframes), dim3(kLineSortThreads), 0, s, P, nframes);
     mark();
-    static const int welsch_gs = getenv("CTAG_WELSCH_GS") ? std::max(1, atoi(getenv("CTAG_WELSCH_GS"))) : 4;   // blocks per frame for the edges of <= 10 points, 64 per wave
-    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? std::max(1, atoi(getenv("CTAG_WELSCH_GX"))) : 72;   // (both at least 1: the grid's two row ranges each own a class of edges)   // triple ranks per frame with a block of their own; a block loops when a frame has more (342 -> 144 -> 72 once the short edges left: fewer empty blocks)
+    static const int welsch_gs = getenv("CTAG_WELSCH_GS") ? std::max(1, atoi(getenv("CTAG_WELSCH_GS"))) : 1;   // blocks per frame for the edges of <= 10 points, 320 per block
+    static const int welsch_gx = getenv("CTAG_WELSCH_GX") ? std::max(1, atoi(getenv("CTAG_WELSCH_GX"))) : 18;   // (both at least 1: the grid's two row ranges each own a class of edges)   // groups of kWE edges per frame with a block of their own; a block loops when a frame has more (the synthetic frames have ~210 edges of more than 10 points: 17.8 groups)
     if (latency && ws.welsch_rs) {  // one wave per (edge, restart); frames it declines (more edges / longer edges than it holds) fall through to k_welsch
         hipLaunchKernelGGL(k_welsch_lat, dim3(20, 512, nframes), dim3(64), 0, s, P, nframes, ws.welsch_rs);
     }
-    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx + welsch_gs), dim3(64), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr, welsch_gx);
+    hipLaunchKernelGGL(k_welsch, dim3(nframes, welsch_gx + welsch_gs), dim3(kWT), 0, s, P, nframes, latency && ws.welsch_rs ? ws.welsch_rs : (const float*)nullptr, welsch_gx);
     mark();
     if (latency) hipLaunchKernelGGL(k_quad_final<8>, dim3(std::min(ws.cand_cap, kLdsCand) / 8, nframes), dim3(64), 0, s, P, ws.g, nframes);
     else hipLaunchKernelGGL(k_quad_final<1>, dim3(std::min(ws.cand_cap, kLdsCand) / 64, nframes), dim3(64), 0, s, P, ws.g, nframes);
@@ -2571,7 +2713,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
         if (h[16] | h[17] | h[18] | h[19])
             fprintf(stderr, "[whole-wave rdp ticks] corner scan %llu split rounds %llu expand_line %llu clusters + erase %llu\n", h[16], h[17], h[18], h[19]),
             fprintf(stderr, "[whole-wave expand_line] initial sums %llu ticks, %llu rounds, %llu of them through the exact fits\n", h[20], h[21], h[22]);
-        if (h[24]) fprintf(stderr, "[k_welsch_lat ticks] restart 0 of the edges of rank 0 / 2 / 4 / 6: %llu %llu %llu %llu; restart 19: %llu %llu %llu %llu\n", h[24], h[25], h[26], h[27], h[28], h[29], h[30], h[31]);
+        if (h[26]) fprintf(stderr, "[k_welsch] %llu restarts in %llu blocks, %llu (%.1f %%) went on after the regroup at iteration %d\n", h[24], h[26], h[25], 100.0 * h[25] / (h[24] ? h[24] : 1), kWRegroupAt);
+        else if (h[24]) fprintf(stderr, "[k_welsch_lat ticks] restart 0 of the edges of rank 0 / 2 / 4 / 6: %llu %llu %llu %llu; restart 19: %llu %llu %llu %llu\n", h[24], h[25], h[26], h[27], h[28], h[29], h[30], h[31]);
         for (int b = 0; b < 16; b += 8) {
             unsigned long long tot = 0;
             h[b + 0] += h[b + 7];  // the row scan is stamped separately; it belongs to the silhouette phase

@@ -816,7 +816,7 @@ def test_gather_deadline_aborts_instead_of_hanging(dictionary):
         with pytest.raises(capi.CtagError) as ei:
             det.gather_end(out.data_ptr())
         dt = time.perf_counter() - t0
-        assert ei.value.status == capi.ERR_HIP and 0.25 < dt < 1.5, (ei.value, dt)
+        assert ei.value.status == capi.ERR_HIP and 0.25 < dt < 2.0, (ei.value, dt)
         assert "300 ms" in str(ei.value) and "aborted" in str(ei.value)
         # the communicator is dead for every handle that shares it
         for d in (det, det2):

@@ -13,7 +13,7 @@ def collect(d, counter):
             if r["Counter_Name"] == counter:
                 out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return out
-def main(fetch_dir, write_dir, frames_per_launch, tag):
+def main(fetch_dir, write_dir, frames_per_launch, tag, size="1920x1080"):
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     detail, total = {}, 0.0
     for k in SWEEP:
@@ -27,12 +27,11 @@ def main(fetch_dir, write_dir, frames_per_launch, tag):
         corr = 2.0 if k in ("k_decimate", "k_threshold_ccl") else 1.0
         detail[k] = {"fetch_bytes_raw": fetch, "fetch_correction": corr, "write_bytes": write, "hbm_bytes": fetch * corr + write}
         total += fetch * corr + write
-    out = {"tag": tag, "frames_per_launch": frames_per_launch, "sweep_bytes_per_launch": total,
+    out = {"tag": tag, "frame_size": size, "frames_per_launch": frames_per_launch, "sweep_bytes_per_launch": total,
            "sweep_bytes_per_frame": total / frames_per_launch, "kernels": detail,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; KiB -> bytes; "
                      "FETCH_SIZE doubled for the wide streaming-read kernels (gfx950 correction, MI355X_MICROARCH.md)"}
-    rnd = (tag or "r01")[:3]
-    json.dump(out, open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", (tag or "r01") + "_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "")
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "", sys.argv[5] if len(sys.argv) > 5 else "1920x1080")
