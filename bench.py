@@ -162,6 +162,39 @@ def host_stream_rate_bgr(det, frames_dev, m, subpix):
             "note": "ctag_detect_batch_bgr8: pinned host BGR frames in (3 B/px), BGR2GRAY on the device, host results out"}
 
 
+def bgr_resident_rate(det, frames_dev, m, subpix, gray_rate):
+    """Side measurement (never `value`): the same frames as device-resident BGR (main.cpp:52-54 hands cvtColor(BGR2GRAY) a colour frame) through
+    ctag_detect_batch_bgr8_device -- three bytes per pixel from HBM; frames of this size take the direct form (the decimation kernel and edgeRefine
+    convert as they load, no gray image is written: CTAG_OPT_BGR_DIRECT)."""
+    import torch
+    import cylindertag_amd as ca
+    g = frames_dev[:m]
+    bgr = torch.empty((m, ROWS, COLS, 3), dtype=torch.uint8, device=g.device)
+    for c in range(3):
+        bgr[..., c] = g  # gray-valued BGR: the converted image is the gray batch itself (1868 + 9617 + 4899 = 16384)
+    torch.cuda.synchronize()
+    out = torch.zeros((m, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=g.device)
+    ref = torch.zeros_like(out)
+    det.detect_batch_device(g.data_ptr(), m, ROWS, COLS, COLS, ROWS * COLS, ref.data_ptr(), 5, subpix, 5)
+    det.detect_batch_bgr_device(bgr.data_ptr(), m, ROWS, COLS, COLS * 3, ROWS * COLS * 3, out.data_ptr(), 5, subpix, 5)
+    det.sync()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        det.detect_batch_device(g.data_ptr(), m, ROWS, COLS, COLS, ROWS * COLS, ref.data_ptr(), 5, subpix, 5)
+    det.sync()
+    tg = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        det.detect_batch_bgr_device(bgr.data_ptr(), m, ROWS, COLS, COLS * 3, ROWS * COLS * 3, out.data_ptr(), 5, subpix, 5)
+    det.sync()
+    tb = (time.perf_counter() - t0) / reps
+    return {"value": round(m / tb, 1), "unit": "frames/s", "frames": m, "gray_same_frames": round(m / tg, 1), "ratio_to_gray": round(tg / tb, 4),
+            "records_equal_gray_path": bool(torch.equal(out, ref)),
+            "note": "ctag_detect_batch_bgr8_device on device-resident BGR frames (3 B/px read from HBM; a 1080p frame's 6.2 MB against 2.1 MB of gray: "
+                    "the bytes alone bound the ratio near 0.85)"}
+
+
 def pose_side(det, m, dev):
     """Side measurement (never `value`; SURVEY.md 8(f) rank 2 / BASELINE config 5's estimatePose leg): camera content --
     the 64-frame sequence derived from the reference's test.bmp (config 2's test.avi substitute, 5 physical markers in
@@ -834,6 +867,8 @@ def main():
         if world == 1 and args.host_frames > 0:
             side("pcie_inclusive", lambda: host_stream_rate(det, frames, min(args.host_frames, n), subpix))
             side("pcie_inclusive_bgr", lambda: host_stream_rate_bgr(det, frames, min(args.host_frames // 2, n), subpix))
+        if world == 1 and args.host_frames > 0 and frames is not None:
+            side("bgr_device_resident", lambda: bgr_resident_rate(det, frames, min(args.host_frames, n), subpix, out["value"]))
         if world == 1 and args.latency_calls > 0:
             side("single_frame_latency", lambda: latency_side(det, state, fs, args.latency_calls))
         if world == 1 and args.pose_frames > 0:

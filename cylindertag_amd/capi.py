@@ -19,7 +19,7 @@ STAGE_NAMES = ["decimate", "threshold_ccl", "seam_merge", "resolve", "candidates
                "line_sort", "welsch", "quad_final", "features", "edge_refine", "markers"]
 QUAD_STAGES = ["quad_pack", "quad_edges", "quad_edges_big", "line_sort", "welsch", "quad_final"]  # a4: edgeExtraction
 
-OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OPT_WAVE_POINTS, OPT_FUSED_SWEEP, OPT_STREAMS, OPT_EXPAND_EXACT = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_MAX_CHUNK, OPT_TIMING, OPT_KEEP_PREMARKERS, OPT_HOST_SUBCHUNK, OPT_GRAPH, OPT_WAVE_POINTS, OPT_FUSED_SWEEP, OPT_STREAMS, OPT_EXPAND_EXACT, OPT_BGR_DIRECT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 # every symbol include/ctag.h declares (tests check the library exports all of them)
 EXPORTS = ["ctag_create", "ctag_create_ex", "ctag_params_default", "ctag_destroy", "ctag_load_marker_file", "ctag_free", "ctag_detect_u8", "ctag_detect_batch_u8",

@@ -95,6 +95,7 @@ struct ctag_handle {
     int max_chunk = 1024;
     int wave_points = 0;  // CTAG_OPT_WAVE_POINTS
     int fuse_mode = -1;   // CTAG_OPT_FUSED_SWEEP
+    int bgr_direct = 1;   // CTAG_OPT_BGR_DIRECT
     bool timing = false;
     bool keep_pre = false;
     // timing (CTAG_OPT_TIMING): one set of CTAG_NUM_STAGES + 1 events per chunk of a public call, read back ONCE after the
@@ -127,7 +128,7 @@ struct ctag_handle {
         const void* frames = nullptr;
         void* out = nullptr;
         const void* ws_base = nullptr;
-        int n = 0, rows = 0, cols = 0, tw = 0, subpix = 0, dist = 0, keep_pre = 0;
+        int n = 0, rows = 0, cols = 0, tw = 0, subpix = 0, dist = 0, keep_pre = 0, channels = 1;
         ptrdiff_t row_stride = 0, frame_stride = 0;
         const void* pend_src = nullptr;  // PendingCtx::src baked into k_markers' arguments (null: no list)
         hipGraphExec_t exec = nullptr;
@@ -445,7 +446,7 @@ static int enqueue_chunk(ctag_handle* h, const Workspace& ws, const uint8_t* fra
     if (!s) s = h->stream;
     h->last_ws = &ws;
     h->last_out = out_dev;
-    h->last_frames = frames_dev;
+    h->last_frames = p.channels == 3 ? nullptr : frames_dev;  // (BGR frames handed to the chain as they are: no gray rows for the half-size probe to decimate)
     h->last_row_stride = row_stride;
     h->last_frame_stride = frame_stride;
     const bool zero_in_k1 = n <= kLatencyFrames;  // a few frames: one launch less at the head of the chain
@@ -453,9 +454,10 @@ static int enqueue_chunk(ctag_handle* h, const Workspace& ws, const uint8_t* fra
     int st = 0;
     auto mark = [&](int i) -> hipError_t { return evs ? hipEventRecord(evs[i], s) : hipSuccess; };
     HIP_TRY(mark(0));
-    const bool fused = sweep_fused(frames_dev, frame_stride, row_stride, n, ws);  // threshold where the pixels are computed: 1 bit per pixel to K2, no `half`
+    const bool fused = sweep_fused(frames_dev, frame_stride, row_stride, n, ws, p.channels == 3);  // threshold where the pixels are computed: 1 bit per pixel to K2, no `half`
     h->last_fused = fused;
-    HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s, fused, zero_in_k1));
+    if (p.channels == 3 && !fused) return CTAG_ERR_UNSUPPORTED;  // (bgr_direct_ok has checked: BGR frames go through k_bgr2gray otherwise)
+    HIP_TRY(launch_decimate(frames_dev, frame_stride, row_stride, n, ws, s, fused, zero_in_k1, p.channels));
     HIP_TRY(mark(++st));
     HIP_TRY(launch_threshold_ccl(n, ws, s, fused));
     HIP_TRY(mark(++st));
@@ -502,7 +504,7 @@ static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, pt
     for (auto& g : h->graphs)
         if (g.frames == frames_dev && g.out == out_dev && g.ws_base == W.base && g.n == n && g.rows == W.g.rows && g.cols == W.g.cols &&
             g.tw == p.adaptive_thresh && g.subpix == p.corner_subpix && g.dist == p.subpix_dist && g.keep_pre == (h->keep_pre ? 1 : 0) &&
-            g.row_stride == row_stride && g.frame_stride == frame_stride && g.pend_src == (pend.list ? (const void*)pend.src : nullptr))
+            g.row_stride == row_stride && g.frame_stride == frame_stride && g.pend_src == (pend.list ? (const void*)pend.src : nullptr) && g.channels == p.channels)
             hit = &g;
     if (!hit) {
         if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) != hipSuccess) return false;
@@ -543,6 +545,7 @@ static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, pt
         g.keep_pre = h->keep_pre ? 1 : 0;
         g.row_stride = row_stride;
         g.frame_stride = frame_stride;
+        g.channels = p.channels;
         g.exec = exec;
         h->graphs.push_back(g);
         hit = &h->graphs.back();
@@ -550,10 +553,10 @@ static bool run_chunk_graph(ctag_handle* h, const uint8_t* frames_dev, int n, pt
     hit->last_use = ++h->graph_clock;
     h->last_ws = &W;
     h->last_out = out_dev;
-    h->last_frames = frames_dev;
+    h->last_frames = p.channels == 3 ? nullptr : frames_dev;  // (BGR frames handed to the chain as they are: no gray rows for the half-size probe to decimate)
     h->last_row_stride = row_stride;
     h->last_frame_stride = frame_stride;
-    h->last_fused = sweep_fused(frames_dev, frame_stride, row_stride, n, W);
+    h->last_fused = sweep_fused(frames_dev, frame_stride, row_stride, n, W, p.channels == 3);
     return hipGraphLaunch(hit->exec, h->stream) == hipSuccess;
 }
 
@@ -621,13 +624,14 @@ static int collect_timings(ctag_handle* h) {
 // again: `frames_dev` itself for gray calls, the BGR source for colour calls), or null for host-memory calls -- their frames
 // pass through staging slabs that are reused, and they find CTAG_PENDING records in the results they download
 static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, int rows, int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
-                              int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev, const PendingCtx* pend) {
+                              int adaptive_thresh, int corner_subpix, int subpix_dist, ctag_frame_result* out_dev, const PendingCtx* pend, int channels = 1) {
     const int rc = check_args(h, frames_dev, n, rows, cols, row_stride, adaptive_thresh, subpix_dist);
     if (rc != CTAG_OK) return rc;
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
     const int chunk = std::min(n, h->max_chunk);
     DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
+    p.channels = channels;
     static const int two_min = getenv("CTAG_STREAMS_MIN") ? std::max(2 * kLatencyFrames + 2, atoi(getenv("CTAG_STREAMS_MIN"))) : 256;
     if (h->streams >= 2 && !h->timing && chunk >= two_min && h->stream2) {
         const int ns = std::min(h->streams, (int)ctag_handle::kMaxStreams);
@@ -687,7 +691,6 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
 // OpenCV's 8-bit BGR2GRAY is fixed point: (B*1868 + G*9617 + R*4899 + 8192) >> 14 (RGB2Gray<uchar>: B2Y, G2Y, R2Y at yuv_shift 14,
 // [OCV-recall of color_rgb.simd.hpp]; the same formula as the host BMP reader, csrc/ctag_io.h).  A lane converts four pixels:
 // three aligned words in, one word out -- consecutive lanes read consecutive 12-byte groups, so a wave's loads are contiguous.
-__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) { return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14; }
 __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bgr, ptrdiff_t frame_stride, ptrdiff_t row_stride, uint8_t* __restrict__ gray,
                                                   ptrdiff_t gframe_stride, ptrdiff_t grow_stride, int rows, int cols, int aligned) {
     const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
@@ -850,6 +853,17 @@ static int detect_bgr_device_impl(ctag_handle* h, const uint8_t* bgr_dev, int n,
     if (rc != CTAG_OK) return rc;
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
+    // The direct form (round 5): frames of a size the fused sweep takes (1080p, 4K, 8K; adaptiveThresh 5), rows and frames 16-byte aligned -- the
+    // decimation kernel loads the BGR bytes themselves and converts as it consumes them, edgeRefine converts the boxes it stages: no gray image is
+    // written or read back (8.3 of the 24 MB a 1080p frame moved through the gray slab).  CTAG_OPT_BGR_DIRECT 0 turns it off.
+    if (h->bgr_direct && sweep_fused_size(rows, cols, adaptive_thresh, h->fuse_mode) && row_stride < (1 << 24) && (long long)rows * row_stride <= 0xffffffffLL &&
+        (((uintptr_t)bgr_dev | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0) {
+        const PendingCtx pc{h->d_pending, h->d_pending_count, h->pending_cap, bgr_dev, (int64_t)frame_stride, (int64_t)row_stride,
+                            rows, cols, 3, adaptive_thresh, corner_subpix, subpix_dist};
+        const int r = detect_device_impl(h, bgr_dev, n, rows, cols, row_stride, frame_stride, adaptive_thresh, corner_subpix, subpix_dist, out_dev, &pc, 3);
+        h->last_was_bgr = false;  // no gray image to probe
+        return r;
+    }
     const int chunk = std::min(n, h->max_chunk);
     const int gr = ensure_gray(h, chunk, rows, cols);
     if (gr != CTAG_OK) return gr;
@@ -1131,6 +1145,10 @@ int ctag_set_option(ctag_handle* h, int option, int64_t value) {
         case CTAG_OPT_FUSED_SWEEP:
             if (value < 0 || value > 2) return CTAG_ERR_ARG;
             h->fuse_mode = (int)value;
+            drop_graphs(h);
+            return CTAG_OK;
+        case CTAG_OPT_BGR_DIRECT:
+            h->bgr_direct = value != 0;
             drop_graphs(h);
             return CTAG_OK;
         case CTAG_OPT_HOST_SUBCHUNK:

@@ -208,13 +208,33 @@ struct DetectParams {
     int dict_rows, dict_cols;
     const int32_t* dict;  // device pointer
     const uint32_t* dict_pos;  // device pointer: [dict_rows][64] column sets per symbol (k_markers), null for > 32 columns
+    int channels = 1;  // 3: the chunk's frames are 8-bit BGR (3 bytes per pixel) and the kernels that read pixels -- the fused decimation, edgeRefine -- convert as they load (bgr_fused)
 };
+#if defined(__HIPCC__)
+// cvtColor(BGR2GRAY) on 8-bit pixels is fixed point in OpenCV: (B*1868 + G*9617 + R*4899 + 8192) >> 14 (RGB2Gray<uchar>: B2Y, G2Y, R2Y at yuv_shift 14,
+// [OCV-recall of color_rgb.simd.hpp]; the same formula as the host BMP reader, csrc/ctag_io.h)
+__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) { return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14; }
+// ... of four pixels at once: twelve bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 -> four gray bytes.  The weights split into bytes (1868 = 7 * 256 + 76,
+// 9617 = 37 * 256 + 145, 4899 = 19 * 256 + 35), so a pixel is two v_dot4_u32_u8 of its three bytes against (76, 145, 35) and (7, 37, 19) -- no byte extraction
+__device__ __forceinline__ uint32_t gray4_of(uint32_t w0, uint32_t w1, uint32_t w2) {
+    constexpr uint32_t kLo = 76u | (145u << 8) | (35u << 16), kHi = 7u | (37u << 8) | (19u << 16);
+    constexpr uint32_t kLo1 = kLo << 8, kHi1 = kHi << 8;  // the weights against bytes 1..3 of a word (pixel 3 sits there)
+    const uint32_t p1 = __builtin_amdgcn_alignbyte(w1, w0, 3), p2 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+    const uint32_t g0 = ((__builtin_amdgcn_udot4(w0, kHi, 0u, false) << 8) + __builtin_amdgcn_udot4(w0, kLo, 8192u, false)) >> 14;
+    const uint32_t g1 = ((__builtin_amdgcn_udot4(p1, kHi, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, kLo, 8192u, false)) >> 14;
+    const uint32_t g2 = ((__builtin_amdgcn_udot4(p2, kHi, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, kLo, 8192u, false)) >> 14;
+    const uint32_t g3 = ((__builtin_amdgcn_udot4(w2, kHi1, 0u, false) << 8) + __builtin_amdgcn_udot4(w2, kLo1, 8192u, false)) >> 14;
+    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+}
+#endif
 
 // kernel launchers (each enqueues on `s`, returns hipGetLastError())
 hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s);  // frame_ncomp, frame_flags, line_count, clp_used, ovf_count
 // fused: k_decimate_mask + the mask front end of K2 (1 bit per pixel between them, no `half`) -- sweep_fused says when that form applies
-bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws);
-hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused = false, bool zero_too = false);
+bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, bool always = false);
+bool sweep_fused_size(int rows, int cols, int tw, int fuse_mode);
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused = false, bool zero_too = false,
+                           int channels = 1);  // channels = 3: BGR frames, fused form only
 hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s, bool fused = false);
 hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s);

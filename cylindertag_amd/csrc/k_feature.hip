@@ -462,6 +462,7 @@ struct RefinePtrs {
     FeatureDev* feat2;
     double* n0;          // [F][CTAG_MAX_FEATURES * 2][4][kRefineSamples]: the search kernel's result per sample (NaN: no edge point), MODE 1 -> 2
     int32_t* frame_long; // [F] 1: the frame has a quad with an edge of more than kRefineSamples samples (those quads take the one-kernel form)
+    int ch;              // 1: gray frames; 3: BGR frames (3 bytes per pixel), converted -- cvtColor(BGR2GRAY), gray_of -- where a pixel is loaded
 };
 constexpr int kRefineSamples = 128;               // samples of an edge searched per pass (the reference's minimum sample count, :615)
 constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: waves 0-1 edge e, waves 2-3 edge e + 1
@@ -673,38 +674,65 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             // inside its row (almost always) the loads are plain -- with the general form's per-thread test inside, every load of the
             // unrolled groups below came out as byte loads + a wait + a word load, one round trip to memory PER ROW (the staging phase
             // was 64 % of a search block's lifetime).
-            auto stage_rows = [&](auto load) {
+            // `load`: what row r of this thread's column needs from memory (requested for a batch of rows before anything is used), `conv`: that -> the word of
+            // four gray pixels
+            auto stage_rows = [&](auto load, auto conv) {
                 int r = r0;
                 if constexpr (MODE == 1) {
                     // the search kernel has its registers free at this point: twelve rows in flight (the usual 10 KB box: 10 per thread)
                     constexpr int kDeep = CTAG_REFINE_STAGE_DEEP;
                     for (; r + (kDeep - 1) * rpp < box_rows; r += kDeep * rpp) {
-                        uint32_t v[kDeep];
+                        decltype(load(0)) v[kDeep];
 #pragma unroll
                         for (int u = 0; u < kDeep; u++) v[u] = load(r + u * rpp);
 #pragma unroll
-                        for (int u = 0; u < kDeep; u++) *reinterpret_cast<uint32_t*>(s_reg + (r + u * rpp) * box_pitch + c4) = v[u];
+                        for (int u = 0; u < kDeep; u++) *reinterpret_cast<uint32_t*>(s_reg + (r + u * rpp) * box_pitch + c4) = conv(v[u]);
                     }
                 }
                 for (; r + 3 * rpp < box_rows; r += 4 * rpp) {
-                    const uint32_t v0 = load(r), v1 = load(r + rpp), v2 = load(r + 2 * rpp), v3 = load(r + 3 * rpp);
-                    *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = v0;
-                    *reinterpret_cast<uint32_t*>(s_reg + (r + rpp) * box_pitch + c4) = v1;
-                    *reinterpret_cast<uint32_t*>(s_reg + (r + 2 * rpp) * box_pitch + c4) = v2;
-                    *reinterpret_cast<uint32_t*>(s_reg + (r + 3 * rpp) * box_pitch + c4) = v3;
+                    const auto v0 = load(r), v1 = load(r + rpp), v2 = load(r + 2 * rpp), v3 = load(r + 3 * rpp);
+                    *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = conv(v0);
+                    *reinterpret_cast<uint32_t*>(s_reg + (r + rpp) * box_pitch + c4) = conv(v1);
+                    *reinterpret_cast<uint32_t*>(s_reg + (r + 2 * rpp) * box_pitch + c4) = conv(v2);
+                    *reinterpret_cast<uint32_t*>(s_reg + (r + 3 * rpp) * box_pitch + c4) = conv(v3);
                 }
-                for (; r < box_rows; r += rpp) *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = load(r);
+                for (; r < box_rows; r += rpp) *reinterpret_cast<uint32_t*>(s_reg + r * box_pitch + c4) = conv(load(r));
             };
-            if (aligned && box_x0 + box_pitch <= cols) {
-                stage_rows([&](int r) -> uint32_t { return *reinterpret_cast<const uint32_t*>(img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx); });
+            auto same = [](uint32_t v) -> uint32_t { return v; };
+            if (P.ch == 3) {  // BGR frames: four pixels are twelve bytes, converted as they are staged
+                struct W3 {
+                    uint32_t a, b, c;
+                };
+                if (aligned && box_x0 + box_pitch <= cols) {
+                    stage_rows(
+                        [&](int r) -> W3 {
+                            const uint32_t* src = reinterpret_cast<const uint32_t*>(img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + 3 * gx);
+                            return W3{src[0], src[1], src[2]};
+                        },
+                        [](const W3& w) -> uint32_t { return gray4_of(w.a, w.b, w.c); });
+                } else {
+                    stage_rows(
+                        [&](int r) -> uint32_t {
+                            const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + 3 * gx;
+                            uint32_t v = 0;
+                            for (int k = 0; k < 4; k++)
+                                if (gx + k < cols) v |= gray_of(src[3 * k], src[3 * k + 1], src[3 * k + 2]) << (8 * k);
+                            return v;
+                        },
+                        same);
+                }
+            } else if (aligned && box_x0 + box_pitch <= cols) {
+                stage_rows([&](int r) -> uint32_t { return *reinterpret_cast<const uint32_t*>(img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx); }, same);
             } else {
-                stage_rows([&](int r) -> uint32_t {
-                    const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx;
-                    uint32_t v = 0;
-                    for (int k = 0; k < 4; k++)
-                        if (gx + k < cols) v |= (uint32_t)src[k] << (8 * k);
-                    return v;
-                });
+                stage_rows(
+                    [&](int r) -> uint32_t {
+                        const uint8_t* src = img + (size_t)__umul24((unsigned)(box_y0 + r), rs) + gx;
+                        uint32_t v = 0;
+                        for (int k = 0; k < 4; k++)
+                            if (gx + k < cols) v |= (uint32_t)src[k] << (8 * k);
+                        return v;
+                    },
+                    same);
             }
         }
         __syncthreads();
@@ -803,7 +831,14 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
                 // the normal search of this sample (:623-657): ctag_refine.h -- the fast form where every pixel of the search is
                 // inside the image, the reference's own arithmetic otherwise or when the fast form declines
                 double Mn = 0, Mcount = 0;
-                auto px = [&](int x, int y) -> unsigned { return img[__umul24((unsigned)y, rs) + (unsigned)x]; };  // 32-bit pixel offsets (checked by the API)
+                const bool bgr = P.ch == 3;
+                auto px = [&](int x, int y) -> unsigned {  // 32-bit pixel offsets (checked by the API)
+                    if (bgr) {
+                        const uint8_t* q = img + __umul24((unsigned)y, rs) + 3u * (unsigned)x;
+                        return gray_of(q[0], q[1], q[2]);
+                    }
+                    return img[__umul24((unsigned)y, rs) + (unsigned)x];
+                };
                 bool done = false;
                 if (subpix <= ctr::kFastMaxSubpix && ctr::interior(x0, y0, nx, ny, subpix, rows, cols)) {
                     if (staged) {  // the walk runs in box coordinates: the address is one multiply-add
@@ -1693,7 +1728,7 @@ hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams&
 }
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s) {
     if (!p.corner_subpix) return hipSuccess;
-    RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2, ws.refine_n0, ws.frame_long};
+    RefinePtrs P{frames, frame_stride, row_stride, ws.nfeat, ws.status, ws.feat1, ws.feat2, ws.refine_n0, ws.frame_long, p.channels == 3 ? 3 : 1};
     static const int refine_gx = getenv("CTAG_REFINE_GX") ? atoi(getenv("CTAG_REFINE_GX")) : 32;  // looping blocks per frame of the other forms
     const bool few = nframes <= kLatencyFrames || !CTAG_REFINE_SPLIT;
     const dim3 grid(few ? CTAG_MAX_FEATURES * 2 : refine_gx, nframes);  // a few frames: a block per quad -- the call is as long as its longest block, and looping blocks triple it

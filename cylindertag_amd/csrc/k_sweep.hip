@@ -28,7 +28,7 @@ static inline int grid_for(int nframes, int per_frame) { return ((nframes + 7) /
 constexpr int kFuseCols = 960;     // half-resolution columns per wave
 constexpr int kFuseLanes = 60;     // ... = 60 lanes x 16 pixels
 constexpr int kFuseTiles = kFuseCols / 5;
-static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s);
+static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, int channels);
 
 // =====================================================================================================
 // K1: bicubic 2x decimation, u8 -> u8.  OpenCV resize(INTER_CUBIC) for an exact 2x scale has the fixed
@@ -392,20 +392,32 @@ __global__ __launch_bounds__(256) void k_decimate_general(const uint8_t* __restr
 // The fused sweep (k_decimate_mask + the mask front end of K2) takes batches of frames whose half size is a multiple of 960 x 135
 // (1080p, 4K, 8K) with the reference's 5x5 window and 16-byte aligned rows; everything else keeps the two-kernel form with `half`.
 // CTAG_FUSED_SWEEP=0 (developer aid, A/B) turns it off.
-bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws) {
+static int fuse_env() {
     static const int env_mode = getenv("CTAG_FUSED_SWEEP") ? atoi(getenv("CTAG_FUSED_SWEEP")) : -1;
-    const int env = ws.fuse_mode >= 0 ? ws.fuse_mode : env_mode >= 0 ? env_mode : 1;  // CTAG_OPT_FUSED_SWEEP: 0 never, 1 batches (default), 2 whenever the frame size allows
+    return env_mode;
+}
+// the frame sizes the fused sweep takes (adaptiveThresh 5; half size a multiple of 960 x 540: 1080p, 4K, 8K), whatever the batch
+bool sweep_fused_size(int rows, int cols, int tw, int fuse_mode) {
+    const int env = fuse_mode >= 0 ? fuse_mode : fuse_env() >= 0 ? fuse_env() : 1;
+    if (!env || (rows & 1) || (cols & 1) || tw != 5) return false;
+    const int hcols = cols / 2, hrows = rows / 2;
+    return hcols % kFuseCols == 0 && hrows % 135 == 0 && (hrows / 135) % 4 == 0;
+}
+// always: BGR frames (they take this form or none: the caller has checked sweep_fused_size and the alignment)
+bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, bool always) {
+    const int env = ws.fuse_mode >= 0 ? ws.fuse_mode : fuse_env() >= 0 ? fuse_env() : 1;  // CTAG_OPT_FUSED_SWEEP: 0 never, 1 batches (default), 2 whenever the frame size allows
     const FrameGeom& g = ws.g;
-    if (!env || (g.rows & 1) || (g.cols & 1) || g.tw != 5 || g.hcols % kFuseCols != 0 || g.hrows % 135 != 0) return false;
+    if (!sweep_fused_size(g.rows, g.cols, g.tw, ws.fuse_mode)) return false;
     if ((((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) != 0) return false;
     const int bands = g.hrows / 135;
-    if (env < 2 && (long)nframes * (g.hcols / kFuseCols) * bands < 2048) return false;  // few frames: short bands and the latency-tuned kernels (launch_decimate)
-    return bands % 4 == 0;
+    if (!always && env < 2 && (long)nframes * (g.hcols / kFuseCols) * bands < 2048) return false;  // few frames: short bands and the latency-tuned kernels (launch_decimate)
+    return true;
 }
 
 hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s);
 // zero_too: the chain's counters have not been zeroed (a call of a few frames): the run-time-band kernel does it, any other form gets k_zero_counters first
-hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused, bool zero_too) {
+hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused, bool zero_too, int channels) {
+    if (channels != 1 && !(channels == 3 && fused)) return hipErrorInvalidValue;  // BGR frames take the fused sweep or none (bgr_fused, ctag_api.hip)
     const FrameGeom& g = ws.g;
     const bool general = (g.rows & 1) || (g.cols & 1) || getenv("CTAG_GENERAL_RESIZE");
     ZeroList Z{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -418,7 +430,7 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
             Z = ZeroList{ws.frame_ncomp, ws.frame_flags, ws.line_count, ws.clp_used, ws.ovf_count, nframes};
         }
     }
-    if (fused) return launch_decimate_mask(frames, frame_stride, row_stride, nframes, ws, s);
+    if (fused) return launch_decimate_mask(frames, frame_stride, row_stride, nframes, ws, s, channels);
     if (general) {  // odd sizes (env: developer aid, runs even sizes through the general kernel)
         hipLaunchKernelGGL(k_decimate_general, dim3((g.hcols + 255) / 256, g.hrows, nframes), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g,
                            nframes, ws.rz_xofs, ws.rz_alpha, ws.rz_yofs, ws.rz_beta);
@@ -748,6 +760,29 @@ __device__ __forceinline__ Raw32 load_row_fuse(const uint8_t* __restrict__ rowp,
     r.w[4] = b.x, r.w[5] = b.y, r.w[6] = b.z, r.w[7] = b.w;
     return r;
 }
+// The same 32 pixels of a BGR row (CH == 3: frames handed over as the camera delivers them, main.cpp:52-54): 96 bytes per lane, converted to gray -- OpenCV's
+// fixed-point cvtColor(BGR2GRAY), gray4_of -- when the row is consumed; the gray image is never written (ctag_detect_batch_bgr8_device, bgr_fused)
+template <int CH>
+struct RawSrc {
+    uint32_t w[8 * CH];
+};
+template <int CH>
+__device__ __forceinline__ RawSrc<CH> load_row_src(const uint8_t* __restrict__ rowp, int x0) {  // every lane loads (inactive ones an in-row dummy): no branch around the loads
+    RawSrc<CH> r;
+#pragma unroll
+    for (int i = 0; i < 2 * CH; i++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(rowp + (ptrdiff_t)CH * x0 + 16 * i);
+        r.w[4 * i] = a.x, r.w[4 * i + 1] = a.y, r.w[4 * i + 2] = a.z, r.w[4 * i + 3] = a.w;
+    }
+    return r;
+}
+template <int CH>
+__device__ __forceinline__ Raw32 gray_row(const RawSrc<CH>& r) {
+    Raw32 g;
+#pragma unroll
+    for (int i = 0; i < 8; i++) g.w[i] = CH == 3 ? gray4_of(r.w[(3 * i) % (8 * CH)], r.w[(3 * i + 1) % (8 * CH)], r.w[(3 * i + 2) % (8 * CH)]) : r.w[i % (8 * CH)];
+    return g;
+}
 // lane i <- lane i - 1 / lane i + 1 across the whole wave (DPP wave_shr:1 / wave_shl:1)
 __device__ __forceinline__ uint32_t wave_from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t wave_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
@@ -766,8 +801,8 @@ __device__ __forceinline__ void hpass_fuse(const Raw32& r, int lane, bool left_e
     t.right2 = right2;
     hpass_wide(t, q);
 }
-template <int BAND, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_decimate_mask(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
+template <int BAND, int WAVES, int CH = 1>  // CH = 3: BGR frames (four source rows of 96 bytes per lane in flight: two waves per SIMD hold them)
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 2 : 3, CH == 3 ? 2 : 3))) void k_decimate_mask(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
                                                                                                     uint8_t* __restrict__ mask, FrameGeom g, KParams kp, int nframes, int xblocks,
                                                                                                     int yblocks) {
     static_assert(BAND % 5 == 0, "a band is whole threshold-tile rows");
@@ -920,12 +955,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
         }
     };
     uint32_t qa[8], qb[8], qc[8], qd[8];
-    auto hp = [&](const Raw32& r, uint32_t (&q)[8]) __attribute__((always_inline)) { hpass_fuse(r, lane, left_edge, right_edge, q); };
+    using Src = RawSrc<CH>;
+    auto ld = [&](int r) __attribute__((always_inline)) { return load_row_src<CH>(rowp(r), x0); };
+    auto hp = [&](const Src& r, uint32_t (&q)[8]) __attribute__((always_inline)) { hpass_fuse(gray_row<CH>(r), lane, left_edge, right_edge, q); };
     {
-        const Raw32 ra = load_row_fuse(rowp(2 * ys - 1), x0);
-        const Raw32 rb = load_row_fuse(rowp(2 * ys), x0);
-        const Raw32 rc = load_row_fuse(rowp(2 * ys + 1), x0);
-        const Raw32 rd = load_row_fuse(rowp(2 * ys + 2), x0);
+        const Src ra = ld(2 * ys - 1);
+        const Src rb = ld(2 * ys);
+        const Src rc = ld(2 * ys + 1);
+        const Src rd = ld(2 * ys + 2);
         hp(ra, qa);
         hp(rb, qb);
         hp(rc, qc);
@@ -937,11 +974,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int k = 0; k < 4; k++) o[k] = vpack4(vpass2(a[2 * k], b[2 * k], c[2 * k], d[2 * k], 0), vpass2(a[2 * k + 1], b[2 * k + 1], c[2 * k + 1], d[2 * k + 1], 0));
         row_done(y, o);
     };
-    Raw32 n0 = load_row_fuse(rowp(2 * ys + 3), x0);
-    Raw32 n1 = load_row_fuse(rowp(2 * ys + 4), x0);
+    Src n0 = ld(2 * ys + 3);
+    Src n1 = ld(2 * ys + 4);
     for (int y = ys; y < ye; y += 2) {
-        const Raw32 m0 = load_row_fuse(rowp(2 * y + 5), x0);
-        const Raw32 m1 = load_row_fuse(rowp(2 * y + 6), x0);
+        const Src m0 = ld(2 * y + 5);
+        const Src m1 = ld(2 * y + 6);
         emit(y, qa, qb, qc, qd);
         uint32_t qe[8], qf[8];
         hp(n0, qe);
@@ -952,17 +989,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
             qa[i] = qe[i];
             qb[i] = qf[i];
         }
-        n0 = load_row_fuse(rowp(2 * y + 7), x0);
-        n1 = load_row_fuse(rowp(2 * y + 8), x0);
+        n0 = ld(2 * y + 7);
+        n1 = ld(2 * y + 8);
         hp(m0, qc);
         hp(m1, qd);
     }
     if (ye == g.hrows) emit_tile_row(g.trows - 1);  // the frame's last tile row has no lower neighbour: a border row (bound 0)
 }
 
-static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s) {
+static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, int channels) {
     const FrameGeom& g = ws.g;
     const int xb = g.hcols / kFuseCols;
+    if (channels == 3) {  // BGR frames: converted where they are loaded
+        const int yblocks = g.hrows / 135 / 4;
+        hipLaunchKernelGGL((k_decimate_mask<135, 4, 3>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+        return hipGetLastError();
+    }
     static const int band_env = getenv("CTAG_FUSE_BAND") ? atoi(getenv("CTAG_FUSE_BAND")) : 135;  // developer aid (A/B): 270-row bands in two-wave blocks
     if (band_env == 270 && g.hrows % 540 == 0) {
         const int yblocks = g.hrows / 270 / 2;
@@ -1458,6 +1500,10 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
         if (tid == 0) base_reg = reserve(npub);
         CCL_SYNC();
     }
+    // The reservation's result goes to LDS NOW, before the label stores are issued: the vector-memory counter is served in order, so the wait for a value
+    // requested before the stores, taken after them, is a wait for every label store of wave 0 as well -- and the other waves then wait for wave 0 at the
+    // barrier (phase clocks, round 5: 21 % of a tile's lifetime in "publish").  Here only the atomic itself is outstanding, issued a phase ago.
+    if (tid == 0) misc_s[9] = base_reg;
     // ---- S11: per-pixel tile-local labels, 8 pixels (16 bytes) per lane
     {
         uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
@@ -1506,8 +1552,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     }
     stamp(8);
     // ---- S10: publish the tile's components in the frame pool
-    if (tid == 0) misc_s[9] = base_reg;
-    CCL_SYNC();  // also orders the S9 LDS atomics before the reads below
+    CCL_SYNC();  // misc_s[9] (the pool entries' base, stored before S11); also orders the S9 LDS atomics before the reads below
     const int base = misc_s[9];
     if (base < 0) {  // second pass only: the frame's pool is exhausted
         // S11 has stored this tile's labels: the dirty bits must say so although the tile publishes nothing (the frame is rerun through the

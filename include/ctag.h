@@ -133,6 +133,9 @@ void* ctag_stream(ctag_handle* h);
 #define CTAG_OPT_FUSED_SWEEP 7     /* the threshold + label sweep as k_decimate_mask -> k_threshold_ccl (thresholds where the half-size pixels are computed, hands
                                       1 bit per pixel on; frames whose half size is a multiple of 960 x 135 -- 1080p, 4K, 8K -- with adaptiveThresh 5):
                                       0 never, 1 (default) batches of 512 frames' worth of bands and more, 2 whenever the frame size allows.  Results do not depend on it. */
+#define CTAG_OPT_BGR_DIRECT 10     /* 1 (default): ctag_detect_batch_bgr8_device hands BGR frames of a size the fused sweep takes (see CTAG_OPT_FUSED_SWEEP), with
+                                      16-byte aligned rows and frames, to the chain as they are -- the decimation kernel and edgeRefine convert (cvtColor(BGR2GRAY),
+                                      main.cpp:36,52-54) as they load, no gray image is written; 0: always convert into a gray image first.  Results do not depend on it. */
 int ctag_set_option(ctag_handle* h, int option, int64_t value);
 
 /* Per-stage device time of the LAST ctag_detect_batch_* call, milliseconds measured with HIP events on

@@ -998,15 +998,55 @@ def test_bgr_ingest_equals_gray_path(detector, oracle, dictionary, test_bmp):
     out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     detector.set_option(capi.OPT_MAX_CHUNK, 4)  # three chunks through one gray slab
+    detector.set_option(capi.OPT_BGR_DIRECT, 0)  # the two-step form: k_bgr2gray into a gray image, then the chain
     try:
         detector.detect_batch_bgr_device(dev.data_ptr(), n, rows, cols, cols * 3, rows * cols * 3, out.data_ptr())
         detector.sync()
     finally:
         detector.set_option(capi.OPT_MAX_CHUNK, 1024)
+        detector.set_option(capi.OPT_BGR_DIRECT, 1)
     got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
     for f in range(n):
         assert_same_record(got[f], want[f], "bgr device batch frame %d" % f)
     assert (detector.debug(1, tk.DBG_GRAY).reshape(rows, cols) == grays[9]).all()  # the last chunk held frames 8, 9
+    # the direct form (default for 1080p / 4K / 8K frames with 16-byte aligned rows): the decimation kernel and edgeRefine read the BGR bytes themselves
+    # and convert as they load -- no gray image exists (the probe says so), the records are the same; in one chunk and in chunks of 4
+    for chunk in (1024, 4):
+        detector.set_option(capi.OPT_MAX_CHUNK, chunk)
+        try:
+            out.zero_()
+            detector.detect_batch_bgr_device(dev.data_ptr(), n, rows, cols, cols * 3, rows * cols * 3, out.data_ptr())
+            detector.sync()
+        finally:
+            detector.set_option(capi.OPT_MAX_CHUNK, 1024)
+        got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+        for f in range(n):
+            assert_same_record(got[f], want[f], "bgr device batch, direct form, chunk %d, frame %d" % (chunk, f))
+        with pytest.raises(ca.CtagError):
+            detector.debug(0, tk.DBG_GRAY)
+    # rows that are not 16-byte aligned (a 4-byte pad per row) take the two-step form by themselves
+    padded = torch.zeros((n, rows, cols * 3 + 4), dtype=torch.uint8, device="cuda")
+    padded[:, :, :cols * 3] = dev.reshape(n, rows, cols * 3)
+    torch.cuda.synchronize()
+    out.zero_()
+    detector.detect_batch_bgr_device(padded.data_ptr(), n, rows, cols, cols * 3 + 4, rows * (cols * 3 + 4), out.data_ptr())
+    detector.sync()
+    got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    for f in range(n):
+        assert_same_record(got[f], want[f], "bgr device batch, padded rows, frame %d" % f)
+    del padded
+    # a 4K BGR frame pair through the direct form (two waves per row: the seam lanes convert their halo pixels too)
+    big = np.stack([_colourise(tk.synth_frame_host(state, 300 + f, rows=2160, cols=3840)[0], 5 + f) for f in range(2)])
+    want4k = [oracle.detect_fast(oracle.bgr2gray(b), state, fs) for b in big]
+    bdev = torch.from_numpy(big).cuda()
+    out4k = torch.zeros((2, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    detector.detect_batch_bgr_device(bdev.data_ptr(), 2, 2160, 3840, 3840 * 3, 2160 * 3840 * 3, out4k.data_ptr())
+    detector.sync()
+    got = np.frombuffer(out4k.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    for f in range(2):
+        assert_same_record(got[f], want4k[f], "4K bgr frame %d, direct form" % f)
+    del bdev, big
     with pytest.raises(ca.CtagError):
         detector.detect_batch_bgr_device(dev.data_ptr(), n, rows, cols, cols * 3 - 1, rows * cols * 3, out.data_ptr())  # stride < 3 * cols
     # a gray call afterwards leaves no stale gray view
