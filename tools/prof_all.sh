@@ -1,5 +1,5 @@
-# usage: tools/prof_all.sh r03   (the round's tag)
-TAG=${1:-r03}
+# usage: tools/prof_all.sh r05   (the round's tag): every profile the round commits, into gpurun_out/ (copy to profiles/ by hand)
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 bash tools/pmc_instmix.sh ${TAG} > gpurun_out/instmix.log 2>&1; tail -3 gpurun_out/instmix.log
 cp profiles/${TAG}_pmc_instmix.json gpurun_out/${TAG}_pmc_instmix.json
@@ -12,3 +12,8 @@ rm -rf gpurun_out/ks gpurun_out/ksl gpurun_out/im_*
 python3 bench.py > gpurun_out/${TAG}_bench_4096.json 2> gpurun_out/bench_err.log; tail -c 600 gpurun_out/${TAG}_bench_4096.json
 python3 bench.py --size 3840x2160 --frames 1024 --chunk 1024 > gpurun_out/${TAG}_bench_4k_1024.json 2>> gpurun_out/bench_err.log; tail -c 300 gpurun_out/${TAG}_bench_4k_1024.json
 bash tools/pmc_traffic.sh ${TAG} > gpurun_out/traffic.log 2>&1; tail -4 gpurun_out/traffic.log
+bash tools/pmc_traffic.sh ${TAG}_4k 3840x2160 256 > gpurun_out/traffic4k.log 2>&1; tail -4 gpurun_out/traffic4k.log
+rm -rf gpurun_out/ks4
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks4 -- python3 bench.py --size 3840x2160 --frames 1024 --chunk 1024 --streams 1 --pipelined-steps 0 --cpu-frames 0 --host-frames 0 --pose-frames 0 --latency-calls 0 > gpurun_out/ks4_bench.log 2>&1; tail -1 gpurun_out/ks4_bench.log | cut -c1-200
+find gpurun_out/ks4 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_kernel_stats_bench4k_1024.csv
+rm -rf gpurun_out/ks4
