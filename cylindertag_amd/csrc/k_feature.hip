@@ -476,51 +476,19 @@ constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: wa
 #define CTAG_REFINE_REGION 21504                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
 #endif
 constexpr int kRefineRegion = CTAG_REFINE_REGION;
-#ifndef CTAG_REFINE_TAILS
-#define CTAG_REFINE_TAILS 4
-#endif
-constexpr int kRefineTails = CTAG_REFINE_TAILS;  // quads whose tails k_edge_refine<2> runs together (8 lanes each for the lines, 4 for the corners); 4: 19.4 KB of LDS, eight blocks per CU
 
 // MODE 0: the whole of edgeRefine for a (feature, quad) in one block of 256 -- calls of a few frames, and quads with an edge of more
 //         than kRefineSamples samples (edges longer than 1024 px; `only_long`).
 // MODE 1: the searches only (256 threads): per sample n0 = Mn / Mcount goes to P.n0 (NaN: no edge point).  No sample rows in LDS, so
 //         a block is the 21.5 KB pixel box and little else.
-// MODE 2: the ordered sums, line parameters and corners only (ONE wave per quad): rebuilds every sample's point from n0 with the
-//         search's own expressions and continues as MODE 0 does.
-// Batches run 1 then 2 (then 0 for the rare long quads).  In one kernel the serial tail -- 48 chains of 128 dependent FP64 adds on one
+// The ordered sums, line parameters and corners of a batch are kernels of their own: k_edge_refine_sums (one wave per quad: rebuilds every sample's point from
+// n0 with the search's own expressions) and k_edge_refine_tail, below.
+// Batches run MODE 1, the sums, the tails (then MODE 0 for the rare long quads).  In one kernel the serial tail -- 48 chains of 128 dependent FP64 adds on one
 // wave, then divisions / atan2 / sin / cos on 8 lanes -- held a 40 KB, four-wave block while three of its waves idled, at four
 // blocks per CU; apart, the search blocks are smaller and the tails of many quads overlap each other.
 #ifndef CTAG_REFINE_SEARCH_WAVES
 #define CTAG_REFINE_SEARCH_WAVES 4
 #endif
-// what k_edge_refine<2> needs from global memory for one quad, requested ahead of its use (a looping block asks for the next quad's
-// while it works on the current one's): the search kernel's n0 of the lane's eight samples and, lanes 0-3, a corner
-#ifndef CTAG_REFINE_SEG
-#define CTAG_REFINE_SEG 32
-#endif
-constexpr int kRefineSeg = CTAG_REFINE_SEG;  // samples of an edge the sums kernel holds in LDS at a time (a divisor of 64)
-static_assert(kRefineSeg == 32 || kRefineSeg == 64, "k_edge_refine<2>: items per lane and segment");
-// the sums kernel's lane <-> sample map: in segment g a lane builds items i = 0 .. 4 kRefineSeg / 64 - 1: with idx = 64 i + tid, the sample
-// kRefineSeg g + idx % kRefineSeg of edge idx / kRefineSeg
-struct RefinePrefetch {
-    double n0[(4 * kRefineSamples) / 64];  // [segment][item]
-    float cx, cy;
-};
-__device__ __forceinline__ void refine_prefetch(const RefinePtrs& P, int frame, int qidx, RefinePrefetch& R) {
-    const int tid = threadIdx.x;
-    const double* src = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples);
-    constexpr int kIps = 4 * kRefineSeg / 64;
-#pragma unroll
-    for (int u = 0; u < (4 * kRefineSamples) / 64; u++) {
-        const int g = u / kIps, idx = (u % kIps) * 64 + tid;
-        R.n0[u] = src[(idx / kRefineSeg) * kRefineSamples + g * kRefineSeg + idx % kRefineSeg];
-    }
-    const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + (qidx >> 1);
-    const int c = (qidx & 1) * 4 + (tid & 3);
-    R.cx = F->c[2 * c];
-    R.cy = F->c[2 * c + 1];
-}
-
 // Tail of edgeRefine for one quad, from its 48 ordered sums A[edge * 12 + pass * 6 + {Mx, My, Mxx, Mxy, Myy, N}]:
 // refine_line: the line of (edge, pass) -> L = {Ex, Ey, nx, ny} (:667-678 / :743-754); refine_corner: corner `it` from the lines (:757-776).
 __device__ __forceinline__ void refine_line(const double* A, double* L) {
@@ -560,9 +528,7 @@ __device__ __forceinline__ void refine_corner(const double* A, int it, int off, 
 }
 
 template <int MODE>
-__device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long,
-                                            const RefinePrefetch* pre = nullptr, double* acc_out = nullptr, double alpha128 = 0.0) {
-    // MODE 2: returns true with the quad's 48 sums in acc_out (the caller runs the tail for several quads at once); else false
+__device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long, double alpha128 = 0.0) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
     // 16 columns of per-sample values: rows 0-3 x of edge 0-3, 4-7 y, 8-11 weight towards the next corner, 12-15 towards the
@@ -570,14 +536,8 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     // pairs: the accumulation reads one element of up to 9 rows per instruction.
     // row 16 holds ones: the factors "1" of the sums Mx = (x * 1) * w, N = (1 * 1) * w are read like any other column, so that
     // every lane of the accumulation walks three unit-stride columns (immediate offsets, no address arithmetic in the loop)
-    // (the sums kernel reads its rows two doubles at a time -- ds_read_b128 moves 16 bytes per lane at twice the rate of the ds_read2_b64 an
-    // 8-byte-aligned row gets -- so its rows are 16-byte aligned: 130 doubles, rows 0-15 then cover the 64 banks exactly once)
-    // MODE 2 (the sums kernel) works on an edge's 128 samples in segments of kRefineSeg = 32: short rows, so that the PRODUCTS x x, x y, y y of every
-    // sample (rows 16-27, written once where the sample is built) fit as well -- a sum then reads two rows per term, (A B) and w, instead of three
-    // (A, B, w): the same two roundings, (A B) first, then times w -- in 9.8 KB instead of 17.8.  The kernel lives on its occupancy: with full-length
-    // rows the products cost 32 KB and it went from 1.25 to 2.0 ms per 4096 frames; 64-sample rows 1.10; 32-sample rows at three waves per SIMD 1.03.
-    constexpr int kPitch = MODE == 2 ? kRefineSeg + 2 : kRefineSamples + 1;
-    constexpr int kRows = MODE == 2 ? 28 : 16;
+    constexpr int kPitch = kRefineSamples + 1;
+    constexpr int kRows = 16;
     // The row of ones sits 16 doubles (32 banks) further than a 17th row would: a row of 130 doubles starts 4 banks after its predecessor, so
     // rows 0-15 tile the 64 banks and a 17th row would share row 0's; the instructions that read ones (factor A or B of a sum) read x / y rows 0-7
     // beside it, never the weight rows 8-15 whose banks it now shares (round 4: the sums kernel's 19 % bank conflicts were these two rows)
@@ -595,7 +555,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     // staged once with coalesced row loads: the 4 x 128 x 49 scattered byte loads of the searches then gather from LDS
     // instead of going through the texture-address path, which was as busy as the vector ALUs (70 % TA busy,
     // profiles/r02a_before_round2_work_instmix.json).  A box that does not fit stays in global memory (uniform per block).
-    __shared__ __attribute__((aligned(16))) uint8_t s_reg[MODE == 2 ? 16 : kRefineRegion];
+    __shared__ __attribute__((aligned(16))) uint8_t s_reg[kRefineRegion];
     const int fi = qidx >> 1, quad = qidx & 1;
     if (fi >= P.nfeat[frame]) return false;
     const int tid = threadIdx.x;
@@ -607,10 +567,10 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     __shared__ int s_ns[4];
     __shared__ int s_box[4];  // x0, y0 of the staged box, its pitch, its rows (0 = not staged)
     if (tid < 4) {
-        s_cx[tid] = MODE == 2 ? pre->cx : F->c[2 * (off + tid)];
-        s_cy[tid] = MODE == 2 ? pre->cy : F->c[2 * (off + tid) + 1];
+        s_cx[tid] = F->c[2 * (off + tid)];
+        s_cy[tid] = F->c[2 * (off + tid) + 1];
     }
-    double* const accp = MODE == 2 ? acc_out : s_acc;
+    double* const accp = s_acc;
     if (MODE != 1 && tid < 48) accp[tid] = 0.0;
     if constexpr (MODE != 1) {
         for (int k = tid; k < kPitch; k += (int)blockDim.x) s_ones[k] = 1.0;
@@ -628,8 +588,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
         s_step[tid][0] = ctr::fast_step(nx / mag);  // the searches' pixel step along this edge's normal, once per edge instead of per sample
         s_step[tid][1] = ctr::fast_step(ny / mag);
     }
-    if (MODE == 2 && tid == 0) s_box[0] = s_box[1] = s_box[2] = s_box[3] = 0;
-    if (MODE != 2 && tid == 64) {  // the box: corners +- (search length + 2), clipped to the image; columns from a multiple of 4
+    if (tid == 64) {  // the box: corners +- (search length + 2), clipped to the image; columns from a multiple of 4
         const float m = (float)(subpix + 3);
         const float fx0 = fminf(fminf(s_cx[0], s_cx[1]), fminf(s_cx[2], s_cx[3])) - m, fx1 = fmaxf(fmaxf(s_cx[0], s_cx[1]), fmaxf(s_cx[2], s_cx[3])) + m;
         const float fy0 = fminf(fminf(s_cy[0], s_cy[1]), fminf(s_cy[2], s_cy[3])) - m, fy1 = fmaxf(fmaxf(s_cy[0], s_cy[1]), fmaxf(s_cy[2], s_cy[3])) + m;
@@ -659,7 +618,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
         if (MODE == 0 && only_long && !long_quad) return false;
     }
     const int box_x0 = s_box[0], box_y0 = s_box[1], box_pitch = s_box[2], box_rows = s_box[3];
-    const bool staged = MODE != 2 && box_rows > 0;
+    const bool staged = box_rows > 0;
     if (staged) {
         // rows of the box, 4 bytes per lane: aligned words when the frame's rows allow it, bytes otherwise.  A thread keeps its
         // column and walks down the rows, four rows requested before the first is stored (the loads of a row-major loop with
@@ -736,77 +695,6 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             }
         }
         __syncthreads();
-    }
-    if constexpr (MODE == 2) {
-        // the samples' points from the search kernel's n0, with the search's own expressions: x0 = alpha ax + (1 - alpha) bx, best = x0 + n0 nx.  A lane's
-        // sample of a half is sm = 64 h + tid of each of the four edges: two position parameters in all, not eight divisions.
-        constexpr int kIps = 4 * kRefineSeg / 64, kSegs = kRefineSamples / kRefineSeg;
-        const int edge_s = tid / 12, r_s = tid - edge_s * 12, pass_s = r_s / 6, which_s = r_s - pass_s * 6;  // this lane's sum (tid < 48)
-        const int es = tid < 48 ? edge_s : 0;
-        // the row of (A B): x 1 = x and y 1 = y exactly, the products from their rows, 1 1 = 1
-        const double* pp = which_s == 0 ? s_bx[es] : which_s == 1 ? s_by[es] : which_s == 2 ? s_v[16 + es] : which_s == 3 ? s_v[20 + es] : which_s == 4 ? s_v[24 + es] : s_ones;
-        const double* pw = s_v[8 + 4 * (tid < 48 ? pass_s : 0) + es];
-        const double2 *pp2 = reinterpret_cast<const double2*>(pp), *pw2 = reinterpret_cast<const double2*>(pw);
-        double acc = 0.0;
-#pragma unroll
-        for (int g = 0; g < kSegs; g++) {
-            const int loc = tid % kRefineSeg;
-            const double alpha = (15.0 + (kRefineSeg * g + loc)) / (kRefineSamples + 30);  // == (15.0 + sm) / (s_ns[edge] + 30): s_ns[edge] == kRefineSamples for every edge of this quad
-            if (g) __syncthreads();  // the sums of the segment before are done with the rows
-#pragma unroll
-            for (int i = 0; i < kIps; i++) {
-                const int edge = (i * 64 + tid) / kRefineSeg;
-                const int a = edge, b = (edge + 1) & 3;
-                const float ax = s_cx[a], ay = s_cy[a], bx = s_cx[b], by = s_cy[b];
-                const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
-                const double x0 = alpha * ax + (1 - alpha) * bx;
-                const double y0 = alpha * ay + (1 - alpha) * by;
-                const double n0 = pre->n0[g * kIps + i];
-                const bool ok = n0 == n0;
-                const double bxv = ok ? x0 + n0 * nx : 0.0, byv = ok ? y0 + n0 * ny : 0.0;
-                s_bx[edge][loc] = bxv;
-                s_by[edge][loc] = byv;
-                s_v[8 + edge][loc] = ok ? 1 - alpha : 0.0;
-                s_v[12 + edge][loc] = ok ? alpha : 0.0;
-                s_v[16 + edge][loc] = bxv * bxv;
-                s_v[20 + edge][loc] = bxv * byv;
-                s_v[24 + edge][loc] = byv * byv;
-            }
-            __syncthreads();
-            if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
-                // the operands of the next eight terms are requested before the current eight are folded in (left to itself the compiler loads a
-                // pair of terms into the same registers every time and waits for the LDS before each pair)
-                double cp[8], cw[8], np[8], nw[8];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const double2 p2 = pp2[u], w2 = pw2[u];
-                    cp[2 * u] = p2.x, cp[2 * u + 1] = p2.y;
-                    cw[2 * u] = w2.x, cw[2 * u + 1] = w2.y;
-                }
-#pragma unroll 1
-                for (int k = 0; k + 16 <= kRefineSeg; k += 8) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const double2 p2 = pp2[(k >> 1) + 4 + u], w2 = pw2[(k >> 1) + 4 + u];
-                        np[2 * u] = p2.x, np[2 * u + 1] = p2.y;
-                        nw[2 * u] = w2.x, nw[2 * u + 1] = w2.y;
-                    }
-                    asm volatile("" ::: "memory");  // the requests above stay above the additions below
-#pragma unroll
-                    for (int u = 0; u < 8; u++) acc += cp[u] * cw[u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        cp[u] = np[u];
-                        cw[u] = nw[u];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) acc += cp[u] * cw[u];  // the last group, already in registers
-            }
-        }
-        if (tid < 48) accp[tid] = acc;
-        __syncthreads();
-        return true;
     }
     const int half = tid >> 7, st = tid & (kRefineSamples - 1);
     double* const n0_quad = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples);
@@ -908,10 +796,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
 }
 
 template <int MODE>
-#ifndef CTAG_REFINE_SUMS_WAVES
-#define CTAG_REFINE_SUMS_WAVES 3  // three waves per SIMD (168 registers, 4 spilled); 1: 194 registers, two waves; 4: 128 registers, 32 spilled -- 4.78 / 4.85 / 5.15 ms edge_refine per 4096 frames
-#endif
-__global__ __launch_bounds__(MODE == 2 ? 64 : kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : (MODE == 2 ? CTAG_REFINE_SUMS_WAVES : 1), MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
+__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
 void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, int per_frame) {
     // per_frame > 0: a 1-D grid of per_frame blocks per frame in which blocks b and b + 8 -- one XCD -- belong to the same frame: the
     // boxes of a frame's quads overlap, and on one XCD the shared pixels come out of its L2 instead of HBM
@@ -924,50 +809,183 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, in
     }
     if (frame >= nframes) return;
     if (P.status[frame] != CTAG_OK) return;
-    if constexpr (MODE == 2) {
-        // a few looping blocks per frame: the next quad's inputs are in flight while the current quad's chains of dependent FP64
-        // operations run (a block is one wave and one global round trip used to head every quad)
-        const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
-        int q = bx;
-        if (q >= nq) return;
-        // the tail of a quad -- five divisions, atan2, sin / cos on 8 lanes, then two divisions on 4 -- is a long dependent chain that
-        // occupies the wave as much as its 128-term sums do: the sums of up to eight quads are kept and their tails run together
-        __shared__ double s_accs[kRefineTails][48];
-        __shared__ int s_q[kRefineTails];
-        const int tid = threadIdx.x;
-        int slot = 0;
-        RefinePrefetch cur, nxt;
-        refine_prefetch(P, frame, q, cur);
-        for (; q < nq; q += gx) {
-            const int qn = q + gx;
-            if (qn < nq) refine_prefetch(P, frame, qn, nxt);
-            const bool have = refine_quad<2>(P, rows, cols, subpix, frame, q, 0, &cur, s_accs[slot]);
-            if (tid == 0) s_q[slot] = have ? q : -1;
-            slot++;
-            __syncthreads();
-            if (slot == kRefineTails || qn >= nq) {
-                const int sl = tid >> 3, ep = tid & 7;
-                if (sl < slot && s_q[sl] >= 0) refine_line(s_accs[sl] + (ep >> 1) * 12 + (ep & 1) * 6, s_accs[sl] + (ep >> 1) * 12 + (ep & 1) * 6);
-                __syncthreads();
-                const int sc = tid >> 2;
-                if (sc < slot && s_q[sc] >= 0) {
-                    const int qq = s_q[sc], fi = qq >> 1;
-                    refine_corner(s_accs[sc], tid & 3, (qq & 1) * 4, P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi, P.feat2 + (size_t)frame * CTAG_MAX_FEATURES + fi);
-                }
-                __syncthreads();
-                slot = 0;
+    // blocks loop over the frame's quads: a grid of one block per possible quad (2 * CTAG_MAX_FEATURES) would launch more blocks
+    // that find nothing to do than blocks that work
+    const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
+    const double alpha128 = (15.0 + (double)((int)threadIdx.x & (kRefineSamples - 1))) / (kRefineSamples + 30);  // == (15.0 + s) / (nsamples + 30) at 128 samples
+    for (int q = bx; q < nq; q += gx) {
+        refine_quad<MODE>(P, rows, cols, subpix, frame, q, 0, alpha128);
+        if (q + gx < nq) __syncthreads();
+    }
+}
+// ---- the sums kernel (round 5): TERMS in LDS.  Its round-4 form (k_edge_refine<2>, docs/history.md) kept rows of x, y, the products and the weights, and every step of
+// a sum was a load of two operands, a multiplication and the (ordered) addition; 64 registers of operand buffers held it to three waves per SIMD and half of its time it
+// waited: 1.03 ms per 4096 frames.  Here the lane that builds a sample also multiplies -- (A B) w, the same two roundings in the same order, for the sample's twelve sums --
+// and a sum's step is one addition: segments of 16 samples (64 lanes = 4 edges x 16), 48 rows of 16 terms (6.9 KB), a chain's row index IS its lane
+// (12 edge + 6 pass + moment), ~100 registers, four waves per SIMD.
+#ifndef CTAG_REFINE_SUMS2_WAVES
+#define CTAG_REFINE_SUMS2_WAVES 4
+#endif
+constexpr int kSumSeg = 16, kSumSegs = kRefineSamples / kSumSeg;
+constexpr int kSumPitch = kSumSeg + 2;  // doubles per row: 36 words -- an odd multiple of four, so the ds_read_b128 of 16 consecutive lanes (rows) cover the 64 banks exactly once
+struct SumsPrefetch {
+    double n0[kSumSegs];  // of sample 16 g + (tid & 15) of edge tid >> 4
+    float cx, cy;
+};
+__device__ __forceinline__ void sums_prefetch(const RefinePtrs& P, int frame, int qidx, SumsPrefetch& R) {
+    const int tid = threadIdx.x;
+    const double* src = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples) + (tid >> 4) * kRefineSamples + (tid & 15);
+#pragma unroll
+    for (int g = 0; g < kSumSegs; g++) R.n0[g] = src[g * kSumSeg];
+    const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + (qidx >> 1);
+    const int c = (qidx & 1) * 4 + (tid & 3);
+    R.cx = F->c[2 * c];
+    R.cy = F->c[2 * c + 1];
+}
+// the 48 ordered sums of one quad -> acc_out[edge * 12 + pass * 6 + {Mx, My, Mxx, Mxy, Myy, N}]; false: no such quad, or one with an edge of more than kRefineSamples samples
+__device__ __forceinline__ bool refine_sums_quad(const RefinePtrs& P, int frame, int qidx, const SumsPrefetch& pre, double* acc_out) {
+    __shared__ __attribute__((aligned(16))) double s_t[48][kSumPitch];
+    __shared__ float s_cx[4], s_cy[4];
+    __shared__ double s_nrm[4][2];
+    __shared__ int s_ns[4];
+    const int tid = threadIdx.x;
+    if ((qidx >> 1) >= P.nfeat[frame]) return false;
+    if (tid < 4) {
+        s_cx[tid] = pre.cx;
+        s_cy[tid] = pre.cy;
+    }
+    __syncthreads();
+    if (tid < 4) {  // :609-615
+        const int a = tid, b = (tid + 1) & 3;
+        const double nx = s_cy[b] - s_cy[a];
+        const double ny = -s_cx[b] + s_cx[a];
+        const double mag = ctm::sqrt64(nx * nx + ny * ny);
+        const double ns_d = mag / 8 > 128.0 ? mag / 8 : 128.0;
+        s_ns[tid] = (int)ns_d;
+        s_nrm[tid][0] = nx / mag;
+        s_nrm[tid][1] = ny / mag;
+    }
+    __syncthreads();
+    if (max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3])) > kRefineSamples) return false;  // k_edge_refine_long's
+    const int edge = tid >> 4, loc = tid & 15;
+    const float ax = s_cx[edge], ay = s_cy[edge], bx = s_cx[(edge + 1) & 3], by = s_cy[(edge + 1) & 3];
+    const double nx = s_nrm[edge][0], ny = s_nrm[edge][1];
+    double* const mine = &s_t[edge * 12][loc];
+    const double2* const row2 = reinterpret_cast<const double2*>(s_t[tid < 48 ? tid : 0]);
+    double acc = 0.0;
+#pragma unroll
+    for (int g = 0; g < kSumSegs; g++) {
+        // the sample's point with the search's own expressions: x0 = alpha ax + (1 - alpha) bx, best = x0 + n0 nx (:619-621, :656-657)
+        const double alpha = (15.0 + (kSumSeg * g + loc)) / (kRefineSamples + 30);  // == (15.0 + s) / (nsamples + 30): every edge of this quad has kRefineSamples samples
+        const double x0 = alpha * ax + (1 - alpha) * bx;
+        const double y0 = alpha * ay + (1 - alpha) * by;
+        const double n0 = pre.n0[g];
+        const bool ok = n0 == n0;  // NaN: no edge point
+        const double x = ok ? x0 + n0 * nx : 0.0, y = ok ? y0 + n0 * ny : 0.0;
+        const double wn = ok ? 1 - alpha : 0.0, wl = ok ? alpha : 0.0;  // weights towards the next / the last corner; a sample without an edge point adds +0.0 to every sum
+        const double xx = x * x, xy = x * y, yy = y * y;
+        if (g) __syncthreads();  // the sums of the segment before are done with the rows
+        mine[0 * kSumPitch] = x * wn;   // (x 1) w: x 1 is exact
+        mine[1 * kSumPitch] = y * wn;
+        mine[2 * kSumPitch] = xx * wn;  // (A B) w: the product first, as the reference's left-to-right evaluation rounds it
+        mine[3 * kSumPitch] = xy * wn;
+        mine[4 * kSumPitch] = yy * wn;
+        mine[5 * kSumPitch] = wn;       // (1 1) w
+        mine[6 * kSumPitch] = x * wl;
+        mine[7 * kSumPitch] = y * wl;
+        mine[8 * kSumPitch] = xx * wl;
+        mine[9 * kSumPitch] = xy * wl;
+        mine[10 * kSumPitch] = yy * wl;
+        mine[11 * kSumPitch] = wl;
+        __syncthreads();
+        if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
+            double t[kSumSeg];
+#pragma unroll
+            for (int u = 0; u < kSumSeg / 2; u++) {
+                const double2 v = row2[u];
+                t[2 * u] = v.x, t[2 * u + 1] = v.y;
             }
-            cur = nxt;
+#pragma unroll
+            for (int u = 0; u < kSumSeg; u++) acc += t[u];
         }
-    } else {
-        // blocks loop over the frame's quads: a grid of one block per possible quad (2 * CTAG_MAX_FEATURES) would launch more blocks
-        // that find nothing to do than blocks that work
-        const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
-        const double alpha128 = (15.0 + (double)((int)threadIdx.x & (kRefineSamples - 1))) / (kRefineSamples + 30);  // == (15.0 + s) / (nsamples + 30) at 128 samples
-        for (int q = bx; q < nq; q += gx) {
-            refine_quad<MODE>(P, rows, cols, subpix, frame, q, 0, nullptr, nullptr, alpha128);
-            if (q + gx < nq) __syncthreads();
+    }
+    if (tid < 48) acc_out[tid] = acc;
+    __syncthreads();
+    return true;
+}
+// The sums go back to global memory -- into the first 49 doubles of the quad's own n0 block, which is dead once they are formed: [0, 48) the sums, [48] 1.0 when the
+// quad has them (0.0: no such quad here, or k_edge_refine_long's) -- and the tails (line parameters, corners) are a kernel of their own, k_edge_refine_tail: five
+// divisions, atan2, sin / cos per line in double are what the sums kernel's registers went to, and a chain as long as a quad's sums that only 8 lanes walk.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_REFINE_SUMS2_WAVES, 8)))
+void k_edge_refine_sums(RefinePtrs P, int nframes, int per_frame) {
+    // per_frame blocks per frame, blocks b and b + 8 -- one XCD -- on the same frame; a block loops over the frame's quads with the next quad's inputs in flight
+    const int b = blockIdx.x;
+    const int frame = ((b >> 3) / per_frame) * 8 + (b & 7);
+    const int bx = (b >> 3) % per_frame;
+    if (frame >= nframes) return;
+    if (P.status[frame] != CTAG_OK) return;
+    const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
+    int q = bx;
+    if (q >= nq) return;
+    __shared__ double s_acc[48];
+    const int tid = threadIdx.x;
+#ifndef CTAG_REFINE_SUMS_DEPTH
+#define CTAG_REFINE_SUMS_DEPTH 1  // quads whose inputs are in flight beyond the current one
+#endif
+    SumsPrefetch cur, nxt;
+    sums_prefetch(P, frame, q, cur);
+#if CTAG_REFINE_SUMS_DEPTH == 2
+    SumsPrefetch nx2;
+    if (q + per_frame < nq) sums_prefetch(P, frame, q + per_frame, nxt);
+#endif
+    for (; q < nq; q += per_frame) {
+#if CTAG_REFINE_SUMS_DEPTH == 2
+        if (q + 2 * per_frame < nq) sums_prefetch(P, frame, q + 2 * per_frame, nx2);
+#else
+        const int qn = q + per_frame;
+        if (qn < nq) sums_prefetch(P, frame, qn, nxt);
+#endif
+        const bool have = refine_sums_quad(P, frame, q, cur, s_acc);
+        double* out = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + q) * (4 * kRefineSamples);
+        if (tid < 48) {
+            if (have) out[tid] = s_acc[tid];
+        } else if (tid == 48) {
+            out[48] = have ? 1.0 : 0.0;
         }
+        __syncthreads();
+        cur = nxt;
+#if CTAG_REFINE_SUMS_DEPTH == 2
+        nxt = nx2;
+#endif
+    }
+}
+// lines and corners of the quads whose sums k_edge_refine_sums left: 8 quads per wave -- a lane per (edge, pass) line (:667-678 / :743-754), then a lane per corner (:757-776)
+__global__ __launch_bounds__(64) void k_edge_refine_tail(RefinePtrs P, int nframes, int per_frame) {
+    const int frame = blockIdx.y;
+    if (frame >= nframes || P.status[frame] != CTAG_OK) return;
+    const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
+    __shared__ double s_L[8][48];
+    __shared__ int s_ok[8];
+    const int tid = threadIdx.x, sl = tid >> 3, ep = tid & 7;
+    for (int q0 = (int)blockIdx.x * 8; q0 < nq; q0 += per_frame * 8) {
+        const int q = q0 + sl;
+        const double* A = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + min(q, nq - 1)) * (4 * kRefineSamples);
+        const bool ok = q < nq && A[48] == 1.0;
+        if (ep == 0) s_ok[sl] = ok ? 1 : 0;
+        if (ok) {
+            double a6[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) a6[k] = A[(ep >> 1) * 12 + (ep & 1) * 6 + k];
+            double* L = s_L[sl] + (ep >> 1) * 12 + (ep & 1) * 6;
+            refine_line(a6, L);
+        }
+        __syncthreads();
+        const int sc = tid >> 2;
+        if (sc < 8 && s_ok[sc]) {
+            const int qq = q0 + sc, fi = qq >> 1;
+            refine_corner(s_L[sc], tid & 3, (qq & 1) * 4, P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi, P.feat2 + (size_t)frame * CTAG_MAX_FEATURES + fi);
+        }
+        __syncthreads();
     }
 }
 // the quads k_edge_refine<1> / <2> left out (an edge of more than kRefineSamples samples), a few blocks per frame looping over the
@@ -1742,8 +1760,8 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
         // still holds it, lost -- 5.13 / 4.95 / 4.84 against 4.71-4.76 ms per 4096 frames: the round trip through HBM is not what the sums kernel waits for)
         if (xcd & 1) hipLaunchKernelGGL(k_edge_refine<1>, dim3(f8 * refine_gx), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_gx);
         else hipLaunchKernelGGL(k_edge_refine<1>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
-        if (xcd & 2) hipLaunchKernelGGL(k_edge_refine<2>, dim3(f8 * refine_sums_gx), dim3(64), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_sums_gx);
-        else hipLaunchKernelGGL(k_edge_refine<2>, dim3(refine_sums_gx, nframes), dim3(64), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
+        hipLaunchKernelGGL(k_edge_refine_sums, dim3(f8 * refine_sums_gx), dim3(64), 0, s, P, nframes, refine_sums_gx);
+        hipLaunchKernelGGL(k_edge_refine_tail, dim3(13, nframes), dim3(64), 0, s, P, nframes, 13);  // 13 x 8 quads: the synthetic frames' 96; a block loops when a frame has more
         hipLaunchKernelGGL(k_edge_refine_long, dim3(4, nframes), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes);
     }
     return hipGetLastError();
