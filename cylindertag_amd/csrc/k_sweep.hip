@@ -1501,8 +1501,11 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
         CCL_SYNC();
     }
     // The reservation's result goes to LDS NOW, before the label stores are issued: the vector-memory counter is served in order, so the wait for a value
-    // requested before the stores, taken after them, is a wait for every label store of wave 0 as well -- and the other waves then wait for wave 0 at the
-    // barrier (phase clocks, round 5: 21 % of a tile's lifetime in "publish").  Here only the atomic itself is outstanding, issued a phase ago.
+    // requested before the stores, taken after them, would be a wait for every label store of wave 0 as well.  (Round 5 moved it here on the suspicion that this
+    // was the 21 % of a tile's lifetime the phase clocks put in "publish"; the kernel's time did not change -- that share is wave 0 waiting at the barrier for the
+    // waves whose label blocks hold the foreground.  Also measured and not kept: path halving in lds_find -- a strip's column is a chain of 30 runs --, 0.985 ->
+    // 0.975 ms; the two block scans on separate scratch words without their trailing barriers and the statistics initialised early at the end of the parents'
+    // region, three barriers of twelve fewer: 1.00 -> 1.00 ms.  Neither chain depth nor barrier count is what a tile's 9 us are made of.)
     if (tid == 0) misc_s[9] = base_reg;
     // ---- S11: per-pixel tile-local labels, 8 pixels (16 bytes) per lane
     {

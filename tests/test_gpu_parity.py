@@ -663,7 +663,7 @@ def test_full_size_batch_properties(detector, oracle, dictionary):
         assert set(found) <= set(planted), f  # never a wrong id
     # a planted marker that does not come out (cylinder-compressed end columns are occasionally too narrow to decode) is the ALGORITHM's miss, not
     # this implementation's: every such frame must be the oracle's record byte for byte, like the sampled ones
-    assert exact >= int(0.9 * n)
+    assert exact >= int(0.94 * n)  # measured: 489 of these 512 frames decode EVERY planted marker (95.5 %; of the bench's 16 384 planted markers 99.2 % come out)
     flagged = [int(f) for f in np.nonzero(a["flags"])[0][:4]]
     for f in sorted(set(list(range(0, n, 16)) + [17, 255, 511] + flagged + inexact)):
         assert_same_record(a[f], oracle.detect_fast(frames[f].cpu().numpy(), state, fs), "synthetic frame %d" % f)
