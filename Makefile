@@ -11,4 +11,5 @@ clean:
 # the vector-instruction issue-cost microbenchmark (runs on the GPU box; not part of the product)
 ubench:
 	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/ubench/valu_rate.hip -o tools/ubench/valu_rate
+	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench/dep_latency.hip -o tools/ubench/dep_latency
 .PHONY: all clean ubench

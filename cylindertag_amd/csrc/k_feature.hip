@@ -527,6 +527,10 @@ __device__ __forceinline__ void refine_corner(const double* A, int it, int off, 
     }
 }
 
+// Barrier of the edgeRefine blocks: their phases exchange data through LDS only, so it waits for LDS traffic and NOT for vector memory -- __syncthreads() would also
+// wait for the block's n0 stores (the vector-memory counter counts stores on gfx9) before the next quad's box may be requested.  A value a thread loaded itself is
+// waited for where it is used, as always.
+#define REFINE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <int MODE>
 __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long, double alpha128 = 0.0) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
@@ -556,8 +560,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     // instead of going through the texture-address path, which was as busy as the vector ALUs (70 % TA busy,
     // profiles/r02a_before_round2_work_instmix.json).  A box that does not fit stays in global memory (uniform per block).
     __shared__ __attribute__((aligned(16))) uint8_t s_reg[kRefineRegion];
-    const int fi = qidx >> 1, quad = qidx & 1;
-    if (fi >= P.nfeat[frame]) return false;
+    const int fi = qidx >> 1, quad = qidx & 1;  // (the caller's loop keeps qidx below twice the frame's feature count: no load of it here, once per quad)
     const int tid = threadIdx.x;
     const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi;
     const uint8_t* __restrict__ img = P.frames + (ptrdiff_t)frame * P.frame_stride;
@@ -575,7 +578,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     if constexpr (MODE != 1) {
         for (int k = tid; k < kPitch; k += (int)blockDim.x) s_ones[k] = 1.0;
     }
-    __syncthreads();
+    REFINE_SYNC();
     if (tid < 4) {  // :609-615
         const int a = tid, b = (tid + 1) & 3;
         const double nx = s_cy[b] - s_cy[a];
@@ -609,7 +612,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
         s_box[2] = pitch;
         s_box[3] = staged;  // rows staged, 0 = the box stays in global memory
     }
-    __syncthreads();
+    REFINE_SYNC();
     const int max_ns = max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3]));
     {   // which form takes this quad: an edge of more than kRefineSamples samples needs several passes -> the one-kernel form
         const bool long_quad = max_ns > kRefineSamples;
@@ -694,7 +697,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
                     same);
             }
         }
-        __syncthreads();
+        REFINE_SYNC();
     }
     const int half = tid >> 7, st = tid & (kRefineSamples - 1);
     double* const n0_quad = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + qidx) * (4 * kRefineSamples);
@@ -763,7 +766,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             }
         }
         if constexpr (MODE == 1) return false;  // one pass: every edge of the quad has kRefineSamples samples
-        __syncthreads();
+        REFINE_SYNC();
         if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
             // every sum has the form (A * B) * w with A, B in {x, y, 1} (x * 1 and 1 * 1 are exact); a sample without an
             // edge point has x = y = w = 0 and adds +0.0, which equals the reference skipping it
@@ -784,13 +787,13 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             for (; k < cntS; k++) acc += (pa[k] * pb[k]) * pw[k];
             accp[tid] = acc;
         }
-        __syncthreads();
+        REFINE_SYNC();
     }
     if (tid < 8) {  // line of (edge, pass)
         const int edge = tid >> 1, pass = tid & 1;
         refine_line(s_acc + edge * 12 + pass * 6, s_acc + edge * 12 + pass * 6);
     }
-    __syncthreads();
+    REFINE_SYNC();
     if (tid < 4) refine_corner(s_acc, tid, off, F, P.feat2 + (size_t)frame * CTAG_MAX_FEATURES + fi);  // one refined corner per lane
     return true;
 }
@@ -815,7 +818,7 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, in
     const double alpha128 = (15.0 + (double)((int)threadIdx.x & (kRefineSamples - 1))) / (kRefineSamples + 30);  // == (15.0 + s) / (nsamples + 30) at 128 samples
     for (int q = bx; q < nq; q += gx) {
         refine_quad<MODE>(P, rows, cols, subpix, frame, q, 0, alpha128);
-        if (q + gx < nq) __syncthreads();
+        if (q + gx < nq) REFINE_SYNC();
     }
 }
 // ---- the sums kernel (round 5): TERMS in LDS.  Its round-4 form (k_edge_refine<2>, docs/history.md) kept rows of x, y, the products and the weights, and every step of
@@ -823,11 +826,19 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, in
 // waited: 1.03 ms per 4096 frames.  Here the lane that builds a sample also multiplies -- (A B) w, the same two roundings in the same order, for the sample's twelve sums --
 // and a sum's step is one addition: segments of 16 samples (64 lanes = 4 edges x 16), 48 rows of 16 terms (6.9 KB), a chain's row index IS its lane
 // (12 edge + 6 pass + moment), ~100 registers, four waves per SIMD.
+// What bounds it now is LDS BANDWIDTH: a quad's 48 x 128 terms are written once and read once, 98 KB, and 393 K quads per 4096 frames are 38.5 GB against the
+// 78 TB/s the 256 CUs' LDS move at 128 B per clock: 0.49 ms; the kernel runs 0.70-0.73.  Timing builds without its global loads, without its stores, without
+// both: 4.40 / 4.40 / 4.39 against 4.45 ms edge_refine -- memory is not what it waits for; halving its vector instructions (the position parameters' divisions,
+// a table now) did not move it either.  The transposition sample-lane -> sum-lane is the work.
 #ifndef CTAG_REFINE_SUMS2_WAVES
 #define CTAG_REFINE_SUMS2_WAVES 4
 #endif
 constexpr int kSumSeg = 16, kSumSegs = kRefineSamples / kSumSeg;
 constexpr int kSumPitch = kSumSeg + 2;  // doubles per row: 36 words -- an odd multiple of four, so the ds_read_b128 of 16 consecutive lanes (rows) cover the 64 banks exactly once
+// The sums kernel's block is ONE wave, and LDS serves a wave's accesses in order: its phases are ordered by a wait for LDS traffic alone.  __syncthreads() would also wait
+// for vector memory -- for the NEXT quad's n0, requested a quad ahead precisely so that nobody waits for it (with __syncthreads() the kernel ran at 0.38 of its
+// vector-issue rate: profiles/r05_pmc_instmix.json).
+#define SUMS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 struct SumsPrefetch {
     double n0[kSumSegs];  // of sample 16 g + (tid & 15) of edge tid >> 4
     float cx, cy;
@@ -843,18 +854,18 @@ __device__ __forceinline__ void sums_prefetch(const RefinePtrs& P, int frame, in
     R.cy = F->c[2 * c + 1];
 }
 // the 48 ordered sums of one quad -> acc_out[edge * 12 + pass * 6 + {Mx, My, Mxx, Mxy, Myy, N}]; false: no such quad, or one with an edge of more than kRefineSamples samples
-__device__ __forceinline__ bool refine_sums_quad(const RefinePtrs& P, int frame, int qidx, const SumsPrefetch& pre, double* acc_out) {
+// (the caller has checked qidx against the frame's feature count; s_alpha: the samples' position parameters, the same for every quad)
+__device__ __forceinline__ bool refine_sums_quad(const SumsPrefetch& pre, const double* s_alpha, double* acc_out) {
     __shared__ __attribute__((aligned(16))) double s_t[48][kSumPitch];
     __shared__ float s_cx[4], s_cy[4];
     __shared__ double s_nrm[4][2];
     __shared__ int s_ns[4];
     const int tid = threadIdx.x;
-    if ((qidx >> 1) >= P.nfeat[frame]) return false;
     if (tid < 4) {
         s_cx[tid] = pre.cx;
         s_cy[tid] = pre.cy;
     }
-    __syncthreads();
+    SUMS_SYNC();
     if (tid < 4) {  // :609-615
         const int a = tid, b = (tid + 1) & 3;
         const double nx = s_cy[b] - s_cy[a];
@@ -865,7 +876,7 @@ __device__ __forceinline__ bool refine_sums_quad(const RefinePtrs& P, int frame,
         s_nrm[tid][0] = nx / mag;
         s_nrm[tid][1] = ny / mag;
     }
-    __syncthreads();
+    SUMS_SYNC();
     if (max(max(s_ns[0], s_ns[1]), max(s_ns[2], s_ns[3])) > kRefineSamples) return false;  // k_edge_refine_long's
     const int edge = tid >> 4, loc = tid & 15;
     const float ax = s_cx[edge], ay = s_cy[edge], bx = s_cx[(edge + 1) & 3], by = s_cy[(edge + 1) & 3];
@@ -876,7 +887,7 @@ __device__ __forceinline__ bool refine_sums_quad(const RefinePtrs& P, int frame,
 #pragma unroll
     for (int g = 0; g < kSumSegs; g++) {
         // the sample's point with the search's own expressions: x0 = alpha ax + (1 - alpha) bx, best = x0 + n0 nx (:619-621, :656-657)
-        const double alpha = (15.0 + (kSumSeg * g + loc)) / (kRefineSamples + 30);  // == (15.0 + s) / (nsamples + 30): every edge of this quad has kRefineSamples samples
+        const double alpha = s_alpha[kSumSeg * g + loc];  // (15.0 + s) / (nsamples + 30) (:619): every edge of this quad has kRefineSamples samples, so the quotient is per sample index
         const double x0 = alpha * ax + (1 - alpha) * bx;
         const double y0 = alpha * ay + (1 - alpha) * by;
         const double n0 = pre.n0[g];
@@ -884,7 +895,7 @@ __device__ __forceinline__ bool refine_sums_quad(const RefinePtrs& P, int frame,
         const double x = ok ? x0 + n0 * nx : 0.0, y = ok ? y0 + n0 * ny : 0.0;
         const double wn = ok ? 1 - alpha : 0.0, wl = ok ? alpha : 0.0;  // weights towards the next / the last corner; a sample without an edge point adds +0.0 to every sum
         const double xx = x * x, xy = x * y, yy = y * y;
-        if (g) __syncthreads();  // the sums of the segment before are done with the rows
+        if (g) SUMS_SYNC();  // the sums of the segment before are done with the rows
         mine[0 * kSumPitch] = x * wn;   // (x 1) w: x 1 is exact
         mine[1 * kSumPitch] = y * wn;
         mine[2 * kSumPitch] = xx * wn;  // (A B) w: the product first, as the reference's left-to-right evaluation rounds it
@@ -897,7 +908,7 @@ __device__ __forceinline__ bool refine_sums_quad(const RefinePtrs& P, int frame,
         mine[9 * kSumPitch] = xy * wl;
         mine[10 * kSumPitch] = yy * wl;
         mine[11 * kSumPitch] = wl;
-        __syncthreads();
+        SUMS_SYNC();
         if (tid < 48) {  // sequential (sample-order) accumulation: bit-identical to the reference's running sums
             double t[kSumSeg];
 #pragma unroll
@@ -910,7 +921,7 @@ __device__ __forceinline__ bool refine_sums_quad(const RefinePtrs& P, int frame,
         }
     }
     if (tid < 48) acc_out[tid] = acc;
-    __syncthreads();
+    SUMS_SYNC();
     return true;
 }
 // The sums go back to global memory -- into the first 49 doubles of the quad's own n0 block, which is dead once they are formed: [0, 48) the sums, [48] 1.0 when the
@@ -928,35 +939,32 @@ void k_edge_refine_sums(RefinePtrs P, int nframes, int per_frame) {
     int q = bx;
     if (q >= nq) return;
     __shared__ double s_acc[48];
+    __shared__ double s_alpha[kRefineSamples];  // a double division per sample and quad otherwise: more than half of the kernel's vector instructions
     const int tid = threadIdx.x;
-#ifndef CTAG_REFINE_SUMS_DEPTH
-#define CTAG_REFINE_SUMS_DEPTH 1  // quads whose inputs are in flight beyond the current one
-#endif
+    for (int k = tid; k < kRefineSamples; k += 64) s_alpha[k] = (15.0 + k) / (kRefineSamples + 30);
+    // The loop is ROTATED so that nothing a quad needs has been requested less than a quad's time ago -- and it took the ISA to see that it was not so: with
+    // "request next, work, store, cur = next" the compiler's wait-count pass, merging the loop's entry (cur's own loads outstanding) with its back edge, put
+    // s_waitcnt vmcnt(0) before the first use of `cur`, right behind the requests for the next quad (so the prefetch hid nothing, here and in round 4's kernel),
+    // and the copy at the end waited for the stores just issued.  Now: cur's first loads are awaited explicitly before the loop (the pass understands
+    // S_WAITCNT), and an iteration is work(cur) -> cur = next (a wait for loads a quad old) -> request the quad after -> store this quad's sums.
     SumsPrefetch cur, nxt;
     sums_prefetch(P, frame, q, cur);
-#if CTAG_REFINE_SUMS_DEPTH == 2
-    SumsPrefetch nx2;
-    if (q + per_frame < nq) sums_prefetch(P, frame, q + per_frame, nxt);
-#endif
-    for (; q < nq; q += per_frame) {
-#if CTAG_REFINE_SUMS_DEPTH == 2
-        if (q + 2 * per_frame < nq) sums_prefetch(P, frame, q + 2 * per_frame, nx2);
-#else
-        const int qn = q + per_frame;
-        if (qn < nq) sums_prefetch(P, frame, qn, nxt);
-#endif
-        const bool have = refine_sums_quad(P, frame, q, cur, s_acc);
-        double* out = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + q) * (4 * kRefineSamples);
-        if (tid < 48) {
-            if (have) out[tid] = s_acc[tid];
-        } else if (tid == 48) {
-            out[48] = have ? 1.0 : 0.0;
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    int qn = q + per_frame;
+    if (qn < nq) sums_prefetch(P, frame, qn, nxt);
+    for (;;) {
+        const bool have = refine_sums_quad(cur, s_alpha, s_acc);
+        const double mine = tid < 48 ? s_acc[tid] : (have ? 1.0 : 0.0);
+        double* const out = P.n0 + ((size_t)frame * (CTAG_MAX_FEATURES * 2) + q) * (4 * kRefineSamples);
+        SUMS_SYNC();
+        q = qn;
+        qn += per_frame;
+        if (q < nq) {
+            cur = nxt;
+            if (qn < nq) sums_prefetch(P, frame, qn, nxt);
         }
-        __syncthreads();
-        cur = nxt;
-#if CTAG_REFINE_SUMS_DEPTH == 2
-        nxt = nx2;
-#endif
+        if (tid < 48 ? have : tid == 48) out[tid] = mine;  // [0, 48): the sums; [48]: 1.0 when the quad has them
+        if (q >= nq) break;
     }
 }
 // lines and corners of the quads whose sums k_edge_refine_sums left: 8 quads per wave -- a lane per (edge, pass) line (:667-678 / :743-754), then a lane per corner (:757-776)
