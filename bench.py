@@ -508,7 +508,7 @@ def launch_ranks(n):
     --nproc-per-node N bench.py <the same arguments>`, one process per GPU -- as a CHILD of this process, which has not imported
     torch and never touches a GPU (a process that has initialised one must not exec another program on this pool).  Rank 0's JSON
     line goes to the inherited stdout; the launcher's exit code (non-zero as soon as one rank fails, and the launcher then ends the
-    other ranks) is this process's."""
+    other ranks) is this process's.  The launcher stays in this process's group and is tied to its life, so nothing outlives a killed run."""
     import signal
     import socket
     import subprocess
@@ -521,19 +521,22 @@ def launch_ranks(n):
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)  # its own process group: a signal to us ends exactly our ranks
+    def tie_to_parent():  # the launcher gets SIGTERM when this process goes away, however that happens (PR_SET_PDEATHSIG): no ranks left behind on the GPUs
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)
+        except Exception:  # noqa: BLE001
+            pass
+    # (same session and process group as this process: whoever ends the group -- a driver's timeout -- ends the ranks too)
+    child = subprocess.Popen(cmd, env=env, preexec_fn=tie_to_parent)
     def forward(sig, _frame):
         try:
-            os.killpg(child.pid, sig)
+            child.send_signal(sig)  # torch.distributed.run hands it on to its workers
         except ProcessLookupError:
             pass
     for sig in (signal.SIGTERM, signal.SIGINT):
         signal.signal(sig, forward)
     rc = child.wait()
-    try:
-        os.killpg(child.pid, signal.SIGKILL)  # ranks the launcher left behind (it does not, normally)
-    except (ProcessLookupError, PermissionError):
-        pass
     return rc if rc >= 0 else 128 - rc
 
 
