@@ -107,12 +107,18 @@ struct GatherState {
 bool order_unref(ncclComm_t c, bool wait_for_last);  // below
 bool order_dead(ncclComm_t c);
 void release_comm(GatherState* g);
+int env_timeout_ms();
+bool stream_idle_within(hipStream_t s, int timeout_ms);  // hipStreamSynchronize with a deadline (0: none)
 
 void gather_state_free(void* p) {
     GatherState* g = static_cast<GatherState*>(p);
     (void)hipSetDevice(g->device);
     release_comm(g);
-    if (g->gstream) (void)hipStreamSynchronize(g->gstream);
+    if (g->gstream && !stream_idle_within(g->gstream, env_timeout_ms())) {
+        // the gather stream does not drain (an aborted collective that never left?): what it may still touch is leaked rather than freed under it
+        delete g;
+        return;
+    }
     if (g->d_packed) (void)hipFree(g->d_packed);
     if (g->d_gathered) (void)hipFree(g->d_gathered);
     if (g->d_off) (void)hipFree(g->d_off);
@@ -285,6 +291,10 @@ WaitResult poll_until(Q ready, ncclComm_t comm, int timeout_ms, int* detail) {
     }
 }
 
+bool stream_idle_within(hipStream_t s, int timeout_ms) {
+    int detail = 0;
+    return poll_until([&] { return hipStreamQuery(s); }, nullptr, timeout_ms, &detail) == kWaitOk;
+}
 // returns whether the communicator is dead (aborted): its owner must not destroy it a second time
 bool order_unref(ncclComm_t c, bool wait_for_last) {
     CommOrder* o = order_lookup(c);

@@ -1024,6 +1024,18 @@ def test_bgr_ingest_equals_gray_path(detector, oracle, dictionary, test_bmp):
             assert_same_record(got[f], want[f], "bgr device batch, direct form, chunk %d, frame %d" % (chunk, f))
         with pytest.raises(ca.CtagError):
             detector.debug(0, tk.DBG_GRAY)
+    # ... and replayed as a hipGraph (CTAG_OPT_GRAPH 1: every chunk): the graph's key carries the channel count
+    detector.set_option(capi.OPT_GRAPH, 1)
+    try:
+        for rep in range(2):
+            out.zero_()
+            detector.detect_batch_bgr_device(dev.data_ptr(), n, rows, cols, cols * 3, rows * cols * 3, out.data_ptr())
+            detector.sync()
+            got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+            for f in range(n):
+                assert_same_record(got[f], want[f], "bgr device batch, direct form, graph replay %d, frame %d" % (rep, f))
+    finally:
+        detector.set_option(capi.OPT_GRAPH, 2)
     # rows that are not 16-byte aligned (a 4-byte pad per row) take the two-step form by themselves
     padded = torch.zeros((n, rows, cols * 3 + 4), dtype=torch.uint8, device="cuda")
     padded[:, :, :cols * 3] = dev.reshape(n, rows, cols * 3)
