@@ -16,7 +16,7 @@ import testkit as tk  # noqa: E402
 from cylindertag_amd import capi  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-rows, cols = 1080, 1920
+cols, rows = (int(v) for v in sys.argv[2].lower().split("x")) if len(sys.argv) > 2 else (1920, 1080)  # tools/bgr_rate.py 512 3840x2160
 state, fs = ca.load_marker_file(os.path.join(ROOT, "tests", "golden", "CTag_2f12c.marker"))
 det = tk.Detector(state, fs)
 det.set_option(capi.OPT_MAX_CHUNK, n)
