@@ -476,6 +476,10 @@ constexpr int kRefineThreads = 2 * kRefineSamples; // two edges side by side: wa
 #define CTAG_REFINE_REGION 21504                   // bytes of the quad's pixel neighbourhood staged in LDS (with the rest: 39.8 KB per block, 4 blocks per CU)
 #endif
 constexpr int kRefineRegion = CTAG_REFINE_REGION;
+#ifndef CTAG_REFINE_REGION_LARGE
+#define CTAG_REFINE_REGION_LARGE 49152             // ... of the search kernel's build for frames above 1920x1200: boxes up to ~220 x 220 px, three blocks per CU
+#endif
+constexpr int kRefineRegionLarge = CTAG_REFINE_REGION_LARGE;
 
 // MODE 0: the whole of edgeRefine for a (feature, quad) in one block of 256 -- calls of a few frames, and quads with an edge of more
 //         than kRefineSamples samples (edges longer than 1024 px; `only_long`).
@@ -531,7 +535,11 @@ __device__ __forceinline__ void refine_corner(const double* A, int it, int off, 
 // wait for the block's n0 stores (the vector-memory counter counts stores on gfx9) before the next quad's box may be requested.  A value a thread loaded itself is
 // waited for where it is used, as always.
 #define REFINE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <int MODE>
+// REGION: bytes of the quad's pixel neighbourhood staged in LDS.  kRefineRegion holds the box of every quad of a 1080p-class frame; frames above 1920x1200 have quads
+// of twice the size (a diagonal strip's box is ~190 x 190 px, up to 240 x 240) and batches of them run the search kernel with kRefineRegionLarge -- three blocks per CU
+// instead of four, but searches that gather from LDS: a box that does not fit leaves its searches to byte gathers from global memory (round 5: a 4K quad cost 2.3 x a
+// 1080p quad for the same 512 searches).
+template <int MODE, int REGION = kRefineRegion>
 __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int cols, int subpix, int frame, int qidx, int only_long, double alpha128 = 0.0) {
     // per edge and sample: refined point and its position parameter; the 48 running sums (4 edges x {next,last}
     // weighting x 6 moments) are then accumulated in sample order, all at once, one sum per lane
@@ -559,7 +567,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     // staged once with coalesced row loads: the 4 x 128 x 49 scattered byte loads of the searches then gather from LDS
     // instead of going through the texture-address path, which was as busy as the vector ALUs (70 % TA busy,
     // profiles/r02a_before_round2_work_instmix.json).  A box that does not fit stays in global memory (uniform per block).
-    __shared__ __attribute__((aligned(16))) uint8_t s_reg[kRefineRegion];
+    __shared__ __attribute__((aligned(16))) uint8_t s_reg[REGION];
     const int fi = qidx >> 1, quad = qidx & 1;  // (the caller's loop keeps qidx below twice the frame's feature count: no load of it here, once per quad)
     const int tid = threadIdx.x;
     const FeatureDev* F = P.feat1 + (size_t)frame * CTAG_MAX_FEATURES + fi;
@@ -604,7 +612,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
             if (bx1 >= bx0 && by1 >= by0) {
                 pitch = (bx1 - bx0 + 4) & ~3;
                 if (((pitch >> 2) & 1) == 0) pitch += 4;  // odd number of banks per row: a column of pixels spreads over the banks
-                staged = ((long long)pitch * (by1 - by0 + 1) <= kRefineRegion && (pitch >> 2) <= kRefineThreads) ? by1 - by0 + 1 : 0;
+                staged = ((long long)pitch * (by1 - by0 + 1) <= REGION && (pitch >> 2) <= kRefineThreads) ? by1 - by0 + 1 : 0;
             }
         }
         s_box[0] = bx0;
@@ -798,8 +806,8 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
     return true;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
+template <int MODE, int REGION = kRefineRegion>
+__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? (REGION > kRefineRegion ? 3 : CTAG_REFINE_SEARCH_WAVES) : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
 void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, int per_frame) {
     // per_frame > 0: a 1-D grid of per_frame blocks per frame in which blocks b and b + 8 -- one XCD -- belong to the same frame: the
     // boxes of a frame's quads overlap, and on one XCD the shared pixels come out of its L2 instead of HBM
@@ -817,7 +825,7 @@ void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, in
     const int nq = 2 * min(P.nfeat[frame], CTAG_MAX_FEATURES);
     const double alpha128 = (15.0 + (double)((int)threadIdx.x & (kRefineSamples - 1))) / (kRefineSamples + 30);  // == (15.0 + s) / (nsamples + 30) at 128 samples
     for (int q = bx; q < nq; q += gx) {
-        refine_quad<MODE>(P, rows, cols, subpix, frame, q, 0, alpha128);
+        refine_quad<MODE, REGION>(P, rows, cols, subpix, frame, q, 0, alpha128);
         if (q + gx < nq) REFINE_SYNC();
     }
 }
@@ -1766,7 +1774,10 @@ hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptr
         const int f8 = ((nframes + 7) / 8) * 8;
         // (round 5: searches and sums alternating over slices of 256 / 512 / 1024 frames, so that a slice's n0 is read back while the memory-side cache
         // still holds it, lost -- 5.13 / 4.95 / 4.84 against 4.71-4.76 ms per 4096 frames: the round trip through HBM is not what the sums kernel waits for)
-        if (xcd & 1) hipLaunchKernelGGL(k_edge_refine<1>, dim3(f8 * refine_gx), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_gx);
+        static const int large_env = getenv("CTAG_REFINE_LARGE") ? atoi(getenv("CTAG_REFINE_LARGE")) : 1;  // 0: the small staging region for every frame size (A/B)
+        const bool large = large_env && (long long)ws.g.rows * ws.g.cols > 1920LL * 1200;
+        if (large) hipLaunchKernelGGL((k_edge_refine<1, kRefineRegionLarge>), dim3(f8 * refine_gx), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_gx);
+        else if (xcd & 1) hipLaunchKernelGGL(k_edge_refine<1>, dim3(f8 * refine_gx), dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, refine_gx);
         else hipLaunchKernelGGL(k_edge_refine<1>, grid, dim3(kRefineThreads), 0, s, P, ws.g.rows, ws.g.cols, p.subpix_dist, nframes, 0);
         hipLaunchKernelGGL(k_edge_refine_sums, dim3(f8 * refine_sums_gx), dim3(64), 0, s, P, nframes, refine_sums_gx);
         hipLaunchKernelGGL(k_edge_refine_tail, dim3(13, nframes), dim3(64), 0, s, P, nframes, 13);  // 13 x 8 quads: the synthetic frames' 96; a block loops when a frame has more
