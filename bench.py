@@ -354,6 +354,8 @@ def issue_rooflines(stage_ms, n_frames):
         if stage == "quad_edges":  # the packed build runs as two kernels (boundary, edge clusters): both belong to the stage
             hits = [v for k, v in prof["kernels"].items() if k.startswith(kname + "<8,")]
             work = hits
+        elif stage == "edge_refine":  # searches (k_edge_refine<1>), ordered sums (k_edge_refine_sums), lines and corners (k_edge_refine_tail), long quads: the stage is all of them
+            work = [v for k, v in prof["kernels"].items() if k.startswith(kname + "<1") or k.startswith(kname + "_")]
         else:
             work = [max(hits, key=lambda v: v["wave_instructions"]["valu"])] if hits else []  # the build that does the work
         if not work or stage_ms.get(stage, 0) <= 0:
