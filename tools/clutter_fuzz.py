@@ -13,7 +13,7 @@ from ctag_testlib import Oracle, read_marker_file, GOLDEN
 from clutter import blob_field, chevron_texture
 state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
 orc, det = Oracle(), tk.Detector(state, fs)
-rng = np.random.RandomState(4242)
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)  # usage: clutter_fuzz.py [n_cases] [seed]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = limit = 0
 sizes = [(1080, 1920), (1080, 1920), (720, 1280), (1200, 1920), (2160, 3840), (902, 1444), (600, 800)]

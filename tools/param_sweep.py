@@ -11,7 +11,7 @@ from ctag_testlib import Oracle, read_bmp_gray, read_marker_file, GOLDEN
 state, fs = read_marker_file(os.path.join(GOLDEN, "CTag_2f12c.marker"))
 bmp = read_bmp_gray(os.path.join(GOLDEN, "test.bmp"))
 orc, det = Oracle(), tk.Detector(state, fs)
-rng = np.random.RandomState(2024)
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)  # usage: param_sweep.py [n_cases] [seed]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
 for case in range(n):
