@@ -24,7 +24,7 @@ det.detect_batch_device(frames.data_ptr(), n, 1080, 1920, 1920, 1080 * 1920, out
 det.sync()
 ns = np.concatenate([det.debug(f, tk.DBG_LINES) for f in range(n)])
 print("synthetic: %d edges in %d frames (%.1f per frame), %d points (%.0f per frame)" % (len(ns), n, len(ns) / n, ns.sum(), ns.sum() / n))
-edges = [0, 2, 10, 16, 32, 48, 64, 96, 128, 192, 256, 100000]
+edges = [0, 2, 10, 11, 12, 13, 16, 32, 48, 64, 96, 128, 192, 256, 100000]
 for a, b in zip(edges[:-1], edges[1:]):
     m = (ns > a) & (ns <= b)
     print("  n in (%d, %d]: %5.1f %% of edges, %5.1f %% of points" % (a, b, 100.0 * m.mean(), 100.0 * ns[m].sum() / ns.sum()))
