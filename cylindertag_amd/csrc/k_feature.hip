@@ -807,7 +807,7 @@ __device__ __forceinline__ bool refine_quad(const RefinePtrs& P, int rows, int c
 }
 
 template <int MODE, int REGION = kRefineRegion>
-__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? (REGION > kRefineRegion ? 3 : CTAG_REFINE_SEARCH_WAVES) : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
+__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? (REGION > 36864 ? 3 : CTAG_REFINE_SEARCH_WAVES) : 1, MODE == 1 ? CTAG_REFINE_SEARCH_WAVES : 8)))
 void k_edge_refine(RefinePtrs P, int rows, int cols, int subpix, int nframes, int per_frame) {
     // per_frame > 0: a 1-D grid of per_frame blocks per frame in which blocks b and b + 8 -- one XCD -- belong to the same frame: the
     // boxes of a frame's quads overlap, and on one XCD the shared pixels come out of its L2 instead of HBM
