@@ -35,12 +35,14 @@ def main():
     want = full.cpu().numpy()
     comm = CommGather(det, dist)
     if "--dead-peer" in sys.argv:
-        # rank 1 leaves without entering the collective (os._exit: no teardown, as a crashed process); rank 0's gather must come back
-        # with CTAG_ERR_HIP within CTAG_GATHER_TIMEOUT_MS instead of hanging, and the process exits non-zero
+        # rank 1 never enters the collective -- it sits there, as a hung process would (were it to EXIT, the launcher would end rank 0 before rank 0
+        # could show anything); rank 0's gather must come back with CTAG_ERR_HIP within CTAG_GATHER_TIMEOUT_MS instead of hanging, and the
+        # process exits non-zero (the launcher then ends rank 1)
         import time
         dist.barrier()
         if rank == 1:
-            os._exit(17)
+            time.sleep(60)
+            os._exit(0)
         lo, hi = shard_range(n_all, rank, world)
         out = torch.zeros((n_all, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
         t0 = time.perf_counter()

@@ -927,7 +927,7 @@ def test_two_rank_rccl_gather_when_two_gpus_are_present(dictionary):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     assert "GATHER_WORKER_OK" in p.stdout
-    # a peer that dies before its collective: the survivor's ctag_gather returns CTAG_ERR_HIP within the deadline and exits non-zero
+    # a peer that never reaches its collective: the other rank's ctag_gather returns CTAG_ERR_HIP within the deadline and exits non-zero
     import time
     cmd[-1:] = [os.path.join(ROOT, "tests", "gather_worker.py"), "--dead-peer"]
     cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
