@@ -1340,11 +1340,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 #endif
             // Unconditional loads from clamped addresses, the lanes / rows outside the box zeroed by a select: a load inside a branch makes the
             // compiler wait for EVERY load in flight where the branch rejoins, and the rows "in flight" arrived one at a time
+            // (Round 5, from the ISA: `ld_ok ? v : 0` behind the load was enough for the compiler to put the load back INSIDE a branch on ld_ok -- with s_waitcnt
+            // vmcnt(0) in front of it: a row was awaited before the next was requested, and the scan, 48 % of this kernel's phase clocks, ran at the latency of one
+            // L2 round trip per row.  Now nothing selects on ld_ok behind the load, an empty asm at the row's consumption reads a word of it -- so the load stays
+            // above it, outside every branch --, and a lane outside the box is neutralised where its tile's labels are looked up: it matches no label.)
             const int gx0 = ld_ok ? gxf : (x_min & ~7), gx1 = ld_ok1 ? gxf + kChunk : (x_min & ~7);
+            auto touch = [](const uint4& v) {  // an empty asm that reads a word of the row: what it reads was loaded ABOVE it, unconditionally
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(v.x));
+#endif
+            };
             auto load_row = [&](int y) {
                 if (CTAG_SCAN_UNCOND) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y, h - 1)) * g.lp + gx0);
-                    return ld_ok ? v : make_uint4(0, 0, 0, 0);
+                    return *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y, h - 1)) * g.lp + gx0);
                 }
                 uint4 r = make_uint4(0, 0, 0, 0);
                 if (ld_ok && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf);
@@ -1352,22 +1360,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             };
             auto load_row1 = [&](int y) {
                 if (CTAG_SCAN_UNCOND) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y, h - 1)) * g.lp + gx1);
-                    return ld_ok1 ? v : make_uint4(0, 0, 0, 0);
+                    return *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + min(y, h - 1)) * g.lp + gx1);
                 }
                 uint4 r = make_uint4(0, 0, 0, 0);
                 if (ld_ok1 && y < h) r = *reinterpret_cast<const uint4*>(limg + (size_t)(y_min + y) * g.lp + gxf + kChunk);
                 return r;
             };
             auto process_row = [&](const uint4& v, const uint4& v1, int y) {
+                if (CTAG_SCAN_UNCOND) {
+                    touch(v);
+                    touch(v1);
+                }
                 const int trow = ((y_min + y) / kTileH) * g.tiles_x;
                 if (trow != cur_trow) {
                     cur_trow = trow;
                     // the tiles' labels in the packed form (label | label << 16) fg_masks takes; 0xffffffff (no label) stays 0xffffffff
                     unsigned la, lb;
                     labels_of_tile(trow + tcol0, la, lb, over0);
+                    if (CTAG_SCAN_UNCOND && !ld_ok) la = lb = 0xffffffffu, over0 = false;  // a lane whose columns lie outside the box loads the box's first columns: it matches nothing
                     LA0 = (la & 0xffffu) * 0x10001u, LB0 = (lb & 0xffffu) * 0x10001u;
                     labels_of_tile(trow + tcol1, la, lb, over1);
+                    if (CTAG_SCAN_UNCOND && !ld_ok1) la = lb = 0xffffffffu, over1 = false;
                     LA1 = (la & 0xffffu) * 0x10001u, LB1 = (lb & 0xffffu) * 0x10001u;
                 }
                 auto one = [&](const uint4& w, uint32_t LA2, uint32_t LB2, bool over, int tile, unsigned valid, uint32_t* tp, uint32_t* bt, uint32_t* sn, int xl0) {
