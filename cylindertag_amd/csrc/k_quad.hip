@@ -1379,9 +1379,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     labels_of_tile(trow + tcol0, la, lb, over0);
                     if (CTAG_SCAN_UNCOND && !ld_ok) la = lb = 0xffffffffu, over0 = false;  // a lane whose columns lie outside the box loads the box's first columns: it matches nothing
                     LA0 = (la & 0xffffu) * 0x10001u, LB0 = (lb & 0xffffu) * 0x10001u;
-                    labels_of_tile(trow + tcol1, la, lb, over1);
-                    if (CTAG_SCAN_UNCOND && !ld_ok1) la = lb = 0xffffffffu, over1 = false;
-                    LA1 = (la & 0xffffu) * 0x10001u, LB1 = (lb & 0xffffu) * 0x10001u;
+                    LA1 = LB1 = 0xffffffffu, over1 = false;
+                    if (SG == 64 || !CTAG_SCAN_UNCOND || ld_ok1) {  // (most boxes are narrower than 64 columns: no second chunk, no second look-up)
+                        labels_of_tile(trow + tcol1, la, lb, over1);
+                        LA1 = (la & 0xffffu) * 0x10001u, LB1 = (lb & 0xffffu) * 0x10001u;
+                    }
                 }
                 auto one = [&](const uint4& w, uint32_t LA2, uint32_t LB2, bool over, int tile, unsigned valid, uint32_t* tp, uint32_t* bt, uint32_t* sn, int xl0) {
                     uint32_t M[4];
