@@ -632,8 +632,13 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
     const int chunk = std::min(n, h->max_chunk);
     DetectParams p{adaptive_thresh, corner_subpix, subpix_dist, h->feature_size, h->dict_rows, h->dict_cols, h->d_dict, h->d_dict_pos};
     p.channels = channels;
-    static const int two_min = getenv("CTAG_STREAMS_MIN") ? std::max(2 * kLatencyFrames + 2, atoi(getenv("CTAG_STREAMS_MIN"))) : 256;
-    if (h->streams >= 2 && !h->timing && chunk >= two_min && h->stream2) {
+    static const bool two_env = getenv("CTAG_STREAMS_MIN") != nullptr;
+    static const int two_min = two_env ? std::max(2 * kLatencyFrames + 2, atoi(getenv("CTAG_STREAMS_MIN"))) : 256;
+    // chunks of [448, 1024) frames stay on one stream: their halves (224-511 frames) leave the stage kernels' grids a partial last round of
+    // blocks on each stream.  Measured (round 5, 1080p, two handles alternating, K frames/s split / whole): 256: 189 / 178, 384: 213 / 214,
+    // 512: 222 / 237, 640: 229 / 234, 768: 232 / 234, 1024: 247 / 241, 2048: 255 / 250 (tools/step_overlap.py).
+    const bool whole = !two_env && chunk >= 448 && chunk < 1024;
+    if (h->streams >= 2 && !h->timing && chunk >= two_min && !whole && h->stream2) {
         const int ns = std::min(h->streams, (int)ctag_handle::kMaxStreams);
         // two halves of every chunk side by side (see WsSlot batch2).  With CTAG_OPT_TIMING the chunk stays on one stream: the HIP events
         // around a kernel would otherwise time the other stream's kernels as well.
