@@ -125,7 +125,8 @@ void* ctag_stream(ctag_handle* h);
 #define CTAG_OPT_STREAMS 8         /* 2 (default): a chunk of >= 256 frames of a device-memory call runs as two halves on two internal streams and workspaces -- the
                                       tail of one half's kernels overlaps the other half's next kernel; the second stream forks from and joins the handle's stream
                                       inside the call, so callers order against ctag_stream() as before.  1: one stream; 3 / 4: thirds / quarters on as many streams (measured on
-                                      4096-frame chunks: 2 and 3 the same within the spread, 4 slower).  A call with CTAG_OPT_TIMING on
+                                      4096-frame chunks: 2 and 3 the same within the spread, 4 slower).  Chunks of 448..1023 frames stay whole (their halves run slower than the chunk,
+                                      docs/history.md).  A call with CTAG_OPT_TIMING on
                                       always uses one stream (the per-kernel events would time the neighbour's kernels too).  Results do not depend on it. */
 #define CTAG_OPT_EXPAND_EXACT 9    /* developer aid: 1 makes expand_line (corner_detector.cpp:125-169) refit the line with the reference's own arithmetic at EVERY step
                                       instead of deciding most distance tests from a filtered estimate (k_quad.hip).  Results do not depend on it -- that is what
