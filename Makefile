@@ -12,4 +12,5 @@ clean:
 ubench:
 	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/ubench/valu_rate.hip -o tools/ubench/valu_rate
 	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench/dep_latency.hip -o tools/ubench/dep_latency
+	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench/read_bw.hip -o tools/ubench/read_bw
 .PHONY: all clean ubench

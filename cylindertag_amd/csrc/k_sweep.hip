@@ -766,6 +766,8 @@ template <int CH>
 struct RawSrc {
     uint32_t w[8 * CH];
 };
+// (measured, round 5: nontemporal loads here -- which stream 7.0 instead of 6.2 TB/s in tools/ubench/read_bw -- make K1f SLOWER, 1.71-1.86 against 1.68 ms per 4096
+// 1080p frames and 2.1-2.3 against 1.79 ms per 1024 4K frames: the tile rows a band shares with its neighbour then come from HBM twice)
 template <int CH>
 __device__ __forceinline__ RawSrc<CH> load_row_src(const uint8_t* __restrict__ rowp, int x0) {  // every lane loads (inactive ones an in-row dummy): no branch around the loads
     RawSrc<CH> r;
