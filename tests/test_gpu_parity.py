@@ -702,6 +702,42 @@ def test_bench_config_chunk4096(detector, oracle, dictionary):
         assert_same_record(big[f], oracle.detect_fast(host[f], state, fs), "chunk-4096 frame %d" % f)
 
 
+def test_records_do_not_depend_on_the_internal_stream_split(detector, dictionary, oracle):
+    """CTAG_OPT_STREAMS (include/ctag.h): a chunk runs whole on the handle's stream or as halves / thirds on internal streams and
+    workspaces -- chunks of 448..1023 frames always whole -- and the records are the same bytes either way.  Sizes on both sides of every
+    threshold (256, 448, 1024), a ragged one, and a sample of frames against the oracle."""
+    import torch
+    state, fs = dictionary
+    rows, cols = 1080, 1920
+    nmax = 1100
+    frames = torch.empty((nmax, rows, cols), dtype=torch.uint8, device="cuda")
+    detector.synth_frames_device(frames.data_ptr(), 7000, nmax, rows, cols, cols, rows * cols)
+    frames[3] = 180
+    frames[300, 500:560, 900:930] = 10
+    torch.cuda.synchronize()
+    out = torch.zeros((nmax, ca.RESULT_DT.itemsize), dtype=torch.uint8, device="cuda")
+    def run(n, streams):
+        detector.set_option(capi.OPT_STREAMS, streams)
+        out.zero_()
+        torch.cuda.synchronize()
+        detector.detect_batch_device(frames.data_ptr(), n, rows, cols, cols, rows * cols, out.data_ptr())
+        detector.sync()
+        return out[:n].cpu().numpy().tobytes()
+    try:
+        detector.set_option(capi.OPT_MAX_CHUNK, 2048)
+        ref = run(nmax, 1)
+        item = ca.RESULT_DT.itemsize
+        for n in (255, 257, 447, 449, 777, 1023, 1025, nmax):
+            for streams in (2, 3):
+                assert run(n, streams) == ref[:n * item], "n %d streams %d" % (n, streams)
+        rec = np.frombuffer(ref, dtype=ca.RESULT_DT)
+        for f in (0, 3, 128, 300, 448, 776, 1024, nmax - 1):
+            assert_same_record(rec[f], oracle.detect_fast(frames[f].cpu().numpy(), state, fs), "frame %d" % f)
+    finally:
+        detector.set_option(capi.OPT_STREAMS, 2)
+        detector.set_option(capi.OPT_MAX_CHUNK, 1024)
+
+
 def test_packed_shards_and_rccl_gather_single_rank(detector, dictionary):
     """include/ctag_gather.h on one GPU: k_pack / k_unpack equal the host restatement of the packed-shard format
     (cylindertag_amd/dist.py) on real detector records, and ctag_gather with a world-1 RCCL communicator (ncclCommInitRank +
