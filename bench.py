@@ -349,6 +349,14 @@ def issue_rooflines(stage_ms, n_frames):
     prof = json.load(open(cands[-1]))
     out = {"source": "instruction counts replayed from %s (rocprofv3 --pmc, 1024-frame pass); times from this run's HIP events" % os.path.relpath(cands[-1], ROOT),
            "model": "issue_bound_ms = sum over instruction classes of count * measured SIMD cycles per wave-instruction (2.1 f32 add/mul and simple int, 4.2 others incl. FP64, 8.2 / 16.1 transcendental; int32 at 3.15) / (1024 SIMDs * 2.4 GHz); profiles/r03_valu_issue_cost.txt", "kernels": {}}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import srcsha
+        psha = (prof.get("sources_sha256") or {}).get("all")
+        out["profile"] = {"file": os.path.relpath(cands[-1], ROOT), "git_head": prof.get("git_head"), "sources_sha256": psha,
+                          "matches_this_tree": None if psha is None else psha == srcsha.sources_sha256()["all"]}
+    except Exception:  # noqa: BLE001
+        pass
     for stage, kname in ISSUE_KERNELS.items():
         hits = [v for k, v in prof["kernels"].items() if k == kname or k.startswith(kname + "<") or (kname.endswith("<5") and k.startswith(kname))]  # template arguments vary; several builds of a kernel
         if stage == "quad_edges":  # the packed build runs as two kernels (boundary, edge clusters): both belong to the stage
@@ -710,7 +718,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     single_stream_dt = None
+    timed_records = None
     if world == 1:
+        # the records the TIMED steps left (the one-stream steps below write the same buffer): what `results_sha256` hashes and `parity` compares
+        timed_records = local_bufs[0][:n].clone()
         det.set_option(capi.OPT_TIMING, 1)
         step()  # warm: the one-stream workspace
         fence()
@@ -766,17 +777,27 @@ def main():
     stage_ms["quad"] = sum(stage_ms[k] for k in capi.QUAD_STAGES)  # a4 edgeExtraction: the six kernels of the quad stage
 
     # ---- outcome of the last step: the job's result list in frame order (gathered when N > 1)
-    final = gathered[last % 2] if world > 1 else local_bufs[0][:n]
+    # N = 1: of the last TIMED step (snapshot taken before the one-stream steps reused the buffer); N > 1: the gathered list of the last timed step
+    final = gathered[last % 2] if world > 1 else timed_records
     res = np.frombuffer(final.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
     ok_frames = int((res["status"] == 0).sum())
     markers_found = int(res["n_markers"].sum())
     sha = hashlib.sha256(res.tobytes()).hexdigest()
     rc = 0
+    one_stream_sha = None
+    if world == 1:  # the one-stream steps (`stage_ms_per_step`, `roofline`) must have produced the very same records
+        one_stream_sha = hashlib.sha256(local_bufs[0][:n].cpu().numpy().tobytes()).hexdigest()
+        if one_stream_sha != sha:
+            print("bench.py: the one-stream steps' records differ from the timed steps' (%s vs %s)" % (one_stream_sha[:16], sha[:16]), file=sys.stderr, flush=True)
+            rc = 1
 
     if rank == 0:
         sweep_ms = sum(stage_ms[k] for k in SWEEP_STAGES)
         achieved = ALGO_BYTES_PER_FRAME * n / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_profile = None, None, None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import srcsha
+        src_sha = srcsha.sources_sha256()
         import glob
         # per-round PMC passes, one file per frame size they were collected on (r05_pmc_traffic.json: 1080p; r05_4k_pmc_traffic.json: 3840x2160); latest round wins
         pat = {(1080, 1920): "r[0-9][0-9]_pmc_traffic.json", (2160, 3840): "r[0-9][0-9]_4k_pmc_traffic.json"}.get((ROWS, COLS))
@@ -784,7 +805,13 @@ def main():
         tpath = cands[-1] if cands else ""
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("sweep_bytes_per_frame") * min(n, chunk)  # measured per frame
+                tprof = json.load(open(tpath))
+                traffic = tprof.get("sweep_bytes_per_frame") * min(n, chunk)  # measured per frame
+                psha = (tprof.get("sources_sha256") or {}).get("sweep")
+                # the profile says which sweep sources it was collected on; a profile of other kernels than this tree's is flagged, not hidden
+                traffic_profile = {"file": os.path.relpath(tpath, ROOT), "git_head": tprof.get("git_head"), "sweep_sources_sha256": psha,
+                                   "this_tree_sweep_sources_sha256": src_sha["sweep"],
+                                   "matches_this_tree": None if psha is None else psha == src_sha["sweep"]}
                 traffic_source = "replayed from %s (separate rocprofv3 --pmc passes; not collected in this run)" % os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
@@ -794,6 +821,7 @@ def main():
             copy_gbs = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "traffic_profile": traffic_profile,
                     "measured_device_copy": None if not copy_gbs else {
                         "GB/s": round(copy_gbs, 1), "frac_of_copy": round(achieved / copy_gbs, 5),
                         "note": "plain device-to-device copy of 2 GiB (read + written bytes), best of 5, measured in this run: the rate a "
@@ -829,7 +857,10 @@ def main():
                    **{k: {"mean": round(frame_counters[k][0], 2), "max": frame_counters[k][1]} for k in capi.COUNTER_NAMES},
                    "note": "per-frame counts of the last chunk of the last step (ctag_get_counters): components the label sweep published, "
                            "candidates (area in [30 px, 1 %]), quads, features, decoded markers"},
-               "frames_ok": ok_frames, "markers_decoded_last_step": markers_found, "results_sha256": sha}
+               "frames_ok": ok_frames, "markers_decoded_last_step": markers_found, "results_sha256": sha,
+               "results_of": "the last TIMED step" + ("" if world > 1 else " (snapshot before the one-stream steps; their records hash %s)"
+                                                      % ("the same" if one_stream_sha == sha else "DIFFERENTLY: " + str(one_stream_sha))),
+               "sources_sha256": src_sha}
         if world > 1:
             out["gather_ms"] = gather_ms
             out["rank_stage_ms"] = rank_stage_ms

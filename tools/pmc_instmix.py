@@ -40,7 +40,9 @@ def main(tag, dirs):
                 acc[k][c].append(v)
             for (_, k), ms in span.items():
                 dur[k].append(ms)
-    out = {"tag": tag, "workload": "bench.py --frames 1024 --chunk 1024 (one pass of 1024 synthetic 1080p frames), means per launch",
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import srcsha
+    out = {"tag": tag, "sources_sha256": srcsha.sources_sha256(), "git_head": srcsha.git_head(), "workload": "bench.py --frames 1024 --chunk 1024 (one pass of 1024 synthetic 1080p frames), means per launch",
            "method": "rocprofv3 --kernel-trace --pmc, four separate passes of <= 8 SQ counters (tools/pmc_instmix.sh); durations are the "
                      "profiled (counter-collecting) launches' and run slower than unprofiled ones",
            "kernels": {}}
