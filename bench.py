@@ -189,8 +189,23 @@ def bgr_resident_rate(det, frames_dev, m, subpix, gray_rate):
         det.detect_batch_bgr_device(bgr.data_ptr(), m, ROWS, COLS, COLS * 3, ROWS * COLS * 3, out.data_ptr(), 5, subpix, 5)
     det.sync()
     tb = (time.perf_counter() - t0) / reps
+    # one device-resident frame per call: a call of a few BGR frames converts first and takes the short-band kernels, like a gray call of that size
+    def one_frame(fn):
+        ts = []
+        for i in range(60):
+            t1 = time.perf_counter()
+            fn()
+            det.sync()
+            ts.append(time.perf_counter() - t1)
+        return round(float(np.median(ts[10:])) * 1e3, 4)
+    lat = {"gray_ms": one_frame(lambda: det.detect_batch_device(g.data_ptr(), 1, ROWS, COLS, COLS, ROWS * COLS, ref.data_ptr(), 5, subpix, 5)),
+           "bgr_ms": one_frame(lambda: det.detect_batch_bgr_device(bgr.data_ptr(), 1, ROWS, COLS, COLS * 3, ROWS * COLS * 3, out.data_ptr(), 5, subpix, 5)),
+           "note": "one device-resident frame per call + sync, median of 50"}
+    det.detect_batch_device(g.data_ptr(), m, ROWS, COLS, COLS, ROWS * COLS, ref.data_ptr(), 5, subpix, 5)
+    det.detect_batch_bgr_device(bgr.data_ptr(), m, ROWS, COLS, COLS * 3, ROWS * COLS * 3, out.data_ptr(), 5, subpix, 5)
+    det.sync()
     return {"value": round(m / tb, 1), "unit": "frames/s", "frames": m, "gray_same_frames": round(m / tg, 1), "ratio_to_gray": round(tg / tb, 4),
-            "records_equal_gray_path": bool(torch.equal(out, ref)),
+            "records_equal_gray_path": bool(torch.equal(out, ref)), "one_frame_latency": lat,
             "note": "ctag_detect_batch_bgr8_device on device-resident BGR frames (3 B/px read from HBM; a 1080p frame's 6.2 MB against 2.1 MB of gray: "
                     "the bytes alone bound the ratio near 0.85)"}
 
@@ -632,7 +647,10 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
             return 3
-        if comm is None and n * world != n_total:
+        if host_gather:
+            gather_impl = ("developer backend %s (ranks share a GPU; RCCL refuses that): ctag_pack_results kernel -> %s all_gather of the packed sizes and "
+                           "shards through host memory -> ctag_gather_end's unpack kernels" % (dist.get_backend(), dist.get_backend()))
+        elif comm is None and n * world != n_total:
             raise SystemExit("the torch.distributed fallback gather needs equal shards")
     # N > 1: consecutive steps alternate between two handles (two streams, two workspaces): a rank's shard is small (512 frames
     # of the 4096 at N = 8) and the tails of its kernels -- a few long boundary / Welsch blocks -- would otherwise idle most of
@@ -682,12 +700,33 @@ def main():
                 pending.append(k)
             else:
                 d.sync()
-                if host_gather:  # developer aid (gloo): through host memory
-                    out_h = torch.empty((n_total, rec_bytes), dtype=torch.uint8)
-                    dist.all_gather_into_tensor(out_h.view(-1), buf[:n].cpu().reshape(-1))
-                    gathered[k % 2].copy_(out_h)
+                if host_gather:
+                    host_packed_gather(d, buf, gathered[k % 2])
                 else:
                     dist.all_gather_into_tensor(gathered[k % 2].view(-1), buf[:n].reshape(-1))
+
+    host_stats = {}
+    packed_dev = [None]
+
+    def host_packed_gather(d, buf, out):
+        """Developer backend (gloo: N ranks on ONE GPU, which RCCL refuses): the library's own protocol with the two ncclAllGather calls
+        replaced by gloo collectives on host copies -- ctag_pack_results kernel -> sizes -> packed shards padded to the largest ->
+        ctag_gather_end's segment table + unpack kernels (testkit hook on a caller-built buffer).  Uneven shards included."""
+        cap = capi.packed_capacity(max(n, 1))
+        if packed_dev[0] is None:
+            packed_dev[0] = torch.empty(cap, dtype=torch.uint8, device=dev)
+        nbytes = d.pack_results(buf.data_ptr(), n, packed_dev[0].data_ptr(), cap)  # waits for the size
+        sizes = torch.zeros(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(sizes, torch.tensor([nbytes], dtype=torch.int64))
+        width = (int(sizes.max()) + 255) & ~255
+        send = torch.zeros(width, dtype=torch.uint8)
+        send[:nbytes] = packed_dev[0][:nbytes].cpu()
+        recv = torch.empty(world * width, dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send)
+        recv_dev = recv.to(dev)
+        d.unpack_gathered(recv_dev.data_ptr(), n_total, world, width, out.data_ptr())
+        d.sync()
+        host_stats.update(packed_local=int(nbytes), padded_per_rank=width, fixed_records_per_rank=n * rec_bytes)
 
     def fence():
         finish_pending()
@@ -768,6 +807,13 @@ def main():
             comm.wait()
             det.sync()
             g = torch.tensor([(time.perf_counter() - g0) * 1e3], dtype=torch.float64, device="cpu" if cpu_side else dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            gather_ms = round(float(g.item()), 3)
+        elif dist.get_backend() != "nccl":
+            fence()
+            g0 = time.perf_counter()
+            host_packed_gather(det, local_bufs[last % len(local_bufs)], gathered[(last + 1) % 2])
+            g = torch.tensor([(time.perf_counter() - g0) * 1e3], dtype=torch.float64)
             dist.all_reduce(g, op=dist.ReduceOp.MAX)
             gather_ms = round(float(g.item()), 3)
         mine = torch.tensor([stage_ms[k] for k in ca.STAGE_NAMES], dtype=torch.float64, device="cpu" if cpu_side else dev)
@@ -867,6 +913,8 @@ def main():
         if comm is not None:
             lb, pb = det.gather_last_bytes()
             out["config"]["gather_bytes"] = {"packed_local": lb, "padded_per_rank": pb, "fixed_records_per_rank": n * rec_bytes}
+        elif host_stats:
+            out["config"]["gather_bytes"] = dict(host_stats)
         # side legs: a failure in one of them is reported in its place and never costs the headline line
         def side(name, fn):
             try:

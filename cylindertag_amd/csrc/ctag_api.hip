@@ -861,7 +861,9 @@ static int detect_bgr_device_impl(ctag_handle* h, const uint8_t* bgr_dev, int n,
     // The direct form (round 5): frames of a size the fused sweep takes (1080p, 4K, 8K; adaptiveThresh 5), rows and frames 16-byte aligned -- the
     // decimation kernel loads the BGR bytes themselves and converts as it consumes them, edgeRefine converts the boxes it stages: no gray image is
     // written or read back (8.3 of the 24 MB a 1080p frame moved through the gray slab).  CTAG_OPT_BGR_DIRECT 0 turns it off.
-    if (h->bgr_direct && sweep_fused_size(rows, cols, adaptive_thresh, h->fuse_mode) && row_stride < (1 << 24) && (long long)rows * row_stride <= 0xffffffffLL &&
+    // Calls of a few frames (round 6): the fused sweep's K1 is one block per frame band group -- 0.19 ms for a single 1080p frame against < 0.02 ms
+    // of the short-band kernels -- so they convert first and take the gray chain, as gray calls of that size do (sweep_fused).
+    if (h->bgr_direct && sweep_fused_size(rows, cols, adaptive_thresh, h->fuse_mode) && sweep_fused_batch(rows, cols, n, h->fuse_mode) && row_stride < (1 << 24) && (long long)rows * row_stride <= 0xffffffffLL &&
         (((uintptr_t)bgr_dev | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0) {
         const PendingCtx pc{h->d_pending, h->d_pending_count, h->pending_cap, bgr_dev, (int64_t)frame_stride, (int64_t)row_stride,
                             rows, cols, 3, adaptive_thresh, corner_subpix, subpix_dist};

@@ -108,13 +108,19 @@ bool order_unref(ncclComm_t c, bool wait_for_last);  // below
 bool order_dead(ncclComm_t c);
 void release_comm(GatherState* g);
 int env_timeout_ms();
+int timeout_of(const struct GatherState* g);
 bool stream_idle_within(hipStream_t s, int timeout_ms);  // hipStreamSynchronize with a deadline (0: none)
 
 void gather_state_free(void* p) {
     GatherState* g = static_cast<GatherState*>(p);
     (void)hipSetDevice(g->device);
+    // the handle's own deadline (ctag_gather_set_timeout), taken before the communicator goes; once the communicator is dead the waits
+    // ahead have had their deadline already: the final drain gets a second, not another full period
+    int drain_ms = g->comm ? timeout_of(g) : env_timeout_ms();
+    const bool was_dead = g->comm && order_dead(g->comm);
     release_comm(g);
-    if (g->gstream && !stream_idle_within(g->gstream, env_timeout_ms())) {
+    if (was_dead || (g->err[0] && drain_ms > 1000)) drain_ms = 1000;
+    if (g->gstream && !stream_idle_within(g->gstream, drain_ms)) {
         // the gather stream does not drain (an aborted collective that never left?): what it may still touch is leaked rather than freed under it
         delete g;
         return;
@@ -164,11 +170,18 @@ struct CommOrder {
     ncclComm_t comm = nullptr;
     hipEvent_t last = nullptr;   // created when the entry is taken (on the device that is current then: a communicator lives on one device), destroyed with it
     bool has = false;
-    bool dead = false;
+    std::atomic<bool> dead{false};  // read without the entry's lock: a collective stuck in its issue (which holds mu) must not stall the pollers or the abort
     int refs = 0;
-    std::mutex mu;     // wait -> issue -> record of one collective; also the abort
+    std::mutex mu;     // wait -> issue -> record of one collective
+    std::thread abort_thread;                         // the ncclCommAbort of this communicator, if one was started: joined (bounded) when the entry is given up
+    std::shared_ptr<std::atomic<bool>> abort_done;
 };
-CommOrder g_order[16];
+constexpr int kOrderEntries = 16;
+CommOrder* const g_order_tab = new CommOrder[kOrderEntries];  // never destroyed: an entry may own a thread that is still inside ncclCommAbort at exit
+struct OrderRange {
+    CommOrder* begin() const { return g_order_tab; }
+    CommOrder* end() const { return g_order_tab + kOrderEntries; }
+} g_order;
 std::mutex g_order_mu;  // the table: comm / refs of every entry
 CommOrder* order_find(ncclComm_t c) {  // caller holds g_order_mu
     for (CommOrder& o : g_order)
@@ -191,7 +204,7 @@ bool order_ref(ncclComm_t c) {
             if (hipEventCreateWithFlags(&o.last, hipEventDisableTiming) != hipSuccess) return false;
             o.comm = c;
             o.has = false;
-            o.dead = false;
+            o.dead.store(false);
             o.refs = 1;
             return true;
         }
@@ -199,32 +212,49 @@ bool order_ref(ncclComm_t c) {
 }
 bool order_dead(ncclComm_t c) {
     CommOrder* o = order_lookup(c);
-    if (!o) return false;
-    std::lock_guard<std::mutex> lk(o->mu);
-    return o->dead;
+    return o && o->dead.load();
 }
 // ncclCommAbort, once per communicator, whichever handle asks first: the collectives in flight end (their kernels leave), the
 // communicator's memory is released by RCCL; nothing may be issued on it afterwards (dead) and its owner must not destroy it again
 void order_abort(ncclComm_t c) {
     CommOrder* o = order_lookup(c);
     if (!o) return;
-    std::lock_guard<std::mutex> lk(o->mu);
-    if (o->dead) return;
-    o->dead = true;
+    // `dead` first and without the entry's lock: another handle's thread may sit in a blocking ncclAllGather issue with the lock held
+    // (that is the situation an abort exists for); nothing new is issued from here on, and the first caller alone starts the abort
+    if (o->dead.exchange(true)) return;
     if (!rccl()->CommAbort) return;
     // ncclCommAbort returns when the communicator's kernels have left -- at once when they are spinning on a peer that is gone, but it
     // waits as long as whatever holds the stream AHEAD of a collective that has not started.  The caller has a deadline to keep: the abort
-    // runs on a thread of its own and is given half a second; if it is still busy then it finishes (or not) without us.
+    // runs on a thread of its own and is given half a second here; the thread stays with the entry and is joined (bounded again) when the
+    // last handle lets go of the communicator.  Should it still be busy then it is detached: such a process must leave through _exit()
+    // (include/ctag_gather.h) -- static destructors of HIP / RCCL under a running abort are not safe.
     auto done = std::make_shared<std::atomic<bool>>(false);
     ncclResult_t (*abort_fn)(ncclComm_t) = rccl()->CommAbort;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::thread([=] {
+    std::thread t([=] {
         (void)hipSetDevice(dev);
         (void)abort_fn(c);
         done->store(true);
-    }).detach();
+    });
+    {
+        std::lock_guard<std::mutex> lk(g_order_mu);  // the table's lock (never held across an RCCL call) guards the thread object
+        o->abort_done = done;
+        o->abort_thread = std::move(t);
+    }
     for (int i = 0; i < 500 && !done->load(); i++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+}
+// the entry's abort thread, if any: joined when it is done within `ms`, detached otherwise.  Caller holds g_order_mu.
+bool order_join_abort(CommOrder* o, int ms) {
+    if (!o->abort_thread.joinable()) return true;
+    for (int i = 0; i < ms && !o->abort_done->load(); i++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    const bool done = o->abort_done->load();
+    if (done)
+        o->abort_thread.join();
+    else
+        o->abort_thread.detach();
+    o->abort_done.reset();
+    return done;
 }
 bool order_unref(ncclComm_t c, bool wait_for_last);  // below: needs the bounded wait
 // one collective on `s`, ordered behind the previous one of this communicator and published for the next, under the entry's lock
@@ -233,7 +263,7 @@ hipError_t ordered_collective(ncclComm_t c, hipStream_t s, F issue, ncclResult_t
     CommOrder* o = order_lookup(c);
     if (!o) return hipErrorInvalidValue;  // ctag_comm_init / _attach registers every communicator
     std::lock_guard<std::mutex> lk(o->mu);
-    if (o->dead) {
+    if (o->dead.load()) {
         *nr = ncclInvalidUsage;  // aborted earlier
         return hipSuccess;
     }
@@ -299,11 +329,11 @@ bool stream_idle_within(hipStream_t s, int timeout_ms) {
 bool order_unref(ncclComm_t c, bool wait_for_last) {
     CommOrder* o = order_lookup(c);
     if (!o) return false;
-    bool has, dead;
-    {
+    bool dead = o->dead.load();
+    bool has = true;
+    if (!dead) {  // (a dead communicator's lock may be held for ever by a collective stuck in its issue)
         std::lock_guard<std::mutex> lk(o->mu);
         has = o->has;
-        dead = o->dead;
     }
     if (wait_for_last && has && !dead) {  // the owner is about to destroy the communicator: nothing issued on it may still run
         int detail = 0;
@@ -315,10 +345,12 @@ bool order_unref(ncclComm_t c, bool wait_for_last) {
     }
     std::lock_guard<std::mutex> lk(g_order_mu);
     if (--o->refs <= 0) {
+        (void)order_join_abort(o, 2000);
         if (o->last) (void)hipEventDestroy(o->last);
         o->comm = nullptr;
         o->last = nullptr;
-        o->has = o->dead = false;
+        o->has = false;
+        o->dead.store(false);
         o->refs = 0;
     }
     return dead;
@@ -351,6 +383,7 @@ int bounded_wait(GatherState* g, Q ready, const char* what) {
     if (w == kWaitOk) return CTAG_OK;
     if (w == kWaitHipError) {
         std::snprintf(g->err, sizeof(g->err), "%s: %s", what, hipGetErrorString((hipError_t)detail));
+        g->in_flight = false;
         return CTAG_ERR_HIP;
     }
     Rccl* R = rccl();
@@ -373,7 +406,7 @@ int bounded_stream(GatherState* g, hipStream_t s, const char* what) {
 // owner then waits for the communicator's last collective, whichever handle issued it, and destroys it -- unless it was aborted
 void release_comm(GatherState* g) {
     if (!g->comm) return;
-    if (g->gstream) (void)bounded_stream(g, g->gstream, "gather stream at communicator release");
+    if (g->gstream && !order_dead(g->comm)) (void)bounded_stream(g, g->gstream, "gather stream at communicator release");  // (dead: that wait has expired once already)
     const bool dead = order_unref(g->comm, g->own_comm);
     if (g->own_comm && !dead && rccl()->CommDestroy) (void)rccl()->CommDestroy(g->comm);
     g->comm = nullptr;

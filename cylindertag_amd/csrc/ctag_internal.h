@@ -233,6 +233,7 @@ hipError_t launch_zero_counters(int nframes, const Workspace& ws, hipStream_t s)
 // fused: k_decimate_mask + the mask front end of K2 (1 bit per pixel between them, no `half`) -- sweep_fused says when that form applies
 bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, bool always = false);
 bool sweep_fused_size(int rows, int cols, int tw, int fuse_mode);
+bool sweep_fused_batch(int rows, int cols, int nframes, int fuse_mode);  // a call of that many frames is a batch for the fused sweep (else: short-band kernels)
 hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, bool fused = false, bool zero_too = false,
                            int channels = 1);  // channels = 3: BGR frames, fused form only
 hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s, bool fused = false);

@@ -534,7 +534,13 @@ __device__ __forceinline__ void refine_corner(const double* A, int it, int off, 
 // Barrier of the edgeRefine blocks: their phases exchange data through LDS only, so it waits for LDS traffic and NOT for vector memory -- __syncthreads() would also
 // wait for the block's n0 stores (the vector-memory counter counts stores on gfx9) before the next quad's box may be requested.  A value a thread loaded itself is
 // waited for where it is used, as always.
+// Holds only while no phase of these blocks hands data to another thread through GLOBAL memory (none does: n0 is re-read by other kernels only).  A build with
+// EXTRA=-DCTAG_REFINE_PLAIN_SYNC=1 replaces both macros by __syncthreads(): the parity tests pass with either (tests/test_refine_sync_gpu.py runs them on that build).
+#if defined(CTAG_REFINE_PLAIN_SYNC) && CTAG_REFINE_PLAIN_SYNC
+#define REFINE_SYNC() __syncthreads()
+#else
 #define REFINE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 // REGION: bytes of the quad's pixel neighbourhood staged in LDS.  kRefineRegion holds the box of every quad of a 1080p-class frame; frames above 1920x1200 have quads
 // of twice the size (a diagonal strip's box is ~190 x 190 px, up to 240 x 240) and batches of them run the search kernel with kRefineRegionLarge -- three blocks per CU
 // instead of four, but searches that gather from LDS: a box that does not fit leaves its searches to byte gathers from global memory (round 5: a 4K quad cost 2.3 x a
@@ -846,7 +852,15 @@ constexpr int kSumPitch = kSumSeg + 2;  // doubles per row: 36 words -- an odd m
 // The sums kernel's block is ONE wave, and LDS serves a wave's accesses in order: its phases are ordered by a wait for LDS traffic alone.  __syncthreads() would also wait
 // for vector memory -- for the NEXT quad's n0, requested a quad ahead precisely so that nobody waits for it (with __syncthreads() the kernel ran at 0.38 of its
 // vector-issue rate: profiles/r05_pmc_instmix.json).
+// No barrier at all: correct ONLY for a block of exactly one wave64 -- k_edge_refine_sums (its only user) checks its launch size and traps otherwise.
+#if defined(CTAG_REFINE_PLAIN_SYNC) && CTAG_REFINE_PLAIN_SYNC
+#define SUMS_SYNC() __syncthreads()
+#else
 #define SUMS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__GFX9__) && defined(__AMDGCN_WAVEFRONT_SIZE__) && __AMDGCN_WAVEFRONT_SIZE__ != 64
+#error "SUMS_SYNC assumes 64-wide wavefronts"
+#endif
 struct SumsPrefetch {
     double n0[kSumSegs];  // of sample 16 g + (tid & 15) of edge tid >> 4
     float cx, cy;
@@ -938,6 +952,7 @@ __device__ __forceinline__ bool refine_sums_quad(const SumsPrefetch& pre, const 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_REFINE_SUMS2_WAVES, 8)))
 void k_edge_refine_sums(RefinePtrs P, int nframes, int per_frame) {
     // per_frame blocks per frame, blocks b and b + 8 -- one XCD -- on the same frame; a block loops over the frame's quads with the next quad's inputs in flight
+    if (blockDim.x != 64) __builtin_trap();  // SUMS_SYNC orders the phases of ONE wave; any other launch size would race silently
     const int b = blockIdx.x;
     const int frame = ((b >> 3) / per_frame) * 8 + (b & 7);
     const int bx = (b >> 3) % per_frame;

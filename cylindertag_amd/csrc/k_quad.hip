@@ -182,6 +182,21 @@ template <int WS, class Pts>
 __device__ __forceinline__ bool welsch_rounds(const Pts pts, int n, double EPS, float* line, double& err, int it0, int it_stop, bool resume, float* wc, int ncache) {
     float prev[4] = {0.f, 0.f, 0.f, 0.f};
     const float c = 1 / 2.9846f;
+#ifdef CTAG_WELSCH_MINERR_IN_LOOP
+    // The other placement of fitLine2D's `if (err < min_err)` (oracle: OracleVariants::welsch_minerr_in_loop): the pair is taken right after calcDist2D, so a restart
+    // hands on the FIRST SMALLEST (err, line) of its iterations instead of (last err, last refit).  The restart ends early on an error below EPS only when that error
+    // improved on its own best; what earlier restarts had reached cannot matter unless two restarts reach different errors below EPS (exactly collinear points give 0).
+    // A restart's best is part of its state here, so this build does not regroup (kWRegroupAt = 30).
+    double berr = 1.7976931348623157e308;
+    float bl[4] = {0.f, 0.f, 0.f, 0.f};
+#define CTAG_WELSCH_HAND_ON()       \
+    do {                            \
+        for (int q = 0; q < 4; q++) line[q] = bl[q]; \
+        err = berr;                 \
+    } while (0)
+#else
+#define CTAG_WELSCH_HAND_ON() do { } while (0)
+#endif
     for (int it = it0; it < 30; it++) {
         if (it > 0 && !(resume && it == it0)) {
             // reference: fabs(acos(clamp(t))) < 0.01f with t a float-valued dot product.  acos64 is decreasing, so the
@@ -192,7 +207,10 @@ __device__ __forceinline__ bool welsch_rounds(const Pts pts, int n, double EPS, 
                 const float dx = ctm::fabs32(line[2] - prev[2]);
                 const float dy = ctm::fabs32(line[3] - prev[3]);
                 const float d = dx > dy ? dx : dy;
-                if (d < 0.01f) return true;
+                if (d < 0.01f) {
+                    CTAG_WELSCH_HAND_ON();
+                    return true;
+                }
             }
         }
         if (it == it_stop) return false;
@@ -223,7 +241,15 @@ __device__ __forceinline__ bool welsch_rounds(const Pts pts, int n, double EPS, 
             err += r;
             sum_w += ctm::exp32_nonpos(-r * r * c * c);
         }
+#ifdef CTAG_WELSCH_MINERR_IN_LOOP
+        if (err < berr) {
+            berr = err;
+            for (int q = 0; q < 4; q++) bl[q] = line[q];
+            if (err < EPS) return true;  // (line, err) are the best already
+        }
+#else
         if (err < EPS) return true;
+#endif
         double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0, w = 0;
         if (ctm::fabs64(sum_w) > 1.1920928955078125e-07) {
             const double inv = 1. / sum_w;
@@ -276,8 +302,10 @@ __device__ __forceinline__ bool welsch_rounds(const Pts pts, int n, double EPS, 
         prev[3] = line[3];
         moments_to_line(x, y, x2, y2, xy, w, line);
     }
+    CTAG_WELSCH_HAND_ON();
     return true;
 }
+#undef CTAG_WELSCH_HAND_ON
 // a restart's result where the selection reads it: the line in res[q * rstride], q = 0..3, the two halves of the error (a double) in q = 4, 5
 __device__ __forceinline__ void restart_store(float* res, int rstride, const float* line, double err) {
     for (int q = 0; q < 4; q++) res[q * rstride] = line[q];
@@ -1982,7 +2010,9 @@ __device__ __forceinline__ void welsch_select(const QuadPtrs& P, int frame, int 
         if (r.err < min_err) {
             min_err = r.err;
             for (int q = 0; q < 4; q++) best[q] = r.line[q];
+#ifndef CTAG_WELSCH_MINERR_IN_LOOP  // (in-loop placement: an error below EPS ends the restart, not the search)
             if (r.err < EPS) break;
+#endif
         }
     }
     float* o = P.line_fit + ((size_t)frame * P.line_cap + lid) * 4;
@@ -2008,6 +2038,10 @@ constexpr int kWB = CTAG_WELSCH_BLOCK_WAVES;
 constexpr int kWT = kWB * 64;   // 256 threads
 constexpr int kWE = kWT / 20;   // 12 edges (16 lanes of the block idle)
 constexpr int kWRes = 10;       // first result row
+#ifdef CTAG_WELSCH_MINERR_IN_LOOP
+#undef CTAG_WELSCH_REGROUP_AT
+#define CTAG_WELSCH_REGROUP_AT 30  // a restart's best (err, line) would have to travel: this build does not regroup
+#endif
 #ifndef CTAG_WELSCH_REGROUP_AT
 #define CTAG_WELSCH_REGROUP_AT 2  // iterations before the regroup (30: never)
 #endif
@@ -2298,6 +2332,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WLAT_WA
         }
         const double EPS = n * 1.1920928955078125e-07;
         double err = 0;
+#ifdef CTAG_WELSCH_MINERR_IN_LOOP
+        double berr = 1.7976931348623157e308;
+        float bl[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
         for (int it = 0; it < 30; it++) {
             if (it > 0) {
                 const float t = line[0] * prev[0] + line[1] * prev[1];
@@ -2331,7 +2369,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WLAT_WA
             __syncthreads();
             err = s_sum[0];
             const double sum_w = s_sum[1];
+#ifdef CTAG_WELSCH_MINERR_IN_LOOP
+            if (err < berr) {
+                berr = err;
+                for (int q = 0; q < 4; q++) bl[q] = line[q];
+                if (err < EPS) break;
+            }
+#else
             if (err < EPS) break;
+#endif
             const bool weighted = ctm::fabs64(sum_w) > 1.1920928955078125e-07;
             const double inv = weighted ? 1. / sum_w : 0.;
             acc = 0;  // lanes 0..5: x, y, x2, y2, xy, w -- each a column added in point order
@@ -2371,6 +2417,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CTAG_WLAT_WA
             prev[3] = line[3];
             moments_to_line(s_sum[2], s_sum[3], s_sum[4], s_sum[5], s_sum[6], s_sum[7], line);  // (the next write of s_sum is behind the next chunk's barrier)
         }
+#ifdef CTAG_WELSCH_MINERR_IN_LOOP
+        for (int q = 0; q < 4; q++) line[q] = bl[q];
+        err = berr;
+#endif
         if (lane == 0) {
             float* o = rs + (((size_t)frame * kLatLines + rank) * 20 + k) * 6;
             o[0] = line[0];
@@ -2396,7 +2446,9 @@ __device__ __forceinline__ void welsch_pick(const QuadPtrs& P, int frame, int ra
         if (e < min_err) {
             min_err = e;
             for (int q = 0; q < 4; q++) best[q] = r[kk * 6 + q];
+#ifndef CTAG_WELSCH_MINERR_IN_LOOP
             if (e < EPS) break;
+#endif
         }
     }
     float* o = P.line_fit + ((size_t)frame * P.line_cap + lid) * 4;

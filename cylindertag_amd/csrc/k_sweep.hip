@@ -121,6 +121,12 @@ __device__ __forceinline__ void hpass(const Raw18& r, uint32_t q[4]) {
     }
 }
 
+// Width of OpenCV's vector body in the vertical pass (8: a 128-bit universal-intrinsics build, the assumption; 16: a 256-bit body -- EXTRA=-DCTAG_RESIZE_SIMD_LANES=16
+// with the oracle's ctago_set_variants(.., 16)).  Frames whose half width is a multiple of 16 (1080p, 4K, 8K, test.bmp) give the same image either way.
+#ifndef CTAG_RESIZE_SIMD_LANES
+#define CTAG_RESIZE_SIMD_LANES 8
+#endif
+static_assert(CTAG_RESIZE_SIMD_LANES == 8 || CTAG_RESIZE_SIMD_LANES == 16, "vector body of 8 or 16 columns");
 // vertical pass.  OpenCV's float vector body computes t = s0*b0 + (s1*b1 + (s2*b2 + s3*b3)) with s = 64*q and
 // b = {-192,1216,1216,-192} * 2^-22 and rounds half-to-even.  Every product and partial sum is a multiple of 2^-10 of
 // magnitude < 2^14, i.e. exactly representable in float, so t == V / 1024 exactly with V = 19*(qb+qc) - 3*(qa+qd) and
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     const int hx0 = (bx * 64 + lane) * 8;
     const int x0 = hx0 * 2;
     const bool active = hx0 < g.hcols;
-    const int tail = (HAS_TAIL && hx0 >= (g.hcols & ~7)) ? 1 : 0;
+    const int tail = (HAS_TAIL && hx0 >= (g.hcols & ~(CTAG_RESIZE_SIMD_LANES - 1))) ? 1 : 0;
     const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
     uint8_t* __restrict__ dst = half + ((size_t)frame * g.hrows) * g.hp;
     const int rmax = g.rows - 1;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256) void k_decimate_general(const uint8_t* __restr
         R[k] = v;
     }
     int out;
-    if (x < (g.hcols & ~7)) {
+    if (x < (g.hcols & ~(CTAG_RESIZE_SIMD_LANES - 1))) {
         const float scale = 1.f / (2048.f * 2048.f);
         float t = (float)R[3] * ((float)b[3] * scale);
         t = (float)R[2] * ((float)b[2] * scale) + t;
@@ -402,6 +408,12 @@ bool sweep_fused_size(int rows, int cols, int tw, int fuse_mode) {
     if (!env || (rows & 1) || (cols & 1) || tw != 5) return false;
     const int hcols = cols / 2, hrows = rows / 2;
     return hcols % kFuseCols == 0 && hrows % 135 == 0 && (hrows / 135) % 4 == 0;
+}
+// whether a call of nframes frames of this size is a batch for the fused sweep's tall bands (the rule sweep_fused applies to gray frames): BGR calls
+// below it take k_bgr2gray + the latency-tuned short-band kernels instead of one 4-wave block per frame walking 135-row bands
+bool sweep_fused_batch(int rows, int cols, int nframes, int fuse_mode) {
+    const int env = fuse_mode >= 0 ? fuse_mode : fuse_env() >= 0 ? fuse_env() : 1;
+    return env >= 2 || (long)nframes * ((cols / 2) / kFuseCols) * ((rows / 2) / 135) >= 2048;
 }
 // always: BGR frames (they take this form or none: the caller has checked sweep_fused_size and the alignment)
 bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, bool always) {
@@ -450,7 +462,7 @@ hipError_t launch_decimate(const uint8_t* frames, ptrdiff_t frame_stride, ptrdif
 #define CTAG_DEC_LAUNCH(AL, B, TL)                                                                                                         \
     hipLaunchKernelGGL((k_decimate<AL, B, TL>), dim3(grid), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, nframes, xblocks, \
                        yblocks, band_rows, Z)
-    const bool has_tail = (g.hcols & 7) != 0;
+    const bool has_tail = (g.hcols & (CTAG_RESIZE_SIMD_LANES - 1)) != 0;
     static const int wide_env = getenv("CTAG_DEC_WIDE") ? atoi(getenv("CTAG_DEC_WIDE")) : 1;  // same-box A/B on 4096 1080p frames: 2.276 -> 2.209 ms (5 waves per SIMD: 2.28)
     if (zero_too && band_rows == 135) {  // (a few frames never get here: their bands are short) the forms below do not zero
         const hipError_t e = launch_zero_counters(nframes, ws, s);

@@ -85,7 +85,10 @@ int ctag_gather(ctag_handle* h, const ctag_frame_result* local_dev, int n_local,
  * flight) polls with a deadline and asks RCCL for asynchronous errors of the communicator (ncclCommGetAsyncError) while it
  * does.  At the deadline, or on such an error, the communicator is aborted (ncclCommAbort: the collectives in flight end), the call
  * returns CTAG_ERR_HIP and ctag_comm_last_error says why; every handle that shares the communicator fails its later gather calls the
- * same way and the process is expected to exit non-zero.  timeout_ms > 0: that many milliseconds; 0: no deadline; < 0: back to the
+ * same way and the process is expected to exit non-zero.  The abort runs on a thread of the library's (half a second is waited for it at
+ * the deadline, two more when the last handle lets go of the communicator); a process whose abort is still busy after that -- RCCL waiting
+ * for work ahead of a collective that never started -- must leave through _exit(), not exit(): HIP / RCCL static teardown under a running
+ * abort is not safe.  timeout_ms > 0: that many milliseconds; 0: no deadline; < 0: back to the
  * default = the environment variable CTAG_GATHER_TIMEOUT_MS, else 60 000 ms.  Without a communicator (one rank) nothing is bounded:
  * there is no peer to wait for. */
 int ctag_gather_set_timeout(ctag_handle* h, int timeout_ms);

@@ -86,6 +86,10 @@ void ctago_threshold(const uint8_t* half, int rows, int cols, int tw, uint8_t* d
 int ctago_ccl(const uint8_t* bin, int rows, int cols, int32_t* labels, int32_t* areas, int areas_cap);
 void ctago_fitline_l2(const int32_t* xy, int n, float* line4);
 void ctago_fitline_welsch(const int32_t* xy, int n, float* line4);
+/* The two assumptions about OpenCV 4.5.3 nothing here can check, as switches (see OracleVariants in ctag_oracle.cpp): process-wide setting for every later
+ * call (defaults 0, 8), and the Welsch fit under either placement of the min_err update for tests/cv2_pins.py to compare a real cv2.fitLine with. */
+void ctago_set_variants(int welsch_minerr_in_loop, int resize_simd_lanes);
+void ctago_fitline_welsch_variant(const int32_t* xy, int n, int variant, float* line4);
 /* op: 0 atan2_64(a,b) 1 sin64(a) 2 cos64(a) 3 exp64(a) 4 acos64(a) 5 atan2_32 6 sin32 7 cos32 8 exp32
  *     9 fast_atan2_deg(a,b) 10 a/b (f64) 11 sqrt(a) (f64) 12 a/b (f32) 13 sqrtf(a) 14 round32(a) */
 void ctago_math_probe(int op, int n, const double* a, const double* b, double* out);

@@ -108,12 +108,25 @@ class Oracle:
         L.ctago_fitline_l2.argtypes = [_p_i32, C.c_int, _p_f32]
         L.ctago_fitline_welsch.argtypes = [_p_i32, C.c_int, _p_f32]
         L.ctago_math_probe.argtypes = [C.c_int, C.c_int, _p_f64, _p_f64, _p_f64]
+        L.ctago_set_variants.argtypes = [C.c_int, C.c_int]
+        L.ctago_set_variants.restype = None
+        L.ctago_fitline_welsch_variant.argtypes = [_p_i32, C.c_int, C.c_int, _p_f32]
         L.ctago_set_params.argtypes = [C.c_void_p]
         L.ctago_set_params.restype = None
 
     def set_params(self, params=None):
         """The tunables of every following run: a cylindertag_amd.ParamsC (the struct ctag_create_ex takes), None = the reference's values."""
         self.L.ctago_set_params(C.byref(params) if params is not None else None)
+
+    def set_variants(self, welsch_minerr_in_loop=0, resize_simd_lanes=8):
+        """The two unverifiable assumptions about OpenCV 4.5.3 as switches (oracle/ctag_oracle.cpp: OracleVariants); process-wide, defaults (0, 8)."""
+        self.L.ctago_set_variants(int(welsch_minerr_in_loop), int(resize_simd_lanes))
+
+    def fitline_welsch_variant(self, pts, variant):
+        pts = np.ascontiguousarray(pts, dtype=np.int32)
+        out = np.zeros(4, np.float32)
+        self.L.ctago_fitline_welsch_variant(_ptr(pts, _p_i32), pts.shape[0], int(variant), _ptr(out, _p_f32))
+        return out
 
     # ---- full traced run -------------------------------------------------------------------------
     def detect(self, gray, state, feature_size, adaptive_thresh=5, subpix=True, subpix_dist=5):

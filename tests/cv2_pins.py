@@ -138,6 +138,34 @@ def pin_fitline(cv2, orc, test_bmp):
     return res
 
 
+def pin_variants(cv2, orc, test_bmp):
+    """Which of the two switchable assumptions (oracle/ctag_oracle.cpp: OracleVariants) this OpenCV matches: the place of fitLine2D's `if (err < min_err)`
+    and the width of resize's vector body.  The answer names the build flag to flip (EXTRA=-DCTAG_WELSCH_MINERR_IN_LOOP / -DCTAG_RESIZE_SIMD_LANES=16)."""
+    out = {"welsch_minerr": {}, "resize_simd_lanes": {}}
+    sets = [p for p in _point_sets(orc, test_bmp) if len(p) >= 9]
+    for variant in (0, 1):
+        eq, worst = 0, 0.0
+        for pts in sets:
+            want = cv2.fitLine(pts.reshape(-1, 1, 2), cv2.DIST_WELSCH, 0, 0.01, 0.01).ravel().astype(np.float32)
+            got = orc.fitline_welsch_variant(pts, variant)
+            eq += want.tobytes() == got.tobytes()
+            d = float(np.abs(want.astype(np.float64) - got.astype(np.float64)).max())
+            worst = max(worst, d if np.isfinite(d) else float("inf"))
+        out["welsch_minerr"]["after_the_loop (default)" if variant == 0 else "in_the_loop (-DCTAG_WELSCH_MINERR_IN_LOOP)"] = {
+            "cases": len(sets), "bitwise_equal": int(eq), "max_abs_diff": worst}
+    discriminating = sum(orc.fitline_welsch_variant(p, 0).tobytes() != orc.fitline_welsch_variant(p, 1).tobytes() for p in sets)
+    out["welsch_minerr"]["cases_where_the_variants_differ"] = int(discriminating)
+    imgs = [(n, im) for n, im in _images(test_bmp) if (im.shape[1] // 2) % 16 >= 8]
+    for lanes in (8, 16):
+        orc.set_variants(0, lanes)
+        try:
+            bad = sum(int((cv2.resize(im, (im.shape[1] // 2, im.shape[0] // 2), None, 0.5, 0.5, cv2.INTER_CUBIC) != orc.resize_half(im)).sum()) for _, im in imgs)
+        finally:
+            orc.set_variants(0, 8)
+        out["resize_simd_lanes"]["%d%s" % (lanes, " (default)" if lanes == 8 else " (-DCTAG_RESIZE_SIMD_LANES=16)")] = {"cases": len(imgs), "mismatching_pixels": int(bad)}
+    return out
+
+
 def pin_fast_atan2(cv2, orc):
     rng = np.random.RandomState(8)
     y = np.concatenate([rng.uniform(-100, 100, 4000), [0, 0, 1, -1, 0, 5, -5, 1e-6]]).astype(np.float32)
@@ -177,6 +205,7 @@ def run_all(orc, test_bmp):
     rep["resize"] = pin_resize(cv2, orc, test_bmp)
     rep["ccl"] = pin_ccl(cv2, orc, test_bmp)
     rep["fitline"] = pin_fitline(cv2, orc, test_bmp)
+    rep["variants"] = pin_variants(cv2, orc, test_bmp)
     rep["fast_atan2"] = pin_fast_atan2(cv2, orc)
     rep["bgr2gray"] = pin_bgr2gray(cv2, orc, test_bmp)
     return rep

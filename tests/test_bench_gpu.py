@@ -65,3 +65,31 @@ def test_a_rank_that_dies_ends_the_job_non_zero():
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0 and time.perf_counter() - t0 < 300
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]  # no line from a job that lost a rank
+
+
+@pytest.mark.parametrize("frames", [256, 250])
+def test_eight_ranks_give_the_one_gpu_list(frames):
+    """BASELINE config 4's shape before it meets eight GPUs: `python bench.py --gpus 8` (self-launched, eight ranks sharing this box's one
+    GPU through the developer backend) on 256 frames and on 250 (uneven shards: two ranks own 32 frames, six 31).  Rank 0's gathered
+    list must hash like the one-GPU list of the same frames, and the line must carry what a SCALE record is read for: `roofline`,
+    `gather_ms`, every rank's per-kernel times and the gather in use.  What the developer backend replaces is the two ncclAllGather
+    calls only: shards are packed by ctag_pack_results and unpacked by ctag_gather_end's kernels."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", str(frames), "--host-frames", "0",
+            "--pose-frames", "0", "--latency-calls", "0", "--cpu-frames", "0", "--pipelined-steps", "0"]
+    p = subprocess.run(base, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    one = _line(p.stdout)
+    assert one["frames_ok"] == frames and one["results_of"].startswith("the last TIMED step") and "the same" in one["results_of"]
+    env = dict(os.environ, CTAG_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run(base + ["--gpus", "8"], capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    eight = _line(p.stdout)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["frames_ok"] == frames
+    assert eight["config"]["frames_per_step"] == frames and eight["config"]["frames_per_gpu"] == (frames + 7) // 8
+    assert eight["results_sha256"] == one["results_sha256"]
+    assert eight["roofline"]["bound"] == "hbm" and eight["roofline"]["frac"] > 0 and eight["roofline"]["frames_per_launch"] == (frames + 7) // 8
+    assert eight["gather_ms"] is not None and eight["gather_ms"] > 0
+    assert len(eight["rank_stage_ms"]) == 8 and all(r["edge_refine"] > 0 and r["decimate"] > 0 for r in eight["rank_stage_ms"])
+    assert "ctag_pack_results" in eight["config"]["gather"]  # on RCCL: "ctag_gather (C ABI -> ncclAllGather of packed shards)"
+    gb = eight["config"]["gather_bytes"]
+    assert 0 < gb["packed_local"] <= gb["padded_per_rank"] < gb["fixed_records_per_rank"]

@@ -1045,8 +1045,19 @@ def test_bgr_ingest_equals_gray_path(detector, oracle, dictionary, test_bmp):
     for f in range(n):
         assert_same_record(got[f], want[f], "bgr device batch frame %d" % f)
     assert (detector.debug(1, tk.DBG_GRAY).reshape(rows, cols) == grays[9]).all()  # the last chunk held frames 8, 9
-    # the direct form (default for 1080p / 4K / 8K frames with 16-byte aligned rows): the decimation kernel and edgeRefine read the BGR bytes themselves
-    # and convert as they load -- no gray image exists (the probe says so), the records are the same; in one chunk and in chunks of 4
+    # a call of a few frames takes the two-step form by itself (round 6: the direct form's decimation is one block per frame band group,
+    # 10x the latency of the short-band kernels a few gray frames get): the gray image exists, the records are the same
+    out.zero_()
+    detector.detect_batch_bgr_device(dev.data_ptr(), n, rows, cols, cols * 3, rows * cols * 3, out.data_ptr())
+    detector.sync()
+    got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=ca.RESULT_DT)
+    for f in range(n):
+        assert_same_record(got[f], want[f], "bgr device batch of a few frames, frame %d" % f)
+    assert (detector.debug(9, tk.DBG_GRAY).reshape(rows, cols) == grays[9]).all()
+    # the direct form (batches -- here forced by CTAG_OPT_FUSED_SWEEP 2 -- of 1080p / 4K / 8K frames with 16-byte aligned rows): the decimation kernel and
+    # edgeRefine read the BGR bytes themselves and convert as they load -- no gray image exists (the probe says so), the records are the same; in one
+    # chunk and in chunks of 4
+    detector.set_option(capi.OPT_FUSED_SWEEP, 2)
     for chunk in (1024, 4):
         detector.set_option(capi.OPT_MAX_CHUNK, chunk)
         try:
@@ -1072,6 +1083,7 @@ def test_bgr_ingest_equals_gray_path(detector, oracle, dictionary, test_bmp):
                 assert_same_record(got[f], want[f], "bgr device batch, direct form, graph replay %d, frame %d" % (rep, f))
     finally:
         detector.set_option(capi.OPT_GRAPH, 2)
+        detector.set_option(capi.OPT_FUSED_SWEEP, 1)
     # rows that are not 16-byte aligned (a 4-byte pad per row) take the two-step form by themselves
     padded = torch.zeros((n, rows, cols * 3 + 4), dtype=torch.uint8, device="cuda")
     padded[:, :, :cols * 3] = dev.reshape(n, rows, cols * 3)
