@@ -467,7 +467,7 @@ static int enqueue_chunk(ctag_handle* h, const Workspace& ws, const uint8_t* fra
     HIP_TRY(mark(++st));
     HIP_TRY(launch_candidates(n, ws, s));
     HIP_TRY(mark(++st));
-    HIP_TRY(launch_quads(n, ws, s, evs ? evs + st + 1 : nullptr));  // records one event after each of its first five kernels
+    HIP_TRY(launch_quads(n, ws, s, evs ? evs + st + 1 : nullptr, fused ? ws.half : nullptr));  // records one event after each of its first five kernels
     st += 5;
     HIP_TRY(mark(++st));
     HIP_TRY(launch_features(n, ws, p, s));

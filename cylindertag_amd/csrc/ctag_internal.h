@@ -240,7 +240,7 @@ hipError_t launch_threshold_ccl(int nframes, const Workspace& ws, hipStream_t s,
 hipError_t launch_seam_merge(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_resolve(int nframes, const Workspace& ws, hipStream_t s);
 hipError_t launch_candidates(int nframes, const Workspace& ws, hipStream_t s);
-hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEvent_t* ev5 = nullptr);  // ev5: 5 events, one after each kernel but the last
+hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEvent_t* ev5 = nullptr, const uint8_t* mask = nullptr);  // mask: the chunk took the fused sweep (ws.half holds its threshold mask)  // ev5: 5 events, one after each kernel but the last
 hipError_t launch_features(int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 hipError_t launch_edge_refine(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, const DetectParams& p, hipStream_t s);
 // sums and maxima over the frames of the last chunk: components, candidates, quads, features, markers -> out10 (device, 5 x int64 sums then 5 x int64 maxima)

@@ -53,6 +53,8 @@ struct QuadPtrs {
     int cand_cap, line_cap;
     uint32_t cl_cap;
     float expand_eps;                 // half-width of expand_line's filter band in units of the frame extent [3e-6]; +inf: always the exact fits (builds that read P)
+    const uint64_t* mask;             // the fused sweep's threshold mask (1 bit per half-size pixel, rows of mask_words 64-bit words), else null: k_silhouette_mask
+    int mask_words;
 };
 
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
@@ -368,9 +370,14 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
 // words of a component in LDS; one that needs more is "big" too (the whole-wave builds scan for themselves)
 constexpr int kScanWords = 2048;
 __host__ __device__ __forceinline__ int scan_need(int w, int h) { return w + 3 * h + 4; }
+// scan_words < 0: the silhouettes come from k_silhouette_mask (fused sweep), which keeps the component's own pixels as h rows of 64-bit words: a box of
+// w columns touches at most (w + 63) / 64 + 1 aligned words per row
+constexpr int kMaskScanWords = 2048;
+__host__ __device__ __forceinline__ int mask_scan_need(int w, int h) { return 2 * h * ((w + 63) / 64 + 1); }
 __host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points, int pack_words, int scan_words = 0) {
     (void)x_min;
-    return pack_need(w, h) > pack_words || pack_points(w, h) > big_points || (scan_words > 0 && scan_need(w, h) > scan_words);
+    return pack_need(w, h) > pack_words || pack_points(w, h) > big_points || (scan_words > 0 && scan_need(w, h) > scan_words) ||
+           (scan_words < 0 && mask_scan_need(w, h) > -scan_words);
 }
 
 // packed 16-bit minimum (v_pk_min_u16)
@@ -819,6 +826,118 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
     }
     nl_out = nl;
     nr_out = nr;
+}
+
+// =====================================================================================================
+// K6m (round 6; batches that took the fused sweep): the silhouette of every packed component from the threshold MASK k_decimate_mask left (1 bit per pixel,
+// still in the workspace) instead of from every label of its bounding box.  corner_detector.cpp:184-232 asks, per row and per column of the box, for the
+// first and last pixel OF THE COMPONENT; the label scan answers by testing every label of the box (~1700 for a bar of ~500 pixels, ~100 instructions per row
+// and wave, 48 % of k_quad_edges_packed's cycles).  Here a lane owns a ROW of the box: it cuts the row's mask words into foreground runs with bit tricks --
+// a run is a maximal horizontal stretch of foreground, hence of ONE component -- and asks for ONE label per run (its first pixel: tile-local label -> pool entry
+// -> root): 1-3 probes per row.  The component's own pixels of the row (the OR of its runs) go to LDS as 64-bit words, the row's extents are their first / last
+// set bits; then a lane owns a COLUMN and walks the rows' words for the column's first / last set bit.  A run cut by the box's edge belongs to another component
+// (the box of ours would otherwise reach further) and says so when probed.  Output: what PHASE 3 of k_quad_edges_packed leaves -- tb / lr in the component's
+// cluster-pool slot, the slot in cand_aux -- so the packed builds run with PRESCAN = true behind it.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_silhouette_mask(QuadPtrs P, FrameGeom g, int nframes) {
+    __shared__ uint64_t s_comp[kMaskScanWords / 2];
+    const int frame = blockIdx.x;
+    if (frame >= nframes) return;
+    const int lane = threadIdx.x;
+    const int nc = min(P.ncand[frame], P.cand_cap);
+    const int npk = nc - P.npacks[2 * frame + 1];  // every packed component: entries [0, nc - oversize) of k_pack's order
+    const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
+    const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
+    const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
+    const uint64_t* __restrict__ mimg = P.mask + (size_t)frame * g.hrows * P.mask_words;
+    for (int pk = blockIdx.y; pk < npk; pk += gridDim.y) {
+        __syncthreads();  // (one wave) the previous component's words are read
+        const int ci = (int)P.pack_order[(size_t)frame * P.cand_cap + pk];
+        const Candidate cd = P.cand[(size_t)frame * P.cand_cap + ci];
+        const int x_min = cd.x_min, y_min = cd.y_min;
+        const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
+        const int C = pack_points(w, h);
+        CandAux* aux = P.cand_aux + (size_t)frame * P.cand_cap + ci;
+        // the component's cluster space (what the packed builds reserve after their traversal) and, in it for now, the silhouette: w + h + 4 <= C + 64 words
+        int p0 = 0;
+        if (lane == 0) p0 = atomicAdd(&P.clp_used[frame], C + 64);
+        p0 = __builtin_amdgcn_readfirstlane(p0);
+        if ((uint32_t)(p0 + C + 64) > P.cl_cap) {
+            if (lane == 0) {
+                atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+                aux->line0 = -1;
+                aux->acx = 0.f;
+                aux->acy = 0.f;
+                aux->n_boundary = 0;
+            }
+            continue;
+        }
+        uint32_t* __restrict__ slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;  // tb: [0, w + 2), lr: [w + 2, w + h + 4)
+        const int j0 = x_min >> 6, sh = x_min & 63, nw = (sh + w + 63) >> 6;
+        for (int y = lane; y < h; y += 64) {
+            const uint64_t* __restrict__ mr = mimg + (size_t)(y_min + y) * P.mask_words + j0;
+            const uint16_t* __restrict__ lrow = limg + (size_t)(y_min + y) * g.lp;
+            const int trow = ((y_min + y) / kTileH) * g.tiles_x;
+            bool cin = false, cmem = false;  // the previous word's last run reaches its bit 63 / belongs to the component
+            int left = -1, right = -1;
+            uint64_t mnext = mr[0];
+            for (int j = 0; j < nw; j++) {
+                uint64_t m = mnext;
+                if (j + 1 < nw) mnext = mr[j + 1];
+                const int lo = j == 0 ? sh : 0, hi = min(64, sh + w - 64 * j);  // the box's columns of this word: bits [lo, hi)
+                m &= (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                uint64_t comp = 0ull, starts = m & ~(m << 1);
+                bool last63 = false;
+                if (cin && (m & 1ull)) {  // the run goes on from the word before: no probe of its own
+                    starts &= ~1ull;
+                    const uint64_t run = ((m + 1ull) ^ m) & m;
+                    if (cmem) comp |= run;
+                    if (run >> 63) last63 = cmem;
+                }
+                while (starts) {
+                    const uint64_t sb = starts & (0ull - starts);
+                    starts ^= sb;
+                    const int x = 64 * (j0 + j) + (int)__builtin_ctzll(sb);
+                    const unsigned l = lrow[x];
+                    // (bit 15: an unpublished speck, never a candidate; a label of this component's root is a pixel of the component)
+                    const bool member = l != 0u && l < 0x8000u && rootof[tbase[trow + x / kTileW] + (int)l - 1] == cd.root;
+                    const uint64_t run = ((m + sb) ^ m) & m;  // the carry of the addition runs through the run and stops behind it
+                    if (member) comp |= run;
+                    if (run >> 63) last63 = member;
+                }
+                cin = (m >> 63) != 0ull;
+                cmem = last63;
+                s_comp[y * nw + j] = comp;
+                if (comp) {
+                    if (left < 0) left = 64 * j + (int)__builtin_ctzll(comp) - sh;
+                    right = 64 * j + 63 - (int)__builtin_clzll(comp) - sh;
+                }
+            }
+            slot[w + 2 + y + 1] = left < 0 ? 0u : ((uint32_t)(left + 2) | ((uint32_t)(right + 2) << 16));
+        }
+        __syncthreads();
+        for (int x = lane; x < w; x += 64) {
+            const int pos = sh + x, j = pos >> 6, b = pos & 63;
+            int top = -1, bot = -1;
+            for (int y = 0; y < h; y++) {
+                if ((s_comp[y * nw + j] >> b) & 1ull) {
+                    if (top < 0) top = y;
+                    bot = y;
+                }
+            }
+            slot[x + 1] = top < 0 ? 0u : ((uint32_t)(top + 2) | ((uint32_t)(bot + 2) << 16));
+        }
+        if (lane == 0) {
+            slot[0] = 0u;
+            slot[w + 1] = 0u;
+            slot[w + 2] = 0u;
+            slot[w + 2 + h + 1] = 0u;
+            aux->line0 = p0;
+            aux->acx = 0.f;
+            aux->acy = 0.f;
+            aux->n_boundary = 0;
+        }
+    }
 }
 
 // =====================================================================================================
@@ -2656,7 +2775,7 @@ __device__ __forceinline__ void quad_final_one(const QuadPtrs& P, const FrameGeo
     }
 }
 
-hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEvent_t* ev5) {
+hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEvent_t* ev5, const uint8_t* mask) {
     int evi = 0;
     auto mark = [&]() {
         if (ev5) (void)hipEventRecord(ev5[evi++], s);
@@ -2684,8 +2803,13 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     // packed build's eight components per wave amortise the chain of dependent loads a component costs better than a wave per component does; a
     // scan-only kernel with the packs' own 8 x 8 lanes at 4 / 5 / 6 waves per SIMD: 4.09 / 4.11 / 4.14 -- the scan is not what the small build waits for)
     const bool small_frames = (long long)ws.g.hrows * ws.g.hcols <= 960LL * 600;
-    const bool prescan = !latency && (prescan_env == 2 || (prescan_env == 1 && !small_frames));
-    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(nframes <= kLatencyFrames ? 1024 : 64), 0, s, P, nframes, pack_max, big_points, pack_words, prescan ? kScanWords : 0);
+    // chunks that took the fused sweep: the silhouettes come from its threshold mask (k_silhouette_mask), whatever the frame size; CTAG_MASK_SCAN=0 (developer aid, A/B) turns it off
+    static const int mask_scan_env = getenv("CTAG_MASK_SCAN") ? atoi(getenv("CTAG_MASK_SCAN")) : 1;
+    const bool mask_scan = mask != nullptr && !latency && mask_scan_env != 0 && (ws.g.hcols & 63) == 0;
+    const bool prescan = mask_scan || (!latency && (prescan_env == 2 || (prescan_env == 1 && !small_frames)));
+    P.mask = reinterpret_cast<const uint64_t*>(mask);
+    P.mask_words = ws.g.hcols >> 6;
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(nframes <= kLatencyFrames ? 1024 : 64), 0, s, P, nframes, pack_max, big_points, pack_words, mask_scan ? -kMaskScanWords : prescan ? kScanWords : 0);
     mark();
     // A few frames per call (the reference's one detect() per camera frame): the call is as long as its slowest component,
     // so the packs and the whole-wave components run side by side (second stream, fork/join by events)
@@ -2709,7 +2833,10 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
 #define CTAG_LAUNCH_PACKED(REF)                                                                                                                              \
     do {                                                                                                                                                     \
         if (prescan) {                                                                                                                                       \
-            hipLaunchKernelGGL((k_quad_edges_packed<64, kScanWords, CTAG_SCAN_WAVES, false, true, 3>), dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
+            if (mask_scan)                                                                                                                                   \
+                hipLaunchKernelGGL(k_silhouette_mask, dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes);                                             \
+            else                                                                                                                                             \
+                hipLaunchKernelGGL((k_quad_edges_packed<64, kScanWords, CTAG_SCAN_WAVES, false, true, 3>), dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (small_cfg) {                                                                                                                                 \
                 hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmall, false, REF, 1, true>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
                 hipLaunchKernelGGL((k_quad_edges_packed<8, kPackWordsSmall, kPackWavesSmallP2, false, REF, 2>), dim3(nframes, pack_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \

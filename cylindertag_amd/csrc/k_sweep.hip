@@ -407,13 +407,16 @@ bool sweep_fused_size(int rows, int cols, int tw, int fuse_mode) {
     const int env = fuse_mode >= 0 ? fuse_mode : fuse_env() >= 0 ? fuse_env() : 1;
     if (!env || (rows & 1) || (cols & 1) || tw != 5) return false;
     const int hcols = cols / 2, hrows = rows / 2;
-    return hcols % kFuseCols == 0 && hrows % 135 == 0 && (hrows / 135) % 4 == 0;
+    // (round 6) half width a multiple of the labelling tile (320 columns: whole mask words, whole threshold tiles, whole 16-pixel lanes), half height of whole
+    // threshold-tile rows; 1080p / 4K / 8K take the compile-time-band build, the others (1920x1200, 1280x720, 2560x1440, 640x480 ...) the run-time-band one
+    return hcols >= kTileW && hcols % kTileW == 0 && hrows >= 10 && hrows % 5 == 0;
 }
+static int fuse_bands(int hrows);
 // whether a call of nframes frames of this size is a batch for the fused sweep's tall bands (the rule sweep_fused applies to gray frames): BGR calls
 // below it take k_bgr2gray + the latency-tuned short-band kernels instead of one 4-wave block per frame walking 135-row bands
 bool sweep_fused_batch(int rows, int cols, int nframes, int fuse_mode) {
     const int env = fuse_mode >= 0 ? fuse_mode : fuse_env() >= 0 ? fuse_env() : 1;
-    return env >= 2 || (long)nframes * ((cols / 2) / kFuseCols) * ((rows / 2) / 135) >= 2048;
+    return env >= 2 || (long)nframes * ((cols / 2 + kFuseCols - 1) / kFuseCols) * fuse_bands(rows / 2) >= 2048;
 }
 // always: BGR frames (they take this form or none: the caller has checked sweep_fused_size and the alignment)
 bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, bool always) {
@@ -421,8 +424,8 @@ bool sweep_fused(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_st
     const FrameGeom& g = ws.g;
     if (!sweep_fused_size(g.rows, g.cols, g.tw, ws.fuse_mode)) return false;
     if ((((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) != 0) return false;
-    const int bands = g.hrows / 135;
-    if (!always && env < 2 && (long)nframes * (g.hcols / kFuseCols) * bands < 2048) return false;  // few frames: short bands and the latency-tuned kernels (launch_decimate)
+    const int bands = fuse_bands(g.hrows);
+    if (!always && env < 2 && (long)nframes * ((g.hcols + kFuseCols - 1) / kFuseCols) * bands < 2048) return false;  // few frames: short bands and the latency-tuned kernels (launch_decimate)
     return true;
 }
 
@@ -801,7 +804,7 @@ __device__ __forceinline__ Raw32 gray_row(const RawSrc<CH>& r) {
 __device__ __forceinline__ uint32_t wave_from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t wave_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
 // left_edge: lane 0 is at the image's left border; right_edge: lane 59 at its right border (else lanes 61 / 60 hold the pixels beyond)
-__device__ __forceinline__ void hpass_fuse(const Raw32& r, int lane, bool left_edge, bool right_edge, uint32_t q[8]) {
+__device__ __forceinline__ void hpass_fuse(const Raw32& r, int lane, bool left_edge, bool right_edge, uint32_t q[8], int last_lane = kFuseLanes - 1) {
     Raw34 t;
 #pragma unroll
     for (int i = 0; i < 8; i++) t.w[i] = r.w[i];
@@ -809,17 +812,21 @@ __device__ __forceinline__ void hpass_fuse(const Raw32& r, int lane, bool left_e
     uint32_t right2 = wave_from_next(r.w[0] & 0xffffu);
     const uint32_t last61 = (uint32_t)__builtin_amdgcn_readlane((int)(r.w[7] >> 24), 61), first0 = (uint32_t)__builtin_amdgcn_readlane((int)(r.w[0] & 0xffffu), 0);
     if (lane == 0) left = left_edge ? (r.w[0] & 0xffu) : last61;
-    if (lane == 59 && right_edge) right2 = (r.w[7] >> 24) * 0x0101u;
+    if (lane == last_lane && right_edge) right2 = (r.w[7] >> 24) * 0x0101u;
     if (lane == 61) right2 = first0;  // (the halo lanes' outer neighbours only reach pixels nobody reads)
     t.left = left;
     t.right2 = right2;
     hpass_wide(t, q);
 }
+// BAND = 0 (round 6): any frame whose half size is a multiple of 320 x 5 -- 1920x1200 (the reference's test.bmp), 1280x720, 2560x1440, 640x480 ... -- the bands are
+// whole threshold-tile rows handed out evenly at run time (`nbands` of them; band b = tile rows [b trows / nbands, (b + 1) trows / nbands)), and the last wave of a row
+// may cover fewer than 960 columns (`nact` lanes of 16 pixels).  BAND = 135 keeps 1080p / 4K / 8K on compile-time bands and full waves.
 template <int BAND, int WAVES, int CH = 1>  // CH = 3: BGR frames (four source rows of 96 bytes per lane in flight: two waves per SIMD hold them)
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 2 : 3, CH == 3 ? 2 : 3))) void k_decimate_mask(const uint8_t* __restrict__ frames, ptrdiff_t frame_stride, ptrdiff_t row_stride,
                                                                                                     uint8_t* __restrict__ mask, FrameGeom g, KParams kp, int nframes, int xblocks,
-                                                                                                    int yblocks) {
+                                                                                                    int yblocks, int nbands) {
     static_assert(BAND % 5 == 0, "a band is whole threshold-tile rows");
+    constexpr bool GEN = BAND == 0;
     __shared__ FuseLds S4[WAVES];
     int frame, idx;
     if (!map_block(blockIdx.x, xblocks * yblocks, nframes, frame, idx)) return;
@@ -834,14 +841,24 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CH =
 #define CTAG_FUSE_MIRROR 1
 #endif
     const int band_actual = by * WAVES + wy;
-    if (band_actual * BAND >= g.hrows) return;  // wave-uniform
+    if (GEN ? band_actual >= nbands : band_actual * BAND >= g.hrows) return;  // wave-uniform
     const bool mirror = CTAG_FUSE_MIRROR && (band_actual & 1);
-    const int band = mirror ? g.hrows / BAND - 1 - band_actual : band_actual;  // the band's index in the (mirrored) frame it walks downward
-    const int y_begin = band * BAND;
+    int y_begin, y_end;  // the band's rows in the (mirrored) frame it walks downward
+    if constexpr (GEN) {
+        const int r0 = 5 * (int)(((long)band_actual * g.trows) / nbands), r1 = 5 * (int)(((long)(band_actual + 1) * g.trows) / nbands);  // in the frame itself
+        if (r0 == r1) return;  // fewer tile rows than bands (tiny frames)
+        y_begin = mirror ? g.hrows - r1 : r0;
+        y_end = mirror ? g.hrows - r0 : r1;
+    } else {
+        const int band = mirror ? g.hrows / BAND - 1 - band_actual : band_actual;
+        y_begin = band * BAND;
+        y_end = min(y_begin + BAND, g.hrows);
+    }
     FuseLds& S = S4[wy];
     const int X0 = bx * kFuseCols;
+    const int nact = GEN ? min(kFuseLanes, (g.hcols - X0) >> 4) : kFuseLanes;  // lanes of this wave that own 16 columns of the frame
     const int hx0 = lane < kFuseLanes ? X0 + 16 * lane : lane == 60 ? X0 + kFuseCols : X0 - 16;
-    const bool active = lane < kFuseLanes || (lane == 60 && X0 + kFuseCols < g.hcols) || (lane == 61 && X0 > 0);
+    const bool active = lane < nact || (lane == 60 && X0 + kFuseCols < g.hcols) || (lane == 61 && X0 > 0);
     const int x0 = active ? hx0 * 2 : 0;  // inactive lanes load the row's first bytes and drop them
     const bool left_edge = X0 == 0, right_edge = X0 + kFuseCols >= g.hcols;
     const uint8_t* __restrict__ src = frames + (ptrdiff_t)frame * frame_stride;
@@ -862,8 +879,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CH =
         for (int q = 0; q < 4; q++) v |= (uint32_t)((16 * lane + 4 * k + q) / 5 - j0) << (8 * q);
         sel[k] = v;
     }
-    const int ys = max(y_begin - 5, 0), ye = min(y_begin + BAND + 5, g.hrows);  // the band plus one tile row above and below (extrema only)
-    const int e_lo = y_begin / 5, e_hi = min(y_begin + BAND, g.hrows) / 5;     // tile rows this wave emits: [e_lo, e_hi)
+    const int ys = max(y_begin - 5, 0), ye = min(y_end + 5, g.hrows);  // the band plus one tile row above and below (extrema only)
+    const int e_lo = y_begin / 5, e_hi = y_end / 5;                    // tile rows this wave emits: [e_lo, e_hi)
     const int tc0 = X0 / 5;
     uint32_t mnE[4], mnO[4], mxE[4], mxO[4];
 #pragma unroll
@@ -929,7 +946,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CH =
             }
         }
         wave_sync();
-        if (lane < kFuseLanes) {
+        if (lane < nact) {
             const uint32_t T4 = (uint32_t)S.tt[j0] | ((uint32_t)S.tt[j0 + 1] << 8) | ((uint32_t)S.tt[j0 + 2] << 16) | ((uint32_t)S.tt[min(j0 + 3, kFuseTiles - 1)] << 24);
             // (mirrored wave: its row 5 e + r is row hrows - 1 - (5 e + r) of the frame)
             uint8_t* mp = mrow0 + (size_t)(mirror ? g.hrows - 1 - 5 * e : 5 * e) * mpitch;
@@ -971,7 +988,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CH =
     uint32_t qa[8], qb[8], qc[8], qd[8];
     using Src = RawSrc<CH>;
     auto ld = [&](int r) __attribute__((always_inline)) { return load_row_src<CH>(rowp(r), x0); };
-    auto hp = [&](const Src& r, uint32_t (&q)[8]) __attribute__((always_inline)) { hpass_fuse(gray_row<CH>(r), lane, left_edge, right_edge, q); };
+    auto hp = [&](const Src& r, uint32_t (&q)[8]) __attribute__((always_inline)) { hpass_fuse(gray_row<CH>(r), lane, left_edge, right_edge, q, nact - 1); };
     {
         const Src ra = ld(2 * ys - 1);
         const Src rb = ld(2 * ys);
@@ -1011,21 +1028,33 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CH =
     if (ye == g.hrows) emit_tile_row(g.trows - 1);  // the frame's last tile row has no lower neighbour: a border row (bound 0)
 }
 
+// bands of the general form: a multiple of four (the four waves of a block), about 90-150 rows each; reproduces the 135-row bands of 1080p / 4K / 8K
+static int fuse_bands(int hrows) { return 4 * ((hrows + 599) / 600); }
+static bool fuse_exact(const FrameGeom& g) { return g.hcols % kFuseCols == 0 && g.hrows % 135 == 0 && (g.hrows / 135) % 4 == 0; }
 static hipError_t launch_decimate_mask(const uint8_t* frames, ptrdiff_t frame_stride, ptrdiff_t row_stride, int nframes, const Workspace& ws, hipStream_t s, int channels) {
     const FrameGeom& g = ws.g;
-    const int xb = g.hcols / kFuseCols;
+    const int xb = (g.hcols + kFuseCols - 1) / kFuseCols;
+    static const int gen_env = getenv("CTAG_FUSE_GENERAL") ? atoi(getenv("CTAG_FUSE_GENERAL")) : 0;  // developer aid: 1 runs 1080p / 4K / 8K through the run-time-band build too
+    if (!fuse_exact(g) || gen_env) {
+        const int nb = fuse_bands(g.hrows), yblocks = nb / 4;
+        if (channels == 3)
+            hipLaunchKernelGGL((k_decimate_mask<0, 4, 3>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks, nb);
+        else
+            hipLaunchKernelGGL((k_decimate_mask<0, 4>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks, nb);
+        return hipGetLastError();
+    }
     if (channels == 3) {  // BGR frames: converted where they are loaded
         const int yblocks = g.hrows / 135 / 4;
-        hipLaunchKernelGGL((k_decimate_mask<135, 4, 3>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+        hipLaunchKernelGGL((k_decimate_mask<135, 4, 3>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks, 0);
         return hipGetLastError();
     }
     static const int band_env = getenv("CTAG_FUSE_BAND") ? atoi(getenv("CTAG_FUSE_BAND")) : 135;  // developer aid (A/B): 270-row bands in two-wave blocks
     if (band_env == 270 && g.hrows % 540 == 0) {
         const int yblocks = g.hrows / 270 / 2;
-        hipLaunchKernelGGL((k_decimate_mask<270, 2>), dim3(grid_for(nframes, xb * yblocks)), dim3(128), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+        hipLaunchKernelGGL((k_decimate_mask<270, 2>), dim3(grid_for(nframes, xb * yblocks)), dim3(128), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks, 0);
     } else {
         const int yblocks = g.hrows / 135 / 4;
-        hipLaunchKernelGGL((k_decimate_mask<135, 4>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks);
+        hipLaunchKernelGGL((k_decimate_mask<135, 4>), dim3(grid_for(nframes, xb * yblocks)), dim3(256), 0, s, frames, frame_stride, row_stride, ws.half, g, ws.kp, nframes, xb, yblocks, 0);
     }
     return hipGetLastError();
 }

@@ -92,3 +92,58 @@ def test_fused_sweep_padded_rows_and_8k(fused, oracle, dictionary):
     for x0 in (1900, 3820, 5750):  # texture across each of the three seams between the four waves of a row (half-size columns 960, 1920, 2880)
         big[:, x0:x0 + 60] = np.clip(rng.normal(70, 35, (4320, 60)), 0, 255).astype(np.uint8)
     _mask_check(fused, oracle, state, fs, big, "8K frame, texture across the wave seams")
+
+
+def test_fused_sweep_at_any_multiple_of_320_by_5(fused, oracle, dictionary, test_bmp):
+    """Round 6: the run-time-band build of k_decimate_mask -- bands of whole threshold-tile rows handed out evenly, a last wave of fewer than 60 lanes --
+    takes every frame whose half size is a multiple of 320 x 5: the reference's own test.bmp (1920x1200: four bands of 150 rows), 1280x720 (a 40-lane
+    wave), 2560x1440 (a full wave + a 20-lane wave per row, a seam between them), 640x480, 3200x1800 (bands that do not divide evenly: 45 tile rows over..),
+    and sizes whose tile rows do not divide by the band count.  Mask bit for bit, every stage behind it, the record."""
+    state, fs = dictionary
+    rng = np.random.RandomState(31)
+    got_bmp = _mask_check(fused, oracle, state, fs, test_bmp, "test.bmp 1920x1200")[1]
+    assert got_bmp["n_markers"] == 5
+    for (w, h, seam) in ((1280, 720, None), (2560, 1440, 1920), (640, 480, None), (3200, 1800, 1920), (1920, 1210, None), (1280, 50, None), (640, 20, None),
+                         (4480, 1090, 3840)):
+        img = tk.synth_frame_host(state, 7, h, w)[0].copy() if h >= 400 else np.clip(rng.normal(80, 40, (h, w)), 0, 255).astype(np.uint8)
+        if seam:  # texture across the seam between two waves of a row (half-size column 960 k)
+            img[:, seam - 40:seam + 40] = np.clip(rng.normal(60, 30, (h, 80)), 0, 255).astype(np.uint8)
+        _mask_check(fused, oracle, state, fs, img, "synthetic %dx%d" % (w, h))
+        noise = np.clip(rng.normal(70, 40, (h, w)), 0, 255).astype(np.uint8)
+        _mask_check(fused, oracle, state, fs, noise, "noise %dx%d" % (w, h))
+
+
+def test_general_fused_build_on_batches_and_bgr(detector, oracle, dictionary, test_bmp):
+    """Batches of 1920x1200 frames through the default rule (a batch takes the fused sweep by itself), gray and device-resident BGR (the direct form: no gray image)."""
+    import torch
+    from test_gpu_parity import _colourise
+    state, fs = dictionary
+    n = 520  # 520 frames x 1 wave x 4 bands >= 2048: a batch
+    base = np.stack([np.roll(test_bmp, 3 * k, axis=1) for k in range(8)])
+    want8, _ = oracle.detect_many(base, state, fs)
+    dev = torch.device("cuda:0")
+    frames = torch.from_numpy(base).to(dev).repeat(n // 8, 1, 1).contiguous()
+    out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    detector.detect_batch_device(frames.data_ptr(), n, 1200, 1920, 1920, 1200 * 1920, out.data_ptr())
+    detector.sync()
+    got = np.frombuffer(out.cpu().numpy().tobytes(), ca.RESULT_DT)
+    for k in range(n):
+        assert_same_record(got[k], want8[k % 8], "1920x1200 batch frame %d" % k)
+    assert (detector.debug(n - 1, tk.DBG_MASK).reshape(600, 960) == (oracle.detect(base[(n - 1) % 8], state, fs)["binary"] > 0)).all()  # the fused form ran: a mask exists
+    del frames
+    bgr8 = np.stack([_colourise(base[k], k) for k in range(8)])
+    wantb = [oracle.detect_fast(oracle.bgr2gray(bgr8[k]), state, fs) for k in range(8)]
+    m = 64
+    bgr = torch.from_numpy(bgr8).to(dev).repeat(m // 8, 1, 1, 1).contiguous()
+    outb = torch.zeros((m, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    detector.set_option(capi.OPT_FUSED_SWEEP, 2)
+    try:
+        detector.detect_batch_bgr_device(bgr.data_ptr(), m, 1200, 1920, 1920 * 3, 1200 * 1920 * 3, outb.data_ptr())
+        detector.sync()
+    finally:
+        detector.set_option(capi.OPT_FUSED_SWEEP, 1)
+    got = np.frombuffer(outb.cpu().numpy().tobytes(), ca.RESULT_DT)
+    for k in range(m):
+        assert_same_record(got[k], wantb[k % 8], "1920x1200 BGR direct frame %d" % k)
+    with pytest.raises(ca.CtagError):
+        detector.debug(0, tk.DBG_GRAY)  # no gray image exists
