@@ -637,6 +637,9 @@ static int detect_device_impl(ctag_handle* h, const uint8_t* frames_dev, int n, 
     // chunks of [448, 1024) frames stay on one stream: their halves (224-511 frames) leave the stage kernels' grids a partial last round of
     // blocks on each stream.  Measured (round 5, 1080p, two handles alternating, K frames/s split / whole): 256: 189 / 178, 384: 213 / 214,
     // 512: 222 / 237, 640: 229 / 234, 768: 232 / 234, 1024: 247 / 241, 2048: 255 / 250 (tools/step_overlap.py).
+    // Scope of the rule: it looks at the call's chunk = min(n, max_chunk), measured at 1080p only -- frames of other sizes take it by frame COUNT all
+    // the same (a 4K frame is four 1080p frames of blocks: its chunks of 112-255 frames, the equivalent window, are below two_min and stay whole anyway); the ragged tail of
+    // a longer call (n = 1100 at max_chunk 1024: 512 + 512 + 76) is a piece of its own on the next stream; CTAG_STREAMS_MIN (developer aid) replaces the rule altogether.
     const bool whole = !two_env && chunk >= 448 && chunk < 1024;
     if (h->streams >= 2 && !h->timing && chunk >= two_min && !whole && h->stream2) {
         const int ns = std::min(h->streams, (int)ctag_handle::kMaxStreams);

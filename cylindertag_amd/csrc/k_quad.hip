@@ -372,7 +372,8 @@ constexpr int kScanWords = 2048;
 __host__ __device__ __forceinline__ int scan_need(int w, int h) { return w + 3 * h + 4; }
 // scan_words < 0: the silhouettes come from k_silhouette_mask (fused sweep), which keeps the component's own pixels as h rows of 64-bit words: a box of
 // w columns touches at most (w + 63) / 64 + 1 aligned words per row
-constexpr int kMaskScanWords = 2048;
+constexpr int kMaskScanWords = 1024, kMaskScanWordsLarge = 2048;  // 32-bit words per component: frames up to 1920x1200 (two components per wave) / larger ones (a wave each)
+// (box-relative words: (w + 63) / 64 per row, + a word per row where rows beyond the first 64 park their extents)
 __host__ __device__ __forceinline__ int mask_scan_need(int w, int h) { return 2 * h * ((w + 63) / 64 + 1); }
 __host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points, int pack_words, int scan_words = 0) {
     (void)x_min;
@@ -447,6 +448,29 @@ __global__ __launch_bounds__(1024) void k_pack(QuadPtrs P, int nframes, int max_
         }
         return np;
     };
+    // scan_words < 0 (the silhouettes come from k_silhouette_mask): the packed components' cluster-pool slots are handed out HERE, in pack order -- an exclusive prefix
+    // sum of their C + 64 words (wave 0) -- instead of by one returning atomic per component in the scan kernel, whose chain of dependent loads it would lengthen
+    auto slot_prefix = [&](int npacked, auto ci_of) {
+        int base = 0;
+        for (int r0 = 0; r0 < npacked; r0 += 64) {
+            const int r = r0 + tid;
+            int v = 0, ci = 0;
+            if (r < npacked) {
+                ci = ci_of(r);
+                const Candidate c = cand[ci];
+                v = pack_points(c.x_max - c.x_min + 1, c.y_max - c.y_min + 1) + 64;
+            }
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d, 64);
+                if (tid >= d) incl += t;
+            }
+            if (r < npacked) P.cand_aux[(size_t)frame * P.cand_cap + ci].line0 = base + incl - v;
+            base += __shfl(incl, 63, 64);
+        }
+        if (tid == 0) P.clp_used[frame] = base;  // (the chain's first kernel that reserves cluster space: nothing has been added yet)
+    };
     if (nc > kLdsCand) {
         // A frame of thousands of blobs (more candidates than the LDS arrays hold).  The order is scheduling only -- results do not
         // depend on it beyond "oversize components last" -- so a counting sort by boundary capacity (descending, capacities of 2047
@@ -481,6 +505,7 @@ __global__ __launch_bounds__(1024) void k_pack(QuadPtrs P, int nframes, int max_
             P.npacks[2 * frame] = np;
             P.npacks[2 * frame + 1] = nc - first_big;
         }
+        if (scan_words < 0) slot_prefix(first_big, [&](int r) { return (int)order[r]; });
         return;
     }
     for (int i = tid; i < nc; i += nt) {
@@ -510,6 +535,7 @@ __global__ __launch_bounds__(1024) void k_pack(QuadPtrs P, int nframes, int max_
         P.npacks[2 * frame] = np;
         P.npacks[2 * frame + 1] = nbig;
     }
+    if (scan_words < 0) slot_prefix(nc - nbig, [&](int r) { return (int)s_ord[r]; });
 }
 
 // wave-level ordering point for the 8-lane sub-groups (no s_barrier: the sub-groups of a wave run in lockstep;
@@ -839,57 +865,123 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
 // (the box of ours would otherwise reach further) and says so when probed.  Output: what PHASE 3 of k_quad_edges_packed leaves -- tb / lr in the component's
 // cluster-pool slot, the slot in cand_aux -- so the packed builds run with PRESCAN = true behind it.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_silhouette_mask(QuadPtrs P, FrameGeom g, int nframes) {
-    __shared__ uint64_t s_comp[kMaskScanWords / 2];
+// Two components per wave, 32 lanes each (the packs' order puts components of similar size side by side); what the kernel waits for is a chain of dependent loads
+// -- order entry -> candidate -> mask words -> labels -> roots -- so (1) the probes of a row are issued TOGETHER, the first four runs of its first 128 columns, then
+// their root look-ups together (a row costs two round trips, not two per run); (2) the next pair's order entry and candidate are requested before the current pair is
+// worked on; (3) 8 KB of LDS per wave and few registers: five waves per SIMD.  A row with more runs, or a box over more than four words, takes the
+// one-probe-at-a-time loop for what is left.  (Round 6, measured per 4096 1080p frames: the first form -- a wave per component, a probe at a time -- 1.08 ms.)
+// kMsRel: box-relative words of a row held in registers and probed as a batch; kMsSub: lanes (rows at a time) per component; kWords: LDS words per component.
+// <2, 32, 1024> for frames up to 1920x1200 (boxes of ~75 x 25), <4, 64, 2048> for larger ones (~200 x 100: a wave per component)
+constexpr int kMsProbes = 4;
+template <int kMsRel, int kMsSub, int kWords>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 2 ? 6 : 4, 8))) void k_silhouette_mask(QuadPtrs P, FrameGeom g, int nframes) {
+    static_assert(64 * kMsRel <= 256, "run starts are packed as eight-bit column offsets");
+    static_assert(kMsSub == 32 || kMsSub == 64, "one or two components per wave");
+    constexpr int kPerWave = 64 / kMsSub;
+    __shared__ uint64_t s_comp2[kPerWave][kWords / 2];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, sub = lane / kMsSub, sl = lane % kMsSub;
+    uint64_t* const s_comp = s_comp2[sub];
     const int nc = min(P.ncand[frame], P.cand_cap);
     const int npk = nc - P.npacks[2 * frame + 1];  // every packed component: entries [0, nc - oversize) of k_pack's order
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
     const uint64_t* __restrict__ mimg = P.mask + (size_t)frame * g.hrows * P.mask_words;
-    for (int pk = blockIdx.y; pk < npk; pk += gridDim.y) {
-        __syncthreads();  // (one wave) the previous component's words are read
-        const int ci = (int)P.pack_order[(size_t)frame * P.cand_cap + pk];
-        const Candidate cd = P.cand[(size_t)frame * P.cand_cap + ci];
+    const uint32_t* __restrict__ order = P.pack_order + (size_t)frame * P.cand_cap;
+    const Candidate* __restrict__ cands = P.cand + (size_t)frame * P.cand_cap;
+    const CandAux* __restrict__ auxs = P.cand_aux + (size_t)frame * P.cand_cap;
+    // this sub-group's components: entries kPerWave * blockIdx.y + sub, + kPerWave * gridDim.y, ...
+    int pk = kPerWave * (int)blockIdx.y + sub;
+    const int step = kPerWave * (int)gridDim.y;
+    int ci_n = (int)order[min(pk, max(npk - 1, 0))];
+    Candidate cd_n = cands[ci_n];
+    int p0_n = auxs[ci_n].line0;  // the component's cluster-pool slot, handed out by k_pack
+    for (; __ballot(pk < npk) != 0ull; pk += step) {  // wave-uniform trip count: the barrier below is the wave's
+        __syncthreads();  // (one wave) the previous components' words are read
+        const bool act = pk < npk;
+        const int ci = ci_n, p0 = p0_n;
+        const Candidate cd = cd_n;
+        {   // the next pair's header, in flight under this pair's work
+            const int pn = min(pk + step, max(npk - 1, 0));
+            ci_n = (int)order[pn];
+            cd_n = cands[ci_n];
+            p0_n = auxs[ci_n].line0;
+        }
         const int x_min = cd.x_min, y_min = cd.y_min;
-        const int w = cd.x_max - cd.x_min + 1, h = cd.y_max - cd.y_min + 1;
+        const int w = act ? cd.x_max - cd.x_min + 1 : 0, h = act ? cd.y_max - cd.y_min + 1 : 0;
         const int C = pack_points(w, h);
         CandAux* aux = P.cand_aux + (size_t)frame * P.cand_cap + ci;
-        // the component's cluster space (what the packed builds reserve after their traversal) and, in it for now, the silhouette: w + h + 4 <= C + 64 words
-        int p0 = 0;
-        if (lane == 0) p0 = atomicAdd(&P.clp_used[frame], C + 64);
-        p0 = __builtin_amdgcn_readfirstlane(p0);
-        if ((uint32_t)(p0 + C + 64) > P.cl_cap) {
-            if (lane == 0) {
-                atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
-                aux->line0 = -1;
-                aux->acx = 0.f;
-                aux->acy = 0.f;
-                aux->n_boundary = 0;
-            }
-            continue;
-        }
-        uint32_t* __restrict__ slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;  // tb: [0, w + 2), lr: [w + 2, w + h + 4)
-        const int j0 = x_min >> 6, sh = x_min & 63, nw = (sh + w + 63) >> 6;
-        for (int y = lane; y < h; y += 64) {
+        // p0: the component's cluster space (what the packed builds reserve after their traversal) and, in it for now, the silhouette: w + h + 4 <= C + 64 words.
+        // The row's bits are brought into BOX-relative words (bit b of word j = column x_min + 64 j + b): ceil(w / 64) of them, only the last one partly valid.
+        const int j0 = x_min >> 6, sh = x_min & 63, nwa = (sh + w + 63) >> 6, nwr = (w + 63) >> 6;
+        // ---- rows: a lane per row
+        uint32_t lr_mine[2] = {0u, 0u};  // of rows sl and sl + kMsSub (more rows: parked in LDS as they are formed)
+        for (int y = sl, yi = 0; y < h; y += kMsSub, yi++) {
             const uint64_t* __restrict__ mr = mimg + (size_t)(y_min + y) * P.mask_words + j0;
-            const uint16_t* __restrict__ lrow = limg + (size_t)(y_min + y) * g.lp;
+            const uint16_t* __restrict__ lrow = limg + (size_t)(y_min + y) * g.lp + x_min;
             const int trow = ((y_min + y) / kTileH) * g.tiles_x;
-            bool cin = false, cmem = false;  // the previous word's last run reaches its bit 63 / belongs to the component
-            int left = -1, right = -1;
-            uint64_t mnext = mr[0];
-            for (int j = 0; j < nw; j++) {
-                uint64_t m = mnext;
-                if (j + 1 < nw) mnext = mr[j + 1];
-                const int lo = j == 0 ? sh : 0, hi = min(64, sh + w - 64 * j);  // the box's columns of this word: bits [lo, hi)
-                m &= (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-                uint64_t comp = 0ull, starts = m & ~(m << 1);
+            auto rel_word = [&](uint64_t a, uint64_t b, int j) -> uint64_t {  // box-relative word j from the aligned words that hold it
+                const uint64_t v = sh ? ((a >> sh) | (b << (64 - sh))) : a;
+                const int nb = w - 64 * j;  // valid bits
+                return nb >= 64 ? v : nb <= 0 ? 0ull : (v & ((1ull << nb) - 1ull));
+            };
+            auto member_of = [&](int xr) -> bool {  // one probe by itself (rows with more runs than the batch below holds): label -> pool entry -> root
+                const unsigned l = lrow[xr];
+                return l != 0u && l < 0x8000u && rootof[tbase[trow + (x_min + xr) / kTileW] + (int)l - 1] == cd.root;  // (bit 15: an unpublished speck, never a candidate)
+            };
+            uint64_t mw[kMsRel];
+            {
+                uint64_t a[kMsRel + 1];
+#pragma unroll
+                for (int j = 0; j <= kMsRel; j++) a[j] = mr[min(j, nwa - 1)];
+#pragma unroll
+                for (int j = 0; j < kMsRel; j++) mw[j] = rel_word(a[j], a[j + 1], j);
+            }
+            // run starts of the row in order (a run that goes on from the word before is not a start): the first kMsProbes of them -- column offsets packed eight bits
+            // each -- are probed at once, labels first, then their roots
+            uint32_t xs = 0u;
+            int nr = 0;
+#pragma unroll
+            for (int j = 0; j < kMsRel; j++) {
+                const uint64_t carry = j > 0 ? (mw[j > 0 ? j - 1 : 0] >> 63) : 0ull;
+                uint64_t st = mw[j] & ~((mw[j] << 1) | carry);
+                while (st && nr < kMsProbes) {
+                    xs |= (uint32_t)(64 * j + (int)__builtin_ctzll(st)) << (8 * nr);
+                    nr++;
+                    st &= st - 1ull;
+                }
+            }
+            // Every load below is UNCONDITIONAL, from an address that is valid whatever the row holds (a probe the row does not have reads the box's first column; a
+            // label that names no pool entry reads entry 0) and its result masked afterwards: a load inside a branch makes the compiler wait for all loads in
+            // flight where the branch rejoins -- the probes would go out one at a time (they did: the first build's ISA).
+            unsigned lp[kMsProbes];
+            int bp[kMsProbes];
+#pragma unroll
+            for (int k = 0; k < kMsProbes; k++) {
+                const int xr = (int)((xs >> (8 * k)) & 255u);
+                lp[k] = lrow[xr];
+                bp[k] = tbase[trow + (x_min + xr) / kTileW];
+            }
+            int rp[kMsProbes];
+            unsigned okm = 0u;
+#pragma unroll
+            for (int k = 0; k < kMsProbes; k++) {
+                const bool ok = k < nr && lp[k] != 0u && lp[k] < 0x8000u;
+                okm |= (ok ? 1u : 0u) << k;
+                rp[k] = rootof[ok ? bp[k] + (int)lp[k] - 1 : 0];
+            }
+            unsigned memb = 0u;
+#pragma unroll
+            for (int k = 0; k < kMsProbes; k++) memb |= (rp[k] == cd.root ? 1u : 0u) << k;
+            memb &= okm;
+            bool cin = false, cmem = false;  // the word before ends in a run / that run belongs to the component
+            int left = -1, right = -1, idx = 0;
+            auto do_word = [&](int j, uint64_t m) {
+                uint64_t comp = 0ull, starts = m & ~((m << 1) | (cin ? 1ull : 0ull));
                 bool last63 = false;
-                if (cin && (m & 1ull)) {  // the run goes on from the word before: no probe of its own
-                    starts &= ~1ull;
+                if (cin && (m & 1ull)) {  // goes on from the word before
                     const uint64_t run = ((m + 1ull) ^ m) & m;
                     if (cmem) comp |= run;
                     if (run >> 63) last63 = cmem;
@@ -897,45 +989,74 @@ __global__ __launch_bounds__(64) void k_silhouette_mask(QuadPtrs P, FrameGeom g,
                 while (starts) {
                     const uint64_t sb = starts & (0ull - starts);
                     starts ^= sb;
-                    const int x = 64 * (j0 + j) + (int)__builtin_ctzll(sb);
-                    const unsigned l = lrow[x];
-                    // (bit 15: an unpublished speck, never a candidate; a label of this component's root is a pixel of the component)
-                    const bool member = l != 0u && l < 0x8000u && rootof[tbase[trow + x / kTileW] + (int)l - 1] == cd.root;
+                    bool member;
+                    if (idx < nr) member = ((memb >> idx) & 1u) != 0u;  // (nr: the runs the batch probed -- the first kMsProbes of the first kMsRel words)
+                    else member = member_of(64 * j + (int)__builtin_ctzll(sb));
+                    idx++;
                     const uint64_t run = ((m + sb) ^ m) & m;  // the carry of the addition runs through the run and stops behind it
                     if (member) comp |= run;
                     if (run >> 63) last63 = member;
                 }
                 cin = (m >> 63) != 0ull;
                 cmem = last63;
-                s_comp[y * nw + j] = comp;
+                s_comp[y * nwr + j] = comp;
                 if (comp) {
-                    if (left < 0) left = 64 * j + (int)__builtin_ctzll(comp) - sh;
-                    right = 64 * j + 63 - (int)__builtin_clzll(comp) - sh;
+                    if (left < 0) left = 64 * j + (int)__builtin_ctzll(comp);
+                    right = 64 * j + 63 - (int)__builtin_clzll(comp);
                 }
-            }
-            slot[w + 2 + y + 1] = left < 0 ? 0u : ((uint32_t)(left + 2) | ((uint32_t)(right + 2) << 16));
+            };
+#pragma unroll
+            for (int j = 0; j < kMsRel; j++)
+                if (j < nwr) do_word(j, mw[j]);
+            for (int j = kMsRel; j < nwr; j++)  // wider boxes: the rest a word at a time (its runs a probe at a time)
+                do_word(j, rel_word(mr[min(j, nwa - 1)], mr[min(j + 1, nwa - 1)], j));
+            const uint32_t v = left < 0 ? 0u : ((uint32_t)(left + 2) | ((uint32_t)(right + 2) << 16));
+            if (yi < 2) lr_mine[yi] = v;
+            else s_comp[h * nwr + y] = (uint64_t)v;  // (further rows: parked behind the words -- mask_scan_need counts a word more per row than the box has)
         }
-        __syncthreads();
-        for (int x = lane; x < w; x += 64) {
-            const int pos = sh + x, j = pos >> 6, b = pos & 63;
-            int top = -1, bot = -1;
-            for (int y = 0; y < h; y++) {
-                if ((s_comp[y * nw + j] >> b) & 1ull) {
-                    if (top < 0) top = y;
-                    bot = y;
-                }
-            }
-            slot[x + 1] = top < 0 ? 0u : ((uint32_t)(top + 2) | ((uint32_t)(bot + 2) << 16));
-        }
-        if (lane == 0) {
-            slot[0] = 0u;
-            slot[w + 1] = 0u;
-            slot[w + 2] = 0u;
-            slot[w + 2 + h + 1] = 0u;
-            aux->line0 = p0;
+        const bool fits = (uint32_t)(p0 + C + 64) <= P.cl_cap;
+        if (act && !fits && sl == 0) {
+            atomicOr(&P.frame_flags[frame], CTAG_FLAG_POOL_OVERFLOW);
+            aux->line0 = -1;
             aux->acx = 0.f;
             aux->acy = 0.f;
             aux->n_boundary = 0;
+        }
+        __syncthreads();
+        if (act && fits) {
+            uint32_t* __restrict__ slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;  // tb: [0, w + 2), lr: [w + 2, w + h + 4)
+            if (sl < h) slot[w + 2 + sl + 1] = lr_mine[0];
+            if (sl + kMsSub < h) slot[w + 2 + sl + kMsSub + 1] = lr_mine[1];
+            for (int y = sl + 2 * kMsSub; y < h; y += kMsSub) slot[w + 2 + y + 1] = (uint32_t)s_comp[h * nwr + y];
+            // columns: a lane per column of one 32-bit half-word at a time -- the sub-group's lanes read the SAME LDS word (a broadcast) and test their own bit; the
+            // column's rows are gathered 32 at a time into a register (three instructions per row: read, bit extract, shift-or), first / last row from its ends
+            const uint32_t* c32 = reinterpret_cast<const uint32_t*>(s_comp);
+            for (int ps = 0; kMsSub * ps < w; ps++) {
+                const int x = kMsSub * ps + sl, hf = x >> 5, bit = x & 31;  // (a sub-group of 64 lanes reads two neighbouring half-words)
+                int top = -1, bot = -1;
+                for (int y0 = 0; y0 < h; y0 += 32) {
+                    uint32_t T = 0u;
+                    const int ye = min(32, h - y0);
+                    const uint32_t* cp = c32 + 2 * (y0 * nwr) + min(hf, 2 * nwr - 1);
+#pragma unroll 8
+                    for (int k = 0; k < ye; k++) T |= ((cp[2 * k * nwr] >> bit) & 1u) << k;
+                    if (T) {
+                        if (top < 0) top = y0 + (int)__builtin_ctz(T);
+                        bot = y0 + 31 - (int)__builtin_clz(T);
+                    }
+                }
+                if (x < w) slot[x + 1] = top < 0 ? 0u : ((uint32_t)(top + 2) | ((uint32_t)(bot + 2) << 16));
+            }
+            if (sl == 0) {
+                slot[0] = 0u;
+                slot[w + 1] = 0u;
+                slot[w + 2] = 0u;
+                slot[w + 2 + h + 1] = 0u;
+                aux->line0 = p0;
+                aux->acx = 0.f;
+                aux->acy = 0.f;
+                aux->n_boundary = 0;
+            }
         }
     }
 }
@@ -2809,7 +2930,7 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     const bool prescan = mask_scan || (!latency && (prescan_env == 2 || (prescan_env == 1 && !small_frames)));
     P.mask = reinterpret_cast<const uint64_t*>(mask);
     P.mask_words = ws.g.hcols >> 6;
-    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(nframes <= kLatencyFrames ? 1024 : 64), 0, s, P, nframes, pack_max, big_points, pack_words, mask_scan ? -kMaskScanWords : prescan ? kScanWords : 0);
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(nframes <= kLatencyFrames ? 1024 : 64), 0, s, P, nframes, pack_max, big_points, pack_words, mask_scan ? -(small_cfg ? kMaskScanWords : kMaskScanWordsLarge) : prescan ? kScanWords : 0);
     mark();
     // A few frames per call (the reference's one detect() per camera frame): the call is as long as its slowest component,
     // so the packs and the whole-wave components run side by side (second stream, fork/join by events)
@@ -2830,11 +2951,13 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
 #define CTAG_SCAN_WAVES 4
 #endif
     static const int scan_gx = getenv("CTAG_SCAN_GX") ? std::max(1, atoi(getenv("CTAG_SCAN_GX"))) : 48;
+    static const int mscan_gx = getenv("CTAG_MSCAN_GX") ? std::max(1, atoi(getenv("CTAG_MSCAN_GX"))) : 48;  // blocks (waves) per frame of k_silhouette_mask, two components each per trip
 #define CTAG_LAUNCH_PACKED(REF)                                                                                                                              \
     do {                                                                                                                                                     \
         if (prescan) {                                                                                                                                       \
             if (mask_scan)                                                                                                                                   \
-                hipLaunchKernelGGL(k_silhouette_mask, dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes);                                             \
+                if (small_cfg) hipLaunchKernelGGL((k_silhouette_mask<2, 32, kMaskScanWords>), dim3(nframes, mscan_gx), dim3(64), 0, s, P, ws.g, nframes);     \
+                else hipLaunchKernelGGL((k_silhouette_mask<4, 64, kMaskScanWordsLarge>), dim3(nframes, 2 * mscan_gx), dim3(64), 0, s, P, ws.g, nframes);      \
             else                                                                                                                                             \
                 hipLaunchKernelGGL((k_quad_edges_packed<64, kScanWords, CTAG_SCAN_WAVES, false, true, 3>), dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (small_cfg) {                                                                                                                                 \

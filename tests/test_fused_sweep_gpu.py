@@ -124,6 +124,7 @@ def test_general_fused_build_on_batches_and_bgr(detector, oracle, dictionary, te
     dev = torch.device("cuda:0")
     frames = torch.from_numpy(base).to(dev).repeat(n // 8, 1, 1).contiguous()
     out = torch.zeros((n, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()  # torch filled the frames on ITS stream; the library's streams do not wait for it
     detector.detect_batch_device(frames.data_ptr(), n, 1200, 1920, 1920, 1200 * 1920, out.data_ptr())
     detector.sync()
     got = np.frombuffer(out.cpu().numpy().tobytes(), ca.RESULT_DT)
@@ -136,6 +137,7 @@ def test_general_fused_build_on_batches_and_bgr(detector, oracle, dictionary, te
     m = 64
     bgr = torch.from_numpy(bgr8).to(dev).repeat(m // 8, 1, 1, 1).contiguous()
     outb = torch.zeros((m, ca.RESULT_DT.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     detector.set_option(capi.OPT_FUSED_SWEEP, 2)
     try:
         detector.detect_batch_bgr_device(bgr.data_ptr(), m, 1200, 1920, 1920 * 3, 1200 * 1920 * 3, outb.data_ptr())

@@ -77,9 +77,10 @@ def test_clutter_in_fused_batches(fused, oracle, dictionary):
     got = fused.detect_batch(frames)
     for f in range(12):
         assert_same_record(got[f], want[f], "clutter batch frame %d" % f)
-    o = oracle.detect(frames[2], state, fs)
-    assert len(o["candidates"]) > 400
-    assert fused.debug(2, tk.DBG_CAND_QUADS).tobytes() == o["candidate_quads"].tobytes()
+    # the blob field that fits the batch workspace, in a batch of its own (the reruns above replaced what the probes look at): every blob a packed component
+    few = np.stack([frames[2], frames[0], frames[2], frames[1], frames[2], frames[3]])
+    _check_batch(fused, oracle, state, fs, few, "blob field in a fused batch", every=2)
+    assert len(oracle.detect(frames[2], state, fs)["candidates"]) > 400
 
 
 def test_mask_and_label_silhouettes_agree_at_4k(fused, oracle, dictionary):
