@@ -370,11 +370,10 @@ __host__ __device__ __forceinline__ int pack_need(int w, int h) {
 // words of a component in LDS; one that needs more is "big" too (the whole-wave builds scan for themselves)
 constexpr int kScanWords = 2048;
 __host__ __device__ __forceinline__ int scan_need(int w, int h) { return w + 3 * h + 4; }
-// scan_words < 0: the silhouettes come from k_silhouette_mask (fused sweep), which keeps the component's own pixels as h rows of 64-bit words: a box of
-// w columns touches at most (w + 63) / 64 + 1 aligned words per row
-constexpr int kMaskScanWords = 1024, kMaskScanWordsLarge = 2048;  // 32-bit words per component: frames up to 1920x1200 (two components per wave) / larger ones (a wave each)
-// (box-relative words: (w + 63) / 64 per row, + a word per row where rows beyond the first 64 park their extents)
-__host__ __device__ __forceinline__ int mask_scan_need(int w, int h) { return 2 * h * ((w + 63) / 64 + 1); }
+// scan_words < 0: the silhouettes come from k_silhouette_mask (fused sweep), which keeps the component's own pixels as h rows of box-relative 32-bit words
+constexpr int kMaskScanWords = 512, kMaskScanWordsLarge = 2048;  // 32-bit words per component: frames up to 1920x1200 (two components per wave) / larger ones (a wave each)
+// (box-relative 32-bit words: (w + 31) / 32 per row, + a word per row where rows beyond the first two passes park their extents)
+__host__ __device__ __forceinline__ int mask_scan_need(int w, int h) { return h * ((w + 31) / 32 + 1); }
 __host__ __device__ __forceinline__ bool pack_big(int x_min, int w, int h, int big_points, int pack_words, int scan_words = 0) {
     (void)x_min;
     return pack_need(w, h) > pack_words || pack_points(w, h) > big_points || (scan_words > 0 && scan_need(w, h) > scan_words) ||
@@ -870,25 +869,32 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
 // their root look-ups together (a row costs two round trips, not two per run); (2) the next pair's order entry and candidate are requested before the current pair is
 // worked on; (3) 8 KB of LDS per wave and few registers: five waves per SIMD.  A row with more runs, or a box over more than four words, takes the
 // one-probe-at-a-time loop for what is left.  (Round 6, measured per 4096 1080p frames: the first form -- a wave per component, a probe at a time -- 1.08 ms.)
-// kMsRel: box-relative words of a row held in registers and probed as a batch; kMsSub: lanes (rows at a time) per component; kWords: LDS words per component.
-// <2, 32, 1024> for frames up to 1920x1200 (boxes of ~75 x 25), <4, 64, 2048> for larger ones (~200 x 100: a wave per component)
+// kMsRel: box-relative 32-bit words of a row held in registers and probed as a batch; kMsSub: lanes (rows at a time) per component; kWords: LDS words per component.
+// <4, 32, 1024> for frames up to 1920x1200 (boxes of ~75 x 25), <8, 64, 2048> for larger ones (~200 x 100: a wave per component).
+// 32-bit words throughout (the first form worked on 64-bit words: every shift, add and bit scan two to four instructions -- 1424 vector instructions per pair of
+// components, 64 % of the SIMD cycles busy): the funnel shift that aligns a row with its box is ONE v_alignbit_b32 per word.
 constexpr int kMsProbes = 4;
+#ifndef CTAG_MS_WAVES
+#define CTAG_MS_WAVES 6  // waves per SIMD of the small build (its 4 KB of LDS per wave would allow eight)
+#endif
 template <int kMsRel, int kMsSub, int kWords>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 2 ? 6 : 4, 8))) void k_silhouette_mask(QuadPtrs P, FrameGeom g, int nframes) {
-    static_assert(64 * kMsRel <= 256, "run starts are packed as eight-bit column offsets");
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 4 ? CTAG_MS_WAVES : 4, 8))) void k_silhouette_mask(QuadPtrs P, FrameGeom g, int nframes) {
+    static_assert(32 * kMsRel <= 256, "run starts are packed as eight-bit column offsets");
     static_assert(kMsSub == 32 || kMsSub == 64, "one or two components per wave");
     constexpr int kPerWave = 64 / kMsSub;
-    __shared__ uint64_t s_comp2[kPerWave][kWords / 2];
+    __shared__ uint32_t s_comp2[kPerWave][kWords];
+    __shared__ int s_tb[kPerWave][8];
     const int frame = blockIdx.x;
     if (frame >= nframes) return;
     const int lane = threadIdx.x, sub = lane / kMsSub, sl = lane % kMsSub;
-    uint64_t* const s_comp = s_comp2[sub];
+    uint32_t* const s_comp = s_comp2[sub];
     const int nc = min(P.ncand[frame], P.cand_cap);
     const int npk = nc - P.npacks[2 * frame + 1];  // every packed component: entries [0, nc - oversize) of k_pack's order
+    const int mwords = 2 * P.mask_words;           // 32-bit words per mask row
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;
     const int32_t* __restrict__ rootof = P.root_of + (size_t)frame * g.pool_cap;
-    const uint64_t* __restrict__ mimg = P.mask + (size_t)frame * g.hrows * P.mask_words;
+    const uint32_t* __restrict__ mimg = reinterpret_cast<const uint32_t*>(P.mask) + (size_t)frame * g.hrows * mwords;
     const uint32_t* __restrict__ order = P.pack_order + (size_t)frame * P.cand_cap;
     const Candidate* __restrict__ cands = P.cand + (size_t)frame * P.cand_cap;
     const CandAux* __restrict__ auxs = P.cand_aux + (size_t)frame * P.cand_cap;
@@ -914,28 +920,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 2 
         const int C = pack_points(w, h);
         CandAux* aux = P.cand_aux + (size_t)frame * P.cand_cap + ci;
         // p0: the component's cluster space (what the packed builds reserve after their traversal) and, in it for now, the silhouette: w + h + 4 <= C + 64 words.
-        // The row's bits are brought into BOX-relative words (bit b of word j = column x_min + 64 j + b): ceil(w / 64) of them, only the last one partly valid.
-        const int j0 = x_min >> 6, sh = x_min & 63, nwa = (sh + w + 63) >> 6, nwr = (w + 63) >> 6;
+        // The row's bits are brought into BOX-relative words (bit b of word j = column x_min + 32 j + b): ceil(w / 32) of them, only the last one partly valid.
+        const int j0 = x_min >> 5, sh = x_min & 31, nwr = (w + 31) >> 5;
+        // What the kernel is bound by is the number of cache lines its lanes touch (a lane per row: every lane's load is a line of its own; the first form: 367 line
+        // accesses per component, the texture addressers 65 % busy): so the row's words come as ONE 16-byte load + one word, a run is probed only by the lanes that have
+        // it, and the label tiles' pool bases -- a handful of values per component -- are loaded once, by the sub-group's first lanes, and handed round through LDS.
+        const int ty0 = y_min / kTileH, tcx0 = x_min / kTileW;
+        const int nty = act ? (y_min + h - 1) / kTileH - ty0 + 1 : 1, ntx = act ? (x_min + w - 1) / kTileW - tcx0 + 1 : 1;
+        const bool tb_regs = nty * ntx <= 8;
+        if (sl < 8) s_tb[sub][sl] = tbase[min((ty0 + sl / ntx) * g.tiles_x + tcx0 + sl % ntx, g.tiles_x * g.tiles_y - 1)];  // lane i < 8: tile (i / ntx, i % ntx) of the box
+        __syncthreads();
         // ---- rows: a lane per row
         uint32_t lr_mine[2] = {0u, 0u};  // of rows sl and sl + kMsSub (more rows: parked in LDS as they are formed)
         for (int y = sl, yi = 0; y < h; y += kMsSub, yi++) {
-            const uint64_t* __restrict__ mr = mimg + (size_t)(y_min + y) * P.mask_words + j0;
+            const uint32_t* __restrict__ mr = mimg + (size_t)(y_min + y) * mwords + j0;
             const uint16_t* __restrict__ lrow = limg + (size_t)(y_min + y) * g.lp + x_min;
             const int trow = ((y_min + y) / kTileH) * g.tiles_x;
-            auto rel_word = [&](uint64_t a, uint64_t b, int j) -> uint64_t {  // box-relative word j from the aligned words that hold it
-                const uint64_t v = sh ? ((a >> sh) | (b << (64 - sh))) : a;
-                const int nb = w - 64 * j;  // valid bits
-                return nb >= 64 ? v : nb <= 0 ? 0ull : (v & ((1ull << nb) - 1ull));
+            auto rel_word = [&](uint32_t lo, uint32_t hi, int j) -> uint32_t {  // box-relative word j from the two aligned words that hold it
+                const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);  // ({hi, lo} >> sh)[31:0]
+                const int nb = w - 32 * j;  // valid bits
+                return nb >= 32 ? v : nb <= 0 ? 0u : (v & ((1u << nb) - 1u));
+            };
+            const int tyi = (y_min + y) / kTileH - ty0;
+            auto base_of = [&](int xr) -> int {  // pool base of the label tile of column x_min + xr in this row
+                const int tc = (x_min + xr) / kTileW;
+                return tb_regs ? s_tb[sub][min(tyi * ntx + tc - tcx0, 7)] : tbase[trow + tc];
             };
             auto member_of = [&](int xr) -> bool {  // one probe by itself (rows with more runs than the batch below holds): label -> pool entry -> root
                 const unsigned l = lrow[xr];
                 return l != 0u && l < 0x8000u && rootof[tbase[trow + (x_min + xr) / kTileW] + (int)l - 1] == cd.root;  // (bit 15: an unpublished speck, never a candidate)
             };
-            uint64_t mw[kMsRel];
+            uint32_t mw[kMsRel];
             {
-                uint64_t a[kMsRel + 1];
+                // kMsRel + 1 consecutive words from the row's first one (beyond the box: masked below; beyond the row: the next row's bytes -- the mask lives in the
+                // workspace's half-size image, eight times its size)
+                uint32_t a[kMsRel + 1];
+                struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
 #pragma unroll
-                for (int j = 0; j <= kMsRel; j++) a[j] = mr[min(j, nwa - 1)];
+                for (int q = 0; q < kMsRel / 4; q++) {
+                    const W4 t = *reinterpret_cast<const W4*>(mr + 4 * q);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a[4 * q + u] = t.v[u];
+                }
+                a[kMsRel] = mr[kMsRel];
 #pragma unroll
                 for (int j = 0; j < kMsRel; j++) mw[j] = rel_word(a[j], a[j + 1], j);
             }
@@ -945,74 +972,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 2 
             int nr = 0;
 #pragma unroll
             for (int j = 0; j < kMsRel; j++) {
-                const uint64_t carry = j > 0 ? (mw[j > 0 ? j - 1 : 0] >> 63) : 0ull;
-                uint64_t st = mw[j] & ~((mw[j] << 1) | carry);
+                const uint32_t carry = j > 0 ? (mw[j > 0 ? j - 1 : 0] >> 31) : 0u;
+                uint32_t st = mw[j] & ~((mw[j] << 1) | carry);
                 while (st && nr < kMsProbes) {
-                    xs |= (uint32_t)(64 * j + (int)__builtin_ctzll(st)) << (8 * nr);
+                    xs |= (uint32_t)(32 * j + (int)__builtin_ctz(st)) << (8 * nr);
                     nr++;
-                    st &= st - 1ull;
+                    st &= st - 1u;
                 }
             }
-            // Every load below is UNCONDITIONAL, from an address that is valid whatever the row holds (a probe the row does not have reads the box's first column; a
-            // label that names no pool entry reads entry 0) and its result masked afterwards: a load inside a branch makes the compiler wait for all loads in
-            // flight where the branch rejoins -- the probes would go out one at a time (they did: the first build's ISA).
+            // The probes go out together: the labels of the runs the row has (a lane without a k-th run sits that load out), then -- nothing in between uses a
+            // loaded value -- their roots.  (The first build's ISA had a wait behind every probe: its loads sat in branches whose results were used at once.)
             unsigned lp[kMsProbes];
             int bp[kMsProbes];
 #pragma unroll
             for (int k = 0; k < kMsProbes; k++) {
                 const int xr = (int)((xs >> (8 * k)) & 255u);
-                lp[k] = lrow[xr];
-                bp[k] = tbase[trow + (x_min + xr) / kTileW];
+                lp[k] = 0u;
+                if (k < nr) lp[k] = lrow[xr];
+                bp[k] = base_of(xr);
             }
             int rp[kMsProbes];
-            unsigned okm = 0u;
 #pragma unroll
             for (int k = 0; k < kMsProbes; k++) {
-                const bool ok = k < nr && lp[k] != 0u && lp[k] < 0x8000u;
-                okm |= (ok ? 1u : 0u) << k;
-                rp[k] = rootof[ok ? bp[k] + (int)lp[k] - 1 : 0];
+                rp[k] = -1;
+                if (lp[k] != 0u && lp[k] < 0x8000u) rp[k] = rootof[bp[k] + (int)lp[k] - 1];  // (bit 15: an unpublished speck, never a candidate)
             }
             unsigned memb = 0u;
 #pragma unroll
             for (int k = 0; k < kMsProbes; k++) memb |= (rp[k] == cd.root ? 1u : 0u) << k;
-            memb &= okm;
             bool cin = false, cmem = false;  // the word before ends in a run / that run belongs to the component
             int left = -1, right = -1, idx = 0;
-            auto do_word = [&](int j, uint64_t m) {
-                uint64_t comp = 0ull, starts = m & ~((m << 1) | (cin ? 1ull : 0ull));
-                bool last63 = false;
-                if (cin && (m & 1ull)) {  // goes on from the word before
-                    const uint64_t run = ((m + 1ull) ^ m) & m;
+            auto do_word = [&](int j, uint32_t m) {
+                uint32_t comp = 0u, starts = m & ~((m << 1) | (cin ? 1u : 0u));
+                bool last31 = false;
+                if (cin && (m & 1u)) {  // goes on from the word before
+                    const uint32_t run = ((m + 1u) ^ m) & m;
                     if (cmem) comp |= run;
-                    if (run >> 63) last63 = cmem;
+                    if (run >> 31) last31 = cmem;
                 }
                 while (starts) {
-                    const uint64_t sb = starts & (0ull - starts);
+                    const uint32_t sb = starts & (0u - starts);
                     starts ^= sb;
                     bool member;
                     if (idx < nr) member = ((memb >> idx) & 1u) != 0u;  // (nr: the runs the batch probed -- the first kMsProbes of the first kMsRel words)
-                    else member = member_of(64 * j + (int)__builtin_ctzll(sb));
+                    else member = member_of(32 * j + (int)__builtin_ctz(sb));
                     idx++;
-                    const uint64_t run = ((m + sb) ^ m) & m;  // the carry of the addition runs through the run and stops behind it
+                    const uint32_t run = ((m + sb) ^ m) & m;  // the carry of the addition runs through the run and stops behind it
                     if (member) comp |= run;
-                    if (run >> 63) last63 = member;
+                    if (run >> 31) last31 = member;
                 }
-                cin = (m >> 63) != 0ull;
-                cmem = last63;
+                cin = (m >> 31) != 0u;
+                cmem = last31;
                 s_comp[y * nwr + j] = comp;
                 if (comp) {
-                    if (left < 0) left = 64 * j + (int)__builtin_ctzll(comp);
-                    right = 64 * j + 63 - (int)__builtin_clzll(comp);
+                    if (left < 0) left = 32 * j + (int)__builtin_ctz(comp);
+                    right = 32 * j + 31 - (int)__builtin_clz(comp);
                 }
             };
 #pragma unroll
             for (int j = 0; j < kMsRel; j++)
                 if (j < nwr) do_word(j, mw[j]);
             for (int j = kMsRel; j < nwr; j++)  // wider boxes: the rest a word at a time (its runs a probe at a time)
-                do_word(j, rel_word(mr[min(j, nwa - 1)], mr[min(j + 1, nwa - 1)], j));
+                do_word(j, rel_word(mr[j], mr[j + 1], j));
             const uint32_t v = left < 0 ? 0u : ((uint32_t)(left + 2) | ((uint32_t)(right + 2) << 16));
             if (yi < 2) lr_mine[yi] = v;
-            else s_comp[h * nwr + y] = (uint64_t)v;  // (further rows: parked behind the words -- mask_scan_need counts a word more per row than the box has)
+            else s_comp[h * nwr + y] = v;  // (further rows: parked behind the words -- mask_scan_need counts a word more per row than the box has)
         }
         const bool fits = (uint32_t)(p0 + C + 64) <= P.cl_cap;
         if (act && !fits && sl == 0) {
@@ -1027,19 +1051,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 2 
             uint32_t* __restrict__ slot = P.cl_pool + (size_t)frame * P.cl_cap + p0;  // tb: [0, w + 2), lr: [w + 2, w + h + 4)
             if (sl < h) slot[w + 2 + sl + 1] = lr_mine[0];
             if (sl + kMsSub < h) slot[w + 2 + sl + kMsSub + 1] = lr_mine[1];
-            for (int y = sl + 2 * kMsSub; y < h; y += kMsSub) slot[w + 2 + y + 1] = (uint32_t)s_comp[h * nwr + y];
-            // columns: a lane per column of one 32-bit half-word at a time -- the sub-group's lanes read the SAME LDS word (a broadcast) and test their own bit; the
+            for (int y = sl + 2 * kMsSub; y < h; y += kMsSub) slot[w + 2 + y + 1] = s_comp[h * nwr + y];
+            // columns: a lane per column, kMsSub columns at a time -- the lanes of one 32-bit word read the SAME LDS address (a broadcast) and test their own bit; the
             // column's rows are gathered 32 at a time into a register (three instructions per row: read, bit extract, shift-or), first / last row from its ends
-            const uint32_t* c32 = reinterpret_cast<const uint32_t*>(s_comp);
             for (int ps = 0; kMsSub * ps < w; ps++) {
-                const int x = kMsSub * ps + sl, hf = x >> 5, bit = x & 31;  // (a sub-group of 64 lanes reads two neighbouring half-words)
+                const int x = kMsSub * ps + sl, wd = min(x >> 5, nwr - 1), bit = x & 31;
                 int top = -1, bot = -1;
                 for (int y0 = 0; y0 < h; y0 += 32) {
                     uint32_t T = 0u;
                     const int ye = min(32, h - y0);
-                    const uint32_t* cp = c32 + 2 * (y0 * nwr) + min(hf, 2 * nwr - 1);
+                    const uint32_t* cp = s_comp + y0 * nwr + wd;
 #pragma unroll 8
-                    for (int k = 0; k < ye; k++) T |= ((cp[2 * k * nwr] >> bit) & 1u) << k;
+                    for (int k = 0; k < ye; k++) T |= ((cp[k * nwr] >> bit) & 1u) << k;
                     if (T) {
                         if (top < 0) top = y0 + (int)__builtin_ctz(T);
                         bot = y0 + 31 - (int)__builtin_clz(T);
@@ -2956,8 +2979,8 @@ hipError_t launch_quads(int nframes, const Workspace& ws, hipStream_t s, hipEven
     do {                                                                                                                                                     \
         if (prescan) {                                                                                                                                       \
             if (mask_scan)                                                                                                                                   \
-                if (small_cfg) hipLaunchKernelGGL((k_silhouette_mask<2, 32, kMaskScanWords>), dim3(nframes, mscan_gx), dim3(64), 0, s, P, ws.g, nframes);     \
-                else hipLaunchKernelGGL((k_silhouette_mask<4, 64, kMaskScanWordsLarge>), dim3(nframes, 2 * mscan_gx), dim3(64), 0, s, P, ws.g, nframes);      \
+                if (small_cfg) hipLaunchKernelGGL((k_silhouette_mask<4, 32, kMaskScanWords>), dim3(nframes, mscan_gx), dim3(64), 0, s, P, ws.g, nframes);     \
+                else hipLaunchKernelGGL((k_silhouette_mask<8, 64, kMaskScanWordsLarge>), dim3(nframes, 2 * mscan_gx), dim3(64), 0, s, P, ws.g, nframes);      \
             else                                                                                                                                             \
                 hipLaunchKernelGGL((k_quad_edges_packed<64, kScanWords, CTAG_SCAN_WAVES, false, true, 3>), dim3(nframes, scan_gx), dim3(64), 0, s, P, ws.g, nframes, 0); \
             if (small_cfg) {                                                                                                                                 \
