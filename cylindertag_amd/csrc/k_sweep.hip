@@ -590,6 +590,8 @@ static_assert(kTileH <= 32, "the per-slot row mask is one 32-bit word");
 size_t threshold_ccl_lds_bytes(int tw) { return ccl_layout(tw).total; }
 
 __device__ __forceinline__ uint64_t mask_le(int b) { return b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull); }
+// set bits of x at positions <= b (0 <= b <= 63): the higher ones are shifted out -- a shift and the count instead of building the mask first
+__device__ __forceinline__ int popc_le(uint64_t x, int b) { return __popcll(x << (63 - b)); }
 
 // Barrier for k_threshold_ccl: its phases exchange data through LDS only, so the barrier waits for LDS traffic
 // (lgkmcnt) and NOT for vector memory (vmcnt) -- __syncthreads() would drain the next tile's prefetch loads and the
@@ -1412,7 +1414,7 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     bool overflow = nruns > RUNCAP;
     for (int i = tid; i < min(nruns, RUNCAP); i += kCclThreads) parent_s[i] = (unsigned)i;
     CCL_SYNC();
-    auto runid = [&](int item, int b) -> int { return runbase_s[item] + __popcll(start_s[item] & mask_le(b)) - 1; };
+    auto runid = [&](int item, int b) -> int { return runbase_s[item] + popc_le(start_s[item], b) - 1; };
 
     stamp(4);
     // ---- S6: unions between vertically adjacent rows (8-connectivity)
@@ -1429,13 +1431,16 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
             const uint64_t B = cur & ~up & ((up << 1) | upL) & ~((cur << 1) | curL);
             const uint64_t C = cur & ~up & ((up >> 1) | (upR << 63)) & ~((cur >> 1) | (curR << 63));
             uint64_t todo = A | B | C;
+            // (this word's and the upper word's starts and run bases once, in registers: the run of a bit is a population count away -- round 6)
+            const uint64_t st_c = start_s[tid], st_u = start_s[up_item];
+            const int rb_c = runbase_s[tid] - 1, rb_u = runbase_s[up_item] - 1;
             while (todo) {
                 const int b = __ffsll((unsigned long long)todo) - 1;
                 todo &= todo - 1;
-                const unsigned c = (unsigned)runid(tid, b);
-                if ((A >> b) & 1) lds_union(parent_s, c, (unsigned)runid(up_item, b));
-                if ((B >> b) & 1) lds_union(parent_s, c, (unsigned)(b > 0 ? runid(up_item, b - 1) : runid(up_item - 1, 63)));
-                if ((C >> b) & 1) lds_union(parent_s, c, (unsigned)(b < 63 ? runid(up_item, b + 1) : runid(up_item + 1, 0)));
+                const unsigned c = (unsigned)(rb_c + popc_le(st_c, b));
+                if ((A >> b) & 1) lds_union(parent_s, c, (unsigned)(rb_u + popc_le(st_u, b)));
+                if ((B >> b) & 1) lds_union(parent_s, c, (unsigned)(b > 0 ? rb_u + popc_le(st_u, b - 1) : runid(up_item - 1, 63)));
+                if ((C >> b) & 1) lds_union(parent_s, c, (unsigned)(b < 63 ? rb_u + popc_le(st_u, b + 1) : runid(up_item + 1, 0)));
             }
         }
     }
@@ -1497,13 +1502,16 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
     if (tid < kTileH * kTileWords) {
         const int r = tid / kTileWords, w = tid - r * kTileWords;
         uint64_t cur = mask_s[tid];
+        // the word's run segments are consecutive runs: the first one is the word's first start -- or, when it goes on from the word before (bit 0 set and not a
+        // start), the run before that -- and every further segment is the next run: no population count per segment (round 6)
+        int rid = runbase_s[tid] - (((cur & 1ull) != 0ull && (start_s[tid] & 1ull) == 0ull) ? 1 : 0);
         while (cur) {
             const int s = __ffsll((unsigned long long)cur) - 1;
             const uint64_t inv = ~(cur >> s);
             const int len = inv ? (__ffsll((unsigned long long)inv) - 1) : (64 - s);
             const int e = s + len - 1;
             cur = (e >= 63) ? 0ull : (cur & ~mask_le(e));
-            const int slot = lab_s[runid(tid, s)];
+            const int slot = lab_s[rid++];
             const int gx0 = tx0 + w * 64 + s, gx1 = tx0 + w * 64 + e, gy = ty0 + r;
             atomicAdd(&st_area[slot], len);
             atomicMin(&st_xmin[slot], gx0);
@@ -1579,11 +1587,12 @@ __device__ __forceinline__ void ccl_tile(unsigned char* smem, const SweepPtrs& P
                 // one run-id lookup per run segment of the group (a run's pixels share its label), then a select per pixel
                 unsigned rest = byte;
                 uint32_t lab8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int rid = runid(item, b0 + __ffs(rest) - 1);  // of the group's first segment; the further ones are the next runs
                 while (rest) {
                     const int sb = __ffs(rest) - 1;
                     const unsigned inv = ~(rest >> sb);
                     const int len = __ffs(inv) - 1;  // rest >> sb has at most 8 significant bits, so inv != 0
-                    const uint32_t lab = (uint32_t)lab_s[runid(item, b0 + sb)] + (BIG ? 0u : 1u);
+                    const uint32_t lab = (uint32_t)lab_s[rid++] + (BIG ? 0u : 1u);
                     const unsigned seg = ((1u << len) - 1u) << sb;
 #pragma unroll
                     for (int k = 0; k < 8; k++) lab8[k] = ((seg >> k) & 1u) ? lab : lab8[k];
