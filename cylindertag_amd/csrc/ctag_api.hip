@@ -861,7 +861,7 @@ static int detect_bgr_device_impl(ctag_handle* h, const uint8_t* bgr_dev, int n,
     if (rc != CTAG_OK) return rc;
     if (n == 0) return CTAG_OK;
     HIP_TRY(hipSetDevice(h->device));
-    // The direct form (round 5): frames of a size the fused sweep takes (1080p, 4K, 8K; adaptiveThresh 5), rows and frames 16-byte aligned -- the
+    // The direct form (round 5): frames of a size the fused sweep takes (half size a multiple of 320 x 5; adaptiveThresh 5), rows and frames 16-byte aligned -- the
     // decimation kernel loads the BGR bytes themselves and converts as it consumes them, edgeRefine converts the boxes it stages: no gray image is
     // written or read back (8.3 of the 24 MB a 1080p frame moved through the gray slab).  CTAG_OPT_BGR_DIRECT 0 turns it off.
     // Calls of a few frames (round 6): the fused sweep's K1 is one block per frame band group -- 0.19 ms for a single 1080p frame against < 0.02 ms

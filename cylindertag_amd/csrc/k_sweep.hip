@@ -395,14 +395,14 @@ __global__ __launch_bounds__(256) void k_decimate_general(const uint8_t* __restr
     half[((size_t)frame * g.hrows + y) * g.hp + x] = (uint8_t)min(max(out, 0), 255);
 }
 
-// The fused sweep (k_decimate_mask + the mask front end of K2) takes batches of frames whose half size is a multiple of 960 x 135
-// (1080p, 4K, 8K) with the reference's 5x5 window and 16-byte aligned rows; everything else keeps the two-kernel form with `half`.
+// The fused sweep (k_decimate_mask + the mask front end of K2) takes batches of frames whose half size is a multiple of 320 x 5 (round 6; 1080p, 4K, 8K,
+// 1920x1200, 1280x720, 2560x1440, 640x480 ...) with the reference's 5x5 window and 16-byte aligned rows; everything else keeps the two-kernel form with `half`.
 // CTAG_FUSED_SWEEP=0 (developer aid, A/B) turns it off.
 static int fuse_env() {
     static const int env_mode = getenv("CTAG_FUSED_SWEEP") ? atoi(getenv("CTAG_FUSED_SWEEP")) : -1;
     return env_mode;
 }
-// the frame sizes the fused sweep takes (adaptiveThresh 5; half size a multiple of 960 x 540: 1080p, 4K, 8K), whatever the batch
+// the frame sizes the fused sweep takes (adaptiveThresh 5; half size a multiple of 320 x 5), whatever the batch
 bool sweep_fused_size(int rows, int cols, int tw, int fuse_mode) {
     const int env = fuse_mode >= 0 ? fuse_mode : fuse_env() >= 0 ? fuse_env() : 1;
     if (!env || (rows & 1) || (cols & 1) || tw != 5) return false;
@@ -754,7 +754,7 @@ constexpr int kVPitch = 352;  // column extrema per threshold-tile row: 5 + 320 
 // extrema of the tile rows just above and below it: those 2 x 5 output rows are decimated again (extrema only: +7 % source reads,
 // which the neighbouring band's wave reads at about the same time on the same XCD).  A wave covers 960 half-resolution columns --
 // 60 lanes x 16 pixels, a multiple of the 5-pixel tile -- and lanes 60 / 61 decimate the 16 columns right / left of the span for
-// the tile column just outside it (4K frames: two waves per row).  Frames with hcols % 960 == 0, hrows % 135 == 0 (1080p, 4K, 8K).
+// the tile column just outside it (4K frames: two waves per row).  BAND = 135: frames with hcols % 960 == 0, hrows % 540 == 0 (1080p, 4K, 8K); BAND = 0: see below.
 // =====================================================================================================
 struct FuseLds {                   // per wave: 12 960 bytes, four waves per block, three blocks per CU
     uint4 ring[10][kFuseLanes];    // the pixels of the tile row being built and of the one waiting for its lower neighbour

@@ -132,7 +132,7 @@ void* ctag_stream(ctag_handle* h);
                                       instead of deciding most distance tests from a filtered estimate (k_quad.hip).  Results do not depend on it -- that is what
                                       the option exists to check. */
 #define CTAG_OPT_FUSED_SWEEP 7     /* the threshold + label sweep as k_decimate_mask -> k_threshold_ccl (thresholds where the half-size pixels are computed, hands
-                                      1 bit per pixel on; frames whose half size is a multiple of 960 x 135 -- 1080p, 4K, 8K -- with adaptiveThresh 5):
+                                      1 bit per pixel on; frames whose half size is a multiple of 320 x 5 -- 1080p, 4K, 8K, 1920x1200, 1280x720 ... -- with adaptiveThresh 5):
                                       0 never, 1 (default) batches of 512 frames' worth of bands and more, 2 whenever the frame size allows.  Results do not depend on it. */
 #define CTAG_OPT_BGR_DIRECT 10     /* 1 (default): ctag_detect_batch_bgr8_device hands BGR frames of a size the fused sweep takes (see CTAG_OPT_FUSED_SWEEP), with
                                       16-byte aligned rows and frames, to the chain as they are -- the decimation kernel and edgeRefine convert (cvtColor(BGR2GRAY),

@@ -1,6 +1,6 @@
 """GPU parity of the fused sweep (-m gpu): k_decimate_mask thresholds the half-size pixels where it computes them and hands K2 one bit
 per pixel (no half-size image in HBM).  CTAG_OPT_FUSED_SWEEP = 2 forces that form for any number of frames of a size that allows it
-(half size a multiple of 960 x 135: 1080p, 4K); the mask must equal the oracle's adaptiveThreshold output (corner_detector.cpp:28-79)
+(half size a multiple of 320 x 5); the mask must equal the oracle's adaptiveThreshold output (corner_detector.cpp:28-79)
 bit for bit, and everything behind it the oracle's stage by stage."""
 import numpy as np
 import pytest

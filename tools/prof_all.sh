@@ -1,5 +1,5 @@
-# usage: tools/prof_all.sh r05   (the round's tag): every profile the round commits, into gpurun_out/ (copy to profiles/ by hand)
-TAG=${1:-r05}
+# usage: tools/prof_all.sh r06   (the round's tag): every profile the round commits, into gpurun_out/ (copy to profiles/ by hand)
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 bash tools/pmc_instmix.sh ${TAG} > gpurun_out/instmix.log 2>&1; tail -3 gpurun_out/instmix.log
 cp profiles/${TAG}_pmc_instmix.json gpurun_out/${TAG}_pmc_instmix.json
@@ -11,6 +11,8 @@ find gpurun_out/ksl -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpuru
 rm -rf gpurun_out/ks gpurun_out/ksl gpurun_out/im_*
 python3 bench.py > gpurun_out/${TAG}_bench_4096.json 2> gpurun_out/bench_err.log; tail -c 600 gpurun_out/${TAG}_bench_4096.json
 python3 bench.py --size 3840x2160 --frames 1024 --chunk 1024 > gpurun_out/${TAG}_bench_4k_1024.json 2>> gpurun_out/bench_err.log; tail -c 300 gpurun_out/${TAG}_bench_4k_1024.json
+# the reference's own frame size (test.bmp: 1920x1200) through the run-time-band build of the fused sweep (round 6)
+python3 bench.py --size 1920x1200 --frames 2048 --chunk 2048 --host-frames 0 --pose-frames 0 --latency-calls 0 > gpurun_out/${TAG}_bench_1920x1200.json 2>> gpurun_out/bench_err.log; tail -c 300 gpurun_out/${TAG}_bench_1920x1200.json
 bash tools/pmc_traffic.sh ${TAG} > gpurun_out/traffic.log 2>&1; tail -4 gpurun_out/traffic.log
 bash tools/pmc_traffic.sh ${TAG}_4k 3840x2160 256 > gpurun_out/traffic4k.log 2>&1; tail -4 gpurun_out/traffic4k.log
 rm -rf gpurun_out/ks4
