@@ -374,8 +374,8 @@ def issue_rooflines(stage_ms, n_frames):
         pass
     for stage, kname in ISSUE_KERNELS.items():
         hits = [v for k, v in prof["kernels"].items() if k == kname or k.startswith(kname + "<") or (kname.endswith("<5") and k.startswith(kname))]  # template arguments vary; several builds of a kernel
-        if stage == "quad_edges":  # the packed build runs as two kernels (boundary, edge clusters): both belong to the stage
-            hits = [v for k, v in prof["kernels"].items() if k.startswith(kname + "<8,")]
+        if stage == "quad_edges":  # the packed build runs as two kernels (boundary, edge clusters) behind the mask-based silhouette scan (round 6): all belong to the stage
+            hits = [v for k, v in prof["kernels"].items() if k.startswith(kname + "<8,") or k.startswith("ctag::k_silhouette_mask")]
             work = hits
         elif stage == "edge_refine":  # searches (k_edge_refine<1>), ordered sums (k_edge_refine_sums), lines and corners (k_edge_refine_tail), long quads: the stage is all of them
             work = [v for k, v in prof["kernels"].items() if k.startswith(kname + "<1") or k.startswith(kname + "_")]
