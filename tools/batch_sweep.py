@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""One-off differential hunt (GPU box): one BATCH of random shape frames through ctag_detect_batch_u8, every record vs the oracle."""
+"""One-off differential hunt (GPU box): one BATCH of random shape frames through ctag_detect_batch_u8, every record vs the oracle.
+usage: [CTAG_FUSED_SWEEP=2] [CTAG_SWEEP_SEED=9000] python tools/batch_sweep.py [frames] [rows cols]   (CTAG_FUSED_SWEEP=2: the fused sweep and the mask-based
+silhouettes whatever the batch size, for the frame sizes that allow them)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +16,8 @@ ns = {"ca": ca, "np": np, "tk": tk}
 exec(src[src.index("def _random_shapes_frame"):src.index("def test_random_shapes_fuzz")], ns)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 rows, cols = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (720, 1152)
-frames = np.stack([ns["_random_shapes_frame"](state, 5000 + i, rows, cols) for i in range(n)])
+seed0 = int(os.environ.get("CTAG_SWEEP_SEED", "5000"))  # another population of shapes
+frames = np.stack([ns["_random_shapes_frame"](state, seed0 + i, rows, cols) for i in range(n)])
 orc, det = Oracle(), tk.Detector(state, fs)
 for chunk in (1024, 37):
     det.set_option(capi.OPT_MAX_CHUNK, chunk)
