@@ -859,23 +859,22 @@ __device__ CTAG_EXPAND_INLINE void sg_expand_line(const uint32_t* W, int n, int 
 // first and last pixel OF THE COMPONENT; the label scan answers by testing every label of the box (~1700 for a bar of ~500 pixels, ~100 instructions per row
 // and wave, 48 % of k_quad_edges_packed's cycles).  Here a lane owns a ROW of the box: it cuts the row's mask words into foreground runs with bit tricks --
 // a run is a maximal horizontal stretch of foreground, hence of ONE component -- and asks for ONE label per run (its first pixel: tile-local label -> pool entry
-// -> root): 1-3 probes per row.  The component's own pixels of the row (the OR of its runs) go to LDS as 64-bit words, the row's extents are their first / last
-// set bits; then a lane owns a COLUMN and walks the rows' words for the column's first / last set bit.  A run cut by the box's edge belongs to another component
+// -> root): 1-3 probes per row.  The component's own pixels of the row (the OR of its runs) go to LDS as box-relative 32-bit words, the row's extents are their
+// first / last set bits; then a lane owns a COLUMN and gathers the rows' bits of its column for the column's first / last set bit.  A run cut by the box's edge belongs to another component
 // (the box of ours would otherwise reach further) and says so when probed.  Output: what PHASE 3 of k_quad_edges_packed leaves -- tb / lr in the component's
 // cluster-pool slot, the slot in cand_aux -- so the packed builds run with PRESCAN = true behind it.
 // =====================================================================================================
-// Two components per wave, 32 lanes each (the packs' order puts components of similar size side by side); what the kernel waits for is a chain of dependent loads
-// -- order entry -> candidate -> mask words -> labels -> roots -- so (1) the probes of a row are issued TOGETHER, the first four runs of its first 128 columns, then
-// their root look-ups together (a row costs two round trips, not two per run); (2) the next pair's order entry and candidate are requested before the current pair is
-// worked on; (3) 8 KB of LDS per wave and few registers: five waves per SIMD.  A row with more runs, or a box over more than four words, takes the
-// one-probe-at-a-time loop for what is left.  (Round 6, measured per 4096 1080p frames: the first form -- a wave per component, a probe at a time -- 1.08 ms.)
+// Two components per wave, 32 lanes each (the packs' order puts components of similar size side by side).  A component is a chain of dependent loads -- order entry ->
+// candidate -> mask words -> labels -> roots -- so (1) the probes of a row are issued TOGETHER, the first four runs of its first kMsRel words, then their root look-ups
+// together (a row costs two round trips, not two per run); (2) the next pair's order entry, candidate and slot are requested before the current pair is worked on; (3) the
+// slots come from k_pack's prefix sum, not from a returning atomic.  A row with more runs, or a box over more words, takes the one-probe-at-a-time loop for what is left.
 // kMsRel: box-relative 32-bit words of a row held in registers and probed as a batch; kMsSub: lanes (rows at a time) per component; kWords: LDS words per component.
-// <4, 32, 1024> for frames up to 1920x1200 (boxes of ~75 x 25), <8, 64, 2048> for larger ones (~200 x 100: a wave per component).
-// 32-bit words throughout (the first form worked on 64-bit words: every shift, add and bit scan two to four instructions -- 1424 vector instructions per pair of
-// components, 64 % of the SIMD cycles busy): the funnel shift that aligns a row with its box is ONE v_alignbit_b32 per word.
+// <4, 32, 512> for frames up to 1920x1200 (boxes of ~75 x 25), <8, 64, 2048> for larger ones (~200 x 100: a wave per component).
+// docs/history.md R6-A has the six forms and what each measured (1.08 -> 0.72 ms per 4096 1080p frames); the funnel shift that aligns a row with its box is ONE
+// v_alignbit_b32 per word.
 constexpr int kMsProbes = 4;
 #ifndef CTAG_MS_WAVES
-#define CTAG_MS_WAVES 6  // waves per SIMD of the small build (its 4 KB of LDS per wave would allow eight)
+#define CTAG_MS_WAVES 6  // waves per SIMD of the small build (its 4 KB of LDS per wave would allow eight: measured 5 / 6 / 7 / 8 -> 3.49 / 3.54 / 3.63 / 3.78 ms quad_edges)
 #endif
 template <int kMsRel, int kMsSub, int kWords>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 4 ? CTAG_MS_WAVES : 4, 8))) void k_silhouette_mask(QuadPtrs P, FrameGeom g, int nframes) {
