@@ -889,6 +889,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kMsRel <= 4 
     uint32_t* const s_comp = s_comp2[sub];
     const int nc = min(P.ncand[frame], P.cand_cap);
     const int npk = nc - P.npacks[2 * frame + 1];  // every packed component: entries [0, nc - oversize) of k_pack's order
+    if (kPerWave * (int)blockIdx.y >= npk) return;  // nothing for this wave (a frame without packed components has no order entry to read, either)
     const int mwords = 2 * P.mask_words;           // 32-bit words per mask row
     const uint16_t* __restrict__ limg = P.labels + ((size_t)frame * g.hrows) * g.lp;
     const int32_t* __restrict__ tbase = P.tile_base + (size_t)frame * g.tiles_x * g.tiles_y;

@@ -87,3 +87,19 @@ def test_mask_and_label_silhouettes_agree_at_4k(fused, oracle, dictionary):
     state, fs = dictionary
     frames = np.stack([_random_shapes_frame(state, 70 + s, 2160, 3840) for s in range(5)])
     _check_batch(fused, oracle, state, fs, frames, "random shapes 3840x2160", every=2)
+
+
+def test_frames_without_components_in_fused_batches(fused, oracle, dictionary):
+    """Blank frames (no component at all, hence no pack order entry), frames of one tiny component and marker frames in one batch."""
+    state, fs = dictionary
+    frames = np.stack([tk.synth_frame_host(state, 400 + f)[0] for f in range(10)])
+    frames[1] = 230
+    frames[4] = 0
+    frames[7] = 200
+    frames[7, 500:520, 900:960] = 20  # one dark bar
+    want, _ = oracle.detect_many(frames, state, fs)
+    assert want["status"][1] != 0 and want["status"][4] != 0
+    for rep in range(2):  # twice: the second pass finds the first one's order entries in the workspace
+        got = fused.detect_batch(frames[::-1] if rep else frames)
+        for f in range(10):
+            assert_same_record(got[f], want[9 - f] if rep else want[f], "blank-frame batch, pass %d, frame %d" % (rep, f))
