@@ -148,5 +148,5 @@ def test_bench_starts_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "8"],
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
     assert p.returncode != 0
-    assert p.stderr.count("bench.py needs a GPU") == 2, p.stderr[-3000:]
+    assert 1 <= p.stderr.count("bench.py needs a GPU") <= 2, p.stderr[-3000:]  # (the launcher ends the second rank as soon as the first has failed: one message or two)
     assert "needs `python -m torch.distributed.run" not in p.stderr  # round 4's launcher check is gone
